@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- field-ops/sec of the MPyC secure-multiplication hot path on MI355X.
+
+Workload (BASELINE.json configs[1], per GPU): a SecFld(GF(2^61-1)) array of n = 10^7
+elements.  One STEP is one pass of the path the reference runs for `a * b` on secure arrays
+(runtime.py:1096-1141 np_multiply -> :603-689 _reshare), for the default 3-party setting
+m=3, t=1:
+    c      = a * b                      n mod-muls        (finfields.py:1105-1112)
+    shares = np_random_split(c, t, m)   n share gens      (thresha.py:47-64, coefficients supplied)
+    y      = np_recombine(2t+1 rows)    n recombinations  (thresha.py:119-132)
+=> 3n field-ops per step (one op = one element through one stage).  Inputs are resident in
+HBM before the timed region; several independent buffer sets are rotated so that no launch
+finds its operands in the 256 MiB Infinity Cache.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (torchrun for N>1, one rank per
+GPU); W untimed warm-up steps, exactly K timed steps between barrier+synchronize, MAX over
+ranks, rank 0 prints ONE JSON line.  Elements shard across ranks with no collective on the
+data path (every element is independent): weak scaling, n per GPU fixed.
+
+Extra objects on the line:
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch time measured with
+                events on the launch stream inside this run; peak = 8 TB/s HBM (spec).
+  kernels       the same for every kernel of the step, plus configs[2] (P64, m=7, t=3) and the
+                measured device-copy bandwidth (achievable-HBM yardstick).
+  cpu_baseline  oracle/fforacle.c (C port of the reference path) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+P61 = 2**61 - 1
+P64 = 2**64 - 189
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s measured copy
+
+
+def uniform_field(gen, n, p, device):
+    """n uniform canonical elements of GF(p), p < 2^64, generated on the device."""
+    nb = p.bit_length()
+    x = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=device, generator=gen)
+    if nb < 64:
+        x = (x >> (64 - nb)) & ((1 << nb) - 1)
+        x = torch.where(x >= p, x - p, x)
+    else:
+        # unsigned compare x >= p on int64 bit patterns: p = 2^64 - c  <=>  signed x in [-c, -1]
+        c = (1 << 64) - p
+        x = torch.where((x < 0) & (x >= -c), x + c, x)
+    return x
+
+
+class StepData:
+    """One rotating buffer set for the gate pass."""
+
+    def __init__(self, ctx, n, t, m, gen):
+        from mpyc_amd.engine import DevArray
+        dev = ctx.torch_device
+        p = ctx.modulus
+        self.a = DevArray(ctx, uniform_field(gen, n, p, dev), n)
+        self.b = DevArray(ctx, uniform_field(gen, n, p, dev), n)
+        self.c = ctx.empty(n)
+        self.coef = ctx.empty_matrix(max(t, 1), n)
+        for j in range(t):
+            self.coef.row(j).t.copy_(uniform_field(gen, n, p, dev))
+        self.shares = ctx.empty_matrix(m, n)
+        self.y = ctx.empty(n)
+        self.rec = None     # pre-marshalled recombination launch
+
+
+def time_launches(fn, sets, reps):
+    """Mean ms per launch of fn(set) over reps passes through all sets (events on the launch stream)."""
+    for s in sets:
+        fn(s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for s in sets:
+            fn(s)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (reps * len(sets))
+
+
+def roof(bytes_per_launch, ms):
+    gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'ms_per_launch': round(ms, 5),
+            'bytes_per_launch': int(bytes_per_launch), 'traffic': None}
+
+
+def cpu_baseline(n_full, t, m, lam, seed=20260925):
+    """C port of the reference path (oracle/fforacle.c) on this host: the same 3-stage pass
+    over the same workload shape.  Also times the reference-style NumPy object-array path
+    (oracle/nporacle.py) on a smaller sample.  Checker/baseline only -- never the product."""
+    from oracle import coracle, nporacle
+    rng = np.random.default_rng(seed)
+    cores = coracle.max_threads()
+    n = n_full
+    a = rng.integers(0, P61, size=n, dtype=np.uint64)
+    b = rng.integers(0, P61, size=n, dtype=np.uint64)
+    coef = rng.integers(0, P61, size=(t, n), dtype=np.uint64)
+    cf = coracle.CField(P61)
+
+    def one_pass():
+        c = cf.ew(coracle.MUL, a, b)
+        sh = cf.split(c, coef, t, m)
+        return cf.recombine([sh[j] for j in range(2 * t + 1)], lam)
+
+    res = {}
+    for label, threads in (('1core', 1), ('allcores', cores)):
+        coracle.set_threads(threads)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            y = one_pass()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res[label] = 3 * n / best
+    coracle.set_threads(1)
+    # reference-style object arrays (what mpyc.finfields / thresha actually execute), 1 core
+    ns = 200_000
+    ao, bo = a[:ns].astype(object), b[:ns].astype(object)
+    co = coef[:, :ns].astype(object)
+    t0 = time.perf_counter()
+    c_ = nporacle.mul(P61, ao, bo)
+    sh_ = nporacle.split(P61, c_, co, t, m)
+    y_ = nporacle.recombine(P61, [sh_[j] for j in range(2 * t + 1)], lam)
+    dt = time.perf_counter() - t0
+    assert [int(v) for v in y_[:100]] == [int(v) for v in y[:100]]
+    return {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'kind': 'port',
+            'sample': f'full workload: n={n} P61 elements x (modmul + split m={m},t={t} + recombine k={2*t+1}), '
+                      f'oracle/fforacle.c with OpenMP, best of 2',
+            'value_1core': round(res['1core'], 1),
+            'reference_style_numpy_object_1core': round(3 * ns / dt, 1),
+            'reference_style_sample': f'n={ns} of the same pass with NumPy dtype=object arrays (oracle/nporacle.py)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--n', type=int, default=10_000_000, help='elements per GPU')
+    ap.add_argument('--sets', type=int, default=4, help='rotating buffer sets')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from mpyc_amd.engine import FieldContext
+    from oracle import pyoracle as po
+
+    n, t, m = args.n, 1, 3
+    k = 2 * t + 1
+    ctx = FieldContext(P61, device=local_rank)
+    gen = torch.Generator(device=ctx.torch_device)
+    gen.manual_seed(20260925 + rank)
+    sets = [StepData(ctx, n, t, m, gen) for _ in range(args.sets)]
+    lam = po.recombination_vector(po.Field(P61), list(range(1, k + 1)), 0)
+
+    def f_mul(s):
+        ctx.mul(s.a, s.b, out=s.c)
+
+    def f_split(s):
+        ctx.split(s.c, s.coef, t, m, out=s.shares)
+
+    for s in sets:
+        s.rec = ctx.recombine_plan([s.shares.row(j) for j in range(k)], lam, s.y)
+
+    def f_rec(s):
+        s.rec()
+
+    def step(i):
+        s = sets[i % len(sets)]
+        f_mul(s)
+        f_split(s)
+        f_rec(s)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    # parity guard inside the bench: recombining the fresh shares gives back a*b
+    torch.cuda.synchronize()
+    s0 = sets[(args.warmup - 1) % len(sets)] if args.warmup else None
+    if s0 is not None and not torch.equal(s0.y.t, s0.c.t):
+        raise SystemExit('bench parity check failed: recombine(split(a*b)) != a*b')
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ops_total = 3.0 * n * world * args.steps
+    value = ops_total / elapsed
+    out = {
+        'metric': 'field-ops/sec (modmul + share+recombine) on 10^7-elt SecFld array',
+        'value': round(value, 1), 'unit': 'field-ops/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 5),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: SecFld(GF(2^61-1)) array, 10^7 elements per GPU; step = '
+                               'modmul + np_random_split(m=3,t=1, coefficients supplied) + np_recombine(k=3)',
+                   'n_per_gpu': n, 'prime': '2^61-1', 'm': m, 't': t, 'k': k, 'field_ops_per_step': 3 * n,
+                   'buffer_sets': args.sets, 'parallelism': f'element-sharded x{world}, no collective'},
+    }
+
+    if rank == 0 and not args.no_extras:
+        eb = 8
+        reps = 10
+        kern = {}
+        ms = time_launches(f_mul, sets, reps)
+        kern['mul_p61'] = dict(roof(3 * eb * n, ms), kernel='k_ew2<PM64<false,true>,MUL>',
+                               algorithmic_bytes_per_unit=3 * eb, units_per_s=round(n / (ms * 1e-3), 1))
+        ms = time_launches(f_split, sets, reps)
+        bpu = (1 + t + m) * eb
+        kern['split_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,1>',
+                                      algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+        ms = time_launches(f_rec, sets, reps)
+        bpu = (k + 1) * eb
+        kern['recombine_p61_k3'] = dict(roof(bpu * n, ms), kernel='k_recombine<PM64<false,true>,3>',
+                                        algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+        # fused local product + share generation (c never written)
+        def f_fused(s):
+            ctx.split(s.a, s.coef, t, m, out=s.shares, mul_by=s.b)
+        ms = time_launches(f_fused, sets, reps)
+        bpu = (2 + t + m) * eb
+        kern['mul_split_fused_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,1,fused>',
+                                                algorithmic_bytes_per_unit=bpu,
+                                                units_per_s=round(n / (ms * 1e-3), 1))
+        # achievable-bandwidth yardstick: the library's streaming copy, 80 MB blocks rotating
+        ms_copy = min(ctx.time_copy(s.a.t, s.c.t, 20) for s in sets)
+        kern['device_copy'] = roof(2 * eb * n, ms_copy)
+        # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
+        del sets[1:]
+        torch.cuda.empty_cache()
+        ctx64 = FieldContext(P64, device=local_rank)
+        t2, m2 = 3, 7
+        sets64 = [StepData(ctx64, n, t2, m2, gen) for _ in range(3)]
+        ms = time_launches(lambda s: ctx64.mul(s.a, s.b, out=s.c), sets64, reps)
+        kern['mul_p64'] = dict(roof(3 * eb * n, ms), algorithmic_bytes_per_unit=3 * eb,
+                               units_per_s=round(n / (ms * 1e-3), 1))
+        ms = time_launches(lambda s: ctx64.split(s.a, s.coef, t2, m2, out=s.shares), sets64, reps)
+        bpu = (1 + t2 + m2) * eb
+        kern['split_p64_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                      units_per_s=round(n / (ms * 1e-3), 1))
+        F64 = po.Field(P64)
+        for kk in (t2 + 1, 2 * t2 + 1):
+            lam64 = po.recombination_vector(F64, list(range(1, kk + 1)), 0)
+            for s in sets64:
+                s.rec = ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y)
+            ms = time_launches(lambda s: s.rec(), sets64, reps)
+            bpu = (kk + 1) * eb
+            kern[f'recombine_p64_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                units_per_s=round(n / (ms * 1e-3), 1))
+        # dominant kernel of the timed step = the one with the largest share of step time
+        step_kernels = ['mul_p61', 'split_p61_m3t1', 'recombine_p61_k3']
+        dom = max(step_kernels, key=lambda q: kern[q]['ms_per_launch'])
+        out['roofline'] = dict({kk_: vv for kk_, vv in kern[dom].items()
+                                if kk_ in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')},
+                               kernel=kern[dom].get('kernel'), name=dom,
+                               ms_per_launch=kern[dom]['ms_per_launch'],
+                               frac_of_measured_copy=round(kern[dom]['achieved'] / kern['device_copy']['achieved'], 4))
+        out['kernels'] = kern
+        out['mulmod_per_s_1gpu'] = kern['mul_p61']['units_per_s']
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,178 @@
+/*
+ * ffgpu.h -- C ABI of libffgpu.so, the MI355X (gfx950) finite-field /
+ * secret-sharing engine that sits behind MPyC's field-array and threshold
+ * sharing interfaces.
+ *
+ * The reference (lschoe/mpyc) is pure Python and has no FFI of its own; the
+ * seams this ABI plugs into are listed per entry point below as
+ * "replaces: <reference file>:<lines>" (paths relative to the mpyc checkout).
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every entry point returns an int status (FFGPU_OK == 0); nothing throws
+ *     across the boundary.  ffgpu_strerror() maps a status to text; the Python
+ *     shim maps statuses to the exceptions the reference raises.
+ *   - all array arguments are DEVICE pointers unless the name says host.
+ *     Elements are fixed-width little-endian limbs in canonical form
+ *     (0 <= x < modulus; for GF(2^n) the bit pattern of the polynomial):
+ *         elem_bytes == 1   GF(2^n), n <= 8           uint8  [n]
+ *         elem_bytes == 4   prime p < 2^32            uint32 [n]
+ *         elem_bytes == 8   prime p < 2^64, GF(2^n) n<=64   uint64 [n]
+ *         elem_bytes == 16  prime p < 2^128, GF(2^n) n<=128 {lo,hi} uint64 pairs
+ *     This is exactly the byte layout of field.to_bytes() (finfields.py:91-102)
+ *     for byte_length in {1,4,8,16}.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     Calls are asynchronous on that stream; nothing synchronises unless the
+ *     name says so.
+ *   - inputs are never written; `out` may alias an input of the same shape for
+ *     the element-wise entry points (in-place operators, finfields.py:1068-1124).
+ *   - thread-safety: a context is immutable after creation and may be shared
+ *     between host threads; the reference only ever calls from one event-loop
+ *     thread (asyncoro.py:416-464).
+ */
+#ifndef FFGPU_H
+#define FFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFGPU_ABI_VERSION 1
+
+/* status codes */
+#define FFGPU_OK          0
+#define FFGPU_EINVAL      1   /* bad argument (null pointer, t >= m, k == 0, ...)   */
+#define FFGPU_ENOTSUP     2   /* field / size outside what this build supports      */
+#define FFGPU_EHIP        3   /* a HIP runtime call failed; see ffgpu_last_hip_error */
+#define FFGPU_EMODULUS    4   /* modulus is not usable (even/zero/one, too wide)     */
+#define FFGPU_ENOMEM      5
+
+/* field kinds */
+#define FFGPU_PRIME   1   /* GF(p), p prime < 2^128       (finfields.py:347-363 pGF)  */
+#define FFGPU_BINARY  2   /* GF(2^n), 1 <= n <= 128       (finfields.py:508-525 xGF,
+                             gfpx.py:848-1121 BinaryPolynomial)                       */
+
+/* reduction strategy picked at context creation (reported for logs/tests) */
+#define FFGPU_RED_PSEUDO_MERSENNE 1  /* p = 2^k - c, small c: fold reduction          */
+#define FFGPU_RED_RECIPROCAL      2  /* arbitrary modulus: Barrett-type reciprocal    */
+#define FFGPU_RED_GF2_SWAR        3  /* GF(2^n), n<=8: packed shift-xor               */
+#define FFGPU_RED_GF2_WIDE        4  /* GF(2^n), n<=128: limb shift-xor               */
+#define FFGPU_RED_MONTGOMERY      5  /* arbitrary odd 65..128-bit p: two-limb REDC    */
+
+typedef struct ffgpu_ctx ffgpu_ctx;
+
+/* ---- library / device ------------------------------------------------- */
+int         ffgpu_abi_version(void);
+const char* ffgpu_strerror(int status);
+const char* ffgpu_last_hip_error(void);          /* text of the last failing HIP call */
+int         ffgpu_device_count(int* count);
+
+/* ---- field context ---------------------------------------------------- */
+/* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p (nlimbs 1..2).
+ * FFGPU_BINARY: bit pattern of the irreducible polynomial including its leading
+ * term (degree n <= 128 needs up to 3 limbs).  Primality / irreducibility is the
+ * caller's job (the reference checks it in pGF/xGF before any array exists).
+ * replaces: finfields.py:23-60 (GF / arrayGF pick the array representation). */
+int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device,
+                     ffgpu_ctx** out);
+int ffgpu_ctx_destroy(ffgpu_ctx* ctx);
+int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8 or 16               */
+int ffgpu_ctx_reduction(const ffgpu_ctx* ctx);    /* one of FFGPU_RED_*          */
+int ffgpu_ctx_device(const ffgpu_ctx* ctx);
+
+/* ---- device memory (optional: any hipMalloc'ed / torch pointer works) -- */
+int ffgpu_malloc(ffgpu_ctx* ctx, size_t bytes, void** dptr);
+int ffgpu_free(ffgpu_ctx* ctx, void* dptr);
+int ffgpu_h2d(ffgpu_ctx* ctx, void* dst, const void* host_src, size_t bytes, void* stream);
+int ffgpu_d2h(ffgpu_ctx* ctx, void* host_dst, const void* src, size_t bytes, void* stream);
+int ffgpu_stream_sync(ffgpu_ctx* ctx, void* stream);
+
+/* ---- canonical reduction ---------------------------------------------- */
+/* out[i] = raw[i] mod modulus for arbitrary limb patterns of elem_bytes width.
+ * replaces: finfields.py:717-725 (`value %= modulus` in FiniteFieldArray.__init__) */
+int ffgpu_reduce(ffgpu_ctx* ctx, const void* raw, void* out, size_t n, void* stream);
+
+/* ---- element-wise field arithmetic, arrays of equal length n ---------- */
+/* replaces: finfields.py:1056-1103 (__add__/__sub__/__iadd__/__isub__),
+ *           :1105-1124 (__mul__/__imul__), :1189-1192 (__neg__);
+ *           GF(2^n): gfpx.py:982-1045 (_add/_mul/_mod).                      */
+int ffgpu_add(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream);
+int ffgpu_sub(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream);
+int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream);
+int ffgpu_neg(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream);
+
+/* array (op) scalar; scalar is a HOST value in canonical limbs (2 x uint64,
+ * little-endian, upper limb 0 for narrow fields).
+ * replaces: the `other` is int / field element branch of finfields.py:1045-1054. */
+int ffgpu_add_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* host_scalar, void* out, size_t n, void* stream);
+int ffgpu_mul_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* host_scalar, void* out, size_t n, void* stream);
+/* out = scalar - a   (finfields.py:1084-1091 __rsub__)                        */
+int ffgpu_rsub_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* host_scalar, void* out, size_t n, void* stream);
+
+/* out = a * b + c   (fused multiply-add; one pass instead of two)            */
+int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, void* out, size_t n, void* stream);
+
+/* ---- Shamir share generation ------------------------------------------ */
+/* shares[i][h] = secrets[h] + sum_{j<t} coeffs[j][h] * (i+1)^(j+1)  (mod modulus),
+ * i = 0..m-1, h = 0..n-1;  coeffs is (t, n) row-major with row stride
+ * coeff_stride elements, shares is (m, n) row-major with row stride
+ * share_stride elements (strides let callers keep rows 16-byte aligned).
+ * For GF(2^n) the x-coordinate of party i is the polynomial with bit pattern i+1.
+ * This is the np-path coefficient convention: coeffs[j] multiplies X^(j+1).
+ * replaces: thresha.py:47-64 np_random_split (C drawn at :60, V @ [s;C] at :61-63).
+ * The list path thresha.py:23-44 random_split is the same map with
+ * coeffs[j][h] = c_h[t-1-j].                              */
+int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride,
+                int t, int m, void* shares, size_t share_stride, size_t n, void* stream);
+
+/* Fused local product + share generation: secrets[h] = a[h]*b[h] is never
+ * written to memory.
+ * replaces: runtime.py:1134-1138 (c = a * b; c = self._reshare(c)) up to the
+ * send at runtime.py:661-667.                                                  */
+int ffgpu_mul_split(ffgpu_ctx* ctx, const void* a, const void* b, const void* coeffs,
+                    size_t coeff_stride, int t, int m, void* shares, size_t share_stride,
+                    size_t n, void* stream);
+
+/* ---- Lagrange recombination ------------------------------------------- */
+/* out[r][h] = sum_{j<k} lambda[r][j] * rows[j][h]  (mod modulus), r < w.
+ * host_rows: HOST array of k device pointers (rows arrive from k peers and need
+ * not be contiguous).  host_lambda: HOST array (w, k) of canonical scalars,
+ * 2 x uint64 limbs each (from _recombination_vector, thresha.py:67-85, computed
+ * on the host and cached there).  out is (w, n) with row stride out_stride.
+ * Products are accumulated unreduced and reduced once, as the reference's
+ * object matmul does (finfields.py:1126-1135).
+ * replaces: thresha.py:119-132 np_recombine, thresha.py:88-116 recombine.     */
+int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda,
+                    int k, int w, void* out, size_t out_stride, size_t n, void* stream);
+
+/* ---- GF(2^8) S-box layer (local / public values) ----------------------- */
+/* out[h] = A * bits(in[h]^254) + B packed back to a byte, with the 8x8 GF(2)
+ * matrix given as 8 row bytes (bit c of host_rows8[r] = A[r][c]) and B as a byte.
+ * replaces: demos/np_aes.py:37-43 sbox() evaluated on public values.           */
+int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b,
+                     void* out, size_t n, void* stream);
+
+/* ---- timing helper ------------------------------------------------------ */
+/* Runs `reps` back-to-back launches of ffgpu_mul on `stream` bracketed by HIP
+ * events on that stream and returns the mean milliseconds per launch.
+ * (bench-side convenience; equivalent entry points exist for split/recombine) */
+int ffgpu_time_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
+                   int reps, void* stream, float* ms_per_launch);
+int ffgpu_time_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride,
+                     int t, int m, void* shares, size_t share_stride, size_t n,
+                     int reps, void* stream, float* ms_per_launch);
+int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda,
+                         int k, int w, void* out, size_t out_stride, size_t n,
+                         int reps, void* stream, float* ms_per_launch);
+/* device-to-device copy of `bytes` with the library's own streaming kernel:
+ * the achievable-bandwidth yardstick reported next to the 8 TB/s nominal peak. */
+int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,
+                    int reps, void* stream, float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFGPU_H */

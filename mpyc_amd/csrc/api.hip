@@ -1,0 +1,376 @@
+// api.hip -- the extern "C" boundary of libffgpu.so (declared in include/ffgpu.h).
+// Host-side only: classifies the modulus, builds the field policy, dispatches
+// to the per-policy launcher tables (ops_*.hip).  No arithmetic on array data
+// happens on the host: if the GPU path cannot run, the call returns an error.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+
+#include "../../include/ffgpu.h"
+#include "kernels.hpp"
+#include "policy_build.hpp"
+
+using namespace ffgpu;
+
+// per-policy launcher tables (one translation unit each, see ops_*.hip)
+const FieldOps* ffgpu_ops_pm64_mersenne();   // PM64<false,true>
+const FieldOps* ffgpu_ops_pm64_k64();        // PM64<true,false>
+const FieldOps* ffgpu_ops_pm64_gen();        // PM64<false,false>
+const FieldOps* ffgpu_ops_rc64();
+const FieldOps* ffgpu_ops_rc32();
+const FieldOps* ffgpu_ops_pm128_k128();      // PM128<true>
+const FieldOps* ffgpu_ops_pm128_gen();       // PM128<false>
+const FieldOps* ffgpu_ops_mont128();
+const FieldOps* ffgpu_ops_gf2p8();
+const FieldOps* ffgpu_ops_gf2w64();
+const FieldOps* ffgpu_ops_gf2w128();
+int ffgpu_launch_sbox(const void* gf2p8_policy, int device, const void* in, const uint8_t* rows8,
+                      uint8_t b, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
+
+struct ffgpu_ctx {
+    int kind;
+    int reduction;
+    int device;
+    int elem_bytes;
+    int policy_kind;
+    const FieldOps* ops;
+    alignas(16) unsigned char policy[128];
+    uint64_t modulus[3];
+};
+
+static thread_local char g_hip_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+    return FFGPU_EHIP;
+}
+#define HIPCHK(call)                                     \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+static int launch_status(int rc) {
+    if (rc == 0) return FFGPU_OK;
+    if (rc & 0x10000) return hip_fail((hipError_t)(rc & 0xffff), "kernel launch");
+    if (rc == 2) return FFGPU_ENOTSUP;
+    return FFGPU_EINVAL;
+}
+
+namespace ffgpu {
+LaunchCfg launch_cfg(int device) {
+    static std::mutex mu;
+    static LaunchCfg cache[64];
+    static bool have[64];
+    std::lock_guard<std::mutex> g(mu);
+    int d = (device >= 0 && device < 64) ? device : 0;
+    if (!have[d]) {
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0)
+            cus = 256;
+        int bpc = 8;
+        const char* e = getenv("FFGPU_BLOCKS_PER_CU");
+        if (e && atoi(e) > 0) bpc = atoi(e);
+        cache[d].num_cu = cus;
+        cache[d].blocks_per_cu = bpc;
+        have[d] = true;
+    }
+    return cache[d];
+}
+}  // namespace ffgpu
+
+struct DeviceGuard {
+    int prev;
+    bool switched;
+    explicit DeviceGuard(int dev) : prev(-1), switched(false) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            if (hipSetDevice(dev) == hipSuccess) switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+static const FieldOps* ops_for(int kind) {
+    switch (kind) {
+        case POL_PM64_MERSENNE: return ffgpu_ops_pm64_mersenne();
+        case POL_PM64_K64: return ffgpu_ops_pm64_k64();
+        case POL_PM64_GEN: return ffgpu_ops_pm64_gen();
+        case POL_RC64: return ffgpu_ops_rc64();
+        case POL_RC32: return ffgpu_ops_rc32();
+        case POL_PM128_K128: return ffgpu_ops_pm128_k128();
+        case POL_PM128_GEN: return ffgpu_ops_pm128_gen();
+        case POL_MONT128: return ffgpu_ops_mont128();
+        case POL_GF2P8: return ffgpu_ops_gf2p8();
+        case POL_GF2W64: return ffgpu_ops_gf2w64();
+        case POL_GF2W128: return ffgpu_ops_gf2w128();
+        default: return nullptr;
+    }
+}
+
+extern "C" {
+
+int ffgpu_abi_version(void) { return FFGPU_ABI_VERSION; }
+
+const char* ffgpu_strerror(int status) {
+    switch (status) {
+        case FFGPU_OK: return "ok";
+        case FFGPU_EINVAL: return "invalid argument";
+        case FFGPU_ENOTSUP: return "field or size not supported by this build";
+        case FFGPU_EHIP: return "HIP runtime error";
+        case FFGPU_EMODULUS: return "unusable modulus";
+        case FFGPU_ENOMEM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char* ffgpu_last_hip_error(void) { return g_hip_err; }
+
+int ffgpu_device_count(int* count) {
+    if (!count) return FFGPU_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return FFGPU_OK;
+}
+
+int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, ffgpu_ctx** out) {
+    if (!modulus || !out || nlimbs < 1 || nlimbs > 3 || device < 0) return FFGPU_EINVAL;
+    ffgpu_ctx* c = (ffgpu_ctx*)calloc(1, sizeof(ffgpu_ctx));
+    if (!c) return FFGPU_ENOMEM;
+    c->kind = kind;
+    c->device = device;
+    for (int i = 0; i < nlimbs; ++i) c->modulus[i] = modulus[i];
+    PolicyBlob pb;
+    memset(&pb, 0, sizeof(pb));
+    int rc;
+    if (kind == FFGPU_PRIME) {
+        if (nlimbs > 2 && modulus[2]) rc = FFGPU_ENOTSUP;
+        else rc = build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+    } else if (kind == FFGPU_BINARY) {
+        rc = build_binary_policy(&pb, modulus, nlimbs);
+    } else {
+        rc = FFGPU_EINVAL;
+    }
+    if (rc == FFGPU_OK) {
+        c->ops = ops_for(pb.kind);
+        if (!c->ops) rc = FFGPU_ENOTSUP;
+    }
+    if (rc != FFGPU_OK) {
+        free(c);
+        return rc;
+    }
+    memcpy(c->policy, pb.bytes, sizeof(c->policy));
+    c->reduction = pb.reduction;
+    c->elem_bytes = pb.elem_bytes;
+    c->policy_kind = pb.kind;
+    *out = c;
+    return FFGPU_OK;
+}
+
+int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
+    free(ctx);
+    return FFGPU_OK;
+}
+int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx) { return ctx ? ctx->elem_bytes : -1; }
+int ffgpu_ctx_reduction(const ffgpu_ctx* ctx) { return ctx ? ctx->reduction : -1; }
+int ffgpu_ctx_device(const ffgpu_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+int ffgpu_malloc(ffgpu_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) return FFGPU_ENOMEM;
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    return FFGPU_OK;
+}
+int ffgpu_free(ffgpu_ctx* ctx, void* dptr) {
+    if (!ctx) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipFree(dptr));
+    return FFGPU_OK;
+}
+int ffgpu_h2d(ffgpu_ctx* ctx, void* dst, const void* host_src, size_t bytes, void* stream) {
+    if (!ctx || (bytes && (!dst || !host_src))) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return FFGPU_OK;
+}
+int ffgpu_d2h(ffgpu_ctx* ctx, void* host_dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || (bytes && (!host_dst || !src))) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return FFGPU_OK;
+}
+int ffgpu_stream_sync(ffgpu_ctx* ctx, void* stream) {
+    if (!ctx) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return FFGPU_OK;
+}
+
+#define ARGCHK(cond) \
+    do {             \
+        if (!(cond)) return FFGPU_EINVAL; \
+    } while (0)
+
+static int do_ew2(ffgpu_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && b && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->ew2(ctx->policy, ctx->device, op, a, b, out, n, (hipStream_t)stream));
+}
+static int do_ew1(ffgpu_ctx* ctx, int op, const void* a, const uint64_t* s, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->ew1(ctx->policy, ctx->device, op, a, s, out, n, (hipStream_t)stream));
+}
+
+int ffgpu_reduce(ffgpu_ctx* ctx, const void* raw, void* out, size_t n, void* stream) {
+    return do_ew1(ctx, OP_REDUCE, raw, nullptr, out, n, stream);
+}
+int ffgpu_add(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return do_ew2(ctx, OP_ADD, a, b, out, n, stream);
+}
+int ffgpu_sub(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return do_ew2(ctx, OP_SUB, a, b, out, n, stream);
+}
+int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return do_ew2(ctx, OP_MUL, a, b, out, n, stream);
+}
+int ffgpu_neg(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return do_ew1(ctx, OP_NEG, a, nullptr, out, n, stream);
+}
+int ffgpu_add_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* s, void* out, size_t n, void* stream) {
+    ARGCHK(s);
+    return do_ew1(ctx, OP_ADD, a, s, out, n, stream);
+}
+int ffgpu_mul_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* s, void* out, size_t n, void* stream) {
+    ARGCHK(s);
+    return do_ew1(ctx, OP_MUL, a, s, out, n, stream);
+}
+int ffgpu_rsub_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* s, void* out, size_t n, void* stream) {
+    ARGCHK(s);
+    return do_ew1(ctx, OP_RSUB, a, s, out, n, stream);
+}
+int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, void* out, size_t n,
+                 void* stream) {
+    ARGCHK(ctx);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && b && c && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->muladd(ctx->policy, ctx->device, a, b, c, out, n, (hipStream_t)stream));
+}
+
+static int do_split(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, const void* coeffs,
+                    size_t coeff_stride, int t, int m, void* shares, size_t share_stride, size_t n,
+                    void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(m >= 1 && t >= 0 && t < m);  // thresha.py:26 "0 <= t < m"
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && shares && (!fused || b) && (t == 0 || coeffs));
+    ARGCHK((m == 1 || share_stride >= n) && (t <= 1 || coeff_stride >= n));
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, coeffs,
+                                         coeff_stride, t, m, shares, share_stride, n, (hipStream_t)stream));
+}
+int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,
+                void* shares, size_t share_stride, size_t n, void* stream) {
+    return do_split(ctx, secrets, nullptr, false, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);
+}
+int ffgpu_mul_split(ffgpu_ctx* ctx, const void* a, const void* b, const void* coeffs, size_t coeff_stride,
+                    int t, int m, void* shares, size_t share_stride, size_t n, void* stream) {
+    return do_split(ctx, a, b, true, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);
+}
+
+int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda, int k, int w,
+                    void* out, size_t out_stride, size_t n, void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(k >= 1 && w >= 1);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(host_rows && host_lambda && out && (w == 1 || out_stride >= n));
+    for (int j = 0; j < k; ++j) ARGCHK(host_rows[j]);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->recombine(ctx->policy, ctx->device, host_rows, host_lambda, k, w, out,
+                                             out_stride, n, (hipStream_t)stream));
+}
+
+int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b, void* out,
+                     size_t n, void* stream) {
+    ARGCHK(ctx && host_rows8);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;
+    GF2P8 f;
+    memcpy(&f, ctx->policy, sizeof(f));
+    if (f.n != 8) return FFGPU_ENOTSUP;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(in && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ffgpu_launch_sbox(ctx->policy, ctx->device, in, host_rows8, b, out, n,
+                                           (hipStream_t)stream));
+}
+
+}  // extern "C"
+
+// ---- timing helpers: HIP events on the launch stream ------------------------
+template <class Fn>
+static int time_loop(ffgpu_ctx* ctx, int reps, void* stream, float* ms, Fn fn) {
+    ARGCHK(ctx && ms && reps >= 1);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int rc = FFGPU_OK;
+    hipError_t he = hipEventRecord(e0, st);
+    for (int i = 0; i < reps && rc == FFGPU_OK && he == hipSuccess; ++i) rc = fn();
+    if (he == hipSuccess) he = hipEventRecord(e1, st);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != FFGPU_OK) return rc;
+    if (he != hipSuccess) return hip_fail(he, "event timing");
+    *ms = t / (float)reps;
+    return FFGPU_OK;
+}
+
+extern "C" {
+
+int ffgpu_time_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, int reps, void* stream,
+                   float* ms) {
+    return time_loop(ctx, reps, stream, ms, [&]() { return ffgpu_mul(ctx, a, b, out, n, stream); });
+}
+int ffgpu_time_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t,
+                     int m, void* shares, size_t share_stride, size_t n, int reps, void* stream, float* ms) {
+    return time_loop(ctx, reps, stream, ms, [&]() {
+        return ffgpu_split(ctx, secrets, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);
+    });
+}
+int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda, int k,
+                         int w, void* out, size_t out_stride, size_t n, int reps, void* stream, float* ms) {
+    return time_loop(ctx, reps, stream, ms, [&]() {
+        return ffgpu_recombine(ctx, host_rows, host_lambda, k, w, out, out_stride, n, stream);
+    });
+}
+int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, int reps, void* stream,
+                    float* ms) {
+    ARGCHK(ctx && src && dst);
+    return time_loop(ctx, reps, stream, ms, [&]() {
+        return launch_status(ffgpu_launch_copy(ctx->device, src, dst, bytes, (hipStream_t)stream));
+    });
+}
+
+}  // extern "C"

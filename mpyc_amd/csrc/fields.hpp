@@ -1,0 +1,813 @@
+// fields.hpp -- field-arithmetic policies used by every kernel in libffgpu.
+//
+// Each policy is a small POD passed BY VALUE as a kernel argument, so its
+// constants (modulus, fold constant, reciprocal, shift) are wave-uniform and
+// live in SGPRs; there is no table to stage in LDS for these fields.
+//
+// A policy F provides
+//     F::elem            addressable storage unit in HBM (uint8/32/64, u128e)
+//     F::word            unit the arithmetic works on (== elem, except the
+//                        packed GF(2^n<=8) policy where a word is 4 elements)
+//     F::EPW             elements per word
+//     add/sub/neg/mul    canonical in, canonical out
+//     reduce_raw         arbitrary bit pattern -> canonical
+//     muladd_small(y,x,c)  y*x + c for a 32-bit public x (Horner step of
+//                        share generation, thresha.py:41-43 / :61-63)
+//     acc / acc_zero / acc_mac / acc_reduce
+//                        unreduced dot-product accumulation with ONE final
+//                        reduction (finfields.py:1126-1135 object matmul)
+//
+// The functions are __host__ __device__ so that tests/hostcheck.cpp can compile
+// this very file with g++ and compare it against Python integers without a GPU.
+// That harness is test-only; the shipped library has no CPU code path.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FF_HD __host__ __device__ __forceinline__
+#else
+#define FF_HD inline
+#endif
+
+typedef unsigned __int128 ff_u128;
+
+struct alignas(16) u128e {
+    uint64_t lo, hi;
+};
+
+FF_HD ff_u128 ff_make128(uint64_t hi, uint64_t lo) { return ((ff_u128)hi << 64) | lo; }
+FF_HD uint64_t ff_lo(ff_u128 x) { return (uint64_t)x; }
+FF_HD uint64_t ff_hi(ff_u128 x) { return (uint64_t)(x >> 64); }
+
+// ---------------------------------------------------------------------------
+// PM64: prime p = 2^k - c, 33 <= k <= 64, c < 2^min(31,(k-1)/2).
+// All default MPyC primes are of this shape (find_prime_root = largest Blum
+// prime below 2^l, finfields.py:311-344): 2^61-1, 2^64-189, ...
+// Reduction = fold the high part down with 2^k == c (mod p); no division.
+// ---------------------------------------------------------------------------
+template <bool K64, bool C1>
+struct PM64 {
+    typedef uint64_t elem;
+    typedef uint64_t word;
+    enum { EPW = 1 };
+    uint64_t p;     // modulus
+    uint64_t mask;  // 2^k - 1
+    uint32_t c;     // 2^k - p
+    uint32_t k;
+
+    struct acc {
+        uint64_t a0, a1, a2;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD uint64_t prep(uint64_t cst) const { return cst; }
+
+
+    FF_HD uint64_t csub(uint64_t x) const { return x >= p ? x - p : x; }
+
+    FF_HD uint64_t add(uint64_t a, uint64_t b) const {
+        uint64_t s = a + b;
+        if (K64) {
+            bool carry = s < a;
+            return (carry || s >= p) ? s - p : s;
+        }
+        return csub(s);
+    }
+    FF_HD uint64_t sub(uint64_t a, uint64_t b) const {
+        uint64_t d = a - b;
+        return a < b ? d + p : d;
+    }
+    FF_HD uint64_t neg(uint64_t a) const { return a ? p - a : 0; }
+
+    // x < 2^(2k) when k < 64; any 128-bit x when k == 64.
+    FF_HD uint64_t red128(ff_u128 x) const {
+        if (K64) {
+            ff_u128 t = (ff_u128)ff_hi(x) * c + ff_lo(x);  // < 2^96
+            uint64_t tl = ff_lo(t);
+            uint64_t u = tl + ff_hi(t) * (uint64_t)c;  // hi(t) <= 2^31
+            if (u < tl) u += c;                        // wrapped: 2^64 == c
+            return csub(u);
+        }
+        uint64_t xh = (uint64_t)(x >> k);
+        uint64_t xl = ff_lo(x) & mask;
+        if (C1) {
+            uint64_t w = xl + xh;  // < 2^(k+1)
+            uint64_t u = (w & mask) + (w >> k);
+            return csub(u);
+        }
+        ff_u128 w = (ff_u128)xh * c + xl;
+        uint64_t wh = (uint64_t)(w >> k);
+        uint64_t u = (ff_lo(w) & mask) + wh * (uint64_t)c;  // < 2p
+        return csub(u);
+    }
+
+    FF_HD uint64_t mul(uint64_t a, uint64_t b) const { return red128((ff_u128)a * b); }
+    FF_HD uint64_t reduce_raw(uint64_t x) const {
+        if (K64) return csub(x);
+        return red128((ff_u128)x);
+    }
+    FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
+        return red128((ff_u128)y * x + cadd);
+    }
+    FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
+        // a*b + c < p^2 + p < 2^(2k) for k<64; may wrap 128 bits only if k==64
+        if (K64) return add(mul(a, b), cadd);
+        return red128((ff_u128)a * b + cadd);
+    }
+
+    FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = s.a2 = 0; }
+    FF_HD void acc_mac(acc& s, uint64_t lam, uint64_t x) const {
+        ff_u128 pr = (ff_u128)lam * x;
+        ff_u128 lo = (ff_u128)s.a0 + ff_lo(pr);
+        s.a0 = ff_lo(lo);
+        ff_u128 mid = (ff_u128)s.a1 + ff_hi(pr) + ff_hi(lo);
+        s.a1 = ff_lo(mid);
+        s.a2 += ff_hi(mid);
+    }
+    // value < 2^(2k+8)  (at most 256 products)
+    FF_HD uint64_t acc_reduce(const acc& s) const {
+        if (K64) {
+            ff_u128 hi2 = ff_make128(s.a2, s.a1);    // < 2^72
+            ff_u128 t = hi2 * (ff_u128)c + s.a0;     // < 2^104
+            return red128(t);
+        }
+        ff_u128 mid = ff_make128(s.a1, s.a0) >> k;
+        ff_u128 top = (ff_u128)s.a2 << (128 - k);
+        ff_u128 xh = top | mid;  // < 2^(k+8)
+        uint64_t xl = s.a0 & mask;
+        ff_u128 t = C1 ? xh + xl : xh * (ff_u128)c + xl;  // < 2^(2k)
+        return red128(t);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// RC64: arbitrary modulus 2 <= p < 2^64.  Barrett-type reduction with a
+// precomputed 64-bit reciprocal of the normalised modulus (Moeller-Granlund
+// "division by invariant integers", 2-by-1 step).  Canonical in/out, so no
+// Montgomery domain conversion at the API boundary.
+// ---------------------------------------------------------------------------
+struct RC64 {
+    typedef uint64_t elem;
+    typedef uint64_t word;
+    enum { EPW = 1 };
+    uint64_t p;  // modulus
+    uint64_t d;  // p << s, top bit set
+    uint64_t v;  // floor((2^128-1)/d) - 2^64
+    uint32_t s;  // normalisation shift = clz(p)
+    uint32_t pad_;
+
+    struct acc {
+        uint64_t a0, a1, a2;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD uint64_t prep(uint64_t cst) const { return cst; }
+
+
+    // (u1:u0) mod d, requires u1 < d
+    FF_HD uint64_t rem21(uint64_t u1, uint64_t u0) const {
+        ff_u128 q = (ff_u128)v * u1 + ff_make128(u1, u0);
+        uint64_t q1 = ff_hi(q) + 1;
+        uint64_t q0 = ff_lo(q);
+        uint64_t r = u0 - q1 * d;
+        if (r > q0) r += d;
+        if (r >= d) r -= d;
+        return r;
+    }
+    FF_HD uint64_t add(uint64_t a, uint64_t b) const {
+        uint64_t t = a + b;
+        bool carry = t < a;
+        return (carry || t >= p) ? t - p : t;
+    }
+    FF_HD uint64_t sub(uint64_t a, uint64_t b) const {
+        uint64_t t = a - b;
+        return a < b ? t + p : t;
+    }
+    FF_HD uint64_t neg(uint64_t a) const { return a ? p - a : 0; }
+    FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
+        ff_u128 x = (ff_u128)(a << s) * b;  // (a*b) << s, high limb < d
+        return rem21(ff_hi(x), ff_lo(x)) >> s;
+    }
+    FF_HD uint64_t reduce_raw(uint64_t x) const {
+        uint64_t u1 = s ? (x >> (64 - s)) : 0;
+        return rem21(u1, x << s) >> s;
+    }
+    FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
+        ff_u128 t = ((ff_u128)y * x + cadd) << s;  // < d * (2^32+1)
+        return rem21(ff_hi(t), ff_lo(t)) >> s;
+    }
+    FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
+        return add(mul(a, b), cadd);
+    }
+    FF_HD void acc_zero(acc& t) const { t.a0 = t.a1 = t.a2 = 0; }
+    FF_HD void acc_mac(acc& t, uint64_t lam, uint64_t x) const {
+        ff_u128 pr = (ff_u128)lam * x;
+        ff_u128 lo = (ff_u128)t.a0 + ff_lo(pr);
+        t.a0 = ff_lo(lo);
+        ff_u128 mid = (ff_u128)t.a1 + ff_hi(pr) + ff_hi(lo);
+        t.a1 = ff_lo(mid);
+        t.a2 += ff_hi(mid);
+    }
+    FF_HD uint64_t acc_reduce(const acc& t) const {
+        // W = V << s as three limbs; V < 2^8 p^2  =>  w2 < 2^8 <= d
+        uint64_t w0 = t.a0 << s;
+        uint64_t w1 = s ? ((t.a1 << s) | (t.a0 >> (64 - s))) : t.a1;
+        uint64_t w2 = s ? ((t.a2 << s) | (t.a1 >> (64 - s))) : t.a2;
+        uint64_t r1 = rem21(w2, w1);
+        return rem21(r1, w0) >> s;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// RC32: arbitrary modulus 2 <= p < 2^32 stored as uint32 (half the HBM bytes of
+// the 64-bit path).  Same reciprocal reduction on 32-bit words.
+// ---------------------------------------------------------------------------
+struct RC32 {
+    typedef uint32_t elem;
+    typedef uint32_t word;
+    enum { EPW = 1 };
+    uint32_t p, d, v, s;
+
+    struct acc {
+        uint64_t lo;  // sum of 64-bit products, low part
+        uint32_t hi;  // carries
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD uint32_t prep(uint32_t cst) const { return cst; }
+
+
+    FF_HD uint32_t rem21(uint32_t u1, uint32_t u0) const {
+        uint64_t q = (uint64_t)v * u1 + (((uint64_t)u1 << 32) | u0);
+        uint32_t q1 = (uint32_t)(q >> 32) + 1;
+        uint32_t q0 = (uint32_t)q;
+        uint32_t r = u0 - q1 * d;
+        if (r > q0) r += d;
+        if (r >= d) r -= d;
+        return r;
+    }
+    FF_HD uint32_t add(uint32_t a, uint32_t b) const {
+        uint32_t t = a + b;
+        bool carry = t < a;
+        return (carry || t >= p) ? t - p : t;
+    }
+    FF_HD uint32_t sub(uint32_t a, uint32_t b) const {
+        uint32_t t = a - b;
+        return a < b ? t + p : t;
+    }
+    FF_HD uint32_t neg(uint32_t a) const { return a ? p - a : 0; }
+    FF_HD uint32_t mul(uint32_t a, uint32_t b) const {
+        uint64_t x = (uint64_t)(a << s) * b;
+        return rem21((uint32_t)(x >> 32), (uint32_t)x) >> s;
+    }
+    FF_HD uint32_t reduce_raw(uint32_t x) const {
+        uint32_t u1 = s ? (x >> (32 - s)) : 0;
+        return rem21(u1, x << s) >> s;
+    }
+    // y*x + c with x < 2^32: up to 64 bits + ; two reduction steps
+    FF_HD uint32_t muladd_small(uint32_t y, uint32_t x, uint32_t cadd) const {
+        // reduce x first (x is a public party index, usually < p already)
+        uint32_t xr = x >= p ? reduce_raw(x) : x;
+        return add(mul(y, xr), cadd);
+    }
+    FF_HD uint32_t muladd(uint32_t a, uint32_t b, uint32_t cadd) const { return add(mul(a, b), cadd); }
+    FF_HD void acc_zero(acc& t) const {
+        t.lo = 0;
+        t.hi = 0;
+    }
+    FF_HD void acc_mac(acc& t, uint32_t lam, uint32_t x) const {
+        uint64_t pr = (uint64_t)lam * x;
+        uint64_t n = t.lo + pr;
+        t.hi += n < pr;
+        t.lo = n;
+    }
+    FF_HD uint32_t acc_reduce(const acc& t) const {
+        // V = hi:lo (96 bits, hi < 2^8);  W = V << s
+        uint32_t a0 = (uint32_t)t.lo, a1 = (uint32_t)(t.lo >> 32), a2 = t.hi;
+        uint32_t w0 = a0 << s;
+        uint32_t w1 = s ? ((a1 << s) | (a0 >> (32 - s))) : a1;
+        uint32_t w2 = s ? ((a2 << s) | (a1 >> (32 - s))) : a2;
+        uint32_t r1 = rem21(w2, w1);
+        return rem21(r1, w0) >> s;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// PM128: prime p = 2^k - c, 65 <= k <= 128, c < 2^31, two 64-bit limbs
+// (2^128-173, 2^127-1, 2^96-17, the 80-bit SecFxp default, ...).
+// ---------------------------------------------------------------------------
+template <bool K128>
+struct PM128 {
+    typedef u128e elem;
+    typedef u128e word;
+    enum { EPW = 1 };
+    uint64_t p_lo, p_hi;        // modulus
+    uint64_t mask_lo, mask_hi;  // 2^k - 1
+    uint32_t c;                 // 2^k - p
+    uint32_t k;
+
+    struct acc {
+        uint64_t a0, a1, a2, a3, a4;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD u128e prep(u128e cst) const { return cst; }
+
+
+    FF_HD ff_u128 P() const { return ff_make128(p_hi, p_lo); }
+    FF_HD ff_u128 M() const { return ff_make128(mask_hi, mask_lo); }
+    static FF_HD ff_u128 U(const u128e& a) { return ff_make128(a.hi, a.lo); }
+    static FF_HD u128e E(ff_u128 x) {
+        u128e r;
+        r.lo = ff_lo(x);
+        r.hi = ff_hi(x);
+        return r;
+    }
+    FF_HD ff_u128 csub(ff_u128 x) const { return x >= P() ? x - P() : x; }
+
+    FF_HD ff_u128 addu(ff_u128 a, ff_u128 b) const {
+        ff_u128 t = a + b;
+        if (K128) {
+            bool carry = t < a;
+            return (carry || t >= P()) ? t - P() : t;
+        }
+        return csub(t);
+    }
+    FF_HD u128e add(const u128e& a, const u128e& b) const { return E(addu(U(a), U(b))); }
+    FF_HD u128e sub(const u128e& a, const u128e& b) const {
+        ff_u128 x = U(a), y = U(b);
+        ff_u128 t = x - y;
+        return E(x < y ? t + P() : t);
+    }
+    FF_HD u128e neg(const u128e& a) const {
+        ff_u128 x = U(a);
+        return E(x ? P() - x : 0);
+    }
+
+    // Final stage: value T = t2*2^128 + (t1:t0) < 2^(k+64)  ->  canonical.
+    template <bool TWO_FOLDS>
+    FF_HD ff_u128 fold3(uint64_t t2, ff_u128 t10) const {
+        ff_u128 u;
+        if (K128) {
+            ff_u128 add_ = (ff_u128)t2 * c;
+            u = t10 + add_;
+            if (u < add_) u += c;  // wrapped 2^128 == c
+            return csub(u);
+        }
+        // wh = T >> k  (fits 64 bits), wl = T & mask
+        uint32_t sh = k - 64;  // 1..63
+        uint64_t wh = (ff_hi(t10) >> sh) | (t2 << (64 - sh));
+        ff_u128 wl = t10 & M();
+        u = wl + (ff_u128)wh * c;
+        if (TWO_FOLDS) {
+            uint64_t wh2 = ff_hi(u) >> sh;
+            u = (u & M()) + (ff_u128)wh2 * c;
+        }
+        return csub(u);
+    }
+
+    // 256-bit product as four limbs
+    static FF_HD void mul256(ff_u128 a, ff_u128 b, uint64_t x[4]) {
+        uint64_t a0 = ff_lo(a), a1 = ff_hi(a), b0 = ff_lo(b), b1 = ff_hi(b);
+        ff_u128 p00 = (ff_u128)a0 * b0;
+        ff_u128 p01 = (ff_u128)a0 * b1;
+        ff_u128 p10 = (ff_u128)a1 * b0;
+        ff_u128 p11 = (ff_u128)a1 * b1;
+        x[0] = ff_lo(p00);
+        ff_u128 m = (ff_u128)ff_hi(p00) + ff_lo(p01) + ff_lo(p10);
+        x[1] = ff_lo(m);
+        ff_u128 h = (ff_u128)ff_hi(m) + ff_hi(p01) + ff_hi(p10) + ff_lo(p11);
+        x[2] = ff_lo(h);
+        x[3] = ff_hi(p11) + ff_hi(h);
+    }
+
+    // value (x3:x2:x1:x0) < 2^(2k)
+    FF_HD ff_u128 red256(const uint64_t x[4]) const {
+        ff_u128 xh, xl;
+        if (K128) {
+            xh = ff_make128(x[3], x[2]);
+            xl = ff_make128(x[1], x[0]);
+        } else {
+            uint32_t sh = k - 64;  // 1..63
+            uint64_t h0 = (x[1] >> sh) | (x[2] << (64 - sh));
+            uint64_t h1 = (x[2] >> sh) | (x[3] << (64 - sh));
+            xh = ff_make128(h1, h0);
+            xl = ff_make128(x[1], x[0]) & M();
+        }
+        // T = xh*c + xl  as (t2 : t10)
+        ff_u128 pl = (ff_u128)ff_lo(xh) * c;
+        ff_u128 ph = (ff_u128)ff_hi(xh) * c;
+        ff_u128 s0 = xl + pl;
+        uint64_t t2 = (s0 < pl) ? 1 : 0;
+        ff_u128 phs = ph << 64;
+        ff_u128 s1 = s0 + phs;
+        t2 += (s1 < phs) ? 1 : 0;
+        t2 += ff_hi(ph);
+        return fold3<false>(t2, s1);
+    }
+
+    FF_HD u128e mul(const u128e& a, const u128e& b) const {
+        uint64_t x[4];
+        mul256(U(a), U(b), x);
+        return E(red256(x));
+    }
+    FF_HD u128e reduce_raw(const u128e& a) const {
+        if (K128) return E(csub(U(a)));
+        return E(fold3<false>(0, U(a)));
+    }
+    FF_HD u128e muladd_small(const u128e& y, uint32_t x, const u128e& cadd) const {
+        // V = y*x + c : three limbs
+        ff_u128 l = (ff_u128)y.lo * x;
+        ff_u128 h = (ff_u128)y.hi * x + ff_hi(l);
+        ff_u128 v10 = ff_make128(ff_lo(h), ff_lo(l));
+        uint64_t v2 = ff_hi(h);
+        ff_u128 cc = U(cadd);
+        ff_u128 t = v10 + cc;
+        if (t < cc) v2 += 1;
+        return E(fold3<false>(v2, t));
+    }
+    FF_HD u128e muladd(const u128e& a, const u128e& b, const u128e& cadd) const {
+        return add(mul(a, b), cadd);
+    }
+
+    FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = 0; }
+    FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& xe) const {
+        uint64_t x[4];
+        mul256(U(lam), U(xe), x);
+        ff_u128 t = (ff_u128)s.a0 + x[0];
+        s.a0 = ff_lo(t);
+        t = (ff_u128)s.a1 + x[1] + ff_hi(t);
+        s.a1 = ff_lo(t);
+        t = (ff_u128)s.a2 + x[2] + ff_hi(t);
+        s.a2 = ff_lo(t);
+        t = (ff_u128)s.a3 + x[3] + ff_hi(t);
+        s.a3 = ff_lo(t);
+        s.a4 += ff_hi(t);
+    }
+    // V < 2^(2k+8)
+    FF_HD u128e acc_reduce(const acc& s) const {
+        // xh = V >> k (three limbs h2:h1:h0, < 2^(k+8)), xl = V & mask
+        uint64_t h0, h1, h2;
+        ff_u128 xl;
+        if (K128) {
+            h0 = s.a2;
+            h1 = s.a3;
+            h2 = s.a4;
+            xl = ff_make128(s.a1, s.a0);
+        } else {
+            uint32_t sh = k - 64;
+            h0 = (s.a1 >> sh) | (s.a2 << (64 - sh));
+            h1 = (s.a2 >> sh) | (s.a3 << (64 - sh));
+            h2 = (s.a3 >> sh) | (s.a4 << (64 - sh));
+            xl = ff_make128(s.a1, s.a0) & M();
+        }
+        // T = xh*c + xl  (< 2^(k+40)): limbs t2 : t10
+        ff_u128 q0 = (ff_u128)h0 * c;
+        ff_u128 q1 = (ff_u128)h1 * c + ff_hi(q0);
+        ff_u128 q2 = (ff_u128)h2 * c + ff_hi(q1);
+        ff_u128 prod10 = ff_make128(ff_lo(q1), ff_lo(q0));
+        uint64_t t2 = ff_lo(q2);
+        ff_u128 t10 = prod10 + xl;
+        if (t10 < xl) t2 += 1;
+        if (K128) {
+            // t2 < 2^40: (t1:t0) + t2*c, one wrap possible
+            return E(fold3<false>(t2, t10));
+        }
+        return E(fold3<true>(t2, t10));
+    }
+};
+
+// ---------------------------------------------------------------------------
+// MONT128: arbitrary odd modulus 2^64 < p < 2^128 (two limbs).  Canonical
+// in/out: mul(a,b) = REDC(REDC(a*b) * R^2) with R = 2^128, i.e. two word-serial
+// Montgomery reductions; chains (Horner, dot products) stay cheap because the
+// public operand is pre-scaled on the host where possible.
+// ---------------------------------------------------------------------------
+struct MONT128 {
+    typedef u128e elem;
+    typedef u128e word;
+    enum { EPW = 1 };
+    uint64_t p_lo, p_hi;
+    uint64_t r2_lo, r2_hi;  // R^2 mod p
+    uint64_t pinv;          // -p^{-1} mod 2^64
+    uint64_t pad_;
+
+    struct acc {
+        uint64_t a0, a1;  // running canonical sum (reduced every step)
+    };
+    // Lagrange / scalar constants are pre-scaled by R so that one REDC per
+    // product suffices in acc_mac (defined below, after montmul)
+
+
+    FF_HD ff_u128 P() const { return ff_make128(p_hi, p_lo); }
+    static FF_HD ff_u128 U(const u128e& a) { return ff_make128(a.hi, a.lo); }
+    static FF_HD u128e E(ff_u128 x) {
+        u128e r;
+        r.lo = ff_lo(x);
+        r.hi = ff_hi(x);
+        return r;
+    }
+    FF_HD ff_u128 addu(ff_u128 a, ff_u128 b) const {
+        ff_u128 t = a + b;
+        bool carry = t < a;
+        return (carry || t >= P()) ? t - P() : t;
+    }
+    FF_HD ff_u128 subu(ff_u128 a, ff_u128 b) const {
+        ff_u128 t = a - b;
+        return a < b ? t + P() : t;
+    }
+    FF_HD u128e add(const u128e& a, const u128e& b) const { return E(addu(U(a), U(b))); }
+    FF_HD u128e sub(const u128e& a, const u128e& b) const { return E(subu(U(a), U(b))); }
+    FF_HD u128e neg(const u128e& a) const {
+        ff_u128 x = U(a);
+        return E(x ? P() - x : 0);
+    }
+    // REDC of T = (x3:x2:x1:x0) < p * 2^128  ->  T * 2^-128 mod p, canonical
+    FF_HD ff_u128 redc(const uint64_t x[4]) const {
+        uint64_t t0 = x[0], t1 = x[1], t2 = x[2], t3 = x[3], t4 = 0;
+        for (int i = 0; i < 2; ++i) {
+            uint64_t m = t0 * pinv;
+            ff_u128 c0 = (ff_u128)m * p_lo + t0;  // low limb becomes 0
+            ff_u128 c1 = (ff_u128)m * p_hi + t1 + ff_hi(c0);
+            ff_u128 c2 = (ff_u128)t2 + ff_hi(c1);
+            ff_u128 c3 = (ff_u128)t3 + ff_hi(c2);
+            t0 = ff_lo(c1);
+            t1 = ff_lo(c2);
+            t2 = ff_lo(c3);
+            t3 = t4 + ff_hi(c3);
+            t4 = 0;
+        }
+        // result = (t2:t1:t0) < 2p, t2 in {0,1}
+        ff_u128 r = ff_make128(t1, t0);
+        if (t2 || r >= P()) r -= P();
+        return r;
+    }
+    FF_HD ff_u128 montmul(ff_u128 a, ff_u128 b) const {
+        uint64_t x[4];
+        PM128<true>::mul256(a, b, x);
+        return redc(x);
+    }
+    FF_HD u128e prep(const u128e& cst) const { return E(montmul(U(cst), ff_make128(r2_hi, r2_lo))); }
+    FF_HD u128e mul(const u128e& a, const u128e& b) const {
+        ff_u128 t = montmul(U(a), U(b));                   // a*b/R
+        return E(montmul(t, ff_make128(r2_hi, r2_lo)));     // * R^2 / R = a*b
+    }
+    FF_HD u128e reduce_raw(const u128e& a) const {
+        // p > 2^64 so at most 2^64 subtractions would be needed in the worst
+        // case; use Montgomery instead: a * R^2 / R / ... -> a*1: REDC(a*R2) = a*R,
+        // REDC(a*R) = a.  Both products are < p*2^128 only if a < 2^128: true.
+        // a*R2 < 2^128 * p ok.
+        ff_u128 t = montmul(U(a), ff_make128(r2_hi, r2_lo));  // a*R mod p
+        uint64_t x[4] = {ff_lo(t), ff_hi(t), 0, 0};
+        return E(redc(x));
+    }
+    FF_HD u128e muladd_small(const u128e& y, uint32_t x, const u128e& cadd) const {
+        u128e xe;
+        xe.lo = x;
+        xe.hi = 0;
+        return add(mul(y, xe), cadd);
+    }
+    FF_HD u128e muladd(const u128e& a, const u128e& b, const u128e& cadd) const {
+        return add(mul(a, b), cadd);
+    }
+    FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = 0; }
+    // host pre-scales lambda by R (lam' = lam*R mod p) so one REDC per term suffices
+    FF_HD void acc_mac(acc& s, const u128e& lamR, const u128e& xe) const {
+        ff_u128 t = montmul(U(lamR), U(xe));
+        ff_u128 r = addu(ff_make128(s.a1, s.a0), t);
+        s.a0 = ff_lo(r);
+        s.a1 = ff_hi(r);
+    }
+    FF_HD u128e acc_reduce(const acc& s) const {
+        u128e r;
+        r.lo = s.a0;
+        r.hi = s.a1;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// GF2P8: GF(2^n), 1 <= n <= 8, one element per byte, arithmetic on four
+// elements packed in a 32-bit word (SWAR shift-and-xor; gfpx.py:988-1003 _mul
+// followed by :1025-1045 _mod, fused so intermediate degree never exceeds n).
+// ---------------------------------------------------------------------------
+struct GF2P8 {
+    typedef uint8_t elem;
+    typedef uint32_t word;
+    enum { EPW = 4 };
+    uint32_t n;     // extension degree
+    uint32_t red;   // modulus without leading term, broadcast to 4 bytes
+    uint32_t top;   // bit n-1 of every byte
+    uint32_t emask; // low n bits of every byte
+
+    struct acc {
+        uint32_t a;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD uint32_t prep(uint32_t cst) const { return cst; }
+
+
+    FF_HD uint32_t add(uint32_t a, uint32_t b) const { return a ^ b; }
+    FF_HD uint32_t sub(uint32_t a, uint32_t b) const { return a ^ b; }
+    FF_HD uint32_t neg(uint32_t a) const { return a; }
+    FF_HD uint32_t reduce_raw(uint32_t a) const {
+        // bytes may hold degree up to 7; reduce bits n..7 (only needed for n<8)
+        if (n == 8) return a;
+        uint32_t r = 0;
+        // Horner over the 8 bits of every byte, MSB first
+        for (int i = 7; i >= 0; --i) {
+            r = xtime(r) ^ ((a >> i) & 0x01010101u);
+        }
+        return r;
+    }
+    FF_HD uint32_t xtime(uint32_t a) const {
+        uint32_t hi = a & top;
+        uint32_t m = hi >> (n - 1);          // 0/1 per byte
+        uint32_t full = (hi - m) | hi;       // low n bits set where hi
+        return ((a ^ hi) << 1) ^ (full & red);
+    }
+    FF_HD uint32_t mul(uint32_t a, uint32_t b) const {
+        uint32_t c = 0;
+        for (int i = (int)n - 1; i >= 0; --i) {
+            uint32_t bm = (b >> i) & 0x01010101u;
+            uint32_t t = bm << 7;
+            uint32_t full = (t - bm) | t;    // 0xff where bit set
+            c = xtime(c) ^ (a & full);
+        }
+        return c;
+    }
+    // y * X(x) + c where X(x) is the polynomial with bit pattern x (< 2^n)
+    FF_HD uint32_t muladd_small(uint32_t y, uint32_t x, uint32_t cadd) const {
+        uint32_t c = 0;
+        for (int i = (int)n - 1; i >= 0; --i) {
+            c = xtime(c);
+            if ((x >> i) & 1) c ^= y;        // x is wave-uniform: scalar branch
+        }
+        return c ^ cadd;
+    }
+    FF_HD uint32_t muladd(uint32_t a, uint32_t b, uint32_t cadd) const { return mul(a, b) ^ cadd; }
+    FF_HD void acc_zero(acc& s) const { s.a = 0; }
+    // lam: single element broadcast to the 4 bytes by the host
+    FF_HD void acc_mac(acc& s, uint32_t lam, uint32_t x) const {
+        // lam is wave-uniform: multiply x by the constant via scalar-branch Horner
+        uint32_t c = 0;
+        uint32_t l = lam & 0xffu;
+        for (int i = (int)n - 1; i >= 0; --i) {
+            c = xtime(c);
+            if ((l >> i) & 1) c ^= x;
+        }
+        s.a ^= c;
+    }
+    FF_HD uint32_t acc_reduce(const acc& s) const { return s.a; }
+};
+
+// ---------------------------------------------------------------------------
+// GF2W64 / GF2W128: GF(2^n) for 9 <= n <= 64 / 65 <= n <= 128, limb shift-xor.
+// ---------------------------------------------------------------------------
+struct GF2W64 {
+    typedef uint64_t elem;
+    typedef uint64_t word;
+    enum { EPW = 1 };
+    uint64_t red;   // modulus without leading term
+    uint64_t emask; // 2^n - 1
+    uint32_t n;
+    uint32_t pad_;
+    struct acc {
+        uint64_t a;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD uint64_t prep(uint64_t cst) const { return cst; }
+
+    FF_HD uint64_t add(uint64_t a, uint64_t b) const { return a ^ b; }
+    FF_HD uint64_t sub(uint64_t a, uint64_t b) const { return a ^ b; }
+    FF_HD uint64_t neg(uint64_t a) const { return a; }
+    FF_HD uint64_t xtime(uint64_t a) const {
+        uint64_t hi = (a >> (n - 1)) & 1;
+        return ((a << 1) & emask) ^ ((0 - hi) & red);
+    }
+    FF_HD uint64_t reduce_raw(uint64_t a) const {
+        if (n == 64) return a;
+        uint64_t r = 0;
+        for (int i = 63; i >= 0; --i) r = xtime(r) ^ ((a >> i) & 1);
+        return r;
+    }
+    FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
+        uint64_t c = 0;
+        for (int i = (int)n - 1; i >= 0; --i) {
+            c = xtime(c) ^ ((0 - ((b >> i) & 1)) & a);
+        }
+        return c;
+    }
+    FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
+        // x < 2^32 public; degree of X(x) < 32
+        uint64_t c = 0;
+        int top = n < 32 ? (int)n - 1 : 31;
+        for (int i = top; i >= 0; --i) {
+            c = xtime(c);
+            if ((x >> i) & 1) c ^= y;
+        }
+        return c ^ cadd;
+    }
+    FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const { return mul(a, b) ^ cadd; }
+    FF_HD void acc_zero(acc& s) const { s.a = 0; }
+    FF_HD void acc_mac(acc& s, uint64_t lam, uint64_t x) const { s.a ^= mul(x, lam); }
+    FF_HD uint64_t acc_reduce(const acc& s) const { return s.a; }
+};
+
+struct GF2W128 {
+    typedef u128e elem;
+    typedef u128e word;
+    enum { EPW = 1 };
+    uint64_t red_lo, red_hi;      // modulus without leading term
+    uint64_t emask_lo, emask_hi;  // 2^n - 1
+    uint32_t n;                   // 65..128
+    uint32_t pad_;
+    struct acc {
+        uint64_t lo, hi;
+    };
+    // constants are used as-is (no domain conversion)
+    FF_HD u128e prep(u128e cst) const { return cst; }
+
+    static FF_HD ff_u128 U(const u128e& a) { return ff_make128(a.hi, a.lo); }
+    static FF_HD u128e E(ff_u128 x) {
+        u128e r;
+        r.lo = ff_lo(x);
+        r.hi = ff_hi(x);
+        return r;
+    }
+    FF_HD u128e add(const u128e& a, const u128e& b) const {
+        u128e r;
+        r.lo = a.lo ^ b.lo;
+        r.hi = a.hi ^ b.hi;
+        return r;
+    }
+    FF_HD u128e sub(const u128e& a, const u128e& b) const { return add(a, b); }
+    FF_HD u128e neg(const u128e& a) const { return a; }
+    FF_HD void xtime(uint64_t& lo, uint64_t& hi) const {
+        uint64_t t = (hi >> (n - 65)) & 1;  // bit n-1
+        uint64_t m = 0 - t;
+        hi = ((hi << 1) | (lo >> 63)) & emask_hi;
+        lo = lo << 1;
+        lo ^= m & red_lo;
+        hi ^= m & red_hi;
+    }
+    FF_HD u128e reduce_raw(const u128e& a) const {
+        if (n == 128) return a;
+        uint64_t lo = 0, hi = 0;
+        for (int i = 127; i >= 0; --i) {
+            xtime(lo, hi);
+            uint64_t bit = i >= 64 ? (a.hi >> (i - 64)) & 1 : (a.lo >> i) & 1;
+            lo ^= bit;
+        }
+        u128e r;
+        r.lo = lo;
+        r.hi = hi;
+        return r;
+    }
+    FF_HD u128e mul(const u128e& a, const u128e& b) const {
+        uint64_t lo = 0, hi = 0;
+        for (int i = (int)n - 1; i >= 64; --i) {
+            xtime(lo, hi);
+            uint64_t m = 0 - ((b.hi >> (i - 64)) & 1);
+            lo ^= m & a.lo;
+            hi ^= m & a.hi;
+        }
+        for (int i = 63; i >= 0; --i) {
+            xtime(lo, hi);
+            uint64_t m = 0 - ((b.lo >> i) & 1);
+            lo ^= m & a.lo;
+            hi ^= m & a.hi;
+        }
+        u128e r;
+        r.lo = lo;
+        r.hi = hi;
+        return r;
+    }
+    FF_HD u128e muladd_small(const u128e& y, uint32_t x, const u128e& cadd) const {
+        uint64_t lo = 0, hi = 0;
+        for (int i = 31; i >= 0; --i) {
+            xtime(lo, hi);
+            if ((x >> i) & 1) {
+                lo ^= y.lo;
+                hi ^= y.hi;
+            }
+        }
+        u128e r;
+        r.lo = lo ^ cadd.lo;
+        r.hi = hi ^ cadd.hi;
+        return r;
+    }
+    FF_HD u128e muladd(const u128e& a, const u128e& b, const u128e& cadd) const {
+        return add(mul(a, b), cadd);
+    }
+    FF_HD void acc_zero(acc& s) const { s.lo = s.hi = 0; }
+    FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& x) const {
+        u128e t = mul(x, lam);
+        s.lo ^= t.lo;
+        s.hi ^= t.hi;
+    }
+    FF_HD u128e acc_reduce(const acc& s) const {
+        u128e r;
+        r.lo = s.lo;
+        r.hi = s.hi;
+        return r;
+    }
+};

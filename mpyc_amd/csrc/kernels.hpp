@@ -1,0 +1,573 @@
+// kernels.hpp -- HIP kernels of libffgpu, templated on a field policy (fields.hpp).
+//
+// Every kernel here is a streaming, HBM-bound integer kernel (no MFMA: there
+// is no dense contraction on this path).  Design rules, from the gfx950 guide:
+//   * 16 bytes per lane per access (global_load/store_dwordx4): a wave touches
+//     1 KiB of contiguous HBM per instruction and array;
+//   * all loads of an iteration are issued before the first use so that
+//     (rows+1) x UNROLL independent 1 KiB requests per wave are in flight;
+//   * grid = a few blocks per CU, grid-stride loop, consecutive blocks (which
+//     land on different XCDs, block b -> XCD b%8) read consecutive 4 KiB
+//     chunks, so every XCD's L2 and all HBM channels see the same uniform
+//     stream -- there is no reuse to localise in an L2, hence no remap;
+//   * per-field constants (modulus, fold constant, Lagrange vector, party
+//     x-coordinates) are wave-uniform kernel arguments -> SGPRs, which beats
+//     staging them in LDS for fields this small.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fields.hpp"
+
+namespace ffgpu {
+
+enum { BLOCK = 256 };
+enum EwOp { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_RSUB = 3, OP_NEG = 4, OP_REDUCE = 5, OP_COPY = 6 };
+
+enum { MAXK = 9, MAXW = 8, MAXK_ANY = 64, MAXT = 4 };
+
+template <class W>
+struct alignas(16) Pack {
+    enum { N = 16 / sizeof(W) };
+    W w[N];
+};
+
+// element <-> word for the scalar tail (identity unless words pack elements)
+template <class F>
+__device__ __forceinline__ typename F::word ld_elem(const typename F::elem* p, size_t i) {
+    if constexpr (F::EPW == 1) {
+        return p[i];
+    } else {
+        return (typename F::word)p[i];
+    }
+}
+template <class F>
+__device__ __forceinline__ void st_elem(typename F::elem* p, size_t i, typename F::word w) {
+    if constexpr (F::EPW == 1) {
+        p[i] = w;
+    } else {
+        p[i] = (typename F::elem)w;
+    }
+}
+
+template <class F, int OP>
+__device__ __forceinline__ typename F::word ew_apply(const F& f, typename F::word a, typename F::word b) {
+    if constexpr (OP == OP_ADD) return f.add(a, b);
+    else if constexpr (OP == OP_SUB) return f.sub(a, b);
+    else if constexpr (OP == OP_MUL) return f.mul(a, b);
+    else if constexpr (OP == OP_RSUB) return f.sub(b, a);
+    else if constexpr (OP == OP_NEG) return f.neg(a);
+    else if constexpr (OP == OP_REDUCE) return f.reduce_raw(a);
+    else return a;
+}
+
+// ---- out = a (op) b --------------------------------------------------------
+template <class F, int OP, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __restrict__ a,
+                                                const typename F::elem* __restrict__ b,
+                                                typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
+        P x[UNROLL], y[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) {
+                x[u] = av[j];
+                y[u] = bv[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) {
+                P r;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x[u].w[q], y[u].w[q]);
+                ov[j] = r;
+            }
+        }
+    }
+    // scalar tail (n not a multiple of the pack size)
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        st_elem<F>(o, e, ew_apply<F, OP>(f, ld_elem<F>(a, e), ld_elem<F>(b, e)));
+    }
+}
+
+// ---- out = a (op) scalar, or unary op (scalar ignored) ---------------------
+template <class F, int OP, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __restrict__ a,
+                                                typename F::word s, typename F::elem* __restrict__ o,
+                                                size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
+        P x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) x[u] = av[j];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) {
+                P r;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x[u].w[q], s);
+                ov[j] = r;
+            }
+        }
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        st_elem<F>(o, e, ew_apply<F, OP>(f, ld_elem<F>(a, e), s));
+    }
+}
+
+// ---- out = a*b + c ---------------------------------------------------------
+template <class F, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* __restrict__ a,
+                                                   const typename F::elem* __restrict__ b,
+                                                   const typename F::elem* __restrict__ c,
+                                                   typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    const P* __restrict__ cv = reinterpret_cast<const P*>(c);
+    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
+        P x[UNROLL], y[UNROLL], z[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) {
+                x[u] = av[j];
+                y[u] = bv[j];
+                z[u] = cv[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            size_t j = i + (size_t)u * gsz;
+            if (j < nvec) {
+                P r;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) r.w[q] = f.muladd(x[u].w[q], y[u].w[q], z[u].w[q]);
+                ov[j] = r;
+            }
+        }
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        st_elem<F>(o, e, f.muladd(ld_elem<F>(a, e), ld_elem<F>(b, e), ld_elem<F>(c, e)));
+    }
+}
+
+// ---- Shamir share generation (thresha.py:47-64), optionally fused with the
+//      local product of secure multiplication (runtime.py:1134) ---------------
+// share_i[h] = s[h] + x_i*(C[0][h] + x_i*(C[1][h] + ... x_i*C[T-1][h])),  x_i = i+1
+// Per pack: 1 (or 2) + T loads of 16 B, m stores of 16 B, m*T Horner steps.
+template <class F, int T, bool FUSE_MUL>
+__global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
+                                                  const typename F::elem* __restrict__ b,
+                                                  const typename F::elem* __restrict__ coef, size_t cstride,
+                                                  int m, typename F::elem* __restrict__ out, size_t ostride,
+                                                  size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P s = av[i];
+        P s2;
+        if constexpr (FUSE_MUL) s2 = bv[i];
+        P c[T > 0 ? T : 1];
+#pragma unroll
+        for (int j = 0; j < T; ++j) c[j] = reinterpret_cast<const P*>(coef + (size_t)j * cstride)[i];
+        if constexpr (FUSE_MUL) {
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
+        }
+        for (int party = 1; party <= m; ++party) {
+            P y;
+            if constexpr (T == 0) {
+                y = s;
+            } else {
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    W acc = c[T - 1].w[q];
+#pragma unroll
+                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j].w[q]);
+                    y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
+                }
+            }
+            reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride)[i] = y;
+        }
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        W s = ld_elem<F>(a, e);
+        if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
+        W c[T > 0 ? T : 1];
+#pragma unroll
+        for (int j = 0; j < T; ++j) c[j] = ld_elem<F>(coef + (size_t)j * cstride, e);
+        for (int party = 1; party <= m; ++party) {
+            W y = s;
+            if constexpr (T > 0) {
+                W acc = c[T - 1];
+#pragma unroll
+                for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j]);
+                y = f.muladd_small(acc, (uint32_t)party, s);
+            }
+            st_elem<F>(out + (size_t)(party - 1) * ostride, e, y);
+        }
+    }
+}
+
+// any degree t: coefficients are re-read per party (they stay in L2/MALL)
+template <class F, bool FUSE_MUL>
+__global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem* __restrict__ a,
+                                                      const typename F::elem* __restrict__ b,
+                                                      const typename F::elem* __restrict__ coef, size_t cstride,
+                                                      int t, int m, typename F::elem* __restrict__ out,
+                                                      size_t ostride, size_t n) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t e = gid; e < n; e += gsz) {
+        W s = ld_elem<F>(a, e);
+        if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
+        for (int party = 1; party <= m; ++party) {
+            W acc = ld_elem<F>(coef + (size_t)(t - 1) * cstride, e);
+            for (int j = t - 2; j >= 0; --j)
+                acc = f.muladd_small(acc, (uint32_t)party, ld_elem<F>(coef + (size_t)j * cstride, e));
+            st_elem<F>(out + (size_t)(party - 1) * ostride, e, f.muladd_small(acc, (uint32_t)party, s));
+        }
+    }
+}
+
+// ---- Lagrange recombination (thresha.py:119-132) ---------------------------
+template <class F, int K>
+struct RecArgs {
+    const typename F::elem* rows[K];
+    typename F::word lam[MAXW * K];  // (w, K) prepared constants
+};
+
+template <class F, int K>
+__global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int w,
+                                                      typename F::elem* __restrict__ out, size_t ostride,
+                                                      size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j] = reinterpret_cast<const P*>(ra.rows[j])[i];
+        for (int r = 0; r < w; ++r) {
+            P y;
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) {
+                typename F::acc s;
+                f.acc_zero(s);
+#pragma unroll
+                for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], x[j].w[q]);
+                y.w[q] = f.acc_reduce(s);
+            }
+            reinterpret_cast<P*>(out + (size_t)r * ostride)[i] = y;
+        }
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        for (int r = 0; r < w; ++r) {
+            typename F::acc s;
+            f.acc_zero(s);
+#pragma unroll
+            for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], ld_elem<F>(ra.rows[j], e));
+            st_elem<F>(out + (size_t)r * ostride, e, f.acc_reduce(s));
+        }
+    }
+}
+
+template <class F>
+struct RecArgsAny {
+    const typename F::elem* rows[MAXK_ANY];
+    typename F::word lam[MAXK_ANY];  // one output row per launch
+};
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_recombine_any(F f, RecArgsAny<F> ra, int k,
+                                                          typename F::elem* __restrict__ out, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t e = gid; e < n; e += gsz) {
+        typename F::acc s;
+        f.acc_zero(s);
+        for (int j = 0; j < k; ++j) f.acc_mac(s, ra.lam[j], ld_elem<F>(ra.rows[j], e));
+        st_elem<F>(out, e, f.acc_reduce(s));
+    }
+}
+
+// ---- launch plumbing -------------------------------------------------------
+struct LaunchCfg {
+    int blocks_per_cu;
+    int num_cu;
+};
+LaunchCfg launch_cfg(int device);
+
+inline unsigned grid_for(size_t iters, const LaunchCfg& lc) {
+    size_t want = (iters + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)lc.blocks_per_cu * (size_t)lc.num_cu;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// host-side table of launchers for one policy type; the context stores the
+// policy blob and a pointer to this table.
+struct FieldOps {
+    int (*ew2)(const void* F, int device, int op, const void* a, const void* b, void* o, size_t n,
+               hipStream_t st);
+    int (*ew1)(const void* F, int device, int op, const void* a, const uint64_t* scalar2, void* o,
+               size_t n, hipStream_t st);
+    int (*muladd)(const void* F, int device, const void* a, const void* b, const void* c, void* o,
+                  size_t n, hipStream_t st);
+    int (*split)(const void* F, int device, const void* a, const void* b, const void* coef,
+                 size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st);
+    int (*recombine)(const void* F, int device, const void* const* rows, const uint64_t* lam2, int k,
+                     int w, void* out, size_t ostride, size_t n, hipStream_t st);
+};
+
+// canonical 2-limb host scalar -> policy word (broadcast for packed fields)
+template <class F>
+inline typename F::word word_from_limbs(const F& f, uint64_t lo, uint64_t hi) {
+    if constexpr (sizeof(typename F::elem) == 16) {
+        typename F::word w;
+        w.lo = lo;
+        w.hi = hi;
+        return w;
+    } else if constexpr (F::EPW == 4) {
+        uint32_t b = (uint32_t)(lo & 0xffu);
+        return b * 0x01010101u;
+    } else {
+        return (typename F::word)lo;
+    }
+}
+
+template <class F>
+inline typename F::word prep_const(const F& f, typename F::word c) {
+    return f.prep(c);
+}
+
+#define FFGPU_CHECK_LAUNCH()                      \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__ | 0x10000; \
+    } while (0)
+
+template <class F>
+struct Launchers {
+    typedef typename F::elem E;
+    typedef typename F::word W;
+    enum { EPV = (16 / sizeof(W)) * F::EPW };  // elements per 16-byte pack
+
+    template <int OP>
+    static void go_ew2(const F& f, const LaunchCfg& lc, const E* a, const E* b, E* o, size_t n, hipStream_t st) {
+        bool vec = aligned16(a) && aligned16(b) && aligned16(o);
+        size_t nvec = vec ? n / EPV : 0;
+        constexpr int U = 2;
+        size_t iters = nvec ? (nvec + U - 1) / U : n;
+        unsigned grid = grid_for(iters, lc);
+        hipLaunchKernelGGL((k_ew2<F, OP, U>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+    }
+    static int ew2(const void* Fp, int device, int op, const void* a, const void* b, void* o, size_t n,
+                   hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        const E* A = (const E*)a;
+        const E* B = (const E*)b;
+        E* O = (E*)o;
+        switch (op) {
+            case OP_ADD: go_ew2<OP_ADD>(f, lc, A, B, O, n, st); break;
+            case OP_SUB: go_ew2<OP_SUB>(f, lc, A, B, O, n, st); break;
+            case OP_MUL: go_ew2<OP_MUL>(f, lc, A, B, O, n, st); break;
+            default: return 1;
+        }
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
+    template <int OP>
+    static void go_ew1(const F& f, const LaunchCfg& lc, const E* a, W s, E* o, size_t n, hipStream_t st) {
+        bool vec = aligned16(a) && aligned16(o);
+        size_t nvec = vec ? n / EPV : 0;
+        constexpr int U = 2;
+        size_t iters = nvec ? (nvec + U - 1) / U : n;
+        unsigned grid = grid_for(iters, lc);
+        hipLaunchKernelGGL((k_ew1<F, OP, U>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
+    }
+    static int ew1(const void* Fp, int device, int op, const void* a, const uint64_t* scalar2, void* o,
+                   size_t n, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        W s = word_from_limbs<F>(f, scalar2 ? scalar2[0] : 0, scalar2 ? scalar2[1] : 0);
+        const E* A = (const E*)a;
+        E* O = (E*)o;
+        switch (op) {
+            case OP_ADD: go_ew1<OP_ADD>(f, lc, A, s, O, n, st); break;
+            case OP_RSUB: go_ew1<OP_RSUB>(f, lc, A, s, O, n, st); break;
+            case OP_MUL: go_ew1<OP_MUL>(f, lc, A, s, O, n, st); break;
+            case OP_NEG: go_ew1<OP_NEG>(f, lc, A, s, O, n, st); break;
+            case OP_REDUCE: go_ew1<OP_REDUCE>(f, lc, A, s, O, n, st); break;
+            case OP_COPY: go_ew1<OP_COPY>(f, lc, A, s, O, n, st); break;
+            default: return 1;
+        }
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
+    static int muladd(const void* Fp, int device, const void* a, const void* b, const void* c, void* o,
+                      size_t n, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        bool vec = aligned16(a) && aligned16(b) && aligned16(c) && aligned16(o);
+        size_t nvec = vec ? n / EPV : 0;
+        constexpr int U = 2;
+        size_t iters = nvec ? (nvec + U - 1) / U : n;
+        unsigned grid = grid_for(iters, lc);
+        hipLaunchKernelGGL((k_muladd<F, U>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, (const E*)b,
+                           (const E*)c, (E*)o, nvec, n);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
+    template <int T, bool FUSE>
+    static void go_split(const F& f, unsigned grid, const E* a, const E* b, const E* coef, size_t cstride,
+                         int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st) {
+        hipLaunchKernelGGL((k_split<F, T, FUSE>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride, m,
+                           out, ostride, nvec, n);
+    }
+    template <bool FUSE>
+    static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
+                       int t, int m, E* out, size_t ostride, size_t n, hipStream_t st) {
+        if (t > MAXT) {
+            unsigned grid = grid_for(n, lc);
+            hipLaunchKernelGGL((k_split_any<F, FUSE>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
+                               t, m, out, ostride, n);
+            return 0;
+        }
+        bool vec = aligned16(a) && (!FUSE || aligned16(b)) && aligned16(out) &&
+                   ((ostride * sizeof(E)) % 16 == 0 || m <= 1) &&
+                   (t == 0 || (aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1)));
+        size_t nvec = vec ? n / EPV : 0;
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        switch (t) {
+            case 0: go_split<0, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 1: go_split<1, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 2: go_split<2, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 3: go_split<3, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 4: go_split<4, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            default: return 1;
+        }
+        return 0;
+    }
+    static int split(const void* Fp, int device, const void* a, const void* b, const void* coef,
+                     size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        int rc = b ? split_t<true>(f, lc, (const E*)a, (const E*)b, (const E*)coef, cstride, t, m, (E*)out,
+                                   ostride, n, st)
+                   : split_t<false>(f, lc, (const E*)a, nullptr, (const E*)coef, cstride, t, m, (E*)out,
+                                    ostride, n, st);
+        if (rc) return rc;
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
+    template <int K>
+    static void go_rec(const F& f, const LaunchCfg& lc, const void* const* rows, const uint64_t* lam2, int w,
+                       E* out, size_t ostride, size_t n, hipStream_t st) {
+        RecArgs<F, K> ra;
+        bool vec = aligned16(out) && ((ostride * sizeof(E)) % 16 == 0 || w <= 1);
+        for (int j = 0; j < K; ++j) {
+            ra.rows[j] = (const E*)rows[j];
+            vec = vec && aligned16(rows[j]);
+        }
+        for (int r = 0; r < w; ++r)
+            for (int j = 0; j < K; ++j) {
+                const uint64_t* l = lam2 + 2 * ((size_t)r * K + j);
+                ra.lam[r * K + j] = f.prep(word_from_limbs<F>(f, l[0], l[1]));
+            }
+        for (int i = w * K; i < MAXW * K; ++i) ra.lam[i] = ra.lam[0];
+        size_t nvec = vec ? n / EPV : 0;
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        hipLaunchKernelGGL((k_recombine<F, K>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride, nvec,
+                           n);
+    }
+    static int recombine(const void* Fp, int device, const void* const* rows, const uint64_t* lam2, int k,
+                         int w, void* out, size_t ostride, size_t n, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        E* O = (E*)out;
+        if (k > MAXK) {
+            if (k > MAXK_ANY) return 2;
+            for (int r = 0; r < w; ++r) {
+                RecArgsAny<F> ra;
+                for (int j = 0; j < k; ++j) {
+                    ra.rows[j] = (const E*)rows[j];
+                    const uint64_t* l = lam2 + 2 * ((size_t)r * k + j);
+                    ra.lam[j] = f.prep(word_from_limbs<F>(f, l[0], l[1]));
+                }
+                for (int j = k; j < MAXK_ANY; ++j) {
+                    ra.rows[j] = ra.rows[0];
+                    ra.lam[j] = ra.lam[0];
+                }
+                unsigned grid = grid_for(n, lc);
+                hipLaunchKernelGGL((k_recombine_any<F>), dim3(grid), dim3(BLOCK), 0, st, f, ra, k,
+                                   O + (size_t)r * ostride, n);
+            }
+            FFGPU_CHECK_LAUNCH();
+            return 0;
+        }
+        for (int r0 = 0; r0 < w; r0 += MAXW) {
+            int wc = (w - r0) < MAXW ? (w - r0) : MAXW;
+            const uint64_t* l = lam2 + 2 * (size_t)r0 * k;
+            E* o = O + (size_t)r0 * ostride;
+            switch (k) {
+                case 1: go_rec<1>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 2: go_rec<2>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 3: go_rec<3>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 4: go_rec<4>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 5: go_rec<5>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 6: go_rec<6>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 7: go_rec<7>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 8: go_rec<8>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                case 9: go_rec<9>(f, lc, rows, l, wc, o, ostride, n, st); break;
+                default: return 1;
+            }
+        }
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
+    static const FieldOps* table() {
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &recombine};
+        return &ops;
+    }
+};
+
+}  // namespace ffgpu

@@ -1,0 +1,5 @@
+// ops_pm128_gen.hip -- launcher table instantiation (one field-policy family per translation unit
+// so that the families compile in parallel).
+#include "kernels.hpp"
+using namespace ffgpu;
+const FieldOps* ffgpu_ops_pm128_gen() { return Launchers<PM128<false> >::table(); }

@@ -1,0 +1,181 @@
+// policy_build.hpp -- host-only: classify a modulus and build the field policy
+// (fields.hpp) that the kernels receive by value.  Shared by api.hip and by the
+// g++-compiled arithmetic check in tests/hostcheck.cpp, so both see identical
+// constants.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "fields.hpp"
+
+namespace ffgpu {
+
+enum PolicyKind {
+    POL_NONE = 0,
+    POL_PM64_MERSENNE,  // PM64<false,true>
+    POL_PM64_K64,       // PM64<true,false>
+    POL_PM64_GEN,       // PM64<false,false>
+    POL_RC64,
+    POL_RC32,
+    POL_PM128_K128,     // PM128<true>
+    POL_PM128_GEN,      // PM128<false>
+    POL_MONT128,
+    POL_GF2P8,
+    POL_GF2W64,
+    POL_GF2W128
+};
+
+// status values mirror include/ffgpu.h
+enum { PB_OK = 0, PB_EINVAL = 1, PB_ENOTSUP = 2, PB_EMODULUS = 4 };
+// reduction tags mirror FFGPU_RED_*
+enum { PB_RED_PM = 1, PB_RED_RC = 2, PB_RED_SWAR = 3, PB_RED_WIDE = 4, PB_RED_MONT = 5 };
+
+struct PolicyBlob {
+    int kind;
+    int reduction;
+    int elem_bytes;
+    alignas(16) unsigned char bytes[128];
+};
+
+template <class F>
+inline void store_policy(PolicyBlob* c, const F& f, int kind, int red) {
+    static_assert(sizeof(F) <= sizeof(c->bytes), "policy blob too small");
+    memset(c->bytes, 0, sizeof(c->bytes));
+    memcpy(c->bytes, &f, sizeof(F));
+    c->kind = kind;
+    c->reduction = red;
+    c->elem_bytes = (int)sizeof(typename F::elem);
+}
+
+inline int bitlen128(ff_u128 x) {
+    int n = 0;
+    while (x) {
+        ++n;
+        x >>= 1;
+    }
+    return n;
+}
+
+inline int build_prime_policy(PolicyBlob* c, ff_u128 p) {
+    if (p < 2) return PB_EMODULUS;
+    int k = bitlen128(p);
+    if (k <= 32) {
+        RC32 f;
+        f.p = (uint32_t)p;
+        f.s = (uint32_t)__builtin_clz(f.p);
+        f.d = f.p << f.s;
+        f.v = (uint32_t)(0xFFFFFFFFFFFFFFFFull / f.d);
+        store_policy(c, f, POL_RC32, PB_RED_RC);
+        return PB_OK;
+    }
+    if (k <= 64) {
+        uint64_t p64 = (uint64_t)p;
+        ff_u128 cc = ((ff_u128)1 << k) - p;
+        int cb = (k - 1) / 2 < 31 ? (k - 1) / 2 : 31;
+        bool k64 = (k == 64);
+        if (cc < ((ff_u128)1 << cb) && !(k64 && cc == 1)) {
+            uint64_t mask = k64 ? ~0ull : ((1ull << k) - 1);
+            if (!k64 && cc == 1) {
+                PM64<false, true> f;
+                f.p = p64; f.mask = mask; f.c = 1; f.k = (uint32_t)k;
+                store_policy(c, f, POL_PM64_MERSENNE, PB_RED_PM);
+            } else if (k64) {
+                PM64<true, false> f;
+                f.p = p64; f.mask = mask; f.c = (uint32_t)cc; f.k = 64;
+                store_policy(c, f, POL_PM64_K64, PB_RED_PM);
+            } else {
+                PM64<false, false> f;
+                f.p = p64; f.mask = mask; f.c = (uint32_t)cc; f.k = (uint32_t)k;
+                store_policy(c, f, POL_PM64_GEN, PB_RED_PM);
+            }
+            return PB_OK;
+        }
+        RC64 f;
+        f.p = p64;
+        f.s = (uint32_t)__builtin_clzll(p64);
+        f.d = p64 << f.s;
+        f.v = (uint64_t)((~(ff_u128)0) / f.d);
+        f.pad_ = 0;
+        store_policy(c, f, POL_RC64, PB_RED_RC);
+        return PB_OK;
+    }
+    // two limbs
+    ff_u128 cc = (k == 128) ? (ff_u128)0 - p : ((ff_u128)1 << k) - p;
+    if (cc < ((ff_u128)1 << 31)) {
+        ff_u128 mask = (k == 128) ? ~(ff_u128)0 : (((ff_u128)1 << k) - 1);
+        if (k == 128) {
+            PM128<true> f;
+            f.p_lo = ff_lo(p); f.p_hi = ff_hi(p); f.mask_lo = ff_lo(mask); f.mask_hi = ff_hi(mask);
+            f.c = (uint32_t)cc; f.k = 128;
+            store_policy(c, f, POL_PM128_K128, PB_RED_PM);
+        } else {
+            PM128<false> f;
+            f.p_lo = ff_lo(p); f.p_hi = ff_hi(p); f.mask_lo = ff_lo(mask); f.mask_hi = ff_hi(mask);
+            f.c = (uint32_t)cc; f.k = (uint32_t)k;
+            store_policy(c, f, POL_PM128_GEN, PB_RED_PM);
+        }
+        return PB_OK;
+    }
+    if (!(p & 1)) return PB_EMODULUS;
+    MONT128 f;
+    f.p_lo = ff_lo(p);
+    f.p_hi = ff_hi(p);
+    // -p^{-1} mod 2^64 by Newton iteration
+    uint64_t inv = f.p_lo;  // correct to 3 bits
+    for (int i = 0; i < 6; ++i) inv *= 2 - f.p_lo * inv;
+    f.pinv = 0 - inv;
+    f.pad_ = 0;
+    // R^2 = 2^256 mod p by 256 modular doublings of 1
+    ff_u128 r = 1;
+    for (int i = 0; i < 256; ++i) r = f.addu(r, r);
+    f.r2_lo = ff_lo(r);
+    f.r2_hi = ff_hi(r);
+    store_policy(c, f, POL_MONT128, PB_RED_MONT);
+    return PB_OK;
+}
+
+inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
+    uint64_t m0 = mod[0], m1 = nlimbs > 1 ? mod[1] : 0, m2 = nlimbs > 2 ? mod[2] : 0;
+    int deg;
+    if (m2) {
+        if (m2 != 1) return PB_ENOTSUP;
+        deg = 128;
+    } else if (m1) {
+        deg = 64 + (63 - __builtin_clzll(m1));
+    } else if (m0) {
+        deg = 63 - __builtin_clzll(m0);
+    } else {
+        return PB_EMODULUS;
+    }
+    if (deg < 1) return PB_EMODULUS;
+    if (deg <= 8) {
+        GF2P8 f;
+        f.n = (uint32_t)deg;
+        uint32_t r = (uint32_t)(m0 ^ (1ull << deg));
+        f.red = r * 0x01010101u;
+        f.top = (1u << (deg - 1)) * 0x01010101u;
+        f.emask = ((1u << deg) - 1) * 0x01010101u;
+        store_policy(c, f, POL_GF2P8, PB_RED_SWAR);
+        return PB_OK;
+    }
+    if (deg <= 64) {
+        GF2W64 f;
+        f.n = (uint32_t)deg;
+        f.emask = deg == 64 ? ~0ull : ((1ull << deg) - 1);
+        f.red = deg == 64 ? m0 : (m0 ^ (1ull << deg));
+        f.pad_ = 0;
+        store_policy(c, f, POL_GF2W64, PB_RED_WIDE);
+        return PB_OK;
+    }
+    GF2W128 f;
+    f.n = (uint32_t)deg;
+    f.red_lo = m0;
+    f.red_hi = deg == 128 ? m1 : (m1 ^ (1ull << (deg - 64)));
+    f.emask_lo = ~0ull;
+    f.emask_hi = deg == 128 ? ~0ull : ((1ull << (deg - 64)) - 1);
+    f.pad_ = 0;
+    store_policy(c, f, POL_GF2W128, PB_RED_WIDE);
+    return PB_OK;
+}
+
+
+}  // namespace ffgpu

@@ -1,0 +1,343 @@
+"""Device-side engine: a field context plus device-resident limb arrays.
+
+This is the layer directly above the C ABI (include/ffgpu.h).  Arrays live in HBM
+as fixed-width little-endian limbs (DevArray); Python integers exist only at the
+API edges (from_ints / to_ints), because boxing 10^7 PyLongs costs more than every
+kernel here put together.  torch is used for device memory (caching allocator,
+streams, interop with torch.distributed); all arithmetic goes through libffgpu.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+_MASK64 = (1 << 64) - 1
+
+
+def _np_dtype(eb: int):
+    return {1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb]
+
+
+def _torch_dtype(eb: int):
+    return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 16: torch.int64}[eb]
+
+
+def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
+    """Canonical Python ints -> limb array ((n,) for eb<=8, (n,2) uint64 for eb=16)."""
+    if isinstance(vals, np.ndarray) and vals.dtype != object:
+        vals = vals.reshape(-1)
+        if eb == 16:
+            out = np.zeros((vals.size, 2), dtype=np.uint64)
+            out[:, 0] = vals.astype(np.uint64)
+            return out
+        return vals.astype(_np_dtype(eb))
+    vals = list(vals) if not isinstance(vals, (list, np.ndarray)) else vals
+    n = len(vals)
+    if eb == 16:
+        buf = b''.join(int(v).to_bytes(16, 'little') for v in vals)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).copy()
+    if n == 0:
+        return np.zeros(0, dtype=_np_dtype(eb))
+    return np.array(vals, dtype=object).astype(np.uint64).astype(_np_dtype(eb))
+
+
+def np_to_ints(arr: np.ndarray, eb: int) -> List[int]:
+    if eb == 16:
+        a = arr.reshape(-1, 2)
+        lo = a[:, 0].astype(object)
+        hi = a[:, 1].astype(object)
+        return list((hi << 64) | lo) if len(a) else []
+    return [int(v) for v in arr.reshape(-1).astype(object)] if arr.size else []
+
+
+class DevArray:
+    """n field elements resident in HBM (row of limbs).  Thin wrapper over a torch tensor."""
+
+    __slots__ = ('ctx', 't', 'n')
+
+    def __init__(self, ctx: 'FieldContext', t: torch.Tensor, n: int):
+        self.ctx, self.t, self.n = ctx, t, n
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def to_numpy(self) -> np.ndarray:
+        a = self.t.cpu().numpy()
+        eb = self.ctx.elem_bytes
+        if eb == 4:
+            a = a.view(np.uint32)
+        elif eb >= 8:
+            a = a.view(np.uint64)
+        return a
+
+    def to_ints(self) -> List[int]:
+        return np_to_ints(self.to_numpy(), self.ctx.elem_bytes)
+
+    def clone(self) -> 'DevArray':
+        return DevArray(self.ctx, self.t.clone(), self.n)
+
+    def __len__(self):
+        return self.n
+
+
+class DevMatrix:
+    """(rows, n) elements with 256-byte aligned rows (so every row takes the 16 B/lane path)."""
+
+    __slots__ = ('ctx', 't', 'rows', 'n', 'stride')
+
+    def __init__(self, ctx, t, rows, n, stride):
+        self.ctx, self.t, self.rows, self.n, self.stride = ctx, t, rows, n, stride
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def row(self, i: int) -> DevArray:
+        eb = self.ctx.elem_bytes
+        if eb == 16:
+            return DevArray(self.ctx, self.t[i, :self.n, :], self.n)
+        return DevArray(self.ctx, self.t[i, :self.n], self.n)
+
+    def to_numpy(self) -> np.ndarray:
+        a = self.t.cpu().numpy()
+        eb = self.ctx.elem_bytes
+        if eb == 4:
+            a = a.view(np.uint32)
+        elif eb >= 8:
+            a = a.view(np.uint64)
+        return a[:, :self.n]
+
+    def to_ints(self) -> List[List[int]]:
+        a = self.to_numpy()
+        return [np_to_ints(a[i], self.ctx.elem_bytes) for i in range(self.rows)]
+
+
+class FieldContext:
+    """One finite field on one GPU.  modulus: prime p, or (binary=True) the bit pattern of the
+    irreducible polynomial.  Mirrors what finfields.GF(modulus) fixes for an array type
+    (finfields.py:23-60)."""
+
+    def __init__(self, modulus: int, binary: bool = False, device: Optional[int] = None):
+        L = _ffi.lib()
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.modulus = int(modulus)
+        self.binary = bool(binary)
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        nl = 3
+        rc = L.ffgpu_ctx_create(_ffi.BINARY if binary else _ffi.PRIME, _ffi.limbs(self.modulus, nl), nl,
+                                self.device, ctypes.byref(h))
+        _ffi.check(rc, 'ctx_create')
+        self._h = h
+        self.elem_bytes = L.ffgpu_ctx_elem_bytes(h)
+        self.reduction = _ffi.RED_NAMES.get(L.ffgpu_ctx_reduction(h), '?')
+        if binary:
+            self.order = 1 << (self.modulus.bit_length() - 1)
+        else:
+            self.order = self.modulus
+        self._L = L
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._L.ffgpu_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- memory ---------------------------------------------------------
+    @property
+    def torch_device(self):
+        return torch.device('cuda', self.device)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, n: int) -> DevArray:
+        eb = self.elem_bytes
+        shape = (n, 2) if eb == 16 else (n,)
+        return DevArray(self, torch.empty(shape, dtype=_torch_dtype(eb), device=self.torch_device), n)
+
+    def empty_matrix(self, rows: int, n: int) -> DevMatrix:
+        eb = self.elem_bytes
+        per = 256 // eb
+        stride = max(per, (n + per - 1) // per * per)
+        shape = (rows, stride, 2) if eb == 16 else (rows, stride)
+        return DevMatrix(self, torch.empty(shape, dtype=_torch_dtype(eb), device=self.torch_device), rows, n,
+                         stride)
+
+    def from_numpy(self, a: np.ndarray) -> DevArray:
+        """a: limb array as produced by ints_to_np (already canonical)."""
+        eb = self.elem_bytes
+        a = np.ascontiguousarray(a)
+        n = a.shape[0]
+        if eb == 4:
+            t = torch.from_numpy(a.view(np.int32))
+        elif eb >= 8:
+            t = torch.from_numpy(a.view(np.int64))
+        else:
+            t = torch.from_numpy(a)
+        return DevArray(self, t.to(self.torch_device), n)
+
+    def from_ints(self, vals: Sequence[int]) -> DevArray:
+        """Canonical ints (0 <= v < order) -> device."""
+        return self.from_numpy(ints_to_np(vals, self.elem_bytes))
+
+    def matrix_from_numpy(self, a: np.ndarray) -> DevMatrix:
+        rows, n = a.shape[0], a.shape[1]
+        mtx = self.empty_matrix(rows, n)
+        for i in range(rows):
+            mtx.row(i).t.copy_(self.from_numpy(a[i]).t)
+        return mtx
+
+    # ---- element-wise -----------------------------------------------------
+    def _ew2(self, fn, a: DevArray, b: DevArray, out: Optional[DevArray]) -> DevArray:
+        if a.n != b.n:
+            raise ValueError('length mismatch')
+        out = out or self.empty(a.n)
+        _ffi.check(fn(self._h, a.ptr, b.ptr, out.ptr, a.n, self._stream()), fn.__name__)
+        return out
+
+    def add(self, a, b, out=None):
+        return self._ew2(self._L.ffgpu_add, a, b, out)
+
+    def sub(self, a, b, out=None):
+        return self._ew2(self._L.ffgpu_sub, a, b, out)
+
+    def mul(self, a, b, out=None):
+        return self._ew2(self._L.ffgpu_mul, a, b, out)
+
+    def neg(self, a, out=None):
+        out = out or self.empty(a.n)
+        _ffi.check(self._L.ffgpu_neg(self._h, a.ptr, out.ptr, a.n, self._stream()), 'neg')
+        return out
+
+    def reduce(self, raw: DevArray, out=None):
+        out = out or self.empty(raw.n)
+        _ffi.check(self._L.ffgpu_reduce(self._h, raw.ptr, out.ptr, raw.n, self._stream()), 'reduce')
+        return out
+
+    def _ews(self, fn, a, scalar: int, out):
+        out = out or self.empty(a.n)
+        _ffi.check(fn(self._h, a.ptr, _ffi.limbs(scalar, 2), out.ptr, a.n, self._stream()), fn.__name__)
+        return out
+
+    def add_scalar(self, a, s: int, out=None):
+        return self._ews(self._L.ffgpu_add_scalar, a, s, out)
+
+    def mul_scalar(self, a, s: int, out=None):
+        return self._ews(self._L.ffgpu_mul_scalar, a, s, out)
+
+    def rsub_scalar(self, a, s: int, out=None):
+        return self._ews(self._L.ffgpu_rsub_scalar, a, s, out)
+
+    def muladd(self, a, b, c, out=None):
+        out = out or self.empty(a.n)
+        _ffi.check(self._L.ffgpu_muladd(self._h, a.ptr, b.ptr, c.ptr, out.ptr, a.n, self._stream()), 'muladd')
+        return out
+
+    # ---- sharing ----------------------------------------------------------
+    def split(self, secrets: DevArray, coeffs: Optional[DevMatrix], t: int, m: int,
+              out: Optional[DevMatrix] = None, mul_by: Optional[DevArray] = None) -> DevMatrix:
+        """np_random_split with the coefficient matrix supplied (thresha.py:47-64).
+        mul_by: fuse the local product secrets*mul_by (runtime.py:1134-1138)."""
+        n = secrets.n
+        if t and (coeffs is None or coeffs.rows < t or coeffs.n != n):
+            raise ValueError('coefficient matrix must be (t, n)')
+        out = out or self.empty_matrix(m, n)
+        cptr = coeffs.ptr if t else None
+        cstride = coeffs.stride if t else 0
+        if mul_by is None:
+            rc = self._L.ffgpu_split(self._h, secrets.ptr, cptr, cstride, t, m, out.ptr, out.stride, n,
+                                     self._stream())
+        else:
+            rc = self._L.ffgpu_mul_split(self._h, secrets.ptr, mul_by.ptr, cptr, cstride, t, m, out.ptr,
+                                         out.stride, n, self._stream())
+        _ffi.check(rc, 'split')
+        return out
+
+    def _rec_args(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int):
+        k = len(rows)
+        if len(lambdas) != w * k:
+            raise ValueError('need w*k lambda values')
+        ptrs = (ctypes.c_void_p * k)(*[r.ptr for r in rows])
+        lam = (ctypes.c_uint64 * (2 * w * k))()
+        for i, v in enumerate(lambdas):
+            v = int(v)
+            lam[2 * i] = v & _MASK64
+            lam[2 * i + 1] = v >> 64
+        return k, ptrs, lam
+
+    def recombine(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int = 1, out=None):
+        """out[r] = sum_j lambdas[r*k+j] * rows[j]  (thresha.py:119-132)."""
+        k, ptrs, lam = self._rec_args(rows, lambdas, w)
+        n = rows[0].n
+        if w == 1:
+            out = out or self.empty(n)
+            stride = n
+        else:
+            out = out or self.empty_matrix(w, n)
+            stride = out.stride
+        _ffi.check(self._L.ffgpu_recombine(self._h, ptrs, lam, k, w, out.ptr, stride, n, self._stream()),
+                   'recombine')
+        return out
+
+    def recombine_plan(self, rows: Sequence[DevArray], lambdas: Sequence[int], out, w: int = 1):
+        """Pre-marshal a recombination (row pointers + Lagrange vector) for repeated launches:
+        the returned callable only issues the kernel (hot loops, benchmarks)."""
+        k, ptrs, lam = self._rec_args(rows, lambdas, w)
+        n = rows[0].n
+        stride = n if w == 1 else out.stride
+        fn, h, optr = self._L.ffgpu_recombine, self._h, out.ptr
+        keep = (rows, out)
+
+        def launch():
+            _ffi.check(fn(h, ptrs, lam, k, w, optr, stride, n, self._stream()), 'recombine')
+            return keep[1]
+        return launch
+
+    def sbox(self, x: DevArray, rows8: Sequence[int], b: int, out=None):
+        out = out or self.empty(x.n)
+        r = (ctypes.c_uint8 * 8)(*rows8)
+        _ffi.check(self._L.ffgpu_gf256_sbox(self._h, x.ptr, r, ctypes.c_uint8(b), out.ptr, x.n, self._stream()),
+                   'sbox')
+        return out
+
+    def sync(self):
+        _ffi.check(self._L.ffgpu_stream_sync(self._h, self._stream()), 'sync')
+
+    # ---- timing (HIP events on the launch stream, inside the library) --------
+    def time_mul(self, a, b, out, reps: int) -> float:
+        ms = ctypes.c_float()
+        _ffi.check(self._L.ffgpu_time_mul(self._h, a.ptr, b.ptr, out.ptr, a.n, reps, self._stream(),
+                                          ctypes.byref(ms)), 'time_mul')
+        return ms.value
+
+    def time_split(self, secrets, coeffs, t, m, out, reps: int) -> float:
+        ms = ctypes.c_float()
+        _ffi.check(self._L.ffgpu_time_split(self._h, secrets.ptr, coeffs.ptr if t else None,
+                                            coeffs.stride if t else 0, t, m, out.ptr, out.stride, secrets.n,
+                                            reps, self._stream(), ctypes.byref(ms)), 'time_split')
+        return ms.value
+
+    def time_recombine(self, rows, lambdas, out, reps: int, w: int = 1) -> float:
+        k, ptrs, lam = self._rec_args(rows, lambdas, w)
+        ms = ctypes.c_float()
+        stride = rows[0].n if w == 1 else out.stride
+        _ffi.check(self._L.ffgpu_time_recombine(self._h, ptrs, lam, k, w, out.ptr, stride, rows[0].n, reps,
+                                                self._stream(), ctypes.byref(ms)), 'time_recombine')
+        return ms.value
+
+    def time_copy(self, src: torch.Tensor, dst: torch.Tensor, reps: int) -> float:
+        ms = ctypes.c_float()
+        nbytes = src.numel() * src.element_size()
+        _ffi.check(self._L.ffgpu_time_copy(self._h, src.data_ptr(), dst.data_ptr(), nbytes, reps,
+                                           self._stream(), ctypes.byref(ms)), 'time_copy')
+        return ms.value

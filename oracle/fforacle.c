@@ -1,0 +1,215 @@
+/*
+ * oracle/fforacle.c -- plain-C restatement of the reference's hot path, for
+ * full-size (10^7 element) parity checks and as the CPU baseline ("port").
+ *
+ * TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg load liboracle; the product (mpyc_amd/, libffgpu.so) never does.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks these functions
+ * against the tests/golden JSON fixtures generated from the real reference (see
+ * tests/golden/make_golden.py), and against oracle/pyoracle.py.
+ *
+ * Deliberately simple arithmetic (compiler-provided 128-bit `%`, shift-and-add
+ * for two-limb moduli, shift-and-xor for GF(2^n)); it shares no code and no
+ * reduction trick with the HIP kernels.
+ *
+ * Element layout: little-endian, width eb in {1,4,8,16} bytes, as include/ffgpu.h.
+ * Reference lines restated (paths relative to the mpyc checkout):
+ *   orc_ew        finfields.py:1056-1124,1189-1192 (+,-,*,neg), :717-725 (reduce),
+ *                 gfpx.py:982-1045 (GF(2^n) add/mul/mod)
+ *   orc_split     thresha.py:47-64 np_random_split
+ *   orc_recombine thresha.py:119-132 np_recombine (vector from :67-85 supplied)
+ *   orc_sbox      demos/np_aes.py:37-43 with runtime.py:1356-1367 (x^254 chain)
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+typedef struct {
+    int binary;   /* 0: GF(p), 1: GF(2^n) */
+    int eb;       /* element bytes */
+    int n;        /* binary: degree */
+    u128 p;       /* prime, or modulus without its leading term (binary) */
+    u128 mask;    /* binary: 2^n - 1 */
+} orc_field;
+
+static int g_threads = 1;
+void orc_set_threads(int t) { g_threads = t > 0 ? t : 1; }
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static u128 mk(const uint64_t* l, int nl) { return ((u128)(nl > 1 ? l[1] : 0) << 64) | l[0]; }
+
+int orc_field_init(orc_field* f, int binary, const uint64_t* mod, int nlimbs, int eb) {
+    memset(f, 0, sizeof(*f));
+    f->binary = binary;
+    f->eb = eb;
+    if (!binary) {
+        f->p = mk(mod, nlimbs);
+        return f->p >= 2 ? 0 : 1;
+    }
+    int deg = -1;
+    if (nlimbs > 2 && mod[2]) deg = 128;
+    else {
+        u128 m = mk(mod, nlimbs);
+        while (m) { ++deg; m >>= 1; }
+    }
+    if (deg < 1) return 1;
+    f->n = deg;
+    f->mask = deg == 128 ? ~(u128)0 : (((u128)1 << deg) - 1);
+    f->p = mk(mod, nlimbs) & f->mask;   /* drop the leading term */
+    return 0;
+}
+
+static inline u128 ld(const unsigned char* p, size_t i, int eb) {
+    u128 v = 0;
+    memcpy(&v, p + i * (size_t)eb, (size_t)eb);
+    return v;
+}
+static inline void st(unsigned char* p, size_t i, int eb, u128 v) { memcpy(p + i * (size_t)eb, &v, (size_t)eb); }
+
+static inline u128 addmod(u128 a, u128 b, u128 p) {
+    u128 s = a + b;
+    if (s < a || s >= p) s -= p;
+    return s;
+}
+static inline u128 submod(u128 a, u128 b, u128 p) { return a >= b ? a - b : a - b + p; }
+
+static inline u128 mulmod(u128 a, u128 b, u128 p) {
+    if ((p >> 64) == 0) return (u128)(((u128)(uint64_t)a * (uint64_t)b) % p);
+    /* two-limb modulus: shift-and-add, a,b < p */
+    u128 r = 0;
+    while (b) {
+        if (b & 1) r = addmod(r, a, p);
+        a = addmod(a, a, p);
+        b >>= 1;
+    }
+    return r;
+}
+
+/* c = a*b in GF(2^n): MSB-first Horner, r stays below degree n */
+static inline u128 gf2mul(const orc_field* f, u128 a, u128 b) {
+    u128 r = 0;
+    for (int i = f->n - 1; i >= 0; --i) {
+        int carry = (int)((r >> (f->n - 1)) & 1);
+        r = (r << 1) & f->mask;
+        if (carry) r ^= f->p;
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+/* reduce an arbitrary bit pattern of width 8*eb */
+static inline u128 gf2red(const orc_field* f, u128 a, int bits) {
+    u128 r = 0;
+    for (int i = bits - 1; i >= 0; --i) {
+        int carry = (int)((r >> (f->n - 1)) & 1);
+        r = (r << 1) & f->mask;
+        if (carry) r ^= f->p;
+        r ^= (a >> i) & 1;
+    }
+    return r;
+}
+
+static inline u128 f_add(const orc_field* f, u128 a, u128 b) { return f->binary ? a ^ b : addmod(a, b, f->p); }
+static inline u128 f_sub(const orc_field* f, u128 a, u128 b) { return f->binary ? a ^ b : submod(a, b, f->p); }
+static inline u128 f_mul(const orc_field* f, u128 a, u128 b) { return f->binary ? gf2mul(f, a, b) : mulmod(a, b, f->p); }
+static inline u128 f_red(const orc_field* f, u128 a) { return f->binary ? gf2red(f, a, 8 * f->eb) : a % f->p; }
+
+enum { ORC_ADD = 0, ORC_SUB = 1, ORC_MUL = 2, ORC_NEG = 3, ORC_REDUCE = 4 };
+
+int orc_ew(const orc_field* f, int op, const unsigned char* a, const unsigned char* b, unsigned char* out,
+           size_t n) {
+    const int eb = f->eb;
+    long long i;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (i = 0; i < (long long)n; ++i) {
+        u128 x = ld(a, (size_t)i, eb), y = b ? ld(b, (size_t)i, eb) : 0, r;
+        switch (op) {
+            case ORC_ADD: r = f_add(f, x, y); break;
+            case ORC_SUB: r = f_sub(f, x, y); break;
+            case ORC_MUL: r = f_mul(f, x, y); break;
+            case ORC_NEG: r = f_sub(f, 0, x); break;
+            default: r = f_red(f, x); break;
+        }
+        st(out, (size_t)i, eb, r);
+    }
+    return 0;
+}
+
+/* shares[i][h] = s[h] + sum_j C[j][h] * x_i^(j+1),  x_i = i+1 */
+int orc_split(const orc_field* f, const unsigned char* s, const unsigned char* coef, size_t cstride, int t,
+              int m, unsigned char* out, size_t ostride, size_t n) {
+    const int eb = f->eb;
+    long long h;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (h = 0; h < (long long)n; ++h) {
+        u128 sv = ld(s, (size_t)h, eb);
+        for (int i = 0; i < m; ++i) {
+            u128 x = f->binary ? (u128)(i + 1) : ((u128)(i + 1)) % f->p;
+            u128 xp = 1, acc = sv;
+            for (int j = 0; j < t; ++j) {
+                xp = f_mul(f, xp, x);
+                acc = f_add(f, acc, f_mul(f, ld(coef, (size_t)j * cstride + (size_t)h, eb), xp));
+            }
+            st(out, (size_t)i * ostride + (size_t)h, eb, acc);
+        }
+    }
+    return 0;
+}
+
+/* out[r][h] = sum_j lam[r][j] * rows[j][h];  lam: (w,k) of two uint64 limbs */
+int orc_recombine(const orc_field* f, const unsigned char* const* rows, const uint64_t* lam, int k, int w,
+                  unsigned char* out, size_t ostride, size_t n) {
+    const int eb = f->eb;
+    long long h;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (h = 0; h < (long long)n; ++h) {
+        for (int r = 0; r < w; ++r) {
+            u128 acc = 0;
+            for (int j = 0; j < k; ++j) {
+                const uint64_t* l = lam + 2 * ((size_t)r * k + j);
+                acc = f_add(f, acc, f_mul(f, mk(l, 2), ld(rows[j], (size_t)h, eb)));
+            }
+            st(out, (size_t)r * ostride + (size_t)h, eb, acc);
+        }
+    }
+    return 0;
+}
+
+int orc_sbox(const unsigned char* in, const uint8_t* rows8, uint8_t b, unsigned char* out, size_t n) {
+    orc_field f;
+    uint64_t mod = 0x11b;
+    orc_field_init(&f, 1, &mod, 1, 1);
+    uint8_t lut[256];
+    for (int v = 0; v < 256; ++v) {
+        /* x^254 by the reference's chain (runtime.py:1356-1367) */
+        u128 d = (u128)v, c = f_mul(&f, d, d), c2;
+        c = f_mul(&f, c, c);
+        c = f_mul(&f, c, c);
+        c = f_mul(&f, c, d);
+        c = f_mul(&f, c, c);
+        c2 = f_mul(&f, c, c); d = f_mul(&f, c, d); c = c2;
+        c2 = f_mul(&f, c, c); d = f_mul(&f, c, d); c = c2;
+        c = f_mul(&f, c, d);
+        c = f_mul(&f, c, c);
+        unsigned iv = (unsigned)c, y = 0;
+        for (int r = 0; r < 8; ++r) y |= (unsigned)(__builtin_popcount(iv & rows8[r]) & 1) << r;
+        lut[v] = (uint8_t)(y ^ b);
+    }
+    long long i;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (i = 0; i < (long long)n; ++i) out[i] = lut[in[i]];
+    return 0;
+}
+
+size_t orc_field_sizeof(void) { return sizeof(orc_field); }

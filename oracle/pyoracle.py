@@ -1,0 +1,286 @@
+"""oracle/pyoracle.py -- CPU restatement of the reference's hot path with Python ints.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under mpyc_amd/ may import this module; it is
+used by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg as
+the CHECKER of the HIP path, never as a computation path of the product.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
+against tests/golden/*.json, which tests/golden/make_golden.py produced by
+running the real reference (lschoe/mpyc v0.11.2, pure Python) in the build
+container, including the reference's own known-answer values
+(tests/test_finfields.py:94-99, SURVEY.md appendix A.1/A.3/A.6, FIPS-197 S-box).
+
+Each function cites the reference lines it restates (paths relative to the mpyc
+checkout).  The code is a restatement, not a copy: plain integers and lists, no
+field/element classes.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence, Tuple
+
+
+class Field:
+    """Minimal description of a field: prime GF(p) or binary GF(2^n).
+
+    modulus: the prime p, or the bit pattern of the irreducible polynomial.
+    (finfields.py:347-363 pGF, :508-525 xGF)
+    """
+
+    def __init__(self, modulus: int, binary: bool = False):
+        self.modulus = int(modulus)
+        self.binary = bool(binary)
+        if binary:
+            self.n = self.modulus.bit_length() - 1
+            self.order = 1 << self.n
+        else:
+            self.n = 1
+            self.order = self.modulus
+
+    def __repr__(self):
+        return f"Field({'2^%d' % self.n if self.binary else self.modulus})"
+
+
+# --------------------------------------------------------------------------
+# GF(2)[x] on bit patterns
+# --------------------------------------------------------------------------
+def clmul(a: int, b: int) -> int:
+    """Carry-less product of two bit patterns (gfpx.py:988-1003 _mul, incl. the
+    squaring shortcut :1005-1015 which computes the same value)."""
+    r = 0
+    while b:
+        if b & 1:
+            r ^= a
+        a <<= 1
+        b >>= 1
+    return r
+
+
+def clmod(a: int, f: int) -> int:
+    """Remainder of bit pattern a modulo f (gfpx.py:1025-1045 _mod)."""
+    df = f.bit_length()
+    while a.bit_length() >= df:
+        a ^= f << (a.bit_length() - df)
+    return a
+
+
+def gf2_inv(a: int, f: int, n: int) -> int:
+    """Inverse in GF(2^n) = a^(2^n - 2); equals gfpx.py:1084-1096 _invert."""
+    if a == 0:
+        raise ZeroDivisionError('inverse does not exist')
+    r = 1
+    e = (1 << n) - 2
+    base = a
+    while e:
+        if e & 1:
+            r = clmod(clmul(r, base), f)
+        base = clmod(clmul(base, base), f)
+        e >>= 1
+    return r
+
+
+# --------------------------------------------------------------------------
+# scalar field operations (canonical ints in, canonical ints out)
+# --------------------------------------------------------------------------
+def reduce(F: Field, x: int) -> int:
+    """Constructor reduction: finfields.py:724 `value %= modulus` (prime: Python
+    modulo, negative wraps; binary: finfields.py:537-541 with gfpx.py:879-880
+    _from_int = abs)."""
+    if F.binary:
+        return clmod(abs(int(x)), F.modulus)
+    return int(x) % F.modulus
+
+
+def add(F: Field, a: int, b: int) -> int:
+    """finfields.py:1056-1063 / gfpx.py:982-984."""
+    return (a ^ b) if F.binary else (a + b) % F.modulus
+
+
+def sub(F: Field, a: int, b: int) -> int:
+    """finfields.py:1075-1082 (char 2: gfpx.py:986 _sub = _add)."""
+    return (a ^ b) if F.binary else (a - b) % F.modulus
+
+
+def neg(F: Field, a: int) -> int:
+    """finfields.py:1189-1192."""
+    return a if F.binary else (-a) % F.modulus
+
+
+def mul(F: Field, a: int, b: int) -> int:
+    """finfields.py:1105-1112: product then reduction (binary: gfpx _mul, _mod)."""
+    if F.binary:
+        return clmod(clmul(a, b), F.modulus)
+    return (a * b) % F.modulus
+
+
+def inv(F: Field, a: int) -> int:
+    """finfields.py:1416-1422 / gfpx.py:1084-1096."""
+    if F.binary:
+        return gf2_inv(a, F.modulus, F.n)
+    if a % F.modulus == 0:
+        raise ZeroDivisionError('inverse does not exist')
+    return pow(a, -1, F.modulus)
+
+
+def vec(op, F: Field, a: Sequence[int], b: Sequence[int]) -> List[int]:
+    return [op(F, x, y) for x, y in zip(a, b)]
+
+
+# --------------------------------------------------------------------------
+# Shamir share generation
+# --------------------------------------------------------------------------
+def np_random_split(F: Field, s: Sequence[int], t: int, m: int, draws: Sequence[int]) -> List[List[int]]:
+    """thresha.py:47-64.  `draws` is the sequence secrets.randbelow(order) returned,
+    in call order: C[j][h] = draws[j*n + h] (row-major (t, n), thresha.py:60).
+    share_i[h] = (s[h] + sum_j C[j][h] * x_i^(j+1)) mod modulus with x_i = i+1
+    (for GF(2^n): the polynomial with bit pattern i+1, thresha.py:61)."""
+    n = len(s)
+    assert 0 <= t < m and len(draws) >= t * n
+    out = [[0] * n for _ in range(m)]
+    for i in range(m):
+        x = i + 1
+        for h in range(n):
+            if F.binary:
+                acc = s[h]
+                xp = 1
+                for j in range(t):
+                    xp = clmul(xp, x)                    # unreduced powers, as np.vander does
+                    acc ^= clmul(draws[j * n + h], xp)
+                out[i][h] = clmod(acc, F.modulus)
+            else:
+                acc = s[h]
+                xp = 1
+                for j in range(t):
+                    xp *= x
+                    acc += draws[j * n + h] * xp
+                out[i][h] = acc % F.modulus
+    return out
+
+
+def random_split(F: Field, s: Sequence[int], t: int, m: int, draws: Sequence[int]) -> List[List[int]]:
+    """thresha.py:23-44 (list path).  For secret h the t draws are consecutive,
+    c = draws[h*t:(h+1)*t], and Horner y = (y + c_j) * x puts c[0] on X^t."""
+    n = len(s)
+    out = [[0] * n for _ in range(m)]
+    for h in range(n):
+        c = draws[h * t:(h + 1) * t]
+        for i in range(m):
+            x = i + 1
+            y = 0
+            for cj in c:
+                y = clmul(y ^ cj, x) if F.binary else (y + cj) * x
+            out[i][h] = clmod(y ^ s[h], F.modulus) if F.binary else (y + s[h]) % F.modulus
+    return out
+
+
+def list_to_np_draws(draws: Sequence[int], t: int, n: int) -> List[int]:
+    """Permutation that feeds the np-convention kernel so that it reproduces the
+    list path: np coefficient row j (X^(j+1)) must be list draw c_h[t-1-j]
+    (SURVEY.md appendix A.1)."""
+    return [draws[h * t + (t - 1 - j)] for j in range(t) for h in range(n)]
+
+
+# --------------------------------------------------------------------------
+# Lagrange recombination
+# --------------------------------------------------------------------------
+def recombination_vector(F: Field, xs: Sequence[int], x_r: int) -> List[int]:
+    """thresha.py:67-85: lambda_i = prod_{j != i} (x_r - x_j) / (x_i - x_j), in the
+    order of xs."""
+    xs = [reduce(F, x) for x in xs]
+    x_r = reduce(F, x_r)
+    out = []
+    for i, xi in enumerate(xs):
+        num, den = 1, 1
+        for j, xj in enumerate(xs):
+            if i != j:
+                num = mul(F, num, sub(F, x_r, xj))
+                den = mul(F, den, sub(F, xi, xj))
+        out.append(mul(F, num, inv(F, den)))
+    return out
+
+
+def np_recombine(F: Field, points: Sequence[Tuple[int, Sequence[int]]], x_rs=0):
+    """thresha.py:119-132: sums = Lambda @ rows, reduced once at the end
+    (finfields.py:1126-1135).  Returns a list (x_rs scalar) or list of lists."""
+    xs = [p[0] for p in points]
+    rows = [[reduce(F, v) for v in p[1]] for p in points]     # field.array(shares), :128
+    scalar = not isinstance(x_rs, list)
+    xr_list = [x_rs] if scalar else x_rs
+    n = len(rows[0])
+    outs = []
+    for x_r in xr_list:
+        lam = recombination_vector(F, xs, x_r)
+        row = []
+        for h in range(n):
+            if F.binary:
+                acc = 0
+                for j in range(len(rows)):
+                    acc ^= clmul(lam[j], rows[j][h])
+                row.append(clmod(acc, F.modulus))
+            else:
+                acc = 0
+                for j in range(len(rows)):
+                    acc += lam[j] * rows[j][h]
+                row.append(acc % F.modulus)
+        outs.append(row)
+    return outs[0] if scalar else outs
+
+
+def recombine_unreduced(F: Field, points: Sequence[Tuple[int, Sequence[int]]], x_r=0) -> List[int]:
+    """thresha.py:88-116 on raw ints: the sums are NOT reduced (:109); callers
+    reduce afterwards (runtime.py:588,682)."""
+    xs = [p[0] for p in points]
+    lam = recombination_vector(F, xs, x_r)
+    n = len(points[0][1])
+    out = []
+    for h in range(n):
+        acc = 0
+        for j, (_, row) in enumerate(points):
+            acc = (acc ^ clmul(row[h], lam[j])) if F.binary else acc + row[h] * lam[j]
+        out.append(acc)
+    return out
+
+
+# --------------------------------------------------------------------------
+# GF(2^8) S-box on public bytes (demos/np_aes.py:37-43)
+# --------------------------------------------------------------------------
+AES_MOD = 0x11b
+
+
+def aes_affine_rows() -> Tuple[List[int], int]:
+    """A = circulant([1,0,0,0,1,1,1,1]) (np_aes.py:23-30: row j is the first row
+    rolled right by j), B = [1,1,0,0,0,1,1,0] little-endian -> 0x63."""
+    r = [1, 0, 0, 0, 1, 1, 1, 1]
+    rows = []
+    for j in range(8):
+        rows.append(sum(r[(c - j) % 8] << c for c in range(8)))
+    b = sum(bit << i for i, bit in enumerate([1, 1, 0, 0, 0, 1, 1, 0]))
+    return rows, b
+
+
+def pow254(F: Field, a: int) -> int:
+    """runtime.py:1356-1367 addition chain (11 multiplications)."""
+    d = a
+    c = mul(F, d, d)
+    c = mul(F, c, c)
+    c = mul(F, c, c)
+    c = mul(F, c, d)
+    c = mul(F, c, c)
+    c, d = mul(F, c, c), mul(F, c, d)
+    c, d = mul(F, c, c), mul(F, c, d)
+    c = mul(F, c, d)
+    return mul(F, c, c)
+
+
+def sbox(x: Iterable[int], rows8: Sequence[int] = None, b: int = None) -> List[int]:
+    """np_aes.py:37-43: bits(x^254) -> A @ bits + B -> byte."""
+    F = Field(AES_MOD, binary=True)
+    if rows8 is None:
+        rows8, b = aes_affine_rows()
+    out = []
+    for v in x:
+        iv = pow254(F, v)
+        y = 0
+        for r in range(8):
+            y |= (bin(iv & rows8[r]).count('1') & 1) << r
+        out.append(y ^ b)
+    return out

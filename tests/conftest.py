@@ -1,0 +1,55 @@
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _newer(src, dst):
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+@pytest.fixture(scope='session')
+def hostcheck():
+    """tests/_hostcheck.so: mpyc_amd/csrc/fields.hpp compiled with g++ (test-only harness)."""
+    src = os.path.join(ROOT, 'tests', 'hostcheck.cpp')
+    dst = os.path.join(ROOT, 'tests', '_hostcheck.so')
+    deps = [src, os.path.join(ROOT, 'mpyc_amd', 'csrc', 'fields.hpp'),
+            os.path.join(ROOT, 'mpyc_amd', 'csrc', 'policy_build.hpp')]
+    if any(_newer(d, dst) for d in deps):
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-o', dst, src], check=True)
+    return ctypes.CDLL(dst)
+
+
+@pytest.fixture(scope='session')
+def golden_fields():
+    with open(os.path.join(GOLDEN, 'fields.json')) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope='session')
+def golden_sbox():
+    with open(os.path.join(GOLDEN, 'sbox.json')) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope='session')
+def coracle():
+    from oracle import coracle as co
+    src = os.path.join(ROOT, 'oracle', 'fforacle.c')
+    dst = os.path.join(ROOT, 'oracle', 'liboracle.so')
+    if _newer(src, dst):
+        co.build()
+    return co

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REAL reference (lschoe/mpyc, pure Python).
+
+Run in the build container only (the reference does not travel to the GPU box):
+
+    cd /tmp && PYTHONPATH=/root/reference python3 /root/repo/tests/golden/make_golden.py
+
+Everything written here is an input/output pair of a reference function on the
+hot path:
+    finfields.FiniteFieldArray + - * neg, ctor reduction     finfields.py:717-725,1056-1124,1189
+    thresha.np_random_split / random_split                   thresha.py:47-64 / 23-44
+    thresha._recombination_vector                            thresha.py:67-85
+    thresha.np_recombine / recombine                         thresha.py:119-132 / 88-116
+    GF(2^8) S-box on public values                           demos/np_aes.py:37-43
+Share generation is made reproducible by replacing secrets.randbelow (looked up at
+call time, thresha.py:37,58) with a replay of a recorded draw list.
+
+Integers are stored as hex strings; the files are small (n ~ 40 per case).
+"""
+import json
+import os
+import random
+import secrets
+import sys
+
+import numpy as np
+
+from mpyc import finfields, gfpx, thresha
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+rng = random.Random(20260925)
+
+P61 = 2**61 - 1
+P64 = 2**64 - 189
+P128 = 2**128 - 173
+P127 = 2**127 - 1
+P96 = 2**96 - 17
+P80 = int(finfields.find_prime_root(80)[0])          # default SecFxp-size prime
+P63G = 0x5BD1E995C6A4A793                            # generic 63-bit, checked prime below
+P128G = None                                         # generic 128-bit prime, found below
+P31 = 2**31 - 1
+P32G = 4294967291                                    # 2^32 - 5
+P40 = int(finfields.find_prime_root(40)[0])
+
+
+def next_prime_from(x):
+    from mpyc import gmpy as g
+    x |= 1
+    while not g.is_prime(x):
+        x += 2
+    return int(x)
+
+
+P63G = next_prime_from(P63G)
+P128G = next_prime_from(0xC2B2AE3D27D4EB4F165667B19E3779F9)   # "random" odd 128-bit start
+P100G = next_prime_from(0x9E3779B97F4A7C15F39CC0605)          # generic ~100-bit
+
+PRIMES = {
+    'P61': P61, 'P64': P64, 'P128': P128, 'P127': P127, 'P96': P96, 'P80': P80,
+    'P63G': P63G, 'P128G': P128G, 'P100G': P100G, 'P31': P31, 'P32G': P32G, 'P40': P40,
+    'GF19': 19, 'GF101': 101, 'GF2': 2, 'GF3': 3, 'GF65537': 65537,
+}
+
+GF2X = gfpx.GFpX(2)
+BINARIES = {
+    'GF2_8': int(finfields.find_irreducible(2, 8)),       # 0x11b, AES
+    'GF2_128': int(finfields.find_irreducible(2, 128)),   # x^128+x^7+x^2+x+1
+    'GF2_4': int(finfields.find_irreducible(2, 4)),
+    'GF2_2': int(finfields.find_irreducible(2, 2)),
+    'GF2_1': int(finfields.find_irreducible(2, 1)),
+    'GF2_16': int(finfields.find_irreducible(2, 16)),
+    'GF2_64': int(finfields.find_irreducible(2, 64)),
+    'GF2_100': int(finfields.find_irreducible(2, 100)),
+}
+
+
+def hx(v):
+    return hex(int(v))
+
+
+def hxl(a):
+    return [hx(v) for v in a]
+
+
+def edge_values(q, bits):
+    e = [0, 1, 2, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, 2**32 - 1, 2**32, 2**63, 2**64 - 1,
+         2**bits - 1, 2**(bits - 1)]
+    return [v % q for v in e]
+
+
+class Replay:
+    def __init__(self, order, count):
+        self.draws = [rng.randrange(order) for _ in range(count)]
+        # sprinkle extremes
+        for i, v in zip(range(0, count, 7), (0, order - 1, 1, order - 2)):
+            self.draws[i] = v % order
+        self.i = 0
+
+    def __call__(self, bound):
+        v = self.draws[self.i]
+        self.i += 1
+        assert v < bound
+        return v
+
+
+def field_case(name, F, is_binary):
+    q = F.order
+    bits = (q - 1).bit_length() if q > 2 else 1
+    ev = edge_values(q, max(bits, 1))
+    a = ev + [rng.randrange(q) for _ in range(27)]
+    b = list(reversed(ev)) + [rng.randrange(q) for _ in range(27)]
+    n = len(a)
+    A, B = F.array(a), F.array(b)
+
+    def ints(arr):
+        return [int(v) for v in arr.value.reshape(-1)]
+
+    case = {'name': name, 'binary': is_binary, 'modulus': hx(int(F.modulus)), 'order': hx(q),
+            'a': hxl(a), 'b': hxl(b)}
+    case['add'] = hxl(ints(A + B))
+    case['sub'] = hxl(ints(A - B))
+    case['mul'] = hxl(ints(A * B))
+    case['neg'] = hxl(ints(-A))
+    sc = a[5] if a[5] else 3 % q
+    case['scalar'] = hx(sc)
+    case['add_scalar'] = hxl(ints(A + F(sc)))
+    case['mul_scalar'] = hxl(ints(A * F(sc)))
+    case['rsub_scalar'] = hxl(ints(F(sc) - A))
+    # raw (unreduced) constructor inputs: finfields.py:724 `value %= modulus`
+    if not is_binary:
+        width = 8 * ((bits + 7) // 8)
+        width = 32 if width <= 32 else 64 if width <= 64 else 128
+        raw = [2**width - 1, 2**width - 2, q, q + 1, 2 * q % 2**width] + [rng.randrange(2**width) for _ in range(11)]
+        case['raw_width'] = width
+        case['raw'] = hxl(raw)
+        case['raw_reduced'] = hxl(ints(F.array(raw)))
+        case['neg_in'] = [-1, -2, -(q // 2), -q, -(q + 1)]
+        case['neg_in_reduced'] = hxl(ints(F.array(case['neg_in'])))
+    else:
+        width = 8 if bits <= 8 else 64 if bits <= 64 else 128
+        raw = [2**width - 1, 2**width - 2, q % 2**width, 1 << (width - 1)] + [rng.randrange(2**width) for _ in range(12)]
+        case['raw_width'] = width
+        case['raw'] = hxl(raw)
+        case['raw_reduced'] = hxl(ints(F.array(raw)))
+
+    # ---- sharing -------------------------------------------------------
+    shares_cases = []
+    s = a[: 13] + a[-5:]
+    n = len(s)
+    tms = [(0, 1), (1, 3), (3, 7), (1, 2), (4, 9)]
+    if name == 'P64':
+        tms += [(2, 5), (5, 11), (1, 4)]
+    for (t, m) in tms:
+        if m >= q:       # thresha needs m < order (sectypes.py:639-647)
+            continue
+        rp = Replay(q, t * n)
+        old = secrets.randbelow
+        secrets.randbelow = rp
+        try:
+            sh_np = thresha.np_random_split(F, F.array(s), t, m)
+        finally:
+            secrets.randbelow = old
+        rp2 = Replay.__new__(Replay)
+        rp2.draws, rp2.i = rp.draws, 0
+        secrets.randbelow = rp2
+        try:
+            sh_list = thresha.random_split(F, list(s), t, m)
+        finally:
+            secrets.randbelow = old
+        sc_ = {'t': t, 'm': m, 'draws': hxl(rp.draws),
+               'np_shares': [hxl(int(v) for v in row) for row in sh_np],
+               'list_shares': [hxl(int(v) for v in row) for row in sh_list]}
+        # recombination from several point sets (orders matter: thresha.py:67-85)
+        recs = []
+        xsets = [tuple(range(1, t + 2)), tuple(range(m - t, m + 1)), tuple((j % m) + 1 for j in range(1, t + 2))]
+        if 2 * t + 1 <= m:
+            xsets.append(tuple(range(1, 2 * t + 2)))
+            xsets.append(tuple(((1 + j) % m) + 1 for j in range(2 * t + 1)))
+        for xs in xsets:
+            if len(set(xs)) != len(xs):
+                continue
+            vec = thresha._recombination_vector(F, xs, 0)
+            pts = [(x, sh_np[x - 1]) for x in xs]
+            y = thresha.np_recombine(F, pts)
+            assert [int(v) for v in y.value] == [int(F(v).value) for v in s], (name, t, m, xs)
+            pts_l = [(x, [int(v) for v in sh_np[x - 1]]) for x in xs]
+            y_l = thresha.recombine(F, pts_l)       # unreduced for raw ints (thresha.py:109)
+            recs.append({'xs': list(xs), 'vector': hxl(int(v) for v in vec),
+                         'np_out': hxl(int(v) for v in y.value),
+                         'list_out_unreduced': hxl(int(v) for v in y_l)})
+        # multi-point recombination (x_rs list, thresha.py:96-97,125-131)
+        xs = tuple(range(1, t + 2))
+        x_rs = [0, m + 1 if m + 1 < q else 0, 1]
+        pts = [(x, sh_np[x - 1]) for x in xs]
+        yw = thresha.np_recombine(F, pts, x_rs)
+        vecs = [thresha._recombination_vector(F, xs, xr) for xr in x_rs]
+        sc_['multi'] = {'xs': list(xs), 'x_rs': x_rs, 'vectors': [hxl(int(v) for v in vv) for vv in vecs],
+                        'out': [hxl(int(v) for v in row) for row in yw.value]}
+        sc_['recombine'] = recs
+        shares_cases.append(sc_)
+    case['sharing'] = shares_cases
+    return case
+
+
+def sbox_case():
+    f256 = finfields.GF(GF2X(BINARIES['GF2_8']))
+    # demos/np_aes.py:23-33: A = circulant([1,0,0,0,1,1,1,1]), B = [1,1,0,0,0,1,1,0]
+    r = [1, 0, 0, 0, 1, 1, 1, 1]
+    A = [[r[(c - j) % 8] for c in range(8)] for j in range(8)]   # np.roll(r, j): row j
+    B = [1, 1, 0, 0, 0, 1, 1, 0]
+    table = []
+    x = f256.array(list(range(256)))
+    inv = x**254
+    for v in inv.value:
+        bits = [(int(v) >> i) & 1 for i in range(8)]
+        y = [(sum(A[rr][c] & bits[c] for c in range(8)) + B[rr]) & 1 for rr in range(8)]
+        table.append(sum(y[i] << i for i in range(8)))
+    assert table[:4] == [0x63, 0x7c, 0x77, 0x7b], table[:4]     # FIPS-197
+    rows8 = [sum(A[rr][c] << c for c in range(8)) for rr in range(8)]
+    bbyte = sum(B[i] << i for i in range(8))
+    kat = {'16*16': int((f256(16) * f256(16)).value), '32*16': int((f256(32) * f256(16)).value),
+           '57*67': int((f256(57) * f256(67)).value), '137/57': int((f256(137) / f256(57)).value),
+           '3*3': int((f256(3) * f256(3)).value), '48*16': int((f256(48) * f256(16)).value)}
+    return {'modulus': hx(BINARIES['GF2_8']), 'rows8': rows8, 'b': bbyte, 'table': table,
+            'pow254': [int(v) for v in inv.value], 'kat': kat}
+
+
+def main():
+    cases = {}
+    for name, p in PRIMES.items():
+        F = finfields.GF(p)
+        cases[name] = field_case(name, F, False)
+    for name, mod in BINARIES.items():
+        F = finfields.GF(GF2X(mod))
+        cases[name] = field_case(name, F, True)
+    with open(os.path.join(OUT, 'fields.json'), 'w') as fh:
+        json.dump(cases, fh, separators=(',', ':'))
+    with open(os.path.join(OUT, 'sbox.json'), 'w') as fh:
+        json.dump(sbox_case(), fh, separators=(',', ':'))
+    # Appendix A.1 spot values recorded in SURVEY.md (list vs np coefficient convention)
+    F = finfields.GF(P61)
+    old = secrets.randbelow
+    it = iter(range(1000, 2000))
+    secrets.randbelow = lambda b: next(it)
+    l_ = thresha.random_split(F, [5, 7, 11], 2, 3)
+    it = iter(range(1000, 2000))
+    n_ = thresha.np_random_split(F, F.array([5, 7, 11]), 2, 3)
+    secrets.randbelow = old
+    with open(os.path.join(OUT, 'convention.json'), 'w') as fh:
+        json.dump({'list': [[int(v) for v in r] for r in l_], 'np': [[int(v) for v in r] for r in n_]}, fh)
+    print('wrote', len(cases), 'field cases; sizes:',
+          {f: os.path.getsize(os.path.join(OUT, f)) for f in ('fields.json', 'sbox.json', 'convention.json')})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,107 @@
+// hostcheck.cpp -- TEST-ONLY harness.  Compiles mpyc_amd/csrc/fields.hpp with
+// plain g++ (no HIP) so that the exact arithmetic the GPU kernels run can be
+// compared against Python integers on a machine without a GPU.  It is built
+// into tests/_hostcheck.so by tests/conftest.py and is never loaded by the
+// product package; libffgpu.so has no CPU execution path.
+#include <stdint.h>
+#include <string.h>
+#include "../mpyc_amd/csrc/policy_build.hpp"
+
+using namespace ffgpu;
+
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7 };
+
+template <class F>
+static typename F::word ldw(const unsigned char* p, size_t i) {
+    typename F::elem e;
+    memcpy(&e, p + i * sizeof(e), sizeof(e));
+    if constexpr (F::EPW == 1) {
+        return e;
+    } else {
+        return (typename F::word)e;
+    }
+}
+template <class F>
+static void stw(unsigned char* p, size_t i, typename F::word w) {
+    typename F::elem e;
+    if constexpr (F::EPW == 1) {
+        e = w;
+    } else {
+        e = (typename F::elem)w;
+    }
+    memcpy(p + i * sizeof(e), &e, sizeof(e));
+}
+
+template <class F>
+static typename F::word cst(const F& f, const uint64_t* l) {
+    if constexpr (sizeof(typename F::elem) == 16) {
+        typename F::word w;
+        w.lo = l[0];
+        w.hi = l[1];
+        return w;
+    } else if constexpr (F::EPW == 4) {
+        return (uint32_t)(l[0] & 0xff) * 0x01010101u;
+    } else {
+        return (typename F::word)l[0];
+    }
+}
+
+// a,b,c: n elements each; for HC_DOT: a holds k rows of n elements, lam holds k
+// canonical 2-limb constants, x ignored.  For HC_MULADD_SMALL x is the small
+// public multiplier.
+template <class F>
+static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsigned char* b,
+               const unsigned char* c, unsigned char* out, size_t n, uint32_t x, const uint64_t* lam, int k) {
+    F f;
+    memcpy(&f, pb.bytes, sizeof(F));
+    for (size_t i = 0; i < n; ++i) {
+        typename F::word r;
+        switch (op) {
+            case HC_ADD: r = f.add(ldw<F>(a, i), ldw<F>(b, i)); break;
+            case HC_SUB: r = f.sub(ldw<F>(a, i), ldw<F>(b, i)); break;
+            case HC_MUL: r = f.mul(ldw<F>(a, i), ldw<F>(b, i)); break;
+            case HC_NEG: r = f.neg(ldw<F>(a, i)); break;
+            case HC_REDUCE: r = f.reduce_raw(ldw<F>(a, i)); break;
+            case HC_MULADD: r = f.muladd(ldw<F>(a, i), ldw<F>(b, i), ldw<F>(c, i)); break;
+            case HC_MULADD_SMALL: r = f.muladd_small(ldw<F>(a, i), x, ldw<F>(c, i)); break;
+            case HC_DOT: {
+                typename F::acc s;
+                f.acc_zero(s);
+                for (int j = 0; j < k; ++j)
+                    f.acc_mac(s, f.prep(cst<F>(f, lam + 2 * j)), ldw<F>(a, (size_t)j * n + i));
+                r = f.acc_reduce(s);
+                break;
+            }
+            default: return 1;
+        }
+        stw<F>(out, i, r);
+    }
+    return 0;
+}
+
+extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, const unsigned char* a,
+                      const unsigned char* b, const unsigned char* c, unsigned char* out, size_t n,
+                      uint32_t x, const uint64_t* lam, int k, int* policy_kind, int* elem_bytes) {
+    PolicyBlob pb;
+    memset(&pb, 0, sizeof(pb));
+    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs)
+                    : build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+    if (rc) return 100 + rc;
+    if (policy_kind) *policy_kind = pb.kind;
+    if (elem_bytes) *elem_bytes = pb.elem_bytes;
+    if (n == 0) return 0;
+    switch (pb.kind) {
+        case POL_PM64_MERSENNE: return run<PM64<false, true> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM64_K64: return run<PM64<true, false> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM64_GEN: return run<PM64<false, false> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_RC64: return run<RC64>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_RC32: return run<RC32>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM128_K128: return run<PM128<true> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM128_GEN: return run<PM128<false> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_MONT128: return run<MONT128>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_GF2P8: return run<GF2P8>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_GF2W128: return run<GF2W128>(pb, op, a, b, c, out, n, x, lam, k);
+        default: return 2;
+    }
+}

@@ -1,0 +1,102 @@
+"""C-ABI boundary checks that need no GPU: the library loads, exports exactly what
+include/ffgpu.h declares, classifies moduli, and rejects bad arguments with status codes
+(no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    from mpyc_amd import _ffi
+    if not os.path.exists(_ffi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _ffi.lib()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'ffgpu.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(ffgpu_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_header_symbols_exported(L):
+    from mpyc_amd import _ffi
+    decl = declared_symbols()
+    assert len(decl) >= 30
+    out = subprocess.run(['nm', '-D', '--defined-only', _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (ffgpu_[a-z0-9_]+)', out))
+    missing = [s for s in decl if s not in exported]
+    assert not missing, f'declared in include/ffgpu.h but not exported: {missing}'
+    assert sorted(_ffi.EXPORTED) == decl, 'python binding and header disagree'
+    for s in decl:
+        getattr(L, s)
+
+
+def test_version_and_strerror(L):
+    assert L.ffgpu_abi_version() == 1
+    assert L.ffgpu_strerror(0) == b'ok'
+    assert b'invalid' in L.ffgpu_strerror(1)
+
+
+def mk(L, kind, modulus, nl=3):
+    from mpyc_amd import _ffi
+    h = ctypes.c_void_p()
+    rc = L.ffgpu_ctx_create(kind, _ffi.limbs(modulus, nl), nl, 0, ctypes.byref(h))
+    return rc, h
+
+
+def test_ctx_classification(L):
+    from mpyc_amd import _ffi
+    cases = [
+        (_ffi.PRIME, 2**61 - 1, 8, 1), (_ffi.PRIME, 2**64 - 189, 8, 1), (_ffi.PRIME, 2**128 - 173, 16, 1),
+        (_ffi.PRIME, 2**127 - 1, 16, 1), (_ffi.PRIME, 2**96 - 17, 16, 1), (_ffi.PRIME, 19, 4, 2),
+        (_ffi.PRIME, 2**31 - 1, 4, 2), (_ffi.PRIME, 6616754906730473363, 8, 2),
+        (_ffi.PRIME, 0xC2B2AE3D27D4EB4F165667B19E377A0F, 16, 5),
+        (_ffi.BINARY, 0x11b, 1, 3), (_ffi.BINARY, 0b111, 1, 3), (_ffi.BINARY, (1 << 64) | 0x1b, 8, 4),
+        (_ffi.BINARY, (1 << 128) | 0x87, 16, 4),
+    ]
+    for kind, mod, eb, red in cases:
+        rc, h = mk(L, kind, mod)
+        assert rc == 0, (hex(mod), rc)
+        assert L.ffgpu_ctx_elem_bytes(h) == eb, hex(mod)
+        assert L.ffgpu_ctx_reduction(h) == red, hex(mod)
+        assert L.ffgpu_ctx_device(h) == 0
+        L.ffgpu_ctx_destroy(h)
+
+
+def test_bad_arguments(L):
+    from mpyc_amd import _ffi
+    assert mk(L, _ffi.PRIME, 0)[0] == _ffi.EMODULUS
+    assert mk(L, _ffi.PRIME, 1)[0] == _ffi.EMODULUS
+    assert mk(L, _ffi.PRIME, 1 << 128)[0] == _ffi.ENOTSUP          # 129-bit "prime"
+    assert mk(L, _ffi.PRIME, (1 << 127) + 2**40)[0] == _ffi.EMODULUS  # even two-limb modulus
+    assert mk(L, 7, 19)[0] == _ffi.EINVAL
+    assert mk(L, _ffi.BINARY, 1)[0] == _ffi.EMODULUS
+    rc, h = mk(L, _ffi.PRIME, 2**61 - 1)
+    assert rc == 0
+    # split: 0 <= t < m (thresha.py:26), null pointers, strides
+    assert L.ffgpu_split(h, 16, 16, 8, 3, 3, 16, 8, 8, None) == _ffi.EINVAL
+    assert L.ffgpu_split(h, None, 16, 8, 1, 3, 16, 8, 8, None) == _ffi.EINVAL
+    assert L.ffgpu_split(h, 16, 16, 8, 1, 3, 16, 4, 8, None) == _ffi.EINVAL      # share_stride < n
+    assert L.ffgpu_split(h, 16, None, 0, 0, 1, 16, 0, 0, None) == _ffi.OK        # n == 0 is a no-op
+    assert L.ffgpu_mul(h, None, None, None, 0, None) == _ffi.OK
+    assert L.ffgpu_mul(h, None, 16, 16, 4, None) == _ffi.EINVAL
+    assert L.ffgpu_recombine(h, None, None, 0, 1, 16, 8, 8, None) == _ffi.EINVAL
+    rows8 = (ctypes.c_uint8 * 8)()
+    assert L.ffgpu_gf256_sbox(h, 16, rows8, 0, 16, 8, None) == _ffi.ENOTSUP    # not GF(2^8)
+    L.ffgpu_ctx_destroy(h)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mpyc_amd import _ffi
+    monkeypatch.setattr(_ffi, '_lib', None)
+    monkeypatch.setattr(_ffi, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_ffi.FfgpuError):
+        _ffi.lib()

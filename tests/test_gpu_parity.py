@@ -1,0 +1,357 @@
+"""GPU parity tests: the HIP path, called through the C ABI (mpyc_amd.engine -> libffgpu.so),
+against (1) the golden vectors produced by the real reference, (2) the pinned oracle on seeded
+inputs, (3) size-independent properties at BASELINE.json's full sizes (10^7).
+Bit-exact everywhere: this is integer / GF(2) arithmetic."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from oracle.coracle import elem_bytes
+from fieldutil import P61, P64, P128, edge_values, field_of, pack, rand_values, unhex, unpack
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def eng():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from mpyc_amd import engine
+    return engine
+
+
+_ctx_cache = {}
+
+
+def ctx_for(eng, modulus, binary):
+    key = (modulus, binary)
+    if key not in _ctx_cache:
+        _ctx_cache[key] = eng.FieldContext(modulus, binary, device=0)
+    return _ctx_cache[key]
+
+
+def dev(ctx, vals):
+    return ctx.from_numpy(pack(vals, ctx.elem_bytes))
+
+
+def host(arr):
+    return unpack(arr.to_numpy(), arr.ctx.elem_bytes)
+
+
+def devmat(ctx, rows_of_ints):
+    eb = ctx.elem_bytes
+    r, n = len(rows_of_ints), len(rows_of_ints[0])
+    flat = pack([v for row in rows_of_ints for v in row], eb)
+    return ctx.matrix_from_numpy(flat.reshape((r, n, 2) if eb == 16 else (r, n)))
+
+
+def hostmat(mtx):
+    a = mtx.to_numpy()
+    return [unpack(a[i], mtx.ctx.elem_bytes) for i in range(mtx.rows)]
+
+
+# ---------------------------------------------------------------------------
+# 1. golden vectors from the reference
+# ---------------------------------------------------------------------------
+def test_golden_elementwise(eng, golden_fields):
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        ctx = ctx_for(eng, F.modulus, F.binary)
+        assert ctx.elem_bytes == elem_bytes(F.modulus, F.binary)
+        a, b = unhex(case['a']), unhex(case['b'])
+        A, B = dev(ctx, a), dev(ctx, b)
+        assert host(ctx.add(A, B)) == unhex(case['add']), name
+        assert host(ctx.sub(A, B)) == unhex(case['sub']), name
+        assert host(ctx.mul(A, B)) == unhex(case['mul']), name
+        assert host(ctx.neg(A)) == unhex(case['neg']), name
+        sc = int(case['scalar'], 16)
+        assert host(ctx.add_scalar(A, sc)) == unhex(case['add_scalar']), name
+        assert host(ctx.mul_scalar(A, sc)) == unhex(case['mul_scalar']), name
+        assert host(ctx.rsub_scalar(A, sc)) == unhex(case['rsub_scalar']), name
+        if case['raw_width'] == 8 * ctx.elem_bytes:
+            assert host(ctx.reduce(dev(ctx, unhex(case['raw'])))) == unhex(case['raw_reduced']), name
+
+
+def test_golden_sharing(eng, golden_fields):
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        ctx = ctx_for(eng, F.modulus, F.binary)
+        a = unhex(case['a'])
+        s = a[:13] + a[-5:]
+        n = len(s)
+        S = dev(ctx, s)
+        for sc in case['sharing']:
+            t, m, draws = sc['t'], sc['m'], unhex(sc['draws'])
+            C = devmat(ctx, [draws[j * n:(j + 1) * n] for j in range(t)]) if t else None
+            sh = ctx.split(S, C, t, m)
+            got = hostmat(sh)
+            assert got == [unhex(r) for r in sc['np_shares']], (name, t, m)
+            # list-path convention = np kernel fed with permuted draws (thresha.py:37-43)
+            if t:
+                perm = po.list_to_np_draws(draws, t, n)
+                Cl = devmat(ctx, [perm[j * n:(j + 1) * n] for j in range(t)])
+                assert hostmat(ctx.split(S, Cl, t, m)) == [unhex(r) for r in sc['list_shares']], (name, t, m)
+            for rec in sc['recombine']:
+                xs = rec['xs']
+                out = ctx.recombine([sh.row(x - 1) for x in xs], unhex(rec['vector']))
+                assert host(out) == unhex(rec['np_out']), (name, t, m, xs)
+            mu = sc['multi']
+            lam = [v for vv in mu['vectors'] for v in unhex(vv)]
+            out = ctx.recombine([sh.row(x - 1) for x in mu['xs']], lam, w=len(mu['x_rs']))
+            assert hostmat(out) == [unhex(r) for r in mu['out']], (name, t, m)
+
+
+def test_golden_sbox_and_kats(eng, golden_sbox):
+    ctx = ctx_for(eng, 0x11b, True)
+    x = dev(ctx, list(range(256)))
+    out = ctx.sbox(x, golden_sbox['rows8'], golden_sbox['b'])
+    assert host(out) == golden_sbox['table']
+    # tests/test_finfields.py:29-30,94-99
+    a = dev(ctx, [16, 32, 57, 3, 48])
+    b = dev(ctx, [16, 16, 67, 3, 16])
+    assert host(ctx.mul(a, b)) == [27, 54, 137, 5, 45]
+    # x^254 * x == 1 for x != 0 (tests/test_runtime.py:818-843), through the mul kernel
+    v = dev(ctx, list(range(1, 256)))
+    d = v
+    c = ctx.mul(d, d); c = ctx.mul(c, c); c = ctx.mul(c, c); c = ctx.mul(c, d); c = ctx.mul(c, c)
+    c, d = ctx.mul(c, c), ctx.mul(c, d)
+    c, d = ctx.mul(c, c), ctx.mul(c, d)
+    c = ctx.mul(c, d); c = ctx.mul(c, c)
+    assert host(c) == golden_sbox['pow254'][1:]
+    assert host(ctx.mul(c, v)) == [1] * 255
+    # big random S-box batch vs the table
+    rng = np.random.default_rng(1)
+    big = rng.integers(0, 256, size=1_000_003, dtype=np.uint8)
+    got = ctx.sbox(ctx.from_numpy(big), golden_sbox['rows8'], golden_sbox['b']).to_numpy()
+    assert (got == np.array(golden_sbox['table'], dtype=np.uint8)[big]).all()
+
+
+# ---------------------------------------------------------------------------
+# 2. seeded inputs vs the pinned C oracle (vector path + scalar tails)
+# ---------------------------------------------------------------------------
+FIELDS = [(P61, False), (P64, False), (P128, False), (2**127 - 1, False), (2**96 - 17, False),
+          (6616754906730473363, False), (0xC2B2AE3D27D4EB4F165667B19E377A0F, False), (2**31 - 1, False),
+          (65537, False), (0x11b, True), (0b10011, True), ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]
+
+
+def rand_np(F, eb, n, seed):
+    """Uniform canonical elements, edge block first."""
+    rng = np.random.default_rng(seed)
+    if F.binary:
+        nb = F.n
+    else:
+        nb = F.modulus.bit_length()
+    raw = rng.integers(0, 2**64, size=(n, 2), dtype=np.uint64)
+    if eb <= 8:
+        if F.binary:
+            v = raw[:, 0] & np.uint64((1 << nb) - 1)
+        else:
+            v = (raw[:, 0] >> np.uint64(64 - nb)) if nb < 64 else raw[:, 0]
+            p = np.uint64(F.modulus)
+            v = np.where(v >= p, v - p, v)
+        out = v.astype({1: np.uint8, 4: np.uint32, 8: np.uint64}[eb])
+    else:
+        hi_bits = nb - 64
+        hi = raw[:, 1] >> np.uint64(64 - hi_bits) if hi_bits < 64 else raw[:, 1]
+        out = np.stack([raw[:, 0], hi], axis=1)
+        # canonicalise with python for the (rare) >= p case
+        if not F.binary:
+            p = F.modulus
+            big = (out[:, 1] > np.uint64(p >> 64)) | ((out[:, 1] == np.uint64(p >> 64)) & (out[:, 0] >= np.uint64(p & (2**64 - 1))))
+            for i in np.nonzero(big)[0]:
+                v = ((int(out[i, 1]) << 64) | int(out[i, 0])) - p
+                out[i, 0], out[i, 1] = v & (2**64 - 1), v >> 64
+    ev = pack(edge_values(F), eb)
+    k = min(len(ev), n)
+    out[:k] = ev[:k]
+    return out
+
+
+@pytest.mark.parametrize('modulus,binary', FIELDS)
+def test_vs_oracle_elementwise(eng, coracle, modulus, binary):
+    F = po.Field(modulus, binary)
+    ctx = ctx_for(eng, modulus, binary)
+    eb = ctx.elem_bytes
+    cf = coracle.CField(modulus, binary)
+    n = 20011 if eb == 16 and (binary or ctx.reduction == 'montgomery') else 100003   # odd: exercises tails
+    A, B, Cc = rand_np(F, eb, n, 11), rand_np(F, eb, n, 12), rand_np(F, eb, n, 13)
+    dA, dB, dC = ctx.from_numpy(A), ctx.from_numpy(B), ctx.from_numpy(Cc)
+    assert (ctx.add(dA, dB).to_numpy() == cf.ew(coracle.ADD, A, B)).all()
+    assert (ctx.sub(dA, dB).to_numpy() == cf.ew(coracle.SUB, A, B)).all()
+    prod = cf.ew(coracle.MUL, A, B)
+    assert (ctx.mul(dA, dB).to_numpy() == prod).all()
+    assert (ctx.neg(dA).to_numpy() == cf.ew(coracle.NEG, A)).all()
+    assert (ctx.muladd(dA, dB, dC).to_numpy() == cf.ew(coracle.ADD, prod, Cc)).all()
+    # in place (finfields.py:1114-1124 __imul__)
+    tmp = dA.clone()
+    ctx.mul(tmp, dB, out=tmp)
+    assert (tmp.to_numpy() == prod).all()
+    # raw reduction of arbitrary limb patterns
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 2**64, size=A.shape, dtype=np.uint64).astype(A.dtype) if eb != 1 else \
+        rng.integers(0, 256, size=A.shape, dtype=np.uint8)
+    assert (ctx.reduce(ctx.from_numpy(raw)).to_numpy() == cf.ew(coracle.REDUCE, raw)).all()
+
+
+@pytest.mark.parametrize('modulus,binary', FIELDS)
+def test_vs_oracle_sharing(eng, coracle, modulus, binary):
+    F = po.Field(modulus, binary)
+    ctx = ctx_for(eng, modulus, binary)
+    eb = ctx.elem_bytes
+    cf = coracle.CField(modulus, binary)
+    n = 3001 if eb == 16 else 30011          # the C oracle's two-limb mulmod is shift-and-add
+    S, B = rand_np(F, eb, n, 21), rand_np(F, eb, n, 22)
+    dS, dB = ctx.from_numpy(S), ctx.from_numpy(B)
+    for (t, m) in [(0, 1), (1, 3), (2, 5), (3, 7), (4, 9), (6, 13)]:
+        if m >= F.order:
+            continue
+        Cn = rand_np(F, eb, max(t, 1) * n, 30 + t).reshape((max(t, 1), n, 2) if eb == 16 else (max(t, 1), n))
+        dC = ctx.matrix_from_numpy(Cn)
+        want = cf.split(S, Cn, t, m)
+        sh = ctx.split(dS, dC, t, m)
+        assert (sh.to_numpy() == want).all(), (t, m)
+        # fused local product + split == split(mul)
+        prod = cf.ew(coracle.MUL, S, B)
+        fused = ctx.split(dS, dC, t, m, mul_by=dB)
+        assert (fused.to_numpy() == cf.split(prod, Cn, t, m)).all(), (t, m)
+        # recombine from t+1 and (if available) 2t+1 rows, rotated x order
+        for k in {t + 1, min(2 * t + 1, m)}:
+            xs = [((3 + j) % m) + 1 for j in range(k)]
+            lam = po.recombination_vector(F, xs, 0)
+            rec = ctx.recombine([sh.row(x - 1) for x in xs], lam)
+            assert (rec.to_numpy() == cf.recombine([want[x - 1] for x in xs], lam)).all(), (t, m, k)
+            assert (rec.to_numpy() == S).all(), (t, m, k)          # round trip: it IS the secret
+
+
+def test_many_rows_and_outputs(eng, coracle):
+    """k > 9 rows (generic kernel), w > 8 outputs, t > 4 (generic split)."""
+    for modulus, binary in [(P64, False), (0x11b, True), (P128, False)]:
+        F = po.Field(modulus, binary)
+        ctx = ctx_for(eng, modulus, binary)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, binary)
+        n, t, m = 5003, 12, 25
+        S = rand_np(F, eb, n, 41)
+        Cn = rand_np(F, eb, t * n, 42).reshape((t, n, 2) if eb == 16 else (t, n))
+        sh = ctx.split(ctx.from_numpy(S), ctx.matrix_from_numpy(Cn), t, m)
+        want = cf.split(S, Cn, t, m)
+        assert (sh.to_numpy() == want).all()
+        xs = list(range(2, 2 + t + 1))
+        lam = po.recombination_vector(F, xs, 0)
+        rec = ctx.recombine([sh.row(x - 1) for x in xs], lam)
+        assert (rec.to_numpy() == S).all()
+        # 11 recombination points at once from 3 rows of a degree-2 sharing
+        Cn2 = rand_np(F, eb, 2 * n, 43).reshape((2, n, 2) if eb == 16 else (2, n))
+        sh2 = ctx.split(ctx.from_numpy(S), ctx.matrix_from_numpy(Cn2), 2, 5)
+        x_rs = list(range(0, 11)) if F.order > 11 else [0, 1, 2]
+        xs = [1, 2, 3]
+        lam = [v for xr in x_rs for v in po.recombination_vector(F, xs, xr)]
+        out = ctx.recombine([sh2.row(x - 1) for x in xs], lam, w=len(x_rs))
+        want2 = cf.recombine([cf.split(S, Cn2, 2, 5)[x - 1] for x in xs], lam, w=len(x_rs))
+        assert (out.to_numpy() == want2).all()
+
+
+def test_ragged_and_unaligned(eng, coracle):
+    """Empty, single-element and 16-byte-misaligned inputs take the scalar path."""
+    for modulus, binary in [(P61, False), (P128, False), (0x11b, True), (2**31 - 1, False)]:
+        F = po.Field(modulus, binary)
+        ctx = ctx_for(eng, modulus, binary)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, binary)
+        e = ctx.empty(0)
+        assert ctx.mul(e, e).n == 0
+        for n in (1, 2, 15, 17, 63, 257):
+            A, B = rand_np(F, eb, n + 3, n), rand_np(F, eb, n + 3, n + 1)
+            dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+            want = cf.ew(coracle.MUL, A, B)
+            assert (ctx.mul(dA, dB).to_numpy() == want).all()
+            if eb < 16:
+                # views starting one element in: pointer not 16-byte aligned
+                va = eng.DevArray(ctx, dA.t[1:1 + n], n)
+                vb = eng.DevArray(ctx, dB.t[1:1 + n], n)
+                out = ctx.mul(va, vb)
+                assert (out.to_numpy() == want[1:1 + n]).all()
+                sh = ctx.split(va, None, 0, 1)
+                assert (sh.to_numpy()[0] == A[1:1 + n]).all()
+
+
+# ---------------------------------------------------------------------------
+# 3. BASELINE.json full sizes: 10^7 elements
+# ---------------------------------------------------------------------------
+N_FULL = 10_000_000
+
+
+def test_full_size_modmul_p61(eng, coracle):
+    """configs[1]: SecFld(GF(2^61-1)) array of 10^7 elements, element-wise modmul, bit-exact."""
+    F = po.Field(P61)
+    ctx = ctx_for(eng, P61, False)
+    cf = coracle.CField(P61)
+    A, B = rand_np(F, 8, N_FULL, 101), rand_np(F, 8, N_FULL, 102)
+    got = ctx.mul(ctx.from_numpy(A), ctx.from_numpy(B)).to_numpy()
+    coracle.set_threads(coracle.max_threads())
+    want = cf.ew(coracle.MUL, A, B)
+    coracle.set_threads(1)
+    assert (got == want).all()
+    assert int(got[12345]) == int(A[12345]) * int(B[12345]) % P61
+
+
+def test_full_size_share_recombine_p64(eng):
+    """configs[2]: m=7, t=3, 10^7 secrets, 64-bit prime: round trip, linearity, zero-coefficient."""
+    F = po.Field(P64)
+    ctx = ctx_for(eng, P64, False)
+    t, m = 3, 7
+    S1, S2 = rand_np(F, 8, N_FULL, 201), rand_np(F, 8, N_FULL, 202)
+    C1 = rand_np(F, 8, t * N_FULL, 203).reshape(t, N_FULL)
+    C2 = rand_np(F, 8, t * N_FULL, 204).reshape(t, N_FULL)
+    dS1, dS2 = ctx.from_numpy(S1), ctx.from_numpy(S2)
+    dC1, dC2 = ctx.matrix_from_numpy(C1), ctx.matrix_from_numpy(C2)
+    sh1 = ctx.split(dS1, dC1, t, m)
+    # round trip from any t+1 rows and from 2t+1 rows
+    for xs in ([1, 2, 3, 4], [7, 5, 3, 1], [1, 2, 3, 4, 5, 6, 7]):
+        lam = po.recombination_vector(F, xs, 0)
+        rec = ctx.recombine([sh1.row(x - 1) for x in xs], lam)
+        assert torch.equal(rec.t, dS1.t), xs
+    # t rows are NOT enough to be the secret (degree really is t)
+    lam3 = po.recombination_vector(F, [1, 2, 3], 0)
+    assert not torch.equal(ctx.recombine([sh1.row(i) for i in range(3)], lam3).t, dS1.t)
+    # linearity: split(s1+s2; c1+c2) == split(s1;c1) + split(s2;c2), row by row
+    sh2 = ctx.split(dS2, dC2, t, m)
+    dSs = ctx.add(dS1, dS2)
+    dCs = ctx.empty_matrix(t, N_FULL)
+    for j in range(t):
+        ctx.add(dC1.row(j), dC2.row(j), out=dCs.row(j))
+    shs = ctx.split(dSs, dCs, t, m)
+    for i in range(m):
+        assert torch.equal(ctx.add(sh1.row(i), sh2.row(i)).t, shs.row(i).t), i
+    # spot-check a few columns against Python integers
+    h = [0, 1, 2, 9_999_999, 5_000_001]
+    for i in (0, 6):
+        x = i + 1
+        col = sh1.row(i).to_numpy()
+        for hh in h:
+            want = (int(S1[hh]) + sum(int(C1[j, hh]) * x**(j + 1) for j in range(t))) % P64
+            assert int(col[hh]) == want
+
+
+def test_full_size_gate_p128(eng):
+    """configs[3] shape on one GPU: 128-bit prime, gate = local product + reshare (m=7,t=3):
+    recombining the 2t+1 re-shared rows at x=0 gives a*b."""
+    F = po.Field(P128)
+    ctx = ctx_for(eng, P128, False)
+    n, t, m = 2_000_000, 3, 7
+    A, B = rand_np(F, 16, n, 301), rand_np(F, 16, n, 302)
+    C = rand_np(F, 16, t * n, 303).reshape(t, n, 2)
+    dA, dB, dC = ctx.from_numpy(A), ctx.from_numpy(B), ctx.matrix_from_numpy(C)
+    prod = ctx.mul(dA, dB)
+    sh = ctx.split(dA, dC, t, m, mul_by=dB)
+    xs = list(range(1, 2 * t + 2))
+    rec = ctx.recombine([sh.row(x - 1) for x in xs], po.recombination_vector(F, xs, 0))
+    assert torch.equal(rec.t, prod.t)
+    pi = prod.to_numpy()
+    for hh in (0, 1, n - 1, n // 2):
+        a = int(A[hh, 0]) | (int(A[hh, 1]) << 64)
+        b = int(B[hh, 0]) | (int(B[hh, 1]) << 64)
+        assert (int(pi[hh, 0]) | (int(pi[hh, 1]) << 64)) == a * b % P128

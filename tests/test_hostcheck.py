@@ -1,0 +1,136 @@
+"""CPU check of the DEVICE arithmetic (mpyc_amd/csrc/fields.hpp compiled with g++) against
+Python integers / the reference's golden outputs.  No GPU needed: this is how reduction
+bugs are caught before spending GPU minutes.  The harness is test-only."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from oracle.coracle import elem_bytes
+from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
+
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT = range(8)
+
+
+def limbs3(x):
+    return (ctypes.c_uint64 * 3)(*[(x >> (64 * i)) & (2**64 - 1) for i in range(3)])
+
+
+def run(hc, F, op, a, b=None, c=None, x=0, lam=None, k=0, n=None):
+    eb = elem_bytes(F.modulus, F.binary)
+    A = pack(a, eb)
+    n = n if n is not None else len(a)
+    B = pack(b, eb) if b is not None else None
+    C = pack(c, eb) if c is not None else None
+    out = np.zeros_like(A[:n] if eb != 16 else A[:n])
+    lam_arr = None
+    if lam is not None:
+        lam_arr = (ctypes.c_uint64 * (2 * len(lam)))()
+        for i, v in enumerate(lam):
+            lam_arr[2 * i], lam_arr[2 * i + 1] = v & (2**64 - 1), v >> 64
+    pk, ebo = ctypes.c_int(), ctypes.c_int()
+    p = lambda z: z.ctypes.data_as(ctypes.c_void_p) if z is not None else None
+    rc = hc.hc_run(int(F.binary), limbs3(F.modulus), 3, op, p(A), p(B), p(C), p(out), ctypes.c_size_t(n),
+                   ctypes.c_uint32(x), lam_arr, k, ctypes.byref(pk), ctypes.byref(ebo))
+    assert rc == 0, rc
+    assert ebo.value == eb
+    return unpack(out, eb), pk.value
+
+
+def all_cases(golden_fields):
+    return sorted(golden_fields)
+
+
+def test_policy_selection(hostcheck, golden_fields):
+    """Which reduction each modulus gets (policy_build.hpp)."""
+    kinds = {}
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        _, pk = run(hostcheck, F, HC_ADD, [0], [0])
+        kinds[name] = pk
+    # PolicyKind enum order in policy_build.hpp
+    PM64_MERS, PM64_K64, PM64_GEN, RC64, RC32, PM128_K128, PM128_GEN, MONT128, GF2P8, GF2W64, GF2W128 = range(1, 12)
+    assert kinds['P61'] == PM64_MERS and kinds['P64'] == PM64_K64 and kinds['P40'] == PM64_GEN
+    assert kinds['P63G'] == RC64 and kinds['P31'] == RC32 and kinds['GF19'] == RC32 and kinds['GF2'] == RC32
+    assert kinds['P128'] == PM128_K128 and kinds['P127'] == PM128_GEN and kinds['P96'] == PM128_GEN
+    assert kinds['P80'] == PM128_GEN and kinds['P128G'] == MONT128 and kinds['P100G'] == MONT128
+    assert kinds['GF2_8'] == GF2P8 and kinds['GF2_4'] == GF2P8 and kinds['GF2_1'] == GF2P8
+    assert kinds['GF2_16'] == GF2W64 and kinds['GF2_64'] == GF2W64
+    assert kinds['GF2_100'] == GF2W128 and kinds['GF2_128'] == GF2W128
+
+
+def test_golden_elementwise(hostcheck, golden_fields):
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        a, b = unhex(case['a']), unhex(case['b'])
+        for op, key in ((HC_ADD, 'add'), (HC_SUB, 'sub'), (HC_MUL, 'mul')):
+            got, _ = run(hostcheck, F, op, a, b)
+            assert got == unhex(case[key]), (name, key)
+        got, _ = run(hostcheck, F, HC_NEG, a)
+        assert got == unhex(case['neg']), name
+        eb = elem_bytes(F.modulus, F.binary)
+        if case['raw_width'] == 8 * eb:
+            got, _ = run(hostcheck, F, HC_REDUCE, unhex(case['raw']))
+            assert got == unhex(case['raw_reduced']), name
+
+
+def test_edges_cross_product(hostcheck, golden_fields):
+    """Every edge value against every edge value, + - * and fused multiply-add."""
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        ev = edge_values(F) + rand_values(F, 6, 1)
+        a, b = cross(ev)
+        for op, fn in ((HC_ADD, po.add), (HC_SUB, po.sub), (HC_MUL, po.mul)):
+            got, _ = run(hostcheck, F, op, a, b)
+            assert got == po.vec(fn, F, a, b), (name, op)
+        c = list(reversed(a))
+        got, _ = run(hostcheck, F, HC_MULADD, a, b, c)
+        assert got == [po.add(F, po.mul(F, x, y), z) for x, y, z in zip(a, b, c)], name
+
+
+def test_random_mul(hostcheck, golden_fields):
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        a, b = rand_values(F, 2000, 7), rand_values(F, 2000, 8)
+        got, _ = run(hostcheck, F, HC_MUL, a, b)
+        assert got == po.vec(po.mul, F, a, b), name
+
+
+def test_muladd_small(hostcheck, golden_fields):
+    """Horner step y*x + c with a public 32-bit x (party index)."""
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        ev = edge_values(F) + rand_values(F, 6, 2)
+        y, c = cross(ev)
+        xs = [1, 2, 3, 7, 255, 256, 65535, 2**31 - 1, 2**32 - 1]
+        for x in xs:
+            if F.binary and x >= F.order:
+                continue
+            got, _ = run(hostcheck, F, HC_MULADD_SMALL, y, None, c, x=x)
+            xr = x if F.binary else x % F.modulus
+            want = [po.add(F, po.mul(F, yy, xr), cc) for yy, cc in zip(y, c)]
+            assert got == want, (name, x)
+
+
+def test_dot(hostcheck, golden_fields):
+    """Unreduced accumulation + single reduction (recombination inner loop)."""
+    r = random.Random(5)
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        q = F.order
+        for k in (1, 2, 3, 7, 9, 64, 255):
+            n = 24
+            extremes = [q - 1] * n
+            rows = [extremes if j % 2 == 0 else rand_values(F, n, 100 + j) for j in range(k)]
+            lam = [q - 1 if j % 3 == 0 else r.randrange(q) for j in range(k)]
+            flat = [v for row in rows for v in row]
+            got, _ = run(hostcheck, F, HC_DOT, flat, lam=lam, k=k, n=n)
+            want = []
+            for h in range(n):
+                acc = 0
+                for j in range(k):
+                    acc = po.add(F, acc, po.mul(F, lam[j], rows[j][h]))
+                want.append(acc)
+            assert got == want, (name, k)
