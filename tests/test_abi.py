@@ -57,8 +57,8 @@ def test_ctx_classification(L):
     cases = [
         (_ffi.PRIME, 2**61 - 1, 8, 1), (_ffi.PRIME, 2**64 - 189, 8, 1), (_ffi.PRIME, 2**128 - 173, 16, 1),
         (_ffi.PRIME, 2**127 - 1, 16, 1), (_ffi.PRIME, 2**96 - 17, 16, 1), (_ffi.PRIME, 19, 4, 2),
-        (_ffi.PRIME, 2**31 - 1, 4, 2), (_ffi.PRIME, 6616754906730473363, 8, 2),
-        (_ffi.PRIME, 0xC2B2AE3D27D4EB4F165667B19E377A0F, 16, 5),
+        (_ffi.PRIME, 2**31 - 1, 4, 2), (_ffi.PRIME, 6616326157076047771, 8, 2),
+        (_ffi.PRIME, 258797994007609146293811961253269568351, 16, 5),
         (_ffi.BINARY, 0x11b, 1, 3), (_ffi.BINARY, 0b111, 1, 3), (_ffi.BINARY, (1 << 64) | 0x1b, 8, 4),
         (_ffi.BINARY, (1 << 128) | 0x87, 16, 4),
     ]

@@ -133,7 +133,7 @@ def test_golden_sbox_and_kats(eng, golden_sbox):
 # 2. seeded inputs vs the pinned C oracle (vector path + scalar tails)
 # ---------------------------------------------------------------------------
 FIELDS = [(P61, False), (P64, False), (P128, False), (2**127 - 1, False), (2**96 - 17, False),
-          (6616754906730473363, False), (0xC2B2AE3D27D4EB4F165667B19E377A0F, False), (2**31 - 1, False),
+          (6616326157076047771, False), (258797994007609146293811961253269568351, False), (2**31 - 1, False),
           (65537, False), (0x11b, True), (0b10011, True), ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]
 
 
