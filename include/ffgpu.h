@@ -167,8 +167,9 @@ int ffgpu_time_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, si
 int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda,
                          int k, int w, void* out, size_t out_stride, size_t n,
                          int reps, void* stream, float* ms_per_launch);
-/* device-to-device copy of `bytes` with the library's own streaming kernel:
- * the achievable-bandwidth yardstick reported next to the 8 TB/s nominal peak. */
+/* device-to-device copy of `bytes` (multiple of 16, 16-byte aligned) with the library's own
+ * streaming kernel: the achievable-bandwidth yardstick reported next to the 8 TB/s nominal peak. */
+int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,
                     int reps, void* stream, float* ms_per_launch);
 

@@ -60,6 +60,7 @@ _SIGS = {
     'ffgpu_time_split': [_vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],
     'ffgpu_time_recombine': [_vp, ctypes.POINTER(_vp), _u64p, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],
     'ffgpu_time_copy': [_vp, _vp, _vp, _sz, _int, _vp, _fp],
+    'ffgpu_copy': [_vp, _vp, _vp, _sz, _vp],
 }
 _RESTYPES = {'ffgpu_strerror': ctypes.c_char_p, 'ffgpu_last_hip_error': ctypes.c_char_p}
 

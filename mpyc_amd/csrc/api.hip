@@ -72,11 +72,13 @@ LaunchCfg launch_cfg(int device) {
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0)
             cus = 256;
-        int bpc = 8;
+        int bpc = 0;  // uncapped
         const char* e = getenv("FFGPU_BLOCKS_PER_CU");
-        if (e && atoi(e) > 0) bpc = atoi(e);
+        if (e && atoi(e) >= 0) bpc = atoi(e);
+        const char* ntv = getenv("FFGPU_NT");
         cache[d].num_cu = cus;
         cache[d].blocks_per_cu = bpc;
+        cache[d].nt = (ntv && atoi(ntv) == 0) ? 0 : 1;
         have[d] = true;
     }
     return cache[d];
@@ -364,6 +366,13 @@ int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uin
     return time_loop(ctx, reps, stream, ms, [&]() {
         return ffgpu_recombine(ctx, host_rows, host_lambda, k, w, out, out_stride, n, stream);
     });
+}
+int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream) {
+    ARGCHK(ctx);
+    if (bytes == 0) return FFGPU_OK;
+    ARGCHK(src && dst);
+    DeviceGuard g(ctx->device);
+    return launch_status(ffgpu_launch_copy(ctx->device, src, dst, bytes, (hipStream_t)stream));
 }
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, int reps, void* stream,
                     float* ms) {

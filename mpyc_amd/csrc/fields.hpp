@@ -107,8 +107,32 @@ struct PM64 {
         if (K64) return csub(x);
         return red128((ff_u128)x);
     }
+    // Horner step y*x + cadd with a 32-bit public x: the value T has only 96 bits
+    // (hi < 2^32, lo), so the fold is written out on (hi, lo) instead of going
+    // through the generic 128-bit path: 3 v_mad_u64_u32 + a few adds for k == 64.
     FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
-        return red128((ff_u128)y * x + cadd);
+        uint64_t p0 = (uint64_t)(uint32_t)y * x;
+        uint64_t p1 = (uint64_t)(uint32_t)(y >> 32) * x + (p0 >> 32);  // < 2^64
+        uint64_t lo = (p1 << 32) | (uint32_t)p0;
+        uint32_t hi = (uint32_t)(p1 >> 32);                              // y*x = hi:lo
+        lo += cadd;
+        hi += lo < cadd;                                                 // hi <= 2^32 - 1
+        if (K64) {
+            uint64_t u = (uint64_t)hi * c + lo;                          // hi*c < 2^63
+            if (u < lo) u += c;                                          // wrapped: 2^64 == c
+            return csub(u);
+        }
+        // k < 64: T = xh*2^k + xl,  xh < 2^(96-k) <= 2^63
+        uint64_t xh = ((uint64_t)hi << (64 - k)) | (lo >> k);
+        uint64_t xl = lo & mask;
+        if (C1) {
+            uint64_t w = xl + xh;                                        // < 2^64 (k >= 33)
+            return csub((w & mask) + (w >> k));
+        }
+        // xh*c may need 94 bits: fold in two steps
+        ff_u128 w = (ff_u128)xh * c + xl;
+        uint64_t wh = (uint64_t)(w >> k);
+        return csub((ff_lo(w) & mask) + wh * (uint64_t)c);
     }
     FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
         // a*b + c < p^2 + p < 2^(2k) for k<64; may wrap 128 bits only if k==64

@@ -4,12 +4,16 @@
 // is no dense contraction on this path).  Design rules, from the gfx950 guide:
 //   * 16 bytes per lane per access (global_load/store_dwordx4): a wave touches
 //     1 KiB of contiguous HBM per instruction and array;
-//   * all loads of an iteration are issued before the first use so that
-//     (rows+1) x UNROLL independent 1 KiB requests per wave are in flight;
-//   * grid = a few blocks per CU, grid-stride loop, consecutive blocks (which
-//     land on different XCDs, block b -> XCD b%8) read consecutive 4 KiB
-//     chunks, so every XCD's L2 and all HBM channels see the same uniform
-//     stream -- there is no reuse to localise in an L2, hence no remap;
+//   * all loads of a pack are issued before the first use, so a wave has
+//     (rows) independent 1 KiB requests in flight and a CU up to 32 x that;
+//   * one 16-byte pack per thread and an UNCAPPED grid (n/2/256 workgroups for
+//     64-bit fields, ~19.5k for n = 10^7): at 40-50 us per launch the hardware
+//     dispatcher balances the tail better than a capped grid-stride loop
+//     (measured: profiles/r01_tuning.md).  Consecutive blocks (which land on
+//     different XCDs, block b -> XCD b%8) touch consecutive 4 KiB chunks, so
+//     every XCD's L2 and all HBM channels see the same uniform stream; there is
+//     no reuse to localise in an L2, hence no XCD remap;
+//   * streamed-once data carries the non-temporal hint (nt) on loads and stores;
 //   * per-field constants (modulus, fold constant, Lagrange vector, party
 //     x-coordinates) are wave-uniform kernel arguments -> SGPRs, which beats
 //     staging them in LDS for fields this small.
@@ -30,6 +34,36 @@ struct alignas(16) Pack {
     enum { N = 16 / sizeof(W) };
     W w[N];
 };
+
+// 16-byte global accesses with an optional non-temporal hint.  Every array here is
+// streamed exactly once per launch, so by default loads and stores carry `nt`
+// (global_load/store_dwordx4 ... nt): measured +4..10 % on the 10^7-element kernels
+// (profiles/r01_tuning.md).  FFGPU_NT=0 turns the hint off.
+typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, class P>
+__device__ __forceinline__ P ldg(const P* p) {
+    static_assert(sizeof(P) == 16, "16-byte packs only");
+    if constexpr (NT) {
+        ff_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ff_u32x4*>(p));
+        P r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    } else {
+        return *p;
+    }
+}
+template <bool NT, class P>
+__device__ __forceinline__ void stg(P* p, const P& x) {
+    static_assert(sizeof(P) == 16, "16-byte packs only");
+    if constexpr (NT) {
+        ff_u32x4 v;
+        __builtin_memcpy(&v, &x, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<ff_u32x4*>(p));
+    } else {
+        *p = x;
+    }
+}
 
 // element <-> word for the scalar tail (identity unless words pack elements)
 template <class F>
@@ -61,7 +95,7 @@ __device__ __forceinline__ typename F::word ew_apply(const F& f, typename F::wor
 }
 
 // ---- out = a (op) b --------------------------------------------------------
-template <class F, int OP, int UNROLL>
+template <class F, int OP, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __restrict__ a,
                                                 const typename F::elem* __restrict__ b,
                                                 typename F::elem* __restrict__ o, size_t nvec, size_t n) {
@@ -71,28 +105,15 @@ __global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __re
     P* __restrict__ ov = reinterpret_cast<P*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
-    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
-        P x[UNROLL], y[UNROLL];
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x = ldg<NT>(av + i);
+        P y = ldg<NT>(bv + i);
+        P r;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) {
-                x[u] = av[j];
-                y[u] = bv[j];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) {
-                P r;
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x[u].w[q], y[u].w[q]);
-                ov[j] = r;
-            }
-        }
+        for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x.w[q], y.w[q]);
+        stg<NT>(ov + i, r);
     }
-    // scalar tail (n not a multiple of the pack size)
+    // scalar tail (n not a multiple of the pack size, or unaligned pointers: nvec == 0)
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t e = done + gid; e < n; e += gsz) {
         st_elem<F>(o, e, ew_apply<F, OP>(f, ld_elem<F>(a, e), ld_elem<F>(b, e)));
@@ -100,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __re
 }
 
 // ---- out = a (op) scalar, or unary op (scalar ignored) ---------------------
-template <class F, int OP, int UNROLL>
+template <class F, int OP, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __restrict__ a,
                                                 typename F::word s, typename F::elem* __restrict__ o,
                                                 size_t nvec, size_t n) {
@@ -109,23 +130,12 @@ __global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __re
     P* __restrict__ ov = reinterpret_cast<P*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
-    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
-        P x[UNROLL];
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x = ldg<NT>(av + i);
+        P r;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) x[u] = av[j];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) {
-                P r;
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x[u].w[q], s);
-                ov[j] = r;
-            }
-        }
+        for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x.w[q], s);
+        stg<NT>(ov + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t e = done + gid; e < n; e += gsz) {
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __re
 }
 
 // ---- out = a*b + c ---------------------------------------------------------
-template <class F, int UNROLL>
+template <class F, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* __restrict__ a,
                                                    const typename F::elem* __restrict__ b,
                                                    const typename F::elem* __restrict__ c,
@@ -146,27 +156,14 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
     P* __restrict__ ov = reinterpret_cast<P*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
-    for (size_t i = gid; i < nvec; i += gsz * UNROLL) {
-        P x[UNROLL], y[UNROLL], z[UNROLL];
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x = ldg<NT>(av + i);
+        P y = ldg<NT>(bv + i);
+        P z = ldg<NT>(cv + i);
+        P r;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) {
-                x[u] = av[j];
-                y[u] = bv[j];
-                z[u] = cv[j];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            size_t j = i + (size_t)u * gsz;
-            if (j < nvec) {
-                P r;
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) r.w[q] = f.muladd(x[u].w[q], y[u].w[q], z[u].w[q]);
-                ov[j] = r;
-            }
-        }
+        for (int q = 0; q < P::N; ++q) r.w[q] = f.muladd(x.w[q], y.w[q], z.w[q]);
+        stg<NT>(ov + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t e = done + gid; e < n; e += gsz) {
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
 //      local product of secure multiplication (runtime.py:1134) ---------------
 // share_i[h] = s[h] + x_i*(C[0][h] + x_i*(C[1][h] + ... x_i*C[T-1][h])),  x_i = i+1
 // Per pack: 1 (or 2) + T loads of 16 B, m stores of 16 B, m*T Horner steps.
-template <class F, int T, bool FUSE_MUL>
+template <class F, int T, bool FUSE_MUL, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
                                                   const typename F::elem* __restrict__ b,
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
@@ -191,12 +188,12 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     const P* __restrict__ av = reinterpret_cast<const P*>(a);
     const P* __restrict__ bv = reinterpret_cast<const P*>(b);
     for (size_t i = gid; i < nvec; i += gsz) {
-        P s = av[i];
+        P s = ldg<NT>(av + i);
         P s2;
-        if constexpr (FUSE_MUL) s2 = bv[i];
+        if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
         P c[T > 0 ? T : 1];
 #pragma unroll
-        for (int j = 0; j < T; ++j) c[j] = reinterpret_cast<const P*>(coef + (size_t)j * cstride)[i];
+        for (int j = 0; j < T; ++j) c[j] = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
         if constexpr (FUSE_MUL) {
 #pragma unroll
             for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
@@ -214,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                     y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
                 }
             }
-            reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride)[i] = y;
+            stg<NT>(reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride) + i, y);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -266,7 +263,7 @@ struct RecArgs {
     typename F::word lam[MAXW * K];  // (w, K) prepared constants
 };
 
-template <class F, int K>
+template <class F, int K, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int w,
                                                       typename F::elem* __restrict__ out, size_t ostride,
                                                       size_t nvec, size_t n) {
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
     for (size_t i = gid; i < nvec; i += gsz) {
         P x[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = reinterpret_cast<const P*>(ra.rows[j])[i];
+        for (int j = 0; j < K; ++j) x[j] = ldg<NT>(reinterpret_cast<const P*>(ra.rows[j]) + i);
         for (int r = 0; r < w; ++r) {
             P y;
 #pragma unroll
@@ -287,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
                 for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], x[j].w[q]);
                 y.w[q] = f.acc_reduce(s);
             }
-            reinterpret_cast<P*>(out + (size_t)r * ostride)[i] = y;
+            stg<NT>(reinterpret_cast<P*>(out + (size_t)r * ostride) + i, y);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -323,14 +320,15 @@ __global__ __launch_bounds__(BLOCK) void k_recombine_any(F f, RecArgsAny<F> ra, 
 
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
-    int blocks_per_cu;
+    int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
     int num_cu;
+    int nt;             // non-temporal loads/stores (default 1)
 };
 LaunchCfg launch_cfg(int device);
 
 inline unsigned grid_for(size_t iters, const LaunchCfg& lc) {
     size_t want = (iters + BLOCK - 1) / BLOCK;
-    size_t cap = (size_t)lc.blocks_per_cu * (size_t)lc.num_cu;
+    size_t cap = lc.blocks_per_cu > 0 ? (size_t)lc.blocks_per_cu * (size_t)lc.num_cu : (size_t)0x7fffffff;
     if (want < 1) want = 1;
     return (unsigned)(want < cap ? want : cap);
 }
@@ -389,10 +387,11 @@ struct Launchers {
     static void go_ew2(const F& f, const LaunchCfg& lc, const E* a, const E* b, E* o, size_t n, hipStream_t st) {
         bool vec = aligned16(a) && aligned16(b) && aligned16(o);
         size_t nvec = vec ? n / EPV : 0;
-        constexpr int U = 2;
-        size_t iters = nvec ? (nvec + U - 1) / U : n;
-        unsigned grid = grid_for(iters, lc);
-        hipLaunchKernelGGL((k_ew2<F, OP, U>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        if (lc.nt)
+            hipLaunchKernelGGL((k_ew2<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        else
+            hipLaunchKernelGGL((k_ew2<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
     }
     static int ew2(const void* Fp, int device, int op, const void* a, const void* b, void* o, size_t n,
                    hipStream_t st) {
@@ -415,10 +414,11 @@ struct Launchers {
     static void go_ew1(const F& f, const LaunchCfg& lc, const E* a, W s, E* o, size_t n, hipStream_t st) {
         bool vec = aligned16(a) && aligned16(o);
         size_t nvec = vec ? n / EPV : 0;
-        constexpr int U = 2;
-        size_t iters = nvec ? (nvec + U - 1) / U : n;
-        unsigned grid = grid_for(iters, lc);
-        hipLaunchKernelGGL((k_ew1<F, OP, U>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        if (lc.nt)
+            hipLaunchKernelGGL((k_ew1<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
+        else
+            hipLaunchKernelGGL((k_ew1<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
     }
     static int ew1(const void* Fp, int device, int op, const void* a, const uint64_t* scalar2, void* o,
                    size_t n, hipStream_t st) {
@@ -446,20 +446,26 @@ struct Launchers {
         LaunchCfg lc = launch_cfg(device);
         bool vec = aligned16(a) && aligned16(b) && aligned16(c) && aligned16(o);
         size_t nvec = vec ? n / EPV : 0;
-        constexpr int U = 2;
-        size_t iters = nvec ? (nvec + U - 1) / U : n;
-        unsigned grid = grid_for(iters, lc);
-        hipLaunchKernelGGL((k_muladd<F, U>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, (const E*)b,
-                           (const E*)c, (E*)o, nvec, n);
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        if (lc.nt)
+            hipLaunchKernelGGL((k_muladd<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
+                               (const E*)b, (const E*)c, (E*)o, nvec, n);
+        else
+            hipLaunchKernelGGL((k_muladd<F, false>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
+                               (const E*)b, (const E*)c, (E*)o, nvec, n);
         FFGPU_CHECK_LAUNCH();
         return 0;
     }
 
     template <int T, bool FUSE>
-    static void go_split(const F& f, unsigned grid, const E* a, const E* b, const E* coef, size_t cstride,
-                         int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st) {
-        hipLaunchKernelGGL((k_split<F, T, FUSE>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride, m,
-                           out, ostride, nvec, n);
+    static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
+                         size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st) {
+        if (nt)
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
+                               cstride, m, out, ostride, nvec, n);
+        else
+            hipLaunchKernelGGL((k_split<F, T, FUSE, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
+                               cstride, m, out, ostride, nvec, n);
     }
     template <bool FUSE>
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
@@ -476,11 +482,11 @@ struct Launchers {
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         switch (t) {
-            case 0: go_split<0, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 1: go_split<1, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 2: go_split<2, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 3: go_split<3, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 4: go_split<4, FUSE>(f, grid, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 0: go_split<0, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 1: go_split<1, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 2: go_split<2, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 3: go_split<3, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 4: go_split<4, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
             default: return 1;
         }
         return 0;
@@ -515,8 +521,12 @@ struct Launchers {
         for (int i = w * K; i < MAXW * K; ++i) ra.lam[i] = ra.lam[0];
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
-        hipLaunchKernelGGL((k_recombine<F, K>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride, nvec,
-                           n);
+        if (lc.nt)
+            hipLaunchKernelGGL((k_recombine<F, K, true>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
+                               nvec, n);
+        else
+            hipLaunchKernelGGL((k_recombine<F, K, false>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
+                               nvec, n);
     }
     static int recombine(const void* Fp, int device, const void* const* rows, const uint64_t* lam2, int k,
                          int w, void* out, size_t ostride, size_t n, hipStream_t st) {

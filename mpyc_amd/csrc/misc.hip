@@ -81,13 +81,9 @@ __global__ __launch_bounds__(BLOCK) void k_copy16(const uint4* __restrict__ src,
                                                    size_t nvec) {
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
-    for (size_t i = gid; i < nvec; i += 2 * gsz) {
-        size_t j = i + gsz;
-        uint4 x = src[i];
-        uint4 y;
-        if (j < nvec) y = src[j];
-        dst[i] = x;
-        if (j < nvec) dst[j] = y;
+    for (size_t i = gid; i < nvec; i += gsz) {
+        uint4 x = ldg<true>(src + i);
+        stg<true>(dst + i, x);
     }
 }
 
@@ -95,7 +91,7 @@ int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipS
     if (!aligned16(src) || !aligned16(dst) || (bytes & 15)) return 1;
     LaunchCfg lc = launch_cfg(device);
     size_t nvec = bytes / 16;
-    unsigned grid = grid_for((nvec + 1) / 2, lc);
+    unsigned grid = grid_for(nvec, lc);
     hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(BLOCK), 0, st, (const uint4*)src, (uint4*)dst, nvec);
     FFGPU_CHECK_LAUNCH();
     return 0;

@@ -335,6 +335,11 @@ class FieldContext:
                                                 self._stream(), ctypes.byref(ms)), 'time_recombine')
         return ms.value
 
+    def copy(self, src: torch.Tensor, dst: torch.Tensor):
+        """Streaming device copy with the library's own kernel (bandwidth yardstick)."""
+        nbytes = src.numel() * src.element_size()
+        _ffi.check(self._L.ffgpu_copy(self._h, src.data_ptr(), dst.data_ptr(), nbytes, self._stream()), 'copy')
+
     def time_copy(self, src: torch.Tensor, dst: torch.Tensor, reps: int) -> float:
         ms = ctypes.c_float()
         nbytes = src.numel() * src.element_size()
