@@ -134,6 +134,56 @@ struct PM64 {
         uint64_t wh = (uint64_t)(w >> k);
         return csub((ff_lo(w) & mask) + wh * (uint64_t)c);
     }
+    // Share generation as ONE lazily reduced dot product per share:
+    //   share = s + sum_j C_j * xp_j,   xp_j = x^(j+1) a public 32-bit integer.
+    // Terms are accumulated as a 64-bit low part + a high part and folded once.
+    // Valid when x^t < 2^32 and (t+1)*c < 2^32 (sacc_ok); otherwise the kernel
+    // uses the Horner form (muladd_small).
+    enum { HAS_SACC = 1 };
+    struct sacc {
+        uint64_t lo, hi;
+    };
+    FF_HD bool sacc_ok(int t, int m) const {
+        double pw = 1.0;
+        for (int j = 0; j < t; ++j) pw *= (double)m;
+        if (!(pw < 4294967296.0) || t > 65535) return false;
+        double tc = (double)(t + 1) * (double)c;
+        if (K64) return tc < 2147483648.0;          // hi*c < 2^63: one wrap, one csub
+        if (C1) return true;
+        // second fold must land below 2p: (t+1) c^2 2^32 < 2^(2k-1)
+        double lim = 1.0;
+        for (uint32_t i = 0; i < 2 * k - 33; ++i) lim *= 2.0;
+        return tc < 4294967296.0 && tc * (double)c < lim;
+    }
+    FF_HD void sacc_init(sacc& a, uint64_t sv) const {
+        a.lo = sv;
+        a.hi = 0;
+    }
+    FF_HD void sacc_mac(sacc& a, uint64_t cj, uint32_t xp) const {
+        uint64_t p0 = (uint64_t)(uint32_t)cj * xp;
+        uint64_t p1 = (uint64_t)(uint32_t)(cj >> 32) * xp + (p0 >> 32);
+        uint64_t tl = (p1 << 32) | (uint32_t)p0;
+        a.lo += tl;
+        a.hi += (p1 >> 32) + (a.lo < tl);
+    }
+    FF_HD uint64_t sacc_reduce(const sacc& a) const {
+        // T = hi*2^64 + lo, hi < (t+1)*2^32
+        if (K64) {
+            uint64_t u = a.hi * (uint64_t)c + a.lo;  // hi*c < 2^64 by sacc_ok
+            if (u < a.lo) u += c;
+            return csub(u);
+        }
+        uint64_t xh = (a.hi << (64 - k)) | (a.lo >> k);  // T >> k < (t+1)*2^32 + 1
+        uint64_t xl = a.lo & mask;
+        if (C1) {
+            uint64_t w = xl + xh;
+            return csub((w & mask) + (w >> k));
+        }
+        uint64_t w = xh * (uint64_t)c;  // < 2^64 by sacc_ok (+ slack from k >= 33)
+        ff_u128 ww = (ff_u128)w + xl;
+        uint64_t wh = (uint64_t)(ww >> k);
+        return csub((ff_lo(ww) & mask) + wh * (uint64_t)c);
+    }
     FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
         // a*b + c < p^2 + p < 2^(2k) for k<64; may wrap 128 bits only if k==64
         if (K64) return add(mul(a, b), cadd);
@@ -189,6 +239,14 @@ struct RC64 {
 
 
     // (u1:u0) mod d, requires u1 < d
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        uint64_t v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, uint64_t sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, uint64_t, uint32_t) const {}
+    FF_HD uint64_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint64_t rem21(uint64_t u1, uint64_t u0) const {
         ff_u128 q = (ff_u128)v * u1 + ff_make128(u1, u0);
         uint64_t q1 = ff_hi(q) + 1;
@@ -260,6 +318,14 @@ struct RC32 {
     FF_HD uint32_t prep(uint32_t cst) const { return cst; }
 
 
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        uint32_t v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, uint32_t sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, uint32_t, uint32_t) const {}
+    FF_HD uint32_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint32_t rem21(uint32_t u1, uint32_t u0) const {
         uint64_t q = (uint64_t)v * u1 + (((uint64_t)u1 << 32) | u0);
         uint32_t q1 = (uint32_t)(q >> 32) + 1;
@@ -452,6 +518,35 @@ struct PM128 {
         return add(mul(a, b), cadd);
     }
 
+    // lazily reduced share generation (see PM64): T = a2*2^128 + (a1:a0)
+    enum { HAS_SACC = 1 };
+    struct sacc {
+        uint64_t a0, a1, a2;
+    };
+    FF_HD bool sacc_ok(int t, int m) const {
+        double pw = 1.0;
+        for (int j = 0; j < t; ++j) pw *= (double)m;
+        return pw < 4294967296.0 && t < 65536;
+    }
+    FF_HD void sacc_init(sacc& a, const u128e& sv) const {
+        a.a0 = sv.lo;
+        a.a1 = sv.hi;
+        a.a2 = 0;
+    }
+    FF_HD void sacc_mac(sacc& a, const u128e& cj, uint32_t xp) const {
+        ff_u128 l = (ff_u128)cj.lo * xp;                 // 96 bits
+        ff_u128 h = (ff_u128)cj.hi * xp + ff_hi(l);      // 96 bits
+        ff_u128 t0 = (ff_u128)a.a0 + ff_lo(l);
+        a.a0 = ff_lo(t0);
+        ff_u128 t1 = (ff_u128)a.a1 + ff_lo(h) + ff_hi(t0);
+        a.a1 = ff_lo(t1);
+        a.a2 += ff_hi(h) + ff_hi(t1);
+    }
+    FF_HD u128e sacc_reduce(const sacc& a) const {
+        // T < (t+1) * 2^(k+32) < 2^(k+64)
+        return E(fold3<true>(a.a2, ff_make128(a.a1, a.a0)));
+    }
+
     FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = 0; }
     FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& xe) const {
         uint64_t x[4];
@@ -570,6 +665,14 @@ struct MONT128 {
         return redc(x);
     }
     FF_HD u128e prep(const u128e& cst) const { return E(montmul(U(cst), ff_make128(r2_hi, r2_lo))); }
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        u128e v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, u128e sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, u128e, uint32_t) const {}
+    FF_HD u128e sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD u128e mul(const u128e& a, const u128e& b) const {
         ff_u128 t = montmul(U(a), U(b));                   // a*b/R
         return E(montmul(t, ff_make128(r2_hi, r2_lo)));     // * R^2 / R = a*b
@@ -629,6 +732,14 @@ struct GF2P8 {
     FF_HD uint32_t prep(uint32_t cst) const { return cst; }
 
 
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        uint32_t v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, uint32_t sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, uint32_t, uint32_t) const {}
+    FF_HD uint32_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint32_t add(uint32_t a, uint32_t b) const { return a ^ b; }
     FF_HD uint32_t sub(uint32_t a, uint32_t b) const { return a ^ b; }
     FF_HD uint32_t neg(uint32_t a) const { return a; }
@@ -700,6 +811,14 @@ struct GF2W64 {
     // constants are used as-is (no domain conversion)
     FF_HD uint64_t prep(uint64_t cst) const { return cst; }
 
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        uint64_t v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, uint64_t sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, uint64_t, uint32_t) const {}
+    FF_HD uint64_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint64_t add(uint64_t a, uint64_t b) const { return a ^ b; }
     FF_HD uint64_t sub(uint64_t a, uint64_t b) const { return a ^ b; }
     FF_HD uint64_t neg(uint64_t a) const { return a; }
@@ -750,6 +869,14 @@ struct GF2W128 {
     // constants are used as-is (no domain conversion)
     FF_HD u128e prep(u128e cst) const { return cst; }
 
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        u128e v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, u128e sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, u128e, uint32_t) const {}
+    FF_HD u128e sacc_reduce(const sacc& a) const { return a.v; }
     static FF_HD ff_u128 U(const u128e& a) { return ff_make128(a.hi, a.lo); }
     static FF_HD u128e E(ff_u128 x) {
         u128e r;

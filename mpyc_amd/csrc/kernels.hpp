@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
 //      local product of secure multiplication (runtime.py:1134) ---------------
 // share_i[h] = s[h] + x_i*(C[0][h] + x_i*(C[1][h] + ... x_i*C[T-1][h])),  x_i = i+1
 // Per pack: 1 (or 2) + T loads of 16 B, m stores of 16 B, m*T Horner steps.
-template <class F, int T, bool FUSE_MUL, bool NT>
+template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
                                                   const typename F::elem* __restrict__ b,
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
@@ -202,6 +202,20 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             P y;
             if constexpr (T == 0) {
                 y = s;
+            } else if constexpr (LAZY) {
+                // public powers x^(j+1): wave-uniform, scalar unit
+                uint32_t xp[T];
+                xp[0] = (uint32_t)party;
+#pragma unroll
+                for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    typename F::sacc acc;
+                    f.sacc_init(acc, s.w[q]);
+#pragma unroll
+                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j].w[q], xp[j]);
+                    y.w[q] = f.sacc_reduce(acc);
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < P::N; ++q) {
@@ -460,11 +474,24 @@ struct Launchers {
     template <int T, bool FUSE>
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
                          size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st) {
+        bool lazy = false;
+        if constexpr (F::HAS_SACC != 0 && T > 0) lazy = f.sacc_ok(T, m);
+        if constexpr (F::HAS_SACC != 0 && T > 0) {
+            if (lazy) {
+                if (nt)
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+                                       coef, cstride, m, out, ostride, nvec, n);
+                else
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, false, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+                                       coef, cstride, m, out, ostride, nvec, n);
+                return;
+            }
+        }
         if (nt)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
                                cstride, m, out, ostride, nvec, n);
         else
-            hipLaunchKernelGGL((k_split<F, T, FUSE, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
+            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
                                cstride, m, out, ostride, nvec, n);
     }
     template <bool FUSE>

@@ -70,7 +70,11 @@ int ffgpu_launch_sbox(const void* policy, int device, const void* in, const uint
     LaunchCfg lc = launch_cfg(device);
     bool vec = aligned16(in) && aligned16(out);
     size_t nvec = vec ? n / 16 : 0;
-    unsigned grid = grid_for(nvec ? nvec : n, lc);
+    // every workgroup builds the 256-entry table first (~1.4k VALU ops per thread), so unlike the
+    // pure streaming kernels this one runs as a persistent grid: 8 workgroups per CU, grid-stride.
+    LaunchCfg capped = lc;
+    if (capped.blocks_per_cu <= 0) capped.blocks_per_cu = 8;
+    unsigned grid = grid_for(nvec ? nvec : n, capped);
     hipLaunchKernelGGL(k_sbox, dim3(grid), dim3(BLOCK), 0, st, f, sa, (const uint8_t*)in, (uint8_t*)out, nvec,
                        n);
     FFGPU_CHECK_LAUNCH();

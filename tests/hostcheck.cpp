@@ -9,7 +9,7 @@
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SACC = 8, HC_SACC_OK = 9 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -71,6 +71,25 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                     f.acc_mac(s, f.prep(cst<F>(f, lam + 2 * j)), ldw<F>(a, (size_t)j * n + i));
                 r = f.acc_reduce(s);
                 break;
+            }
+            case HC_SACC: {
+                // a: secrets (n), c: k rows of n coefficients, x: party; share = s + sum_j C_j x^(j+1)
+                typename F::sacc s;
+                f.sacc_init(s, ldw<F>(a, i));
+                uint32_t xp = x;
+                for (int j = 0; j < k; ++j) {
+                    f.sacc_mac(s, ldw<F>(c, (size_t)j * n + i), xp);
+                    xp *= x;
+                }
+                r = f.sacc_reduce(s);
+                break;
+            }
+            case HC_SACC_OK: {
+                r = ldw<F>(a, i);
+                if (i == 0) *((unsigned char*)out + 0) = 0;
+                stw<F>(out, i, r);
+                if (i == 0) out[0] = (unsigned char)(F::HAS_SACC != 0 && f.sacc_ok(k, (int)x));
+                continue;
             }
             default: return 1;
         }

@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT = range(8)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SACC, HC_SACC_OK = range(10)
 
 
 def limbs3(x):
@@ -134,3 +134,31 @@ def test_dot(hostcheck, golden_fields):
                     acc = po.add(F, acc, po.mul(F, lam[j], rows[j][h]))
                 want.append(acc)
             assert got == want, (name, k)
+
+
+def test_lazy_share_accumulator(hostcheck, golden_fields):
+    """share = s + sum_j C_j x^(j+1) accumulated unreduced and folded once (PM64/PM128 policies),
+    for every (t, m) the policy itself declares safe (sacc_ok), at extreme operands."""
+    checked = 0
+    for name, case in golden_fields.items():
+        F = field_of(case)
+        if F.binary:
+            continue
+        q = F.order
+        for (t, m) in [(1, 3), (2, 5), (3, 7), (4, 9), (3, 255), (4, 255), (2, 65535), (1, 2**31)]:
+            if m >= q:
+                continue
+            ok, _ = run(hostcheck, F, HC_SACC_OK, [0], x=m, k=t)
+            if not ok[0] & 1:
+                continue
+            n = 40
+            ev = edge_values(F)
+            s = ([q - 1] * 4 + ev + rand_values(F, n, 3))[:n]
+            rows = [([q - 1] * 4 + rand_values(F, n, 10 + j))[:n] for j in range(t)]
+            flat = [v for row in rows for v in row]
+            for party in {1, 2, m // 2 + 1, m}:
+                got, _ = run(hostcheck, F, HC_SACC, s, None, flat, x=party, k=t, n=n)
+                want = [(s[h] + sum(rows[j][h] * party**(j + 1) for j in range(t))) % q for h in range(n)]
+                assert got == want, (name, t, m, party)
+                checked += 1
+    assert checked > 50
