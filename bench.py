@@ -365,6 +365,27 @@ def main():
                                kernel=kern[dom].get('kernel'), name=dom,
                                ms_per_launch=kern[dom]['ms_per_launch'],
                                frac_of_measured_copy=round(kern[dom]['achieved'] / kern['device_copy']['achieved'], 4))
+        # HBM traffic per launch from PMC counters (collected separately with rocprofv3 --pmc, see
+        # profiles/r01_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+                pmc = json.load(fh)
+            names = {'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
+                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true>',
+                     'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
+                     'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
+                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true>',
+                     'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
+                     'device_copy': 'k_copy16'}
+            for q, kn in names.items():
+                if q in kern and kn in pmc and n == 10_000_000:
+                    kern[q]['traffic'] = pmc[kn]['traffic_bytes']
+            if n == 10_000_000 and names.get(dom) in pmc:
+                out['roofline']['traffic'] = pmc[names[dom]]['traffic_bytes']
+                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+        except (OSError, ValueError):
+            pass
+        out['roofline']['bytes_per_launch'] = kern[dom]['bytes_per_launch']
         out['kernels'] = kern
         out['mulmod_per_s_1gpu'] = kern['mul_p61']['units_per_s']
 

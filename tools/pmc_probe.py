@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Launch each hot kernel a few times on rotating buffers; run under
+   rocprofv3 --kernel-trace --pmc FETCH_SIZE   (and a second pass with --pmc WRITE_SIZE)
+to get HBM traffic per launch.  k_copy16 (exactly 80 MB read + 80 MB written) calibrates the counters."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from mpyc_amd.engine import FieldContext
+from oracle import pyoracle as po
+
+torch.cuda.set_device(0)
+n = 10_000_000
+gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
+for P, t, m in ((bench.P61, 1, 3), (bench.P64, 3, 7)):
+    ctx = FieldContext(P, device=0)
+    sets = [bench.StepData(ctx, n, t, m, gen) for _ in range(4)]
+    k = 2 * t + 1
+    lam = po.recombination_vector(po.Field(P), list(range(1, k + 1)), 0)
+    for s in sets:
+        s.rec = ctx.recombine_plan([s.shares.row(j) for j in range(k)], lam, s.y)
+    for rep in range(3):
+        for s in sets:
+            ctx.copy(s.a.t, s.y.t)
+            ctx.mul(s.a, s.b, out=s.c)
+            ctx.split(s.c, s.coef, t, m, out=s.shares)
+            s.rec()
+    torch.cuda.synchronize()
+    assert torch.equal(sets[0].y.t, sets[0].c.t)
+    del sets
+    torch.cuda.empty_cache()
+print('pmc probe done')
