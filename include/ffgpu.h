@@ -136,6 +136,23 @@ int ffgpu_mul_split(ffgpu_ctx* ctx, const void* a, const void* b, const void* co
                     size_t coeff_stride, int t, int m, void* shares, size_t share_stride,
                     size_t n, void* stream);
 
+/* ---- share generation with the on-device CSPRNG ------------------------- */
+/* Same maps as ffgpu_split / ffgpu_mul_split, but the t*n coefficients are drawn inside the
+ * kernel from a ChaCha keystream (host_key32: 32 bytes from the host CSPRNG, fresh per call or
+ * with a fresh nonce; rounds: 20, 12 or 8; 0 = 20) and never touch HBM.  The keystream layout and
+ * the 2^-64-bias field sampler are documented in mpyc_amd/csrc/rng.hpp; ffgpu_rng_coeffs writes
+ * exactly the coefficient matrix the fused kernels consume for the same (key, nonce, rounds, t),
+ * so split_rng(key) == split(rng_coeffs(key)) bit for bit.
+ * replaces: the secrets.randbelow draws of thresha.py:37 and :58-60 (one OS-CSPRNG call per
+ * coefficient in the reference).                                                            */
+int ffgpu_rng_coeffs(ffgpu_ctx* ctx, const uint8_t* host_key32, uint64_t nonce, int rounds, int t,
+                     void* coeffs, size_t coeff_stride, size_t n, void* stream);
+int ffgpu_split_rng(ffgpu_ctx* ctx, const void* secrets, const uint8_t* host_key32, uint64_t nonce,
+                    int rounds, int t, int m, void* shares, size_t share_stride, size_t n, void* stream);
+int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint8_t* host_key32,
+                        uint64_t nonce, int rounds, int t, int m, void* shares, size_t share_stride,
+                        size_t n, void* stream);
+
 /* ---- Lagrange recombination ------------------------------------------- */
 /* out[r][h] = sum_{j<k} lambda[r][j] * rows[j][h]  (mod modulus), r < w.
  * host_rows: HOST array of k device pointers (rows arrive from k peers and need

@@ -38,6 +38,7 @@ struct ffgpu_ctx {
     int elem_bytes;
     int policy_kind;
     const FieldOps* ops;
+    uint64_t rng_r[2];  // 2^W mod p for the keystream sampler
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
 };
@@ -175,6 +176,7 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     c->reduction = pb.reduction;
     c->elem_bytes = pb.elem_bytes;
     c->policy_kind = pb.kind;
+    rng_const(pb, c->rng_r);
     *out = c;
     return FFGPU_OK;
 }
@@ -286,7 +288,38 @@ static int do_split(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, co
     ARGCHK((m == 1 || share_stride >= n) && (t <= 1 || coeff_stride >= n));
     DeviceGuard g(ctx->device);
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, coeffs,
-                                         coeff_stride, t, m, shares, share_stride, n, (hipStream_t)stream));
+                                         coeff_stride, t, m, shares, share_stride, n, (hipStream_t)stream,
+                                         nullptr));
+}
+
+static int make_rng(const ffgpu_ctx* ctx, const uint8_t* key32, uint64_t nonce, int rounds, RngArgs* ra) {
+    if (!key32) return FFGPU_EINVAL;
+    if (rounds == 0) rounds = 20;
+    if (rounds != 20 && rounds != 12 && rounds != 8) return FFGPU_EINVAL;
+    memset(ra, 0, sizeof(*ra));
+    memcpy(ra->rk.key, key32, 32);  // little-endian words, as RFC 8439
+    ra->rk.nonce[0] = (uint32_t)nonce;
+    ra->rk.nonce[1] = (uint32_t)(nonce >> 32);
+    ra->rk.rounds = (uint32_t)rounds;
+    ra->r0 = ctx->rng_r[0];
+    ra->r1 = ctx->rng_r[1];
+    return FFGPU_OK;
+}
+
+static int do_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, const uint8_t* key32,
+                        uint64_t nonce, int rounds, int t, int m, void* shares, size_t share_stride, size_t n,
+                        void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(m >= 1 && t >= 0 && t < m);
+    RngArgs ra;
+    int rc = make_rng(ctx, key32, nonce, rounds, &ra);
+    if (rc != FFGPU_OK) return rc;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && shares && (!fused || b));
+    ARGCHK(m == 1 || share_stride >= n);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, nullptr, 0, t, m,
+                                         shares, share_stride, n, (hipStream_t)stream, t > 0 ? &ra : nullptr));
 }
 int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,
                 void* shares, size_t share_stride, size_t n, void* stream) {
@@ -295,6 +328,29 @@ int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t 
 int ffgpu_mul_split(ffgpu_ctx* ctx, const void* a, const void* b, const void* coeffs, size_t coeff_stride,
                     int t, int m, void* shares, size_t share_stride, size_t n, void* stream) {
     return do_split(ctx, a, b, true, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);
+}
+
+int ffgpu_rng_coeffs(ffgpu_ctx* ctx, const uint8_t* host_key32, uint64_t nonce, int rounds, int t, void* coeffs,
+                     size_t coeff_stride, size_t n, void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(t >= 1);
+    RngArgs ra;
+    int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
+    if (rc != FFGPU_OK) return rc;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(coeffs && (t == 1 || coeff_stride >= n));
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->rng_coeffs(ctx->policy, ctx->device, coeffs, coeff_stride, t, n,
+                                              (hipStream_t)stream, &ra));
+}
+int ffgpu_split_rng(ffgpu_ctx* ctx, const void* secrets, const uint8_t* host_key32, uint64_t nonce, int rounds,
+                    int t, int m, void* shares, size_t share_stride, size_t n, void* stream) {
+    return do_split_rng(ctx, secrets, nullptr, false, host_key32, nonce, rounds, t, m, shares, share_stride, n,
+                        stream);
+}
+int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint8_t* host_key32, uint64_t nonce,
+                        int rounds, int t, int m, void* shares, size_t share_stride, size_t n, void* stream) {
+    return do_split_rng(ctx, a, b, true, host_key32, nonce, rounds, t, m, shares, share_stride, n, stream);
 }
 
 int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda, int k, int w,

@@ -20,7 +20,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "fields.hpp"
+#include "rng.hpp"
 
 namespace ffgpu {
 
@@ -175,14 +177,20 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
 //      local product of secure multiplication (runtime.py:1134) ---------------
 // share_i[h] = s[h] + x_i*(C[0][h] + x_i*(C[1][h] + ... x_i*C[T-1][h])),  x_i = i+1
 // Per pack: 1 (or 2) + T loads of 16 B, m stores of 16 B, m*T Horner steps.
-template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY>
+struct RngArgs {
+    RngKey rk;
+    uint64_t r0, r1;  // 2^W mod p for the sampler
+};
+
+template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
                                                   const typename F::elem* __restrict__ b,
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
-                                                  size_t nvec, size_t n) {
+                                                  size_t nvec, size_t n, RngArgs ra) {
     typedef Pack<typename F::word> P;
     typedef typename F::word W;
+    constexpr int TT = T > 0 ? T : 1;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     const P* __restrict__ av = reinterpret_cast<const P*>(a);
@@ -191,9 +199,17 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
         P s = ldg<NT>(av + i);
         P s2;
         if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
-        P c[T > 0 ? T : 1];
+        W c[TT][P::N];
+        if constexpr (RNG && T > 0) {
+            rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, c);
+        } else {
 #pragma unroll
-        for (int j = 0; j < T; ++j) c[j] = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
+            for (int j = 0; j < T; ++j) {
+                P t_ = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+            }
+        }
         if constexpr (FUSE_MUL) {
 #pragma unroll
             for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                 y = s;
             } else if constexpr (LAZY) {
                 // public powers x^(j+1): wave-uniform, scalar unit
-                uint32_t xp[T];
+                uint32_t xp[TT];
                 xp[0] = (uint32_t)party;
 #pragma unroll
                 for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
@@ -213,28 +229,44 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                     typename F::sacc acc;
                     f.sacc_init(acc, s.w[q]);
 #pragma unroll
-                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j].w[q], xp[j]);
+                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
                     y.w[q] = f.sacc_reduce(acc);
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < P::N; ++q) {
-                    W acc = c[T - 1].w[q];
+                    W acc = c[T - 1][q];
 #pragma unroll
-                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j].w[q]);
+                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
                     y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
                 }
             }
             stg<NT>(reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride) + i, y);
         }
     }
-    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    // scalar tail: elements past the last full pack (or everything, if pointers are unaligned)
+    constexpr int EPV = P::N * F::EPW;
+    const size_t done = nvec * (size_t)EPV;
     for (size_t e = done + gid; e < n; e += gsz) {
         W s = ld_elem<F>(a, e);
         if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
-        W c[T > 0 ? T : 1];
+        W c[TT];
+        if constexpr (RNG && T > 0) {
+            W cc[TT][P::N];
+            rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)(e / EPV), cc);
+            const int q = (int)((e % EPV) / F::EPW);
 #pragma unroll
-        for (int j = 0; j < T; ++j) c[j] = ld_elem<F>(coef + (size_t)j * cstride, e);
+            for (int j = 0; j < T; ++j) {
+                W v = cc[j][0];
+#pragma unroll
+                for (int qq = 1; qq < P::N; ++qq) v = (qq == q) ? cc[j][qq] : v;
+                if constexpr (F::EPW > 1) v = (W)((v >> (8 * (e % F::EPW))) & 0xffu);
+                c[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) c[j] = ld_elem<F>(coef + (size_t)j * cstride, e);
+        }
         for (int party = 1; party <= m; ++party) {
             W y = s;
             if constexpr (T > 0) {
@@ -248,24 +280,107 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     }
 }
 
-// any degree t: coefficients are re-read per party (they stay in L2/MALL)
-template <class F, bool FUSE_MUL>
+// materialise the coefficient matrix the fused kernel would draw (tests, debugging, and callers
+// that want the coefficients): identical keystream layout.
+template <class F, int T>
+__global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __restrict__ coef, size_t cstride,
+                                                       size_t nvec, size_t n, RngArgs ra) {
+    typedef Pack<typename F::word> P;
+    typedef typename F::word W;
+    constexpr int EPV = P::N * F::EPW;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const size_t npacks = (n + EPV - 1) / EPV;
+    for (size_t i = gid; i < npacks; i += gsz) {
+        W c[T][P::N];
+        rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, c);
+        if (i < nvec) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                P t_;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) t_.w[q] = c[j][q];
+                stg<true>(reinterpret_cast<P*>(coef + (size_t)j * cstride) + i, t_);
+            }
+        } else {
+            for (int j = 0; j < T; ++j)
+                for (int q = 0; q < P::N; ++q)
+                    for (int b_ = 0; b_ < F::EPW; ++b_) {
+                        size_t e = i * EPV + (size_t)q * F::EPW + b_;
+                        if (e < n) {
+                            W v = c[j][q];
+                            if constexpr (F::EPW > 1) v = (W)((v >> (8 * b_)) & 0xffu);
+                            st_elem<F>(coef + (size_t)j * cstride, e, v);
+                        }
+                    }
+        }
+    }
+}
+
+// any degree t: coefficients are re-read per party (they stay in L2/MALL).  With RNG each row j
+// is its own keystream (nonce word 1 + j + 1) in the T = 1 layout.
+template <class F, bool FUSE_MUL, bool RNG>
 __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem* __restrict__ a,
                                                       const typename F::elem* __restrict__ b,
                                                       const typename F::elem* __restrict__ coef, size_t cstride,
                                                       int t, int m, typename F::elem* __restrict__ out,
-                                                      size_t ostride, size_t n) {
+                                                      size_t ostride, size_t n, RngArgs ra) {
     typedef typename F::word W;
+    typedef Pack<W> P;
+    constexpr int EPV = P::N * F::EPW;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
+    auto coef_at = [&](int j, size_t e) -> W {
+        if constexpr (RNG) {
+            RngArgs rj = ra;
+            rj.rk.nonce[1] += (uint32_t)(j + 1);
+            W cc[1][P::N];
+            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)(e / EPV), cc);
+            const int q = (int)((e % EPV) / F::EPW);
+            W v = cc[0][0];
+#pragma unroll
+            for (int qq = 1; qq < P::N; ++qq) v = (qq == q) ? cc[0][qq] : v;
+            if constexpr (F::EPW > 1) v = (W)((v >> (8 * (e % F::EPW))) & 0xffu);
+            return v;
+        } else {
+            return ld_elem<F>(coef + (size_t)j * cstride, e);
+        }
+    };
     for (size_t e = gid; e < n; e += gsz) {
         W s = ld_elem<F>(a, e);
         if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
         for (int party = 1; party <= m; ++party) {
-            W acc = ld_elem<F>(coef + (size_t)(t - 1) * cstride, e);
-            for (int j = t - 2; j >= 0; --j)
-                acc = f.muladd_small(acc, (uint32_t)party, ld_elem<F>(coef + (size_t)j * cstride, e));
+            W acc = coef_at(t - 1, e);
+            for (int j = t - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, coef_at(j, e));
             st_elem<F>(out + (size_t)(party - 1) * ostride, e, f.muladd_small(acc, (uint32_t)party, s));
+        }
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_rng_coeffs_any(F f, typename F::elem* __restrict__ coef, size_t cstride,
+                                                           int t, size_t n, RngArgs ra) {
+    typedef typename F::word W;
+    typedef Pack<W> P;
+    constexpr int EPV = P::N * F::EPW;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const size_t npacks = (n + EPV - 1) / EPV;
+    for (size_t i = gid; i < npacks; i += gsz) {
+        for (int j = 0; j < t; ++j) {
+            RngArgs rj = ra;
+            rj.rk.nonce[1] += (uint32_t)(j + 1);
+            W cc[1][P::N];
+            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)i, cc);
+            for (int q = 0; q < P::N; ++q)
+                for (int b_ = 0; b_ < F::EPW; ++b_) {
+                    size_t e = i * EPV + (size_t)q * F::EPW + b_;
+                    if (e < n) {
+                        W v = cc[0][q];
+                        if constexpr (F::EPW > 1) v = (W)((v >> (8 * b_)) & 0xffu);
+                        st_elem<F>(coef + (size_t)j * cstride, e, v);
+                    }
+                }
         }
     }
 }
@@ -358,8 +473,12 @@ struct FieldOps {
                size_t n, hipStream_t st);
     int (*muladd)(const void* F, int device, const void* a, const void* b, const void* c, void* o,
                   size_t n, hipStream_t st);
+    // coef == nullptr && rng != nullptr: coefficients are drawn in-kernel from the keystream
     int (*split)(const void* F, int device, const void* a, const void* b, const void* coef,
-                 size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st);
+                 size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st,
+                 const RngArgs* rng);
+    int (*rng_coeffs)(const void* F, int device, void* coef, size_t cstride, int t, size_t n, hipStream_t st,
+                      const RngArgs* rng);
     int (*recombine)(const void* F, int device, const void* const* rows, const uint64_t* lam2, int k,
                      int w, void* out, size_t ostride, size_t n, hipStream_t st);
 };
@@ -471,62 +590,98 @@ struct Launchers {
         return 0;
     }
 
-    template <int T, bool FUSE>
+    template <int T, bool FUSE, bool RNG>
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
-                         size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st) {
+                         size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st,
+                         const RngArgs& ra) {
         bool lazy = false;
         if constexpr (F::HAS_SACC != 0 && T > 0) lazy = f.sacc_ok(T, m);
         if constexpr (F::HAS_SACC != 0 && T > 0) {
             if (lazy) {
-                if (nt)
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
-                                       coef, cstride, m, out, ostride, nvec, n);
+                if (nt || RNG)
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a,
+                                       b, coef, cstride, m, out, ostride, nvec, n, ra);
                 else
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, false, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
-                                       coef, cstride, m, out, ostride, nvec, n);
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, false, true, false>), dim3(grid), dim3(BLOCK), 0, st, f,
+                                       a, b, coef, cstride, m, out, ostride, nvec, n, ra);
                 return;
             }
         }
-        if (nt)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
-                               cstride, m, out, ostride, nvec, n);
+        if (nt || RNG)
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+                               coef, cstride, m, out, ostride, nvec, n, ra);
         else
-            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef,
-                               cstride, m, out, ostride, nvec, n);
+            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+                               coef, cstride, m, out, ostride, nvec, n, ra);
     }
-    template <bool FUSE>
+    template <bool FUSE, bool RNG>
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
-                       int t, int m, E* out, size_t ostride, size_t n, hipStream_t st) {
+                       int t, int m, E* out, size_t ostride, size_t n, hipStream_t st, const RngArgs& ra) {
         if (t > MAXT) {
             unsigned grid = grid_for(n, lc);
-            hipLaunchKernelGGL((k_split_any<F, FUSE>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
-                               t, m, out, ostride, n);
+            hipLaunchKernelGGL((k_split_any<F, FUSE, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
+                               t, m, out, ostride, n, ra);
             return 0;
         }
         bool vec = aligned16(a) && (!FUSE || aligned16(b)) && aligned16(out) &&
                    ((ostride * sizeof(E)) % 16 == 0 || m <= 1) &&
-                   (t == 0 || (aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1)));
+                   (RNG || t == 0 || (aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1)));
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
+        bool nt = lc.nt != 0;
         switch (t) {
-            case 0: go_split<0, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 1: go_split<1, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 2: go_split<2, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 3: go_split<3, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
-            case 4: go_split<4, FUSE>(f, grid, lc.nt != 0, a, b, coef, cstride, m, out, ostride, nvec, n, st); break;
+            case 0: go_split<0, FUSE, false>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
+            case 1: go_split<1, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
+            case 2: go_split<2, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
+            case 3: go_split<3, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
+            case 4: go_split<4, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
             default: return 1;
         }
         return 0;
     }
     static int split(const void* Fp, int device, const void* a, const void* b, const void* coef,
-                     size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st) {
+                     size_t cstride, int t, int m, void* out, size_t ostride, size_t n, hipStream_t st,
+                     const RngArgs* rng) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        int rc = b ? split_t<true>(f, lc, (const E*)a, (const E*)b, (const E*)coef, cstride, t, m, (E*)out,
-                                   ostride, n, st)
-                   : split_t<false>(f, lc, (const E*)a, nullptr, (const E*)coef, cstride, t, m, (E*)out,
-                                    ostride, n, st);
+        RngArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        int rc;
+        if (rng) {
+            ra = *rng;
+            rc = b ? split_t<true, true>(f, lc, (const E*)a, (const E*)b, nullptr, 0, t, m, (E*)out, ostride, n, st, ra)
+                   : split_t<false, true>(f, lc, (const E*)a, nullptr, nullptr, 0, t, m, (E*)out, ostride, n, st, ra);
+        } else {
+            rc = b ? split_t<true, false>(f, lc, (const E*)a, (const E*)b, (const E*)coef, cstride, t, m, (E*)out,
+                                          ostride, n, st, ra)
+                   : split_t<false, false>(f, lc, (const E*)a, nullptr, (const E*)coef, cstride, t, m, (E*)out,
+                                           ostride, n, st, ra);
+        }
         if (rc) return rc;
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+    static int rng_coeffs(const void* Fp, int device, void* coef, size_t cstride, int t, size_t n, hipStream_t st,
+                          const RngArgs* rng) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        E* C = (E*)coef;
+        size_t npacks = (n + EPV - 1) / EPV;
+        unsigned grid = grid_for(npacks, lc);
+        if (t > MAXT) {
+            hipLaunchKernelGGL((k_rng_coeffs_any<F>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, t, n, *rng);
+            FFGPU_CHECK_LAUNCH();
+            return 0;
+        }
+        bool vec = aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1);
+        size_t nvec = vec ? n / EPV : 0;
+        switch (t) {
+            case 1: hipLaunchKernelGGL((k_rng_coeffs<F, 1>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
+            case 2: hipLaunchKernelGGL((k_rng_coeffs<F, 2>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
+            case 3: hipLaunchKernelGGL((k_rng_coeffs<F, 3>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
+            case 4: hipLaunchKernelGGL((k_rng_coeffs<F, 4>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
+            default: return 1;
+        }
         FFGPU_CHECK_LAUNCH();
         return 0;
     }
@@ -602,7 +757,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &recombine};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine};
         return &ops;
     }
 };

@@ -178,4 +178,33 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
 }
 
 
+
+// 2^W mod p for the keystream sampler (rng.hpp): W = 32 / 64 / 128 by storage width.
+template <class F>
+inline void rng_const_prime(const PolicyBlob& pb, int W, uint64_t out[2]) {
+    F f;
+    memcpy(&f, pb.bytes, sizeof(F));
+    typename F::word r;
+    memset(&r, 0, sizeof(r));
+    ((unsigned char*)&r)[0] = 1;  // little-endian 1
+    for (int i = 0; i < W; ++i) r = f.add(r, r);
+    out[0] = out[1] = 0;
+    memcpy(out, &r, sizeof(r) < 16 ? sizeof(r) : 16);
+}
+
+inline void rng_const(const PolicyBlob& pb, uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    switch (pb.kind) {
+        case POL_PM64_MERSENNE: rng_const_prime<PM64<false, true> >(pb, 64, out); break;
+        case POL_PM64_K64: rng_const_prime<PM64<true, false> >(pb, 64, out); break;
+        case POL_PM64_GEN: rng_const_prime<PM64<false, false> >(pb, 64, out); break;
+        case POL_RC64: rng_const_prime<RC64>(pb, 64, out); break;
+        case POL_RC32: rng_const_prime<RC32>(pb, 32, out); break;
+        case POL_PM128_K128: rng_const_prime<PM128<true> >(pb, 128, out); break;
+        case POL_PM128_GEN: rng_const_prime<PM128<false> >(pb, 128, out); break;
+        case POL_MONT128: rng_const_prime<MONT128>(pb, 128, out); break;
+        default: break;  // binary fields: masks only
+    }
+}
+
 }  // namespace ffgpu

@@ -1,0 +1,158 @@
+// rng.hpp -- on-device CSPRNG for share-generation coefficients.
+//
+// The reference draws each Shamir coefficient with secrets.randbelow(order) on the host
+// (thresha.py:37,58-60), one OS-CSPRNG call per coefficient -- the dominant cost of its
+// share generation.  Here coefficients come from a ChaCha keystream (block function of
+// RFC 8439 / DJB ChaCha, 20 rounds by default) computed in registers by the thread that
+// consumes them, keyed per call with 256 bits from the host's CSPRNG.
+//
+// Keystream -> field element ("sample"): W + 64 uniform bits reduced mod p (bias < 2^-64,
+// the same idea as thresha.PRF's 16 extra bytes, thresha.py:234-236); exact for GF(2^n).
+//
+// Public layout (what tests/oracle reproduce): the thread that owns 16-byte pack i of an
+// array draws B = ceil(EPV*t*S/64) consecutive 64-byte blocks with block counters
+// i*B .. i*B+B-1; sample number (j*EPV + e) of those blocks (S bytes each, in keystream
+// order) is the coefficient C[j][i*EPV + e]  (j < t rows, e < EPV elements per pack).
+// Tail elements past the last full pack are drawn the same way with the pack index they
+// would have had (EPV consecutive elements always share blocks).
+#pragma once
+#include <stdint.h>
+#include "fields.hpp"
+
+namespace ffgpu {
+
+struct RngKey {
+    uint32_t key[8];    // 256-bit ChaCha key
+    uint32_t nonce[2];  // stream id: unique per call (words 14, 15 of the state)
+    uint32_t rounds;    // 20 (default), 12 or 8
+    uint32_t pad_;
+};
+
+FF_HD uint32_t ff_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+#define FF_QR(a, b, c, d) \
+    a += b; d ^= a; d = ff_rotl32(d, 16); \
+    c += d; b ^= c; b = ff_rotl32(b, 12); \
+    a += b; d ^= a; d = ff_rotl32(d, 8);  \
+    c += d; b ^= c; b = ff_rotl32(b, 7);
+
+// one 64-byte block; (w12,w13) = 64-bit block counter, (w14,w15) = nonce
+FF_HD void chacha_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                        int rounds, uint32_t out[16]) {
+    uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+    uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3];
+    uint32_t x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+    uint32_t x12 = w12, x13 = w13, x14 = w14, x15 = w15;
+    for (int i = 0; i < rounds; i += 2) {
+        FF_QR(x0, x4, x8, x12)
+        FF_QR(x1, x5, x9, x13)
+        FF_QR(x2, x6, x10, x14)
+        FF_QR(x3, x7, x11, x15)
+        FF_QR(x0, x5, x10, x15)
+        FF_QR(x1, x6, x11, x12)
+        FF_QR(x2, x7, x8, x13)
+        FF_QR(x3, x4, x9, x14)
+    }
+    out[0] = x0 + 0x61707865u; out[1] = x1 + 0x3320646eu; out[2] = x2 + 0x79622d32u; out[3] = x3 + 0x6b206574u;
+    out[4] = x4 + key[0]; out[5] = x5 + key[1]; out[6] = x6 + key[2]; out[7] = x7 + key[3];
+    out[8] = x8 + key[4]; out[9] = x9 + key[5]; out[10] = x10 + key[6]; out[11] = x11 + key[7];
+    out[12] = x12 + w12; out[13] = x13 + w13; out[14] = x14 + w14; out[15] = x15 + w15;
+}
+
+// Per-policy sampling: S = bytes of keystream per sample, sample(f, R, words) -> canonical word.
+// R = 2^W mod p (W = 32 for RC32, 64 for the one-limb and 128 for the two-limb prime policies),
+// computed once on the host (policy_build.hpp rng_const).
+template <class F>
+struct Sampler;
+
+template <class F>
+struct SamplerPrime64 {
+    enum { S = 16 };
+    static FF_HD uint64_t sample(const F& f, uint64_t R, uint64_t, const uint32_t* w) {
+        uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        uint64_t hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        return f.add(f.mul(f.reduce_raw(hi), R), f.reduce_raw(lo));
+    }
+};
+template <bool A, bool B>
+struct Sampler<PM64<A, B> > : SamplerPrime64<PM64<A, B> > {};
+template <>
+struct Sampler<RC64> : SamplerPrime64<RC64> {};
+
+template <>
+struct Sampler<RC32> {
+    enum { S = 16 };  // 96 bits used, 32 skipped (keeps samples 16-byte aligned in the block)
+    static FF_HD uint32_t sample(const RC32& f, uint64_t R, uint64_t, const uint32_t* w) {
+        uint32_t r = f.reduce_raw(w[2]);
+        r = f.add(f.mul(r, (uint32_t)R), f.reduce_raw(w[1]));
+        r = f.add(f.mul(r, (uint32_t)R), f.reduce_raw(w[0]));
+        return r;
+    }
+};
+
+template <class F>
+struct SamplerPrime128 {
+    enum { S = 32 };
+    static FF_HD u128e sample(const F& f, uint64_t Rlo, uint64_t Rhi, const uint32_t* w) {
+        u128e lo, hi, R;
+        lo.lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        lo.hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        hi.lo = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
+        hi.hi = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+        R.lo = Rlo;
+        R.hi = Rhi;
+        return f.add(f.mul(f.reduce_raw(hi), R), f.reduce_raw(lo));
+    }
+};
+template <bool A>
+struct Sampler<PM128<A> > : SamplerPrime128<PM128<A> > {};
+template <>
+struct Sampler<MONT128> : SamplerPrime128<MONT128> {};
+
+template <>
+struct Sampler<GF2P8> {
+    enum { S = 4 };  // one 32-bit word = 4 packed elements, masked to n bits each
+    static FF_HD uint32_t sample(const GF2P8& f, uint64_t, uint64_t, const uint32_t* w) { return w[0] & f.emask; }
+};
+template <>
+struct Sampler<GF2W64> {
+    enum { S = 8 };
+    static FF_HD uint64_t sample(const GF2W64& f, uint64_t, uint64_t, const uint32_t* w) {
+        return ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & f.emask;
+    }
+};
+template <>
+struct Sampler<GF2W128> {
+    enum { S = 16 };
+    static FF_HD u128e sample(const GF2W128& f, uint64_t, uint64_t, const uint32_t* w) {
+        u128e r;
+        r.lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & f.emask_lo;
+        r.hi = ((uint64_t)w[2] | ((uint64_t)w[3] << 32)) & f.emask_hi;
+        return r;
+    }
+};
+
+// Draw the T*WPP words (WPP = words per pack) owned by pack `pack`: c[j][q], j < T, q < WPP.
+// Sample index within the thread's blocks is j*WPP + q.
+template <class F, int T, int WPP>
+FF_HD void rng_draw_pack(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1, uint64_t pack,
+                         typename F::word c[][WPP]) {
+    typedef Sampler<F> Smp;
+    constexpr int SPB = 64 / Smp::S;                   // samples per block
+    constexpr int NS = T * WPP;                         // samples per pack
+    constexpr int B = (NS + SPB - 1) / SPB;             // blocks per pack
+    uint64_t ctr0 = pack * (uint64_t)B;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        uint32_t blk[16];
+        uint64_t ctr = ctr0 + (uint64_t)b;
+        chacha_block(rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk.nonce[0], rk.nonce[1], (int)rk.rounds, blk);
+#pragma unroll
+        for (int sidx = 0; sidx < SPB; ++sidx) {
+            int sn = b * SPB + sidx;
+            if (sn < NS) c[sn / WPP][sn % WPP] = Smp::sample(f, R0, R1, blk + sidx * (Smp::S / 4));
+        }
+    }
+}
+
+}  // namespace ffgpu

@@ -267,6 +267,39 @@ class FieldContext:
         _ffi.check(rc, 'split')
         return out
 
+    def rng_coeffs(self, key: bytes, nonce: int, t: int, n: int, rounds: int = 20,
+                   out: Optional[DevMatrix] = None) -> DevMatrix:
+        """Materialise the (t, n) coefficient matrix the fused split_rng kernel draws for
+        (key, nonce, rounds) -- device CSPRNG, mpyc_amd/csrc/rng.hpp."""
+        if len(key) != 32:
+            raise ValueError('key must be 32 bytes')
+        out = out or self.empty_matrix(t, n)
+        _ffi.check(self._L.ffgpu_rng_coeffs(self._h, key, nonce, rounds, t, out.ptr, out.stride, n,
+                                            self._stream()), 'rng_coeffs')
+        return out
+
+    def split_rng(self, secrets: DevArray, t: int, m: int, key: Optional[bytes] = None, nonce: int = 0,
+                  rounds: int = 20, out: Optional[DevMatrix] = None,
+                  mul_by: Optional[DevArray] = None) -> DevMatrix:
+        """np_random_split with coefficients drawn on the device (production mode): the t*n
+        random coefficients never touch HBM.  key: 32 bytes; default = fresh from the host CSPRNG
+        (the reference draws from `secrets` too, thresha.py:58)."""
+        import secrets as _secrets
+        if key is None:
+            key = _secrets.token_bytes(32)
+        if len(key) != 32:
+            raise ValueError('key must be 32 bytes')
+        n = secrets.n
+        out = out or self.empty_matrix(m, n)
+        if mul_by is None:
+            rc = self._L.ffgpu_split_rng(self._h, secrets.ptr, key, nonce, rounds, t, m, out.ptr, out.stride, n,
+                                         self._stream())
+        else:
+            rc = self._L.ffgpu_mul_split_rng(self._h, secrets.ptr, mul_by.ptr, key, nonce, rounds, t, m, out.ptr,
+                                             out.stride, n, self._stream())
+        _ffi.check(rc, 'split_rng')
+        return out
+
     def _rec_args(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int):
         k = len(rows)
         if len(lambdas) != w * k:

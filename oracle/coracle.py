@@ -91,6 +91,26 @@ class CField:
         return out[0] if w == 1 else out
 
 
+def chacha_block(key32: bytes, w12_15, rounds: int = 20):
+    """RFC 8439 section 2.3 block function on explicit state words 12..15."""
+    key = (ctypes.c_uint32 * 8).from_buffer_copy(key32)
+    w = (ctypes.c_uint32 * 4)(*w12_15)
+    out = (ctypes.c_uint32 * 16)()
+    lib().orc_chacha_block(key, w, rounds, out)
+    return list(out)
+
+
+def rng_coeffs(cf: 'CField', key32: bytes, nonce: int, rounds: int, t: int, n: int) -> np.ndarray:
+    """(t, n) coefficient matrix exactly as the device CSPRNG draws it (mpyc_amd/csrc/rng.hpp)."""
+    eb = cf.eb
+    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb]
+    shape = (t, n, 2) if eb == 16 else (t, n)
+    out = np.zeros(shape, dtype=dt)
+    lib().orc_rng_coeffs(cf._buf, key32, ctypes.c_uint64(nonce), rounds, t, out.ctypes.data_as(ctypes.c_void_p),
+                         ctypes.c_size_t(n), ctypes.c_size_t(n))
+    return out
+
+
 def sbox(x: np.ndarray, rows8, b: int) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.uint8)
     out = np.empty_like(x)

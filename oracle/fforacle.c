@@ -212,4 +212,103 @@ int orc_sbox(const unsigned char* in, const uint8_t* rows8, uint8_t b, unsigned 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Device CSPRNG restatement (mpyc_amd/csrc/rng.hpp).  The reference has no counterpart (it calls
+ * secrets.randbelow per coefficient, thresha.py:37,58-60); this pins the *published algorithm*:
+ * ChaCha block function (RFC 8439 section 2.3, checked against its test vector 2.3.2 in
+ * tests/test_rng.py) + "W+64 uniform bits mod p" sampling + the documented keystream layout.
+ * ------------------------------------------------------------------------------------------ */
+static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+static void qround(uint32_t* s, int a, int b, int c, int d) {
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = rotl(s[d], 16);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = rotl(s[b], 12);
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = rotl(s[d], 8);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = rotl(s[b], 7);
+}
+void orc_chacha_block(const uint32_t key[8], const uint32_t w12_15[4], int rounds, uint32_t out[16]) {
+    static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    uint32_t init[16], st[16];
+    for (int i = 0; i < 4; ++i) init[i] = sigma[i];
+    for (int i = 0; i < 8; ++i) init[4 + i] = key[i];
+    for (int i = 0; i < 4; ++i) init[12 + i] = w12_15[i];
+    memcpy(st, init, sizeof(st));
+    for (int r = 0; r < rounds / 2; ++r) {
+        qround(st, 0, 4, 8, 12); qround(st, 1, 5, 9, 13); qround(st, 2, 6, 10, 14); qround(st, 3, 7, 11, 15);
+        qround(st, 0, 5, 10, 15); qround(st, 1, 6, 11, 12); qround(st, 2, 7, 8, 13); qround(st, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; ++i) out[i] = st[i] + init[i];
+}
+
+/* one sample from S bytes of keystream (little-endian words) */
+static u128 orc_sample(const orc_field* f, const uint32_t* w) {
+    const int eb = f->eb;
+    if (f->binary) {
+        if (eb == 1) return (u128)(w[0]) ; /* caller masks per byte */
+        if (eb == 8) return (((u128)w[1] << 32) | w[0]) & f->mask;
+        return (((u128)w[3] << 96) | ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0]) & f->mask;
+    }
+    if (eb == 4) {
+        u128 v = ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0];
+        return v % f->p;
+    }
+    if (eb == 8) {
+        u128 lo = ((u128)w[1] << 32) | w[0], hi = ((u128)w[3] << 32) | w[2];
+        u128 R = (((u128)1) << 64) % f->p;
+        return (mulmod(hi % f->p, R, f->p) + lo % f->p) % f->p;
+    }
+    u128 lo = ((u128)w[3] << 96) | ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0];
+    u128 hi = ((u128)w[7] << 96) | ((u128)w[6] << 64) | ((u128)w[5] << 32) | w[4];
+    u128 R = 1;
+    for (int i = 0; i < 128; ++i) R = addmod(R, R, f->p);   /* 2^128 mod p */
+    return addmod(mulmod(hi % f->p, R, f->p), lo % f->p, f->p);
+}
+
+/* coefficient matrix (t, n), row stride cstride elements, exactly as the device draws it */
+int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, int rounds, int t,
+                   unsigned char* out, size_t cstride, size_t n) {
+    const int eb = f->eb;
+    const int EPV = 16 / eb;                         /* elements per 16-byte pack */
+    const int packed = (f->binary && eb == 1);       /* GF(2^n<=8): a word holds 4 elements */
+    const int WPP = packed ? 4 : EPV;                /* sampled words per pack */
+    const int S = packed ? 4 : (f->binary ? eb : (eb == 16 ? 32 : 16));
+    const int SPB = 64 / S;
+    uint32_t key[8];
+    memcpy(key, key32, 32);
+    if (rounds == 0) rounds = 20;
+    const size_t npacks = (n + EPV - 1) / EPV;
+    const int rows_per_draw = t <= 4 ? t : 1;
+    const int draws = t <= 4 ? 1 : t;
+    for (int d = 0; d < draws; ++d) {
+        const int T = rows_per_draw;
+        const int NS = T * WPP;
+        const int B = (NS + SPB - 1) / SPB;
+        uint32_t n0 = (uint32_t)nonce, n1 = (uint32_t)(nonce >> 32);
+        if (t > 4) n1 += (uint32_t)(d + 1);
+        for (size_t i = 0; i < npacks; ++i) {
+            uint32_t ks[16 * 8];
+            for (int b = 0; b < B; ++b) {
+                uint64_t ctr = (uint64_t)i * B + b;
+                uint32_t w[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), n0, n1};
+                orc_chacha_block(key, w, rounds, ks + 16 * b);
+            }
+            for (int sn = 0; sn < NS; ++sn) {
+                int j = sn / WPP, q = sn % WPP;
+                const uint32_t* w = ks + 16 * (sn / SPB) + (sn % SPB) * (S / 4);
+                int row = t > 4 ? d : j;
+                if (packed) {
+                    uint32_t word = w[0] & (uint32_t)(0x01010101u * (uint32_t)f->mask);
+                    for (int b_ = 0; b_ < 4; ++b_) {
+                        size_t e = i * EPV + (size_t)q * 4 + b_;
+                        if (e < n) st(out, (size_t)row * cstride + e, eb, (word >> (8 * b_)) & 0xff);
+                    }
+                } else {
+                    size_t e = i * EPV + (size_t)q;
+                    if (e < n) st(out, (size_t)row * cstride + e, eb, orc_sample(f, w));
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 size_t orc_field_sizeof(void) { return sizeof(orc_field); }

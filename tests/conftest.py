@@ -27,7 +27,8 @@ def hostcheck():
     src = os.path.join(ROOT, 'tests', 'hostcheck.cpp')
     dst = os.path.join(ROOT, 'tests', '_hostcheck.so')
     deps = [src, os.path.join(ROOT, 'mpyc_amd', 'csrc', 'fields.hpp'),
-            os.path.join(ROOT, 'mpyc_amd', 'csrc', 'policy_build.hpp')]
+            os.path.join(ROOT, "mpyc_amd", "csrc", "policy_build.hpp"),
+            os.path.join(ROOT, "mpyc_amd", "csrc", "rng.hpp")]
     if any(_newer(d, dst) for d in deps):
         subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-o', dst, src], check=True)
     return ctypes.CDLL(dst)

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../mpyc_amd/csrc/policy_build.hpp"
+#include "../mpyc_amd/csrc/rng.hpp"
 
 using namespace ffgpu;
 
@@ -121,6 +122,81 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
         case POL_GF2P8: return run<GF2P8>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W128: return run<GF2W128>(pb, op, a, b, c, out, n, x, lam, k);
+        default: return 2;
+    }
+}
+
+// ---- device CSPRNG (rng.hpp) on the host ---------------------------------------------------
+extern "C" void hc_chacha_block(const uint32_t key[8], const uint32_t w[4], int rounds, uint32_t out[16]) {
+    chacha_block(key, w[0], w[1], w[2], w[3], rounds, out);
+}
+
+template <class F, int T>
+static void draw_rows(const PolicyBlob& pb, const RngKey& rk, unsigned char* out, size_t cstride, size_t n, int row0) {
+    F f;
+    memcpy(&f, pb.bytes, sizeof(F));
+    uint64_t R[2];
+    rng_const(pb, R);
+    constexpr int WPP = 16 / sizeof(typename F::word);
+    constexpr int EPV = WPP * F::EPW;
+    size_t npacks = (n + EPV - 1) / EPV;
+    for (size_t i = 0; i < npacks; ++i) {
+        typename F::word c[T][WPP];
+        rng_draw_pack<F, T, WPP>(f, rk, R[0], R[1], (uint64_t)i, c);
+        for (int j = 0; j < T; ++j)
+            for (int q = 0; q < WPP; ++q)
+                for (int b = 0; b < F::EPW; ++b) {
+                    size_t e = i * EPV + (size_t)q * F::EPW + b;
+                    if (e >= n) continue;
+                    typename F::word v = c[j][q];
+                    if constexpr (F::EPW > 1) v = (typename F::word)((v >> (8 * b)) & 0xffu);
+                    stw<F>(out + (size_t)(row0 + j) * cstride * sizeof(typename F::elem), e, v);
+                }
+    }
+}
+
+template <class F>
+static int rng_rows(const PolicyBlob& pb, RngKey rk, int t, unsigned char* out, size_t cstride, size_t n) {
+    switch (t) {
+        case 1: draw_rows<F, 1>(pb, rk, out, cstride, n, 0); return 0;
+        case 2: draw_rows<F, 2>(pb, rk, out, cstride, n, 0); return 0;
+        case 3: draw_rows<F, 3>(pb, rk, out, cstride, n, 0); return 0;
+        case 4: draw_rows<F, 4>(pb, rk, out, cstride, n, 0); return 0;
+        default:
+            for (int j = 0; j < t; ++j) {
+                RngKey rj = rk;
+                rj.nonce[1] += (uint32_t)(j + 1);
+                draw_rows<F, 1>(pb, rj, out, cstride, n, j);
+            }
+            return 0;
+    }
+}
+
+extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, const unsigned char* key32,
+                             uint64_t nonce, int rounds, int t, unsigned char* out, size_t cstride, size_t n) {
+    PolicyBlob pb;
+    memset(&pb, 0, sizeof(pb));
+    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs)
+                    : build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+    if (rc) return 100 + rc;
+    RngKey rk;
+    memset(&rk, 0, sizeof(rk));
+    memcpy(rk.key, key32, 32);
+    rk.nonce[0] = (uint32_t)nonce;
+    rk.nonce[1] = (uint32_t)(nonce >> 32);
+    rk.rounds = rounds ? (uint32_t)rounds : 20u;
+    switch (pb.kind) {
+        case POL_PM64_MERSENNE: return rng_rows<PM64<false, true> >(pb, rk, t, out, cstride, n);
+        case POL_PM64_K64: return rng_rows<PM64<true, false> >(pb, rk, t, out, cstride, n);
+        case POL_PM64_GEN: return rng_rows<PM64<false, false> >(pb, rk, t, out, cstride, n);
+        case POL_RC64: return rng_rows<RC64>(pb, rk, t, out, cstride, n);
+        case POL_RC32: return rng_rows<RC32>(pb, rk, t, out, cstride, n);
+        case POL_PM128_K128: return rng_rows<PM128<true> >(pb, rk, t, out, cstride, n);
+        case POL_PM128_GEN: return rng_rows<PM128<false> >(pb, rk, t, out, cstride, n);
+        case POL_MONT128: return rng_rows<MONT128>(pb, rk, t, out, cstride, n);
+        case POL_GF2P8: return rng_rows<GF2P8>(pb, rk, t, out, cstride, n);
+        case POL_GF2W64: return rng_rows<GF2W64>(pb, rk, t, out, cstride, n);
+        case POL_GF2W128: return rng_rows<GF2W128>(pb, rk, t, out, cstride, n);
         default: return 2;
     }
 }

@@ -226,6 +226,51 @@ def test_vs_oracle_sharing(eng, coracle, modulus, binary):
             assert (rec.to_numpy() == S).all(), (t, m, k)          # round trip: it IS the secret
 
 
+KEY = bytes(range(100, 132))
+
+
+@pytest.mark.parametrize('modulus,binary', FIELDS)
+def test_device_rng(eng, coracle, modulus, binary):
+    """On-device CSPRNG: coefficient matrix == oracle restatement of ChaCha + sampler + layout;
+    fused split_rng == split(materialised coefficients), incl. tails, unaligned input, t > 4."""
+    F = po.Field(modulus, binary)
+    ctx = ctx_for(eng, modulus, binary)
+    eb = ctx.elem_bytes
+    cf = coracle.CField(modulus, binary)
+    for (t, m, n, rounds, nonce) in [(1, 3, 4099, 20, 0), (3, 7, 2051, 20, 0xabcdef0123456789), (2, 5, 1025, 12, 3),
+                                     (4, 9, 517, 8, 9), (6, 13, 300, 20, 0xffffffff00000001)]:
+        if m >= F.order:
+            continue
+        C = ctx.rng_coeffs(KEY, nonce, t, n, rounds)
+        want = coracle.rng_coeffs(cf, KEY, nonce, rounds, t, n)
+        assert (C.to_numpy() == want).all(), (t, n)
+        S, B = rand_np(F, eb, n, 61), rand_np(F, eb, n, 62)
+        dS, dB = ctx.from_numpy(S), ctx.from_numpy(B)
+        ref = ctx.split(dS, C, t, m)
+        got = ctx.split_rng(dS, t, m, key=KEY, nonce=nonce, rounds=rounds)
+        assert (got.to_numpy() == ref.to_numpy()).all(), (t, m, n)
+        assert (got.to_numpy() == cf.split(S, want, t, m)).all(), (t, m, n)
+        fused = ctx.split_rng(dS, t, m, key=KEY, nonce=nonce, rounds=rounds, mul_by=dB)
+        assert (fused.to_numpy() == ctx.split(dS, C, t, m, mul_by=dB).to_numpy()).all(), (t, m, n)
+        if eb < 16:
+            # unaligned secrets pointer -> scalar path draws the same coefficients per element
+            k_ = n - 1
+            va = eng.DevArray(ctx, dS.t[1:], k_)
+            got_u = ctx.split_rng(va, t, m, key=KEY, nonce=nonce, rounds=rounds)
+            Ck = ctx.rng_coeffs(KEY, nonce, t, k_, rounds)
+            assert (got_u.to_numpy() == ctx.split(va, Ck, t, m).to_numpy()).all(), (t, m, 'unaligned')
+    # fresh key per call by default: two calls differ, both recombine to the secret
+    if F.order > 3:
+        n = 1000
+        S = rand_np(F, eb, n, 63)
+        dS = ctx.from_numpy(S)
+        a, b = ctx.split_rng(dS, 1, 3), ctx.split_rng(dS, 1, 3)
+        assert not (a.to_numpy() == b.to_numpy()).all()
+        lam = po.recombination_vector(F, [1, 2], 0)
+        for sh in (a, b):
+            assert (ctx.recombine([sh.row(0), sh.row(1)], lam).to_numpy() == S).all()
+
+
 def test_many_rows_and_outputs(eng, coracle):
     """k > 9 rows (generic kernel), w > 8 outputs, t > 4 (generic split)."""
     for modulus, binary in [(P64, False), (0x11b, True), (P128, False)]:
