@@ -252,6 +252,12 @@ def main():
         bpu = (k + 1) * eb
         kern['recombine_p61_k3'] = dict(roof(bpu * n, ms), kernel='k_recombine<PM64<false,true>,3>',
                                         algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+        for rounds in (20, 8):
+            ms = time_launches(lambda s: ctx.split_rng(s.c, t, m, key=bytes(range(32)), nonce=3, rounds=rounds,
+                                                       out=s.shares), sets, reps)
+            bpu = (1 + m) * eb
+            kern[f'split_rng_p61_m3t1_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                              units_per_s=round(n / (ms * 1e-3), 1))
         # fused local product + share generation (c never written)
         def f_fused(s):
             ctx.split(s.a, s.coef, t, m, out=s.shares, mul_by=s.b)
@@ -276,6 +282,14 @@ def main():
         bpu = (1 + t2 + m2) * eb
         kern['split_p64_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                       units_per_s=round(n / (ms * 1e-3), 1))
+        # production mode: coefficients from the on-device CSPRNG (never in HBM): 8 read + 56 written
+        key = bytes(range(32))
+        for rounds in (20, 12, 8):
+            ms = time_launches(lambda s: ctx64.split_rng(s.a, t2, m2, key=key, nonce=7, rounds=rounds, out=s.shares),
+                               sets64, reps)
+            bpu = (1 + m2) * eb
+            kern[f'split_rng_p64_m7t3_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                              units_per_s=round(n / (ms * 1e-3), 1))
         F64 = po.Field(P64)
         for kk in (t2 + 1, 2 * t2 + 1):
             lam64 = po.recombination_vector(F64, list(range(1, kk + 1)), 0)

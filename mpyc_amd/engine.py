@@ -181,6 +181,8 @@ class FieldContext:
         """a: limb array as produced by ints_to_np (already canonical)."""
         eb = self.elem_bytes
         a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
         n = a.shape[0]
         if eb == 4:
             t = torch.from_numpy(a.view(np.int32))

@@ -1,0 +1,789 @@
+"""Host-side mirror of mpyc.finfields on the MI355X engine.
+
+Same names and argument meaning as the reference (mpyc/finfields.py) for the part of the
+module that sits on the hot path:
+
+    GF(modulus)                      finfields.py:23-42    field type + `.array` type
+    find_prime_root, find_irreducible  :311-344, :502-505 the default moduli MPyC picks
+    PrimeFieldElement / BinaryFieldElement   :366-, :528-  scalar elements (host, Python ints)
+    FieldArray (= field.array)       :695-1368              arrays: device-resident limbs, every
+                                                            element-wise op is a HIP kernel launch
+
+Scalars stay on the host (there is nothing to parallelise in one field element); arrays never
+compute on the host: an operation the engine cannot run raises NotImplementedError, it does not
+fall back to NumPy object arrays.  `.value` materialises the reference's representation (object
+ndarray of canonical Python ints, finfields.py:703-709) lazily and read-only, for the callers
+that read it directly (runtime.py:561,643,...) or pickle it for the wire.
+"""
+from __future__ import annotations
+
+import functools
+import math
+import random as _random
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .engine import DevArray, DevMatrix, FieldContext, ints_to_np, np_to_ints
+from .gfpx import BinaryPolynomial, GFpX, _clinvert, _clmod, _clmul
+
+__all__ = ['GF', 'find_prime_root', 'find_irreducible', 'FieldArray', 'PrimeFieldElement', 'BinaryFieldElement']
+
+
+# --------------------------------------------------------------------------------------------
+# number theory helpers (mpyc/gmpy.py stubs :122-290 do the same in pure Python)
+# --------------------------------------------------------------------------------------------
+_SMALL_PRIMES = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+
+
+def is_prime(n: int) -> bool:
+    if n < 2:
+        return False
+    for q in _SMALL_PRIMES:
+        if n % q == 0:
+            return n == q
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    # deterministic for n < 3.3e24 with the first 12 primes; add random bases beyond that
+    bases = list(_SMALL_PRIMES)
+    if n.bit_length() > 81:
+        rng = _random.Random(n)
+        bases += [rng.randrange(2, n - 1) for _ in range(24)]
+    for a in bases:
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def prev_prime(n: int) -> int:
+    n -= 1
+    while n >= 2 and not is_prime(n):
+        n -= 1
+    return n
+
+
+def find_prime_root(l, blum=True, n=1):
+    """finfields.py:311-344: prime of bit length l (largest [Blum] prime below 2^l for n <= 2)."""
+    if l <= 2:
+        if not blum:
+            return 2, 1, 1
+        return 3, 2, 2
+    if n <= 2:
+        p = prev_prime(1 << l)
+        if blum:
+            while p % 4 != 3:
+                p = prev_prime(p)
+        return p, n, (p - 1 if n == 2 else 1)
+    raise NotImplementedError('roots of unity of order n > 2 (finfields.py:331-343) are not on the accelerated path')
+
+
+def find_irreducible(p, d):
+    """finfields.py:502-505: lexicographically first irreducible polynomial of degree d."""
+    if p != 2:
+        raise NotImplementedError('only characteristic 2 extension fields are accelerated')
+    return BinaryPolynomial.next_irreducible(p**d - 1)
+
+
+# --------------------------------------------------------------------------------------------
+# field elements (host scalars)
+# --------------------------------------------------------------------------------------------
+class FiniteFieldElement:
+    """finfields.py:63-221.  Invariant: `value` is reduced w.r.t. the modulus."""
+
+    __slots__ = 'value'
+    modulus = None
+    order = None
+    characteristic = None
+    ext_deg = None
+    byte_length = None
+    is_signed = None
+    array = None
+    _binary = False
+
+    def __init__(self, value):
+        self.value = self._reduce(value)
+
+    # -- wire format: fixed-width little-endian (finfields.py:91-102) --
+    @classmethod
+    def to_bytes(cls, x):
+        r = cls.byte_length
+        return b''.join(int(v).to_bytes(r, 'little') for v in x)
+
+    @classmethod
+    def from_bytes(cls, data):
+        r = cls.byte_length
+        return [int.from_bytes(data[i:i + r], 'little') for i in range(0, len(data), r)]
+
+    @classmethod
+    def _coerce(cls, other):
+        if isinstance(other, cls):
+            return int(other.value)
+        if isinstance(other, (int, np.integer)) and not isinstance(other, bool):
+            return cls._reduce_int(int(other))
+        if isinstance(other, BinaryPolynomial) and cls._binary:
+            return cls._reduce_int(int(other))
+        return None
+
+    def __add__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._add(int(self.value), o))
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._sub(int(self.value), o))
+
+    def __rsub__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._sub(o, int(self.value)))
+
+    def __mul__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._mul(int(self.value), o))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return type(self)(self._sub(0, int(self.value)))
+
+    def __truediv__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._mul(int(self.value), self._inv(o)))
+
+    def __rtruediv__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else type(self)(self._mul(o, self._inv(int(self.value))))
+
+    def __pow__(self, e):
+        if not isinstance(e, int):
+            return NotImplemented
+        base = int(self.value)
+        if e < 0:
+            base, e = self._inv(base), -e
+        r = 1
+        while e:
+            if e & 1:
+                r = self._mul(r, base)
+            base = self._mul(base, base)
+            e >>= 1
+        return type(self)(r)
+
+    def reciprocal(self):
+        return type(self)(self._inv(int(self.value)))
+
+    def __eq__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else int(self.value) == o
+
+    def __hash__(self):
+        return hash((type(self).__name__, int(self.value)))
+
+    def __bool__(self):
+        return bool(int(self.value))
+
+    def __repr__(self):
+        return f'{int(self)}'
+
+
+class PrimeFieldElement(FiniteFieldElement):
+    """finfields.py:366-500."""
+
+    __slots__ = ()
+
+    @classmethod
+    def _reduce_int(cls, v):
+        return v % cls.modulus
+
+    def _reduce(self, value):
+        if isinstance(value, FiniteFieldElement):
+            value = value.value
+        if not isinstance(value, (int, np.integer)) or isinstance(value, bool):
+            raise TypeError(f'int required, got {type(value).__name__}')      # finfields.py:379
+        return int(value) % self.modulus
+
+    @classmethod
+    def _add(cls, a, b):
+        return (a + b) % cls.modulus
+
+    @classmethod
+    def _sub(cls, a, b):
+        return (a - b) % cls.modulus
+
+    @classmethod
+    def _mul(cls, a, b):
+        return a * b % cls.modulus
+
+    @classmethod
+    def _inv(cls, a):
+        if a % cls.modulus == 0:
+            raise ZeroDivisionError('inverse does not exist')                 # gmpy.py:197-210
+        return pow(a, -1, cls.modulus)
+
+    def signed_(self):
+        v = int(self.value)
+        return v - self.modulus if v > self.modulus >> 1 else v              # finfields.py:1395-1398 rule
+
+    def unsigned_(self):
+        return int(self.value)
+
+    def __int__(self):
+        return self.signed_() if self.is_signed else self.unsigned_()
+
+
+class BinaryFieldElement(FiniteFieldElement):
+    """finfields.py:528-692 for characteristic 2; `value` is a BinaryPolynomial (gfpx.py:848)."""
+
+    __slots__ = ()
+    _binary = True
+
+    @classmethod
+    def _reduce_int(cls, v):
+        return _clmod(abs(int(v)), int(cls.modulus))
+
+    def _reduce(self, value):
+        if isinstance(value, FiniteFieldElement):
+            value = value.value
+        if isinstance(value, float):
+            raise TypeError('int or polynomial required')
+        return BinaryPolynomial(_clmod(int(BinaryPolynomial(value)), int(self.modulus)))
+
+    @classmethod
+    def _add(cls, a, b):
+        return a ^ b
+
+    _sub = _add
+
+    @classmethod
+    def _mul(cls, a, b):
+        return _clmod(_clmul(a, b), int(cls.modulus))
+
+    @classmethod
+    def _inv(cls, a):
+        if a == 0:
+            raise ZeroDivisionError('inverse does not exist')
+        return _clinvert(a, int(cls.modulus))
+
+    def __int__(self):
+        return int(self.value)
+
+
+# --------------------------------------------------------------------------------------------
+# field factories
+# --------------------------------------------------------------------------------------------
+def GF(modulus):
+    """Create a finite field for a prime modulus (int) or an irreducible binary polynomial
+    (mpyc_amd.gfpx.BinaryPolynomial); also creates the GPU-backed array type (finfields.py:23-42)."""
+    if isinstance(modulus, BinaryPolynomial):
+        return _xGF(int(modulus))
+    if isinstance(modulus, tuple):
+        modulus = modulus[0]
+    if isinstance(modulus, (int, np.integer)) and not isinstance(modulus, bool):
+        return _pGF(int(modulus))
+    raise TypeError('modulus must be a prime int or a BinaryPolynomial')
+
+
+def _make_array(field):
+    arr = type(f'Array{field.__name__}', (FieldArray,), {'__slots__': ()})     # finfields.py:45-60
+    arr.field = field
+    field.array = arr
+    return arr
+
+
+@functools.lru_cache(maxsize=None)
+def _pGF(p):
+    if not is_prime(p):
+        raise ValueError('modulus is not a prime')                            # finfields.py:351
+    if p.bit_length() > 128:
+        raise NotImplementedError('primes above 128 bits are not supported by the device path')
+    F = type(f'GF({p})', (PrimeFieldElement,), {'__slots__': ()})
+    F.modulus, F.order, F.characteristic, F.ext_deg = p, p, p, 1
+    F.byte_length = (p.bit_length() + 7) >> 3
+    F.is_signed = True
+    F.nth, F.root = (1, 1) if p == 2 else (2, p - 1)
+    _make_array(F)
+    return F
+
+
+@functools.lru_cache(maxsize=None)
+def _xGF(mod):
+    if not BinaryPolynomial.is_irreducible(mod):
+        raise ValueError('modulus is not irreducible')                        # finfields.py:514
+    d = mod.bit_length() - 1
+    if d > 128:
+        raise NotImplementedError('GF(2^n) beyond n = 128 is not supported by the device path')
+    F = type(f'GF(2^{d})', (BinaryFieldElement,), {'__slots__': ()})
+    F.modulus, F.order, F.characteristic, F.ext_deg = BinaryPolynomial(mod), 2**d, 2, d
+    F.byte_length = ((2**d).bit_length() + 7) >> 3                            # NB 2 for GF(2^8): finfields.py:524
+    _make_array(F)
+    return F
+
+
+_ctx_cache = {}
+
+
+def _context(field, device: Optional[int] = None) -> FieldContext:
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    key = (field, device)
+    ctx = _ctx_cache.get(key)
+    if ctx is None:
+        ctx = FieldContext(int(field.modulus), binary=field._binary, device=device)
+        _ctx_cache[key] = ctx
+    return ctx
+
+
+# --------------------------------------------------------------------------------------------
+# arrays
+# --------------------------------------------------------------------------------------------
+class FieldArray:
+    """GPU-backed counterpart of finfields.FiniteFieldArray (finfields.py:695-1368).
+
+    ctor (value, check=True, copy=False) as in the reference: `value` may be nested lists / ndarrays
+    of ints (any integer dtype or object), another FieldArray, or an engine DevArray; with
+    check=True inputs are reduced into canonical form (negative ints wrap Python-style)."""
+
+    __slots__ = ('_dev', '_shape', '_cache')
+    field = None            # set per field by GF()
+    __array_priority__ = 100
+
+    def __init__(self, value, check=True, copy=False):
+        F = type(self).field
+        ctx = _context(F)
+        self._cache = None
+        if isinstance(value, FieldArray):
+            if value.field is not F:
+                raise TypeError('array over a different field')
+            self._dev = value._dev.clone() if copy else value._dev
+            self._shape = value._shape
+            return
+        if isinstance(value, DevArray):
+            self._dev = ctx.reduce(value) if check else (value.clone() if copy else value)
+            self._shape = (value.n,)
+            return
+        if isinstance(value, torch.Tensor):
+            raise TypeError('wrap raw limb tensors in an engine.DevArray')
+        # lists go through dtype=object so that big Python ints are never coerced to float64
+        a = value if isinstance(value, np.ndarray) else np.array(value, dtype=object)
+        if a.dtype.kind == 'f' or a.dtype.kind == 'c':
+            raise TypeError('float values are not field elements')            # tests/test_finfields.py:372-382
+        shape = a.shape
+        flat = a.reshape(-1)
+        if flat.dtype == object:
+            if any(isinstance(v, (float, complex, np.floating)) for v in flat):
+                raise TypeError('float values are not field elements')
+            flat = np.array([int(v.value) if isinstance(v, FiniteFieldElement) else int(v) for v in flat],
+                            dtype=object) if flat.size else flat
+        if check and flat.size:
+            flat = self._canonical_host(flat, F)
+        self._dev = ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes)) if flat.size else ctx.empty(0)
+        self._shape = tuple(shape)
+
+    @staticmethod
+    def _canonical_host(flat, F):
+        """`value %= modulus` (finfields.py:724) for inputs that arrive as host integers."""
+        if F._binary:
+            mod = int(F.modulus)
+            if flat.dtype != object:
+                flat = flat.astype(object)
+            return np.array([_clmod(abs(int(v)), mod) for v in flat], dtype=object)
+        p = F.modulus
+        if flat.dtype != object:
+            if flat.dtype.kind == 'u' and flat.dtype.itemsize * 8 < p.bit_length():
+                return flat                                                   # already < p
+            flat = flat.astype(object)
+        return flat % p
+
+    # ---- representation --------------------------------------------------------------
+    @property
+    def ctx(self) -> FieldContext:
+        return self._dev.ctx
+
+    @property
+    def value(self) -> np.ndarray:
+        """Object ndarray of canonical Python ints (BinaryPolynomial objects for GF(2^n)), as the
+        reference stores it.  Materialised on first use, read-only snapshot."""
+        if self._cache is None:
+            ints = self._dev.to_ints()
+            if type(self).field._binary:
+                ints = [BinaryPolynomial(v) for v in ints]
+            v = np.empty(len(ints), dtype=object)
+            v[:] = ints
+            v = v.reshape(self._shape)
+            v.flags.writeable = False
+            self._cache = v
+        return self._cache
+
+    @value.setter
+    def value(self, v):
+        other = type(self)(v, check=False)
+        self._dev, self._shape, self._cache = other._dev, other._shape, None
+
+    @property
+    def device_array(self) -> DevArray:
+        return self._dev
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self._shape, dtype=np.int64)) if self._shape else 1
+
+    def __len__(self):
+        if not self._shape:
+            raise TypeError('len() of unsized object')
+        return self._shape[0]
+
+    @classmethod
+    def _wrap(cls, dev: DevArray, shape) -> 'FieldArray':
+        o = cls.__new__(cls)
+        o._dev, o._shape, o._cache = dev, tuple(shape), None
+        return o
+
+    def copy(self):
+        return self._wrap(self._dev.clone(), self._shape)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        n = self.size
+        if -1 in shape:
+            known = -int(np.prod(shape))
+            shape = tuple(n // known if s == -1 else s for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) != n:
+            raise ValueError(f'cannot reshape array of size {n} into shape {shape}')
+        return self._wrap(self._dev, shape)                                   # view: same device data
+
+    def flatten(self):
+        return self._wrap(self._dev.clone(), (self.size,))
+
+    def ravel(self):
+        return self.reshape(-1)
+
+    def _limb_view(self):
+        """limb tensor shaped like the array (+ trailing 2 for two-limb fields)."""
+        t = self._dev.t
+        return t.reshape(tuple(self._shape) + ((2,) if self.ctx.elem_bytes == 16 else ()))
+
+    def __getitem__(self, key):
+        t = self._limb_view()
+        if self.ctx.elem_bytes == 16:
+            key = key if isinstance(key, tuple) else (key,)
+            sub = t[key + (Ellipsis, slice(None))] if Ellipsis not in key else t[key]
+            shape = sub.shape[:-1]
+        else:
+            sub = t[key]
+            shape = sub.shape
+        if len(shape) == 0:
+            flat = sub.reshape(1, 2) if self.ctx.elem_bytes == 16 else sub.reshape(1)
+            return type(self).field(DevArray(self.ctx, flat, 1).to_ints()[0])
+        n = int(np.prod(shape, dtype=np.int64))
+        flat = sub.reshape(n, 2) if self.ctx.elem_bytes == 16 else sub.reshape(n)
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        return self._wrap(DevArray(self.ctx, flat, n), shape)
+
+    def __setitem__(self, key, value):
+        cls = type(self)
+        if isinstance(value, FiniteFieldElement) or isinstance(value, (int, np.integer)):
+            value = cls([value]).reshape(())
+        elif not isinstance(value, FieldArray):
+            value = cls(value)
+        src = value._limb_view()
+        t = self._limb_view()
+        if self.ctx.elem_bytes == 16:
+            key = key if isinstance(key, tuple) else (key,)
+            t[key + (Ellipsis, slice(None))] = src
+        else:
+            t[key] = src
+        self._cache = None
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    # ---- operand handling (finfields.py:1045-1054 _coerce) ---------------------------------
+    def _operand(self, other):
+        """-> ('array', FieldArray) | ('scalar', int) | None"""
+        cls, F = type(self), type(self).field
+        if isinstance(other, FieldArray):
+            if other.field is not F:
+                raise TypeError('arrays over different fields')
+            return ('array', other) if other.size != 1 or other.ndim > self.ndim else ('scalar', other._dev.to_ints()[0])
+        if isinstance(other, FiniteFieldElement):
+            if type(other) is not F:
+                raise TypeError('element of a different field')
+            return 'scalar', int(other.value)
+        if isinstance(other, bool):
+            return None
+        if isinstance(other, (int, np.integer)):
+            return 'scalar', F._reduce_int(int(other))
+        if isinstance(other, BinaryPolynomial) and F._binary:
+            return 'scalar', F._reduce_int(int(other))
+        if isinstance(other, float):
+            raise TypeError('float operand')
+        if isinstance(other, (np.ndarray, list, tuple)):
+            arr = cls(other)                         # raises TypeError for float dtypes
+            return ('array', arr) if arr.size != 1 else ('scalar', arr._dev.to_ints()[0])
+        return None
+
+    def _broadcast(self, other: 'FieldArray'):
+        if self._shape == other._shape:
+            return self._dev, other._dev, self._shape
+        shape = tuple(np.broadcast_shapes(self._shape, other._shape))
+        out = []
+        for x in (self, other):
+            if x._shape == shape:
+                out.append(x._dev)
+                continue
+            t = x._limb_view()
+            if x.ctx.elem_bytes == 16:
+                t = t.expand(*shape, 2).contiguous().view(-1, 2)
+            else:
+                t = t.expand(*shape).contiguous().view(-1)
+            out.append(DevArray(x.ctx, t, t.shape[0]))
+        return out[0], out[1], shape
+
+    def _binop(self, other, arr_op, scalar_op, reflected_scalar_op=None, inplace=False):
+        opd = self._operand(other)
+        if opd is None:
+            return NotImplemented
+        ctx = self.ctx
+        kind, o = opd
+        if kind == 'scalar':
+            fn = reflected_scalar_op or scalar_op
+            res = fn(ctx, self._dev, o, self._dev if inplace else None)
+            shape = self._shape
+        else:
+            a, b, shape = self._broadcast(o)
+            if inplace and shape != self._shape:
+                raise ValueError('non-broadcastable output operand')
+            res = arr_op(ctx, a, b, self._dev if inplace else None)
+        if inplace:
+            self._cache = None
+            return self
+        return self._wrap(res, shape)
+
+    # ---- arithmetic (finfields.py:1056-1124, 1189-1197) --------------------------------------
+    def __add__(self, other):
+        return self._binop(other, FieldContext.add, FieldContext.add_scalar)
+
+    __radd__ = __add__
+
+    def __iadd__(self, other):
+        return self._binop(other, FieldContext.add, FieldContext.add_scalar, inplace=True)
+
+    def __sub__(self, other):
+        def sub_scalar(ctx, a, s, out):
+            F = type(self).field
+            return ctx.add_scalar(a, F._sub(0, s), out)
+        return self._binop(other, FieldContext.sub, sub_scalar)
+
+    def __rsub__(self, other):
+        opd = self._operand(other)
+        if opd is None:
+            return NotImplemented
+        kind, o = opd
+        if kind == 'scalar':
+            return self._wrap(self.ctx.rsub_scalar(self._dev, o), self._shape)
+        return o.__sub__(self)
+
+    def __isub__(self, other):
+        def sub_scalar(ctx, a, s, out):
+            return ctx.add_scalar(a, type(self).field._sub(0, s), out)
+        return self._binop(other, FieldContext.sub, sub_scalar, inplace=True)
+
+    def __mul__(self, other):
+        return self._binop(other, FieldContext.mul, FieldContext.mul_scalar)
+
+    __rmul__ = __mul__
+
+    def __imul__(self, other):
+        return self._binop(other, FieldContext.mul, FieldContext.mul_scalar, inplace=True)
+
+    def __neg__(self):
+        return self._wrap(self.ctx.neg(self._dev), self._shape)
+
+    def __pos__(self):
+        return self.copy()
+
+    def __pow__(self, e):
+        if not isinstance(e, (int, np.integer)) or isinstance(e, bool):
+            return NotImplemented
+        e = int(e)
+        if e < 0:
+            return self.reciprocal() ** (-e)
+        ctx = self.ctx
+        if e == 0:
+            return self._wrap(ctx.add_scalar(ctx.mul_scalar(self._dev, 0), 1), self._shape)
+        # left-to-right square and multiply, every step a device launch
+        result = None
+        base = self._dev
+        while True:
+            if e & 1:
+                result = base.clone() if result is None else ctx.mul(result, base)
+            e >>= 1
+            if not e:
+                break
+            base = ctx.mul(base, base)
+        return self._wrap(result, self._shape)
+
+    def reciprocal(self):
+        """Element-wise inverse a^(q-2) on the device (finfields.py:1278-1281, :1416-1422)."""
+        if self.size and bool((self._zero_mask()).any()):
+            raise ZeroDivisionError('inverse of 0 does not exist')
+        return self ** (type(self).field.order - 2)
+
+    def __truediv__(self, other):
+        opd = self._operand(other)
+        if opd is None:
+            return NotImplemented
+        kind, o = opd
+        if kind == 'scalar':
+            return self * type(self).field._inv(o)
+        return self * o.reciprocal()
+
+    def __rtruediv__(self, other):
+        return self.reciprocal() * other
+
+    def __lshift__(self, k):
+        if not isinstance(k, (int, np.integer)):
+            return NotImplemented
+        F = type(self).field                                                    # finfields.py:1227-1234
+        return self * (F._reduce_int(1 << int(k)) if F._binary else pow(2, int(k), F.modulus))
+
+    def __rshift__(self, k):
+        if not isinstance(k, (int, np.integer)):
+            return NotImplemented
+        F = type(self).field
+        if F._binary:
+            return self * F._inv(F._reduce_int(1 << int(k)))
+        return self * F._inv(pow(2, int(k), F.modulus))                        # :1250-1258
+
+    # ---- small-matrix products (finfields.py:1126-1157) --------------------------------------
+    def __rmatmul__(self, other):
+        """A @ self for a small public/host matrix A (w, k) and self (k, n): the shape of the
+        Vandermonde and Lagrange products in thresha (one pass over HBM, unreduced accumulation)."""
+        if self.ndim != 2:
+            raise NotImplementedError('left operand @ array needs a 2-D array on the right')
+        F = type(self).field
+        A = np.asarray(other.value if isinstance(other, FieldArray) else other, dtype=object)
+        vec = A.ndim == 1
+        A2 = A.reshape(1, -1) if vec else A
+        if A2.ndim != 2 or A2.shape[1] != self._shape[0]:
+            raise ValueError('matmul: shape mismatch')
+        if A2.size > 4096:
+            raise NotImplementedError('dense modular matmul is not on the accelerated path yet')
+        lam = [F._reduce_int(int(v.value) if isinstance(v, FiniteFieldElement) else int(v)) for v in A2.reshape(-1)]
+        k, n = self._shape
+        rows = [self[j]._dev for j in range(k)]
+        w = A2.shape[0]
+        out = self.ctx.recombine(rows, lam, w=w)
+        if w == 1:
+            res = self._wrap(out, (n,))
+            return res if vec else res.reshape(1, n)
+        return _matrix_to_array(type(self), out)
+
+    def __matmul__(self, other):
+        raise NotImplementedError('array @ x is only accelerated with the small operand on the left')
+
+    # ---- comparisons (finfields.py:1031-1043) --------------------------------------------------
+    def _zero_mask(self):
+        t = self._dev.t
+        z = (t == 0)
+        return z.all(dim=-1) if self.ctx.elem_bytes == 16 else z
+
+    def __eq__(self, other):
+        opd = self._operand(other)
+        if opd is None:
+            return NotImplemented
+        kind, o = opd
+        if kind == 'scalar':
+            o = type(self)([o])
+        a, b, shape = self._broadcast(o)
+        eq = (a.t == b.t)
+        if self.ctx.elem_bytes == 16:
+            eq = eq.all(dim=-1)
+        return eq.cpu().numpy().reshape(shape)
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else ~r
+
+    __hash__ = None
+
+    # ---- integer views (finfields.py:1375-1406) --------------------------------------------------
+    def unsigned_(self):
+        return np.array(self._dev.to_ints(), dtype=object).reshape(self._shape)
+
+    def signed_(self):
+        p = type(self).field.modulus
+        return np.array([v - p if v > p >> 1 else v for v in self._dev.to_ints()], dtype=object).reshape(self._shape)
+
+    @classmethod
+    def intarray(cls, a):
+        if cls.field._binary:
+            return a.unsigned_()
+        return a.signed_() if cls.field.is_signed else a.unsigned_()
+
+    def tolist(self):
+        return self.unsigned_().tolist()
+
+    # ---- wire format (finfields.py:91-102) straight from device limbs ------------------------------
+    def to_wire(self) -> bytes:
+        """field.to_bytes(self.value) without boxing Python ints when byte_length == limb width."""
+        F, eb = type(self).field, self.ctx.elem_bytes
+        raw = self._dev.to_numpy()
+        if F.byte_length == eb:
+            return raw.tobytes()
+        n = self.size
+        b = np.frombuffer(raw.tobytes(), dtype=np.uint8).reshape(n, eb)
+        if F.byte_length < eb:
+            return np.ascontiguousarray(b[:, :F.byte_length]).tobytes()
+        pad = np.zeros((n, F.byte_length - eb), dtype=np.uint8)                # e.g. GF(2^8): 2-byte wire elements
+        return np.concatenate([b, pad], axis=1).tobytes()
+
+    @classmethod
+    def from_wire(cls, data: bytes, shape=None) -> 'FieldArray':
+        F = cls.field
+        ctx = _context(F)
+        eb, r = ctx.elem_bytes, F.byte_length
+        n = len(data) // r
+        b = np.frombuffer(data, dtype=np.uint8).reshape(n, r)
+        if r < eb:
+            b = np.concatenate([b, np.zeros((n, eb - r), dtype=np.uint8)], axis=1)
+        elif r > eb:
+            b = b[:, :eb]
+        raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb])
+        raw = raw.reshape(n, 2) if eb == 16 else raw.reshape(n)
+        return cls._wrap(ctx.from_numpy(raw), shape if shape is not None else (n,))
+
+    def __repr__(self):
+        return f'{self.intarray(self)}'
+
+
+def _matrix_to_array(cls, mtx: DevMatrix) -> FieldArray:
+    """(rows, n) DevMatrix with padded pitch -> contiguous (rows, n) FieldArray."""
+    ctx = mtx.ctx
+    if ctx.elem_bytes == 16:
+        t = mtx.t[:, :mtx.n, :].contiguous().view(-1, 2)
+    else:
+        t = mtx.t[:, :mtx.n].contiguous().view(-1)
+    return cls._wrap(DevArray(ctx, t, mtx.rows * mtx.n), (mtx.rows, mtx.n))

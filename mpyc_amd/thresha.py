@@ -1,0 +1,199 @@
+"""Host-side mirror of mpyc.thresha (threshold secret sharing) on the MI355X engine.
+
+Same names, argument meaning and return shapes as the reference (mpyc/thresha.py):
+
+    random_split(field, s, t, m)          thresha.py:23-44    list path (lists of ints in/out)
+    np_random_split(field, s, t, m)       thresha.py:47-64    array path -> (m, n) share matrix
+    _recombination_vector(field, xs, x_r) thresha.py:67-85    host, cached (k <= m scalars)
+    recombine(field, points, x_rs=0)      thresha.py:88-116   list path
+    np_recombine(field, points, x_rs=0)   thresha.py:119-132  array path -> field.array
+
+Randomness.  The reference draws every coefficient with secrets.randbelow (thresha.py:37,58-60).
+Here the default is the on-device CSPRNG keyed from `secrets` (csrc/rng.hpp).  For bit-exact
+parity with the reference set the module attribute `randbelow` to a callable (the same trick the
+reference's tests use by patching secrets.randbelow): coefficients are then drawn through it on
+the host in the reference's order and convention, and uploaded.
+
+All share arithmetic runs on the GPU; the only host arithmetic is the k-entry Lagrange vector.
+"""
+from __future__ import annotations
+
+import functools
+import secrets
+
+import numpy as np
+
+from .engine import DevArray, DevMatrix
+from .finfields import FieldArray, FiniteFieldElement, _context, _matrix_to_array
+
+__all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector']
+
+randbelow = None      # parity hook: callable(order) -> int, else device CSPRNG
+rng_rounds = 20       # ChaCha rounds of the device CSPRNG (20, 12 or 8)
+_nonce = 0
+
+
+def _next_nonce():
+    global _nonce
+    _nonce += 1
+    return _nonce
+
+
+def _as_field_array(field, s) -> FieldArray:
+    if isinstance(s, FieldArray):
+        return s
+    vals = [int(v.value) if isinstance(v, FiniteFieldElement) else v for v in s] if not isinstance(s, np.ndarray) else s
+    return field.array(vals)
+
+
+def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
+    ctx = S.ctx
+    n = S.size
+    dev = S.device_array if S.ndim == 1 else S.reshape(-1).device_array
+    if t == 0 or n == 0:
+        return ctx.split(dev, None, 0, m)
+    if randbelow is None:
+        return ctx.split_rng(dev, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds)
+    order = field.order
+    draws = [randbelow(order) for _ in range(t * n)]
+    if np_convention:
+        rows = [draws[j * n:(j + 1) * n] for j in range(t)]                    # C[j][h] = d[j*n+h], thresha.py:60
+    else:
+        # list path: secret h uses d[h*t : (h+1)*t], c[0] on X^t ... c[t-1] on X (thresha.py:37-43)
+        rows = [[draws[h * t + (t - 1 - j)] for h in range(n)] for j in range(t)]
+    from .engine import ints_to_np
+    eb = ctx.elem_bytes
+    C = ctx.empty_matrix(t, n)
+    for j in range(t):
+        C.row(j).t.copy_(ctx.from_numpy(ints_to_np(rows[j], eb)).t)
+    return ctx.split(dev, C, t, m)
+
+
+class ShareMatrix:
+    """Result of np_random_split: behaves like the reference's (m, n) ndarray for what the
+    runtime does with it (iterate rows, index rows, len, .shape, pickle a row's .value), but the
+    rows stay on the GPU until someone asks for Python ints."""
+
+    def __init__(self, field, mtx: DevMatrix):
+        self.field, self._mtx = field, mtx
+        self.shape = (mtx.rows, mtx.n)
+
+    def __len__(self):
+        return self._mtx.rows
+
+    def __getitem__(self, i) -> FieldArray:
+        if isinstance(i, tuple):
+            return self[i[0]][i[1:]] if len(i) > 1 else self[i[0]]
+        if i < 0:
+            i += self._mtx.rows
+        if not 0 <= i < self._mtx.rows:
+            raise IndexError(i)
+        return self.field.array._wrap(self._mtx.row(i), (self._mtx.n,))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def value(self) -> np.ndarray:
+        """The reference's return value: plain object ndarray (m, n) of canonical ints."""
+        out = np.empty(self.shape, dtype=object)
+        for i in range(self.shape[0]):
+            out[i] = self[i].value
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        return self.value
+
+
+def np_random_split(field, s, t, m) -> ShareMatrix:
+    """Split each secret in s into m random Shamir shares of degree t (0 <= t < m); one row per
+    party (thresha.py:47-64)."""
+    if not 0 <= t < m:
+        raise ValueError('need 0 <= t < m')
+    S = _as_field_array(field, s)
+    return ShareMatrix(field, _split_device(field, S, t, m, np_convention=True))
+
+
+def random_split(field, s, t, m):
+    """List path (thresha.py:23-44): s is a list of ints or field elements; returns m lists of ints."""
+    if not 0 <= t < m:
+        raise ValueError('need 0 <= t < m')
+    if len(s) == 0:
+        return [[] for _ in range(m)]
+    S = _as_field_array(field, list(s))
+    mtx = _split_device(field, S, t, m, np_convention=False)
+    rows = mtx.to_ints()
+    if field._binary:
+        from .gfpx import BinaryPolynomial
+        rows = [[BinaryPolynomial(v) for v in r] for r in rows]
+    return rows
+
+
+@functools.lru_cache(maxsize=None)
+def _recombination_vector(field, xs, x_r):
+    """Lagrange coefficients for interpolation points xs evaluated at x_r, in the order of xs
+    (thresha.py:67-85).  Host scalars; cached per (field, xs, x_r) like the reference."""
+    xs = [field._reduce_int(int(x)) for x in xs]
+    x_r = field._reduce_int(int(x_r))
+    vector = []
+    for i, x_i in enumerate(xs):
+        num, den = 1, 1
+        for j, x_j in enumerate(xs):
+            if i != j:
+                num = field._mul(num, field._sub(x_r, x_j))
+                den = field._mul(den, field._sub(x_i, x_j))
+        vector.append(field._mul(num, field._inv(den)))
+    return vector
+
+
+def _rows_on_device(field, shares):
+    rows = []
+    for sh in shares:
+        if isinstance(sh, FieldArray):
+            rows.append((sh if sh.ndim == 1 else sh.reshape(-1)).device_array)
+        elif isinstance(sh, DevArray):
+            rows.append(sh)
+        else:
+            rows.append(field.array(sh).reshape(-1).device_array)               # reduces, like :128
+    return rows
+
+
+def np_recombine(field, points, x_rs=0):
+    """Recombine shares given by points [(x_j, row_j)] into secrets at x-coordinate(s) x_rs
+    (thresha.py:119-132).  Returns field.array of shape (n,), or (w, n) if x_rs is a list."""
+    xs, shares = list(zip(*points))
+    scalar = not isinstance(x_rs, list)
+    xr = (x_rs,) if scalar else tuple(x_rs)
+    lam = [v for x_r in xr for v in _recombination_vector(field, tuple(xs), x_r)]
+    rows = _rows_on_device(field, shares)
+    ctx = rows[0].ctx
+    out = ctx.recombine(rows, lam, w=len(xr))
+    if scalar:
+        return field.array._wrap(out, (rows[0].n,))
+    if len(xr) == 1:
+        return field.array._wrap(out, (1, rows[0].n))
+    return _matrix_to_array(field.array, out)
+
+
+def recombine(field, points, x_rs=0):
+    """List path (thresha.py:88-116).  The reference returns UNREDUCED integer sums for raw-int
+    shares (:109) and field elements for field-element shares (:110-113); callers reduce the
+    former (runtime.py:588,682).  This mirror returns canonical values in both cases: ints for
+    int shares (congruent to the reference's sums modulo the field modulus) and field elements
+    for field-element shares."""
+    xs, shares = list(zip(*points))
+    if len(shares[0]) == 0:
+        return [] if not isinstance(x_rs, list) else [[] for _ in x_rs]
+    T_is_field = isinstance(shares[0][0], field)
+    rows = [[int(v.value) if isinstance(v, FiniteFieldElement) else v for v in sh] for sh in shares]
+    out = np_recombine(field, list(zip(xs, rows)), x_rs)
+    vals = out.unsigned_().tolist()
+
+    def conv(row):
+        if T_is_field:
+            return [field(v) for v in row]
+        if field._binary:
+            from .gfpx import BinaryPolynomial
+            return [BinaryPolynomial(v) for v in row]
+        return row
+    return conv(vals) if not isinstance(x_rs, list) else [conv(r) for r in vals]

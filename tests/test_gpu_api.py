@@ -1,0 +1,203 @@
+"""GPU tests of the host-side mirror (mpyc_amd.finfields / mpyc_amd.thresha): the reference's own
+tests for this path restated against the mirror (tests/test_thresha.py:15-40 round trips,
+tests/test_finfields.py:94-99,327-335,372-404 array behaviour), plus bit-exact parity with the
+golden vectors through the public API using the `randbelow` hook (the reference's tests patch
+secrets.randbelow the same way)."""
+import random
+
+import numpy as np
+import pytest
+
+from fieldutil import unhex
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def api():
+    assert torch.cuda.is_available()
+    from mpyc_amd import finfields, gfpx, thresha
+    return finfields, gfpx, thresha
+
+
+def field_from_case(api, case):
+    finfields, gfpx, _ = api
+    mod = int(case['modulus'], 16)
+    return finfields.GF(gfpx.BinaryPolynomial(mod)) if case['binary'] else finfields.GF(mod)
+
+
+def ints(a):
+    return [int(v) for v in np.asarray(a.value).reshape(-1)]
+
+
+def test_thresha_round_trips(api):
+    """tests/test_thresha.py:15-40: random_split -> recombine for t in [0,8), m = 2t+1 and m = 17."""
+    finfields, gfpx, thresha = api
+    for field in (finfields.GF(19), finfields.GF(gfpx.GFpX(2)(0x11b)), finfields.GF(2**61 - 1),
+                  finfields.GF(2**128 - 173)):
+        a = [field(0), field(1), field(field.order - 1)] + [field(i + 2) for i in range(5)]
+        for t in range(8):
+            for m in (2 * t + 1, 17):
+                if m >= field.order:
+                    continue
+                shares = thresha.random_split(field, a, t, m)
+                assert len(shares) == m and len(shares[0]) == len(a)
+                pts = [(i + 1, shares[i]) for i in range(t + 1)]
+                b = thresha.recombine(field, pts)
+                assert [int(x) for x in b] == [int(x.value) for x in a], (field, t, m)
+                pts = [(i + 1, [field(int(v)) for v in shares[i]]) for i in range(m - t - 1, m)]
+                b = thresha.recombine(field, pts)
+                assert b == a, (field, t, m)
+                # array path
+                sh = thresha.np_random_split(field, field.array([int(x.value) for x in a]), t, m)
+                assert sh.shape == (m, len(a))
+                y = thresha.np_recombine(field, [(j + 1, sh[j]) for j in range(t + 1)])
+                assert isinstance(y, field.array) and ints(y) == [int(x.value) for x in a]
+    assert thresha.random_split(finfields.GF(19), [], 1, 3) == [[], [], []]
+
+
+def test_golden_parity_through_api(api, golden_fields):
+    """np_random_split / random_split / np_recombine reproduce the reference bit for bit when the
+    same draws are replayed (the two paths use different conventions)."""
+    finfields, gfpx, thresha = api
+    try:
+        for name, case in golden_fields.items():
+            field = field_from_case(api, case)
+            a = unhex(case['a'])
+            s = a[:13] + a[-5:]
+            for sc in case['sharing']:
+                t, m, draws = sc['t'], sc['m'], unhex(sc['draws'])
+                it = iter(draws)
+                thresha.randbelow = lambda bound: next(it)
+                sh = thresha.np_random_split(field, field.array(s), t, m)
+                assert [[int(v) for v in row] for row in sh.value] == [unhex(r) for r in sc['np_shares']], (name, t, m)
+                it = iter(draws)
+                li = thresha.random_split(field, list(s), t, m)
+                assert [[int(v) for v in row] for row in li] == [unhex(r) for r in sc['list_shares']], (name, t, m)
+                for rec in sc['recombine']:
+                    xs = tuple(rec['xs'])
+                    assert [int(v) for v in thresha._recombination_vector(field, xs, 0)] == unhex(rec['vector'])
+                    y = thresha.np_recombine(field, [(x, sh[x - 1]) for x in xs])
+                    assert ints(y) == unhex(rec['np_out']), (name, xs)
+                    # rows as plain object ndarrays (what pickle.loads hands the runtime)
+                    y2 = thresha.np_recombine(field, [(x, sh[x - 1].value) for x in xs])
+                    assert ints(y2) == unhex(rec['np_out'])
+                mu = sc['multi']
+                yw = thresha.np_recombine(field, [(x, sh[x - 1]) for x in mu['xs']], mu['x_rs'])
+                assert yw.shape == (len(mu['x_rs']), len(s))
+                assert [[int(v) for v in row] for row in yw.value] == [unhex(r) for r in mu['out']], name
+    finally:
+        thresha.randbelow = None
+
+
+def test_array_semantics(api, golden_fields):
+    finfields, gfpx, _ = api
+    for name in ('P61', 'P64', 'P128', 'P127', 'GF19', 'GF2_8', 'GF2_128', 'P31'):
+        case = golden_fields[name]
+        F = field_from_case(api, case)
+        a, b = unhex(case['a']), unhex(case['b'])
+        A, B = F.array(a), F.array(b)
+        assert A.shape == (len(a),) and A.ndim == 1 and len(A) == len(a) and A.size == len(a)
+        assert ints(A + B) == unhex(case['add']) and ints(A - B) == unhex(case['sub'])
+        assert ints(A * B) == unhex(case['mul']) and ints(-A) == unhex(case['neg'])
+        sc = int(case['scalar'], 16)
+        for other in (sc, F(sc), np.int64(sc) if sc < 2**63 else sc):
+            assert ints(A + other) == unhex(case['add_scalar']), name
+            assert ints(other + A) == unhex(case['add_scalar']), name
+            assert ints(A * other) == unhex(case['mul_scalar']), name
+            assert ints(other - A) == unhex(case['rsub_scalar']), name
+        # ndarray operand (finfields.py:1045-1054)
+        assert ints(A * np.array(b, dtype=object)) == unhex(case['mul'])
+        # in place
+        C = A.copy()
+        C *= B
+        assert ints(C) == unhex(case['mul'])
+        C = A.copy()
+        C += B
+        C -= B
+        assert ints(C) == a
+        # raw inputs are reduced, not rejected (finfields.py:724); negatives wrap (test_finfields.py:327-335)
+        assert ints(F.array(unhex(case['raw']))) == unhex(case['raw_reduced'])
+        if 'neg_in' in case:
+            assert ints(F.array(case['neg_in'])) == unhex(case['neg_in_reduced'])
+        # value is the reference representation
+        v = A.value
+        assert v.dtype == object and v.shape == (len(a),)
+        if case['binary']:
+            assert isinstance(v[0], gfpx.BinaryPolynomial)
+        # wire format == field.to_bytes / from_bytes (finfields.py:91-102)
+        assert A.to_wire() == F.to_bytes(a)
+        assert ints(F.array.from_wire(F.to_bytes(a))) == a
+        assert F.from_bytes(A.to_wire()) == a
+        # reciprocal / division / pow
+        nz = [x for x in a if x][:12]
+        N = F.array(nz)
+        inv = N.reciprocal()
+        assert ints(inv * N) == [1] * len(nz)
+        assert ints(N / N) == [1] * len(nz)
+        assert ints(N ** 3) == [int((F(x) ** 3).value) for x in nz]
+        assert ints(N ** 0) == [1] * len(nz)
+        assert ints(N ** -1) == ints(inv)
+        with pytest.raises(ZeroDivisionError):
+            F.array([1, 0, 2] if F.order > 2 else [1, 0]).reciprocal()
+        # equality
+        assert (A == A).all() and not (A != A).any()
+        assert list(A == B) == [x == y for x, y in zip(a, b)]
+
+
+def test_type_errors_and_shapes(api):
+    finfields, gfpx, _ = api
+    F = finfields.GF(101)
+    G = finfields.GF(19)
+    with pytest.raises(TypeError):
+        F.array([1.5, 2.0])                          # tests/test_finfields.py:372-382
+    with pytest.raises(TypeError):
+        F.array([1, 2]) + 1.5
+    with pytest.raises(TypeError):
+        F.array([1, 2]) + G.array([1, 2])            # :296-314 mixed fields
+    with pytest.raises(ValueError):
+        finfields.GF(15)
+    with pytest.raises(ValueError):
+        finfields.GF(gfpx.BinaryPolynomial(0b101))   # x^2+1 is reducible
+    a = F.array([[1, 2, 3], [4, 5, 6]])
+    assert a.shape == (2, 3) and a.ndim == 2
+    assert ints(a + F.array([10, 20, 30])) == [11, 22, 33, 14, 25, 36]      # broadcasting
+    assert ints(a * F.array([[2], [3]])) == [2, 4, 6, 12, 15, 18]
+    assert ints(a.reshape(3, 2)) == [1, 2, 3, 4, 5, 6] and a.reshape(-1).shape == (6,)
+    assert ints(a[1]) == [4, 5, 6] and int(a[1][2].value) == 6 and int(a[0, 1].value) == 2
+    assert ints(a[:, 1]) == [2, 5]
+    b = a.copy()
+    b[0] = F.array([7, 8, 9])
+    b[1, 2] = 100
+    assert ints(b) == [7, 8, 9, 4, 5, 100] and ints(a) == [1, 2, 3, 4, 5, 6]
+    assert ints(a << 2) == [4, 8, 12, 16, 20, 24]
+    assert ints((a << 2) >> 2) == [1, 2, 3, 4, 5, 6]
+    assert [int(v) for v in a.signed_().reshape(-1)] == [1, 2, 3, 4, 5, 6]
+    assert [int(v) for v in (-a).signed_().reshape(-1)] == [-1, -2, -3, -4, -5, -6]
+    # small public matrix @ array (Vandermonde / Lagrange shape, finfields.py:1126-1135)
+    rng = random.Random(3)
+    P = finfields.GF(2**127 - 1)
+    p = P.modulus
+    X = [[rng.randrange(p) for _ in range(50)] for _ in range(4)]
+    M = [[rng.randrange(p) for _ in range(4)] for _ in range(3)]
+    got = np.array(M, dtype=object) @ P.array(X)
+    want = (np.array(M, dtype=object) @ np.array(X, dtype=object)) % p
+    assert got.shape == (3, 50) and [[int(v) for v in r] for r in got.value] == [[int(v) for v in r] for r in want]
+    v = np.array(M[0], dtype=object) @ P.array(X)
+    assert v.shape == (50,) and ints(v) == [int(x) for x in want[0]]
+
+
+def test_large_prime_array_ops(api):
+    """tests/test_finfields.py:389-404 shape: a 2^127-1 prime array: multiply, add, reciprocal."""
+    finfields, _, _ = api
+    p = 2**127 - 1
+    F = finfields.GF(p)
+    rng = random.Random(9)
+    a = [rng.randrange(1, p) for _ in range(1000)]
+    b = [rng.randrange(p) for _ in range(1000)]
+    A, B = F.array(a), F.array(b)
+    assert ints(A * B) == [x * y % p for x, y in zip(a, b)]
+    assert ints(A + B) == [(x + y) % p for x, y in zip(a, b)]
+    assert ints(A.reciprocal()) == [pow(x, -1, p) for x in a]
+    assert ints(B / A) == [y * pow(x, -1, p) % p for x, y in zip(a, b)]
