@@ -330,6 +330,71 @@ def _xGF(mod):
     return F
 
 
+
+# --------------------------------------------------------------------------------------------
+# scalar-op adapter: lets FieldArray / thresha work with this module's field classes AND with the
+# reference's own (mpyc.finfields) classes when the array type is substituted into mpyc
+# (INTEGRATION.md section 2): only `modulus` / `order` are read from the field class.
+# --------------------------------------------------------------------------------------------
+class _FieldOps:
+    __slots__ = ('binary', 'modulus', 'order', 'poly_type')
+
+    def __init__(self, field):
+        mod = field.modulus
+        self.binary = not isinstance(mod, (int, np.integer))
+        if self.binary and getattr(type(mod), 'p', 2) != 2:
+            raise NotImplementedError('extension fields of odd characteristic are not accelerated')
+        self.modulus = int(mod)
+        self.order = int(field.order)
+        self.poly_type = type(mod) if self.binary else None
+
+    def reduce_int(self, v):
+        return _clmod(abs(int(v)), self.modulus) if self.binary else int(v) % self.modulus
+
+    def add(self, a, b):
+        return a ^ b if self.binary else (a + b) % self.modulus
+
+    def sub(self, a, b):
+        return a ^ b if self.binary else (a - b) % self.modulus
+
+    def mul(self, a, b):
+        return _clmod(_clmul(a, b), self.modulus) if self.binary else a * b % self.modulus
+
+    def inv(self, a):
+        if self.binary:
+            if a == 0:
+                raise ZeroDivisionError('inverse does not exist')
+            return _clinvert(a, self.modulus)
+        if a % self.modulus == 0:
+            raise ZeroDivisionError('inverse does not exist')
+        return pow(a, -1, self.modulus)
+
+    def box(self, v):
+        """canonical int -> what the reference stores in `.value` (int, or a polynomial object)"""
+        return self.poly_type(v) if self.binary else v
+
+
+_fops_cache = {}
+
+
+def _fops(field) -> _FieldOps:
+    ops = _fops_cache.get(field)
+    if ops is None:
+        ops = _fops_cache[field] = _FieldOps(field)
+    return ops
+
+
+def _scalar_value(x):
+    """field element (this module's or the reference's) -> canonical int, else None"""
+    v = getattr(x, 'value', None)
+    if v is None or isinstance(x, (np.ndarray, FieldArray)):
+        return None
+    try:
+        return int(v)
+    except (TypeError, ValueError):
+        return None
+
+
 _ctx_cache = {}
 
 
@@ -339,7 +404,8 @@ def _context(field, device: Optional[int] = None) -> FieldContext:
     key = (field, device)
     ctx = _ctx_cache.get(key)
     if ctx is None:
-        ctx = FieldContext(int(field.modulus), binary=field._binary, device=device)
+        ops = _fops(field)
+        ctx = FieldContext(ops.modulus, binary=ops.binary, device=device)
         _ctx_cache[key] = ctx
     return ctx
 
@@ -383,8 +449,8 @@ class FieldArray:
         if flat.dtype == object:
             if any(isinstance(v, (float, complex, np.floating)) for v in flat):
                 raise TypeError('float values are not field elements')
-            flat = np.array([int(v.value) if isinstance(v, FiniteFieldElement) else int(v) for v in flat],
-                            dtype=object) if flat.size else flat
+            flat = np.array([int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v))
+                             for v in flat], dtype=object) if flat.size else flat
         if check and flat.size:
             flat = self._canonical_host(flat, F)
         self._dev = ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes)) if flat.size else ctx.empty(0)
@@ -393,12 +459,13 @@ class FieldArray:
     @staticmethod
     def _canonical_host(flat, F):
         """`value %= modulus` (finfields.py:724) for inputs that arrive as host integers."""
-        if F._binary:
-            mod = int(F.modulus)
+        ops = _fops(F)
+        if ops.binary:
+            mod = ops.modulus
             if flat.dtype != object:
                 flat = flat.astype(object)
             return np.array([_clmod(abs(int(v)), mod) for v in flat], dtype=object)
-        p = F.modulus
+        p = ops.modulus
         if flat.dtype != object:
             if flat.dtype.kind == 'u' and flat.dtype.itemsize * 8 < p.bit_length():
                 return flat                                                   # already < p
@@ -416,8 +483,9 @@ class FieldArray:
         reference stores it.  Materialised on first use, read-only snapshot."""
         if self._cache is None:
             ints = self._dev.to_ints()
-            if type(self).field._binary:
-                ints = [BinaryPolynomial(v) for v in ints]
+            ops = _fops(type(self).field)
+            if ops.binary:
+                ints = [ops.box(v) for v in ints]
             v = np.empty(len(ints), dtype=object)
             v[:] = ints
             v = v.reshape(self._shape)
@@ -502,8 +570,8 @@ class FieldArray:
 
     def __setitem__(self, key, value):
         cls = type(self)
-        if isinstance(value, FiniteFieldElement) or isinstance(value, (int, np.integer)):
-            value = cls([value]).reshape(())
+        if isinstance(value, (int, np.integer)) or _scalar_value(value) is not None:
+            value = cls([int(value) if isinstance(value, (int, np.integer)) else _scalar_value(value)]).reshape(())
         elif not isinstance(value, FieldArray):
             value = cls(value)
         src = value._limb_view()
@@ -523,25 +591,26 @@ class FieldArray:
     def _operand(self, other):
         """-> ('array', FieldArray) | ('scalar', int) | None"""
         cls, F = type(self), type(self).field
+        ops = _fops(F)
         if isinstance(other, FieldArray):
             if other.field is not F:
                 raise TypeError('arrays over different fields')
             return ('array', other) if other.size != 1 or other.ndim > self.ndim else ('scalar', other._dev.to_ints()[0])
-        if isinstance(other, FiniteFieldElement):
-            if type(other) is not F:
-                raise TypeError('element of a different field')
-            return 'scalar', int(other.value)
         if isinstance(other, bool):
             return None
         if isinstance(other, (int, np.integer)):
-            return 'scalar', F._reduce_int(int(other))
-        if isinstance(other, BinaryPolynomial) and F._binary:
-            return 'scalar', F._reduce_int(int(other))
+            return 'scalar', ops.reduce_int(int(other))
         if isinstance(other, float):
             raise TypeError('float operand')
         if isinstance(other, (np.ndarray, list, tuple)):
             arr = cls(other)                         # raises TypeError for float dtypes
             return ('array', arr) if arr.size != 1 else ('scalar', arr._dev.to_ints()[0])
+        if hasattr(other, 'modulus') and hasattr(other, 'value'):      # a field element
+            if type(other) is not F:
+                raise TypeError('element of a different field')
+            return 'scalar', int(other.value)
+        if ops.binary and ops.poly_type is not None and isinstance(other, (ops.poly_type, BinaryPolynomial)):
+            return 'scalar', ops.reduce_int(int(other))
         return None
 
     def _broadcast(self, other: 'FieldArray'):
@@ -592,8 +661,7 @@ class FieldArray:
 
     def __sub__(self, other):
         def sub_scalar(ctx, a, s, out):
-            F = type(self).field
-            return ctx.add_scalar(a, F._sub(0, s), out)
+            return ctx.add_scalar(a, _fops(type(self).field).sub(0, s), out)
         return self._binop(other, FieldContext.sub, sub_scalar)
 
     def __rsub__(self, other):
@@ -607,7 +675,7 @@ class FieldArray:
 
     def __isub__(self, other):
         def sub_scalar(ctx, a, s, out):
-            return ctx.add_scalar(a, type(self).field._sub(0, s), out)
+            return ctx.add_scalar(a, _fops(type(self).field).sub(0, s), out)
         return self._binop(other, FieldContext.sub, sub_scalar, inplace=True)
 
     def __mul__(self, other):
@@ -649,7 +717,7 @@ class FieldArray:
         """Element-wise inverse a^(q-2) on the device (finfields.py:1278-1281, :1416-1422)."""
         if self.size and bool((self._zero_mask()).any()):
             raise ZeroDivisionError('inverse of 0 does not exist')
-        return self ** (type(self).field.order - 2)
+        return self ** (_fops(type(self).field).order - 2)
 
     def __truediv__(self, other):
         opd = self._operand(other)
@@ -657,7 +725,7 @@ class FieldArray:
             return NotImplemented
         kind, o = opd
         if kind == 'scalar':
-            return self * type(self).field._inv(o)
+            return self * _fops(type(self).field).inv(o)
         return self * o.reciprocal()
 
     def __rtruediv__(self, other):
@@ -666,16 +734,16 @@ class FieldArray:
     def __lshift__(self, k):
         if not isinstance(k, (int, np.integer)):
             return NotImplemented
-        F = type(self).field                                                    # finfields.py:1227-1234
-        return self * (F._reduce_int(1 << int(k)) if F._binary else pow(2, int(k), F.modulus))
+        ops = _fops(type(self).field)                                          # finfields.py:1227-1234
+        return self * (ops.reduce_int(1 << int(k)) if ops.binary else pow(2, int(k), ops.modulus))
 
     def __rshift__(self, k):
         if not isinstance(k, (int, np.integer)):
             return NotImplemented
-        F = type(self).field
-        if F._binary:
-            return self * F._inv(F._reduce_int(1 << int(k)))
-        return self * F._inv(pow(2, int(k), F.modulus))                        # :1250-1258
+        ops = _fops(type(self).field)
+        if ops.binary:
+            return self * ops.inv(ops.reduce_int(1 << int(k)))
+        return self * ops.inv(pow(2, int(k), ops.modulus))                     # :1250-1258
 
     # ---- small-matrix products (finfields.py:1126-1157) --------------------------------------
     def __rmatmul__(self, other):
@@ -691,7 +759,9 @@ class FieldArray:
             raise ValueError('matmul: shape mismatch')
         if A2.size > 4096:
             raise NotImplementedError('dense modular matmul is not on the accelerated path yet')
-        lam = [F._reduce_int(int(v.value) if isinstance(v, FiniteFieldElement) else int(v)) for v in A2.reshape(-1)]
+        ops = _fops(F)
+        lam = [ops.reduce_int(int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v)))
+               for v in A2.reshape(-1)]
         k, n = self._shape
         rows = [self[j]._dev for j in range(k)]
         w = A2.shape[0]
@@ -734,12 +804,12 @@ class FieldArray:
         return np.array(self._dev.to_ints(), dtype=object).reshape(self._shape)
 
     def signed_(self):
-        p = type(self).field.modulus
+        p = _fops(type(self).field).modulus
         return np.array([v - p if v > p >> 1 else v for v in self._dev.to_ints()], dtype=object).reshape(self._shape)
 
     @classmethod
     def intarray(cls, a):
-        if cls.field._binary:
+        if _fops(cls.field).binary:
             return a.unsigned_()
         return a.signed_() if cls.field.is_signed else a.unsigned_()
 

@@ -24,7 +24,7 @@ import secrets
 import numpy as np
 
 from .engine import DevArray, DevMatrix
-from .finfields import FieldArray, FiniteFieldElement, _context, _matrix_to_array
+from .finfields import FieldArray, FiniteFieldElement, _context, _fops, _matrix_to_array, _scalar_value
 
 __all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector']
 
@@ -42,7 +42,8 @@ def _next_nonce():
 def _as_field_array(field, s) -> FieldArray:
     if isinstance(s, FieldArray):
         return s
-    vals = [int(v.value) if isinstance(v, FiniteFieldElement) else v for v in s] if not isinstance(s, np.ndarray) else s
+    vals = [v if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v)) for v in s] \
+        if not isinstance(s, np.ndarray) else s
     return field.array(vals)
 
 
@@ -123,9 +124,9 @@ def random_split(field, s, t, m):
     S = _as_field_array(field, list(s))
     mtx = _split_device(field, S, t, m, np_convention=False)
     rows = mtx.to_ints()
-    if field._binary:
-        from .gfpx import BinaryPolynomial
-        rows = [[BinaryPolynomial(v) for v in r] for r in rows]
+    ops = _fops(field)
+    if ops.binary:
+        rows = [[ops.box(v) for v in r] for r in rows]
     return rows
 
 
@@ -133,16 +134,17 @@ def random_split(field, s, t, m):
 def _recombination_vector(field, xs, x_r):
     """Lagrange coefficients for interpolation points xs evaluated at x_r, in the order of xs
     (thresha.py:67-85).  Host scalars; cached per (field, xs, x_r) like the reference."""
-    xs = [field._reduce_int(int(x)) for x in xs]
-    x_r = field._reduce_int(int(x_r))
+    ops = _fops(field)
+    xs = [ops.reduce_int(int(x)) for x in xs]
+    x_r = ops.reduce_int(int(x_r))
     vector = []
     for i, x_i in enumerate(xs):
         num, den = 1, 1
         for j, x_j in enumerate(xs):
             if i != j:
-                num = field._mul(num, field._sub(x_r, x_j))
-                den = field._mul(den, field._sub(x_i, x_j))
-        vector.append(field._mul(num, field._inv(den)))
+                num = ops.mul(num, ops.sub(x_r, x_j))
+                den = ops.mul(den, ops.sub(x_i, x_j))
+        vector.append(ops.mul(num, ops.inv(den)))
     return vector
 
 
@@ -185,15 +187,15 @@ def recombine(field, points, x_rs=0):
     if len(shares[0]) == 0:
         return [] if not isinstance(x_rs, list) else [[] for _ in x_rs]
     T_is_field = isinstance(shares[0][0], field)
-    rows = [[int(v.value) if isinstance(v, FiniteFieldElement) else v for v in sh] for sh in shares]
+    rows = [[v if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v)) for v in sh] for sh in shares]
     out = np_recombine(field, list(zip(xs, rows)), x_rs)
     vals = out.unsigned_().tolist()
 
     def conv(row):
         if T_is_field:
             return [field(v) for v in row]
-        if field._binary:
-            from .gfpx import BinaryPolynomial
-            return [BinaryPolynomial(v) for v in row]
+        ops = _fops(field)
+        if ops.binary:
+            return [ops.box(v) for v in row]
         return row
     return conv(vals) if not isinstance(x_rs, list) else [conv(r) for r in vals]

@@ -1,0 +1,51 @@
+"""Worker for tests/test_multiprocess.py (world_size 2, gloo, CPU): exercises the sharding and
+the party-major exchange bookkeeping of mpyc_amd.multigpu on plain limb tensors."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpyc_amd import multigpu  # noqa: E402
+
+
+def main():
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    for n in (0, 1, 5, 1000, 1001):
+        # element sharding covers [0, n) exactly once, in order
+        ranges = [multigpu.shard_range(n, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        assert max(h - l for l, h in ranges) - min(h - l for l, h in ranges) <= 1
+    for limbs in (1, 2):          # one-limb (n,) and two-limb (n, 2) elements
+        for n in (7, 1000):
+            k = 5
+            shape = (n,) if limbs == 1 else (n, 2)
+            full = [torch.arange(n * limbs, dtype=torch.int64).reshape(shape) + 1_000_000 * (j + 1) for j in range(k)]
+            local = {j: full[j] for j in range(k) if multigpu.row_owner(j, world) == rank}
+            row_ids = [3, 0, 4, 1, 2]           # any order (x-coordinates rotate in _reshare)
+            got = multigpu.exchange_party_major(local, row_ids, n)
+            lo, hi = multigpu.shard_range(n, rank, world)
+            for idx, j in enumerate(row_ids):
+                assert torch.equal(got[idx], full[j][lo:hi]), (rank, j)
+            # concatenating the shards of all ranks gives back the whole row
+            mine = got[0]
+            gathered = [torch.empty_like(full[0][slice(*multigpu.shard_range(n, r, world))]) for r in range(world)]
+            dist.all_gather(gathered, mine) if all(g.shape == mine.shape for g in gathered) else None
+    rows = multigpu.allgather_rows(torch.full((11,), rank, dtype=torch.int64))
+    assert [int(r[0]) for r in rows] == list(range(world))
+    # MAX-over-ranks reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == world
+    dist.barrier()
+    if rank == 0:
+        print('DIST_OK')
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
