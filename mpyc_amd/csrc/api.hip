@@ -27,9 +27,12 @@ const FieldOps* ffgpu_ops_mont128();
 const FieldOps* ffgpu_ops_gf2p8();
 const FieldOps* ffgpu_ops_gf2w64();
 const FieldOps* ffgpu_ops_gf2w128();
-int ffgpu_launch_sbox(const void* gf2p8_policy, int device, const void* in, const uint8_t* rows8,
-                      uint8_t b, void* out, size_t n, hipStream_t st);
+int ffgpu_sbox_build_lut(const void* gf2p8_policy, const uint8_t* rows8, uint8_t b, uint8_t* lut256);
+int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
+int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
+int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, const void* b, void* out, size_t n,
+                             hipStream_t st);
 
 struct ffgpu_ctx {
     int kind;
@@ -39,6 +42,12 @@ struct ffgpu_ctx {
     int policy_kind;
     const FieldOps* ops;
     uint64_t rng_r[2];  // 2^W mod p for the keystream sampler
+    int gf8_tab_min;    // GF(2^n<=8): arrays of at least this many elements multiply through LDS tables
+    alignas(16) unsigned char gf8_tables[1536];
+    // last S-box table built for this context (depends only on rows8, b)
+    uint8_t sbox_key[9];
+    int sbox_valid;
+    uint8_t sbox_lut[256];
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
 };
@@ -177,6 +186,12 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     c->elem_bytes = pb.elem_bytes;
     c->policy_kind = pb.kind;
     rng_const(pb, c->rng_r);
+    c->gf8_tab_min = 0;
+    if (pb.kind == POL_GF2P8 && ffgpu_gf8_build_tables(c->policy, c->gf8_tables) == 0) {
+        const char* e = getenv("FFGPU_GF8_TABLE_MIN");
+        c->gf8_tab_min = e ? atoi(e) : (1 << 18);   // below this the shift-xor kernel has lower latency
+        if (c->gf8_tab_min <= 0) c->gf8_tab_min = 0x7fffffff;
+    }
     *out = c;
     return FFGPU_OK;
 }
@@ -252,6 +267,11 @@ int ffgpu_sub(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
     return do_ew2(ctx, OP_SUB, a, b, out, n, stream);
 }
 int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    if (ctx && ctx->gf8_tab_min && n >= (size_t)ctx->gf8_tab_min && a && b && out) {
+        DeviceGuard g(ctx->device);
+        return launch_status(ffgpu_launch_gf8_mul_tab(ctx->gf8_tables, ctx->device, a, b, out, n,
+                                                      (hipStream_t)stream));
+    }
     return do_ew2(ctx, OP_MUL, a, b, out, n, stream);
 }
 int ffgpu_neg(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
@@ -374,9 +394,22 @@ int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, 
     if (f.n != 8) return FFGPU_ENOTSUP;
     if (n == 0) return FFGPU_OK;
     ARGCHK(in && out);
+    uint8_t lut[256];
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        uint8_t key[9];
+        memcpy(key, host_rows8, 8);
+        key[8] = b;
+        if (!ctx->sbox_valid || memcmp(key, ctx->sbox_key, 9) != 0) {
+            ffgpu_sbox_build_lut(ctx->policy, host_rows8, b, ctx->sbox_lut);
+            memcpy(ctx->sbox_key, key, 9);
+            ctx->sbox_valid = 1;
+        }
+        memcpy(lut, ctx->sbox_lut, 256);
+    }
     DeviceGuard g(ctx->device);
-    return launch_status(ffgpu_launch_sbox(ctx->policy, ctx->device, in, host_rows8, b, out, n,
-                                           (hipStream_t)stream));
+    return launch_status(ffgpu_launch_sbox(lut, ctx->device, in, out, n, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -226,6 +226,28 @@ def test_vs_oracle_sharing(eng, coracle, modulus, binary):
             assert (rec.to_numpy() == S).all(), (t, m, k)          # round trip: it IS the secret
 
 
+def test_gf2n_table_multiplication(eng, coracle):
+    """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
+    answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""
+    for mod in (0x11b, 0b10011, 0b111, 0b11, 0b1011, 0x12b):
+        F = po.Field(mod, True)
+        ctx = ctx_for(eng, mod, True)
+        cf = coracle.CField(mod, True)
+        q = F.order
+        n = 1 << 19
+        rng = np.random.default_rng(mod)
+        A = rng.integers(0, q, size=n, dtype=np.uint8)
+        B = rng.integers(0, q, size=n, dtype=np.uint8)
+        pairs = np.array([(x, y) for x in range(q) for y in range(q)], dtype=np.uint8)
+        A[:len(pairs)] = pairs[:, 0]
+        B[:len(pairs)] = pairs[:, 1]
+        for nn in (n, n - 5):                       # aligned + ragged tail
+            got = ctx.mul(ctx.from_numpy(A[:nn]), ctx.from_numpy(B[:nn])).to_numpy()
+            assert (got == cf.ew(coracle.MUL, A[:nn], B[:nn])).all(), (hex(mod), nn)
+        small = ctx.mul(ctx.from_numpy(A[:4096]), ctx.from_numpy(B[:4096])).to_numpy()   # shift-xor path
+        assert (small == got[:4096]).all()
+
+
 KEY = bytes(range(100, 132))
 
 
