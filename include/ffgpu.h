@@ -115,6 +115,20 @@ int ffgpu_rsub_scalar(ffgpu_ctx* ctx, const void* a, const uint64_t* host_scalar
 /* out = a * b + c   (fused multiply-add; one pass instead of two)            */
 int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, void* out, size_t n, void* stream);
 
+/* ---- second-tier element-wise operations -------------------------------- */
+/* out[i] = a[i]^e for a public exponent e >= 0 (little-endian uint64 limbs, exp_limbs <= 2).
+ * One pass: square-and-multiply in registers.
+ * replaces: finfields.py:1159-1187 (__pow__), :1408-1414 (_pow via gmpy2.powmod per element);
+ * sqrt for p = 3 mod 4 is pow by (p+1)/4 (:1424-1458), Legendre symbol pow by (p-1)/2 (:1460-1470). */
+int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_limbs, void* out, size_t n,
+              void* stream);
+/* out[i] = a[i]^-1.  Batched with Montgomery's trick inside each thread (3 products per element
+ * plus one exponentiation per 16..128 elements).  a[i] == 0 gives out[i] = 0 and ORs 1 into
+ * *dev_zero_flag (device int32, may be NULL): the reference raises ZeroDivisionError there
+ * (gmpy.py:197-210), which the host wrapper does after reading the flag.
+ * replaces: finfields.py:1278-1281 (reciprocal), :1416-1422 (_reciprocal via gmpy2.invert per element). */
+int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero_flag, void* stream);
+
 /* ---- Shamir share generation ------------------------------------------ */
 /* shares[i][h] = secrets[h] + sum_{j<t} coeffs[j][h] * (i+1)^(j+1)  (mod modulus),
  * i = 0..m-1, h = 0..n-1;  coeffs is (t, n) row-major with row stride

@@ -298,6 +298,69 @@ int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, vo
     return launch_status(ctx->ops->muladd(ctx->policy, ctx->device, a, b, c, out, n, (hipStream_t)stream));
 }
 
+static int make_exp(const uint64_t* e, int limbs, ExpArgs* ex) {
+    if (!e || limbs < 1 || limbs > 2) return FFGPU_EINVAL;
+    ex->e[0] = e[0];
+    ex->e[1] = limbs > 1 ? e[1] : 0;
+    int nb = 0;
+    for (int i = 127; i >= 0; --i)
+        if ((ex->e[i >> 6] >> (i & 63)) & 1) {
+            nb = i + 1;
+            break;
+        }
+    ex->nbits = nb;
+    return FFGPU_OK;
+}
+
+int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_limbs, void* out, size_t n,
+              void* stream) {
+    ARGCHK(ctx);
+    ExpArgs ex;
+    int rc = make_exp(host_exp, exp_limbs, &ex);
+    if (rc != FFGPU_OK) return rc;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && out);
+    DeviceGuard g(ctx->device);
+    if (ex.nbits == 0) {
+        // a^0 = 1 (also for a = 0, as pow(0, 0, p) = 1): 0*a + 1
+        uint64_t zero[2] = {0, 0}, one[2] = {1, 0};
+        rc = launch_status(ctx->ops->ew1(ctx->policy, ctx->device, OP_MUL, a, zero, out, n, (hipStream_t)stream));
+        if (rc != FFGPU_OK) return rc;
+        return launch_status(ctx->ops->ew1(ctx->policy, ctx->device, OP_ADD, out, one, out, n, (hipStream_t)stream));
+    }
+    return launch_status(ctx->ops->pow(ctx->policy, ctx->device, a, &ex, out, n, (hipStream_t)stream));
+}
+
+int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero_flag, void* stream) {
+    ARGCHK(ctx);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && out);
+    // exponent q - 2 (order of the multiplicative group minus one)
+    ff_u128 q;
+    if (ctx->kind == FFGPU_PRIME) {
+        q = ff_make128(ctx->modulus[1], ctx->modulus[0]);
+    } else {
+        int deg = ctx->modulus[2] ? 128 : (ctx->modulus[1] ? 64 + (63 - __builtin_clzll(ctx->modulus[1]))
+                                                           : 63 - __builtin_clzll(ctx->modulus[0]));
+        q = deg == 128 ? (ff_u128)0 : ((ff_u128)1 << deg);   // 2^128 wraps to 0; q-2 below is still right
+    }
+    ff_u128 e = q - 2;
+    uint64_t el[2] = {ff_lo(e), ff_hi(e)};
+    DeviceGuard g(ctx->device);
+    if (ctx->kind == FFGPU_PRIME && q == 2) {   // GF(2): 1^-1 = 1
+        ExpArgs one;
+        one.e[0] = 1; one.e[1] = 0; one.nbits = 1;
+        return launch_status(ctx->ops->inv(ctx->policy, ctx->device, a, &one, out, n, (int*)dev_zero_flag,
+                                           (hipStream_t)stream));
+    }
+    ExpArgs ex;
+    int rc = make_exp(el, 2, &ex);
+    if (rc != FFGPU_OK) return rc;
+    if (ex.nbits == 0) { ex.e[0] = 1; ex.nbits = 1; }        // GF(2^1): q - 2 = 0 -> x^-1 = x
+    return launch_status(ctx->ops->inv(ctx->policy, ctx->device, a, &ex, out, n, (int*)dev_zero_flag,
+                                       (hipStream_t)stream));
+}
+
 static int do_split(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, const void* coeffs,
                     size_t coeff_stride, int t, int m, void* shares, size_t share_stride, size_t n,
                     void* stream) {

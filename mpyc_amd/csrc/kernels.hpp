@@ -447,6 +447,146 @@ __global__ __launch_bounds__(BLOCK) void k_recombine_any(F f, RecArgsAny<F> ra, 
     }
 }
 
+
+// ---- helpers for the exponentiation / inversion kernels ---------------------------------------
+template <class F>
+FF_HD typename F::word ff_one(const F&) {
+    if constexpr (sizeof(typename F::word) == 16) {
+        typename F::word w;
+        w.lo = 1;
+        w.hi = 0;
+        return w;
+    } else if constexpr (F::EPW == 4) {
+        return (typename F::word)0x01010101u;
+    } else {
+        return (typename F::word)1;
+    }
+}
+// zero elements are replaced by one (so that products stay invertible); zm remembers where
+template <class F>
+FF_HD typename F::word ff_zero_fix(const F&, typename F::word v, uint32_t& zm) {
+    if constexpr (sizeof(typename F::word) == 16) {
+        zm = (v.lo | v.hi) == 0;
+        if (zm) v.lo = 1;
+        return v;
+    } else if constexpr (F::EPW == 4) {
+        uint32_t t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v;   // bit 7 of each byte set iff byte != 0
+        uint32_t z = (~t & 0x80808080u) >> 7;                   // 0x01 where the byte is zero
+        zm = z;
+        return v | z;
+    } else {
+        zm = v == 0;
+        return zm ? (typename F::word)1 : v;
+    }
+}
+template <class F>
+FF_HD typename F::word ff_zero_apply(const F&, typename F::word r, uint32_t zm) {
+    if constexpr (sizeof(typename F::word) == 16) {
+        if (zm) r.lo = r.hi = 0;
+        return r;
+    } else if constexpr (F::EPW == 4) {
+        return r & ~(zm * 0xffu);
+    } else {
+        return zm ? (typename F::word)0 : r;
+    }
+}
+
+struct ExpArgs {
+    uint64_t e[2];   // public exponent, little-endian limbs
+    int nbits;       // bit length of the exponent (>= 1)
+};
+
+// left-to-right square and multiply, exponent wave-uniform (scalar branch per bit)
+template <class F>
+__device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
+    typename F::word r = a;
+    for (int i = ex.nbits - 2; i >= 0; --i) {
+        r = f.mul(r, r);
+        if ((ex.e[i >> 6] >> (i & 63)) & 1) r = f.mul(r, a);
+    }
+    return r;
+}
+
+// ---- out = a^e, public exponent e >= 1 (finfields.py:1159-1187, :1408-1414) ------------------
+template <class F, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
+                                                typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x = ldg<NT>(av + i);
+        P r;
+#pragma unroll
+        for (int q = 0; q < P::N; ++q) r.w[q] = ff_pow(f, x.w[q], ex);
+        stg<NT>(ov + i, r);
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) st_elem<F>(o, e, ff_pow(f, ld_elem<F>(a, e), ex));
+}
+
+// ---- out = a^-1, batched (finfields.py:1278-1281, :1416-1422) ----------------------------------
+// Montgomery's trick inside each thread: CH packs -> prefix products, ONE exponentiation by q-2,
+// back-substitution: 3 multiplications per element + (1.5 log2 q)/(CH*N).  Zero inputs give zero
+// and set *flag (the reference raises ZeroDivisionError; the host wrapper checks the flag).
+template <class F, int CH, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
+                                                      typename F::elem* __restrict__ o, size_t nvec, size_t n,
+                                                      int* __restrict__ flag) {
+    typedef Pack<typename F::word> P;
+    typedef typename F::word W;
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    uint32_t anyzero = 0;
+    for (size_t i0 = gid; i0 < nvec; i0 += gsz * CH) {
+        W x[CH][P::N], pre[CH][P::N];
+        uint32_t zm[CH][P::N];
+        W run = ff_one(f);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            size_t j = i0 + (size_t)c * gsz;
+            P t_;
+            if (j < nvec) t_ = ldg<NT>(av + j);
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) {
+                W v = (j < nvec) ? t_.w[q] : ff_one(f);
+                v = ff_zero_fix(f, v, zm[c][q]);
+                anyzero |= (j < nvec) ? zm[c][q] : 0u;
+                x[c][q] = v;
+                pre[c][q] = run;            // product of everything BEFORE this element
+                run = f.mul(run, v);
+            }
+        }
+        W inv = ff_pow(f, run, ex);         // (prod of all)^-1
+#pragma unroll
+        for (int c = CH - 1; c >= 0; --c) {
+            size_t j = i0 + (size_t)c * gsz;
+            P r;
+#pragma unroll
+            for (int q = P::N - 1; q >= 0; --q) {
+                r.w[q] = ff_zero_apply(f, f.mul(inv, pre[c][q]), zm[c][q]);
+                inv = f.mul(inv, x[c][q]);
+            }
+            if (j < nvec) stg<NT>(ov + j, r);
+        }
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        uint32_t z;
+        W v = ff_zero_fix(f, ld_elem<F>(a, e), z);
+        if constexpr (F::EPW > 1) z &= 1u;   // a tail element occupies byte 0 only
+        anyzero |= z;
+        W r = ff_pow(f, v, ex);
+        if constexpr (F::EPW > 1) r = z ? (W)0 : r; else r = ff_zero_apply(f, r, z);
+        st_elem<F>(o, e, r);
+    }
+    if (anyzero && flag) atomicOr(flag, 1);
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -481,6 +621,9 @@ struct FieldOps {
                       const RngArgs* rng);
     int (*recombine)(const void* F, int device, const void* const* rows, const uint64_t* lam2, int k,
                      int w, void* out, size_t ostride, size_t n, hipStream_t st);
+    int (*pow)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, hipStream_t st);
+    int (*inv)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
+               hipStream_t st);
 };
 
 // canonical 2-limb host scalar -> policy word (broadcast for packed fields)
@@ -756,8 +899,34 @@ struct Launchers {
         return 0;
     }
 
+    static int pow(const void* Fp, int device, const void* a, const ExpArgs* ex, void* out, size_t n,
+                   hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        bool vec = aligned16(a) && aligned16(out);
+        size_t nvec = vec ? n / EPV : 0;
+        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        hipLaunchKernelGGL((k_pow<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out, nvec, n);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+    static int inv(const void* Fp, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
+                   hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        bool vec = aligned16(a) && aligned16(out);
+        size_t nvec = vec ? n / EPV : 0;
+        constexpr int CH = sizeof(W) == 16 ? 8 : 8;   // packs per thread
+        size_t iters = nvec ? (nvec + CH - 1) / CH : n;
+        unsigned grid = grid_for(iters, lc);
+        hipLaunchKernelGGL((k_inv_batch<F, CH, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out,
+                           nvec, n, flag);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv};
         return &ops;
     }
 };

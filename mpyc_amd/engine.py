@@ -249,6 +249,25 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_muladd(self._h, a.ptr, b.ptr, c.ptr, out.ptr, a.n, self._stream()), 'muladd')
         return out
 
+    def pow(self, a, e: int, out=None):
+        """a ** e for a public exponent 0 <= e < 2^128, one kernel (finfields.py:1159-1187)."""
+        if e < 0 or e >> 128:
+            raise ValueError('exponent out of range')
+        out = out or self.empty(a.n)
+        _ffi.check(self._L.ffgpu_pow(self._h, a.ptr, _ffi.limbs(e, 2), 2, out.ptr, a.n, self._stream()), 'pow')
+        return out
+
+    def inv(self, a, out=None, check_zero: bool = True):
+        """Element-wise inverse (batched, one kernel).  Raises ZeroDivisionError like the reference
+        if any element is zero (costs one device->host flag read); check_zero=False skips that."""
+        out = out or self.empty(a.n)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.torch_device) if check_zero else None
+        _ffi.check(self._L.ffgpu_inv(self._h, a.ptr, out.ptr, a.n, flag.data_ptr() if check_zero else None,
+                                     self._stream()), 'inv')
+        if check_zero and int(flag.item()):
+            raise ZeroDivisionError('inverse of 0 does not exist')
+        return out
+
     # ---- sharing ----------------------------------------------------------
     def split(self, secrets: DevArray, coeffs: Optional[DevMatrix], t: int, m: int,
               out: Optional[DevMatrix] = None, mul_by: Optional[DevArray] = None) -> DevMatrix:

@@ -698,26 +698,41 @@ class FieldArray:
         e = int(e)
         if e < 0:
             return self.reciprocal() ** (-e)
-        ctx = self.ctx
-        if e == 0:
-            return self._wrap(ctx.add_scalar(ctx.mul_scalar(self._dev, 0), 1), self._shape)
-        # left-to-right square and multiply, every step a device launch
-        result = None
-        base = self._dev
-        while True:
-            if e & 1:
-                result = base.clone() if result is None else ctx.mul(result, base)
-            e >>= 1
-            if not e:
-                break
-            base = ctx.mul(base, base)
-        return self._wrap(result, self._shape)
+        order1 = _fops(type(self).field).order - 1
+        if e >> 128:
+            e = e % order1 if e % order1 or not e else order1      # a^(q-1) = 1 for a != 0, keep 0^e = 0
+        return self._wrap(self.ctx.pow(self._dev, e), self._shape)    # one kernel: finfields.py:1159-1187
 
     def reciprocal(self):
-        """Element-wise inverse a^(q-2) on the device (finfields.py:1278-1281, :1416-1422)."""
-        if self.size and bool((self._zero_mask()).any()):
-            raise ZeroDivisionError('inverse of 0 does not exist')
-        return self ** (_fops(type(self).field).order - 2)
+        """Element-wise inverse, batched on the device (finfields.py:1278-1281, :1416-1422); raises
+        ZeroDivisionError if any element is zero, as the reference does (gmpy.py:197-210)."""
+        return self._wrap(self.ctx.inv(self._dev), self._shape)
+
+    def sqrt(self, INV=False):
+        """Modular (inverse) square root (finfields.py:1283-1290, :1424-1458 / :1550-1563): for
+        p = 3 mod 4 a^((p+1)/4) (resp. a^((3p-5)/4)); for GF(2^n) a^(q/2) (resp. q/2 - 1)."""
+        ops = _fops(type(self).field)
+        if INV and self.size and bool(self._zero_mask().any()):
+            raise ZeroDivisionError('no inverse sqrt of 0')
+        if ops.binary:
+            e = (ops.order >> 1) - (1 if INV else 0)
+        elif ops.modulus == 2:
+            return self.copy()
+        elif ops.modulus & 3 == 3:
+            e = (ops.modulus * 3 - 5) >> 2 if INV else (ops.modulus + 1) >> 2
+        else:
+            raise NotImplementedError('sqrt for p = 1 mod 4 (Tonelli-Shanks, finfields.py:447-478) is not accelerated')
+        if e == 0:
+            return self ** 0
+        return self._wrap(self.ctx.pow(self._dev, e), self._shape)
+
+    def is_sqr(self):
+        """Quadratic residuosity (finfields.py:1292-1295, :1460-1470): a^((p-1)/2) != p-1."""
+        ops = _fops(type(self).field)
+        if ops.binary or ops.modulus == 2:
+            return np.full(self._shape, True, dtype=bool)
+        leg = self._wrap(self.ctx.pow(self._dev, (ops.modulus - 1) >> 1), self._shape)
+        return leg != (ops.modulus - 1)
 
     def __truediv__(self, other):
         opd = self._operand(other)

@@ -201,3 +201,27 @@ def test_large_prime_array_ops(api):
     assert ints(A + B) == [(x + y) % p for x, y in zip(a, b)]
     assert ints(A.reciprocal()) == [pow(x, -1, p) for x in a]
     assert ints(B / A) == [y * pow(x, -1, p) % p for x, y in zip(a, b)]
+
+
+def test_sqrt_and_is_sqr(api):
+    """tests/test_finfields.py:389-404 (sqrt of squares over a Blum prime), GF(2^8) sqrt."""
+    finfields, gfpx, _ = api
+    for p in (2**61 - 1, 2**127 - 1, 2**64 - 189, 19):
+        F = finfields.GF(p)
+        rng = random.Random(p)
+        a = [rng.randrange(1, p) for _ in range(500)]
+        A = F.array(a)
+        sq = A * A
+        r = sq.sqrt()
+        assert ints(r * r) == ints(sq)
+        assert sq.is_sqr().all()
+        leg = A.is_sqr()
+        assert list(leg) == [pow(x, (p - 1) // 2, p) != p - 1 for x in a]
+        ri = sq.sqrt(INV=True)
+        assert ints(ri * ri * sq) == [1] * len(a)
+    G = finfields.GF(gfpx.GFpX(2)(0x11b))
+    x = G.array(list(range(256)))
+    r = x.sqrt()
+    assert ints(r * r) == list(range(256))
+    with pytest.raises(ZeroDivisionError):
+        x.sqrt(INV=True)

@@ -226,6 +226,53 @@ def test_vs_oracle_sharing(eng, coracle, modulus, binary):
             assert (rec.to_numpy() == S).all(), (t, m, k)          # round trip: it IS the secret
 
 
+@pytest.mark.parametrize('modulus,binary', FIELDS)
+def test_pow_and_inverse_kernels(eng, modulus, binary):
+    """Second-tier ops (finfields.py:1159-1187,1278-1281,1408-1422): in-register pow with a public
+    exponent and the batched inverse, against Python integers / the GF(2^n) oracle."""
+    F = po.Field(modulus, binary)
+    ctx = ctx_for(eng, modulus, binary)
+    eb = ctx.elem_bytes
+    q = F.order
+    n = 3000 + 7
+    A = rand_np(F, eb, n, 71)
+    vals = unpack(A, eb)
+    dA = ctx.from_numpy(A)
+
+    def fpow(x, e):
+        if not binary:
+            return pow(x, e, modulus)
+        r, b = 1, x
+        while e:
+            if e & 1:
+                r = po.mul(F, r, b)
+            b = po.mul(F, b, b)
+            e >>= 1
+        return r
+
+    for e in (0, 1, 2, 3, 254, 65537, q - 2, q - 1, (q + 1) // 4 if q > 4 else 1):
+        if e < 0:
+            continue
+        got = unpack(ctx.pow(dA, e).to_numpy(), eb)
+        sample = range(0, n, 97) if eb == 16 and e > 1000 else range(n)
+        assert all(got[i] == fpow(vals[i], e) for i in sample), (hex(modulus), e)
+    # inverse: zeros are flagged (ZeroDivisionError) and map to 0 when unchecked
+    with pytest.raises(ZeroDivisionError):
+        ctx.inv(dA)                                   # edge block contains 0
+    inv = unpack(ctx.inv(dA, check_zero=False).to_numpy(), eb)
+    for i in range(n):
+        if vals[i] == 0:
+            assert inv[i] == 0
+        else:
+            assert po.mul(F, inv[i], vals[i]) == 1, (hex(modulus), i)
+    nz = [v if v else 1 for v in vals]
+    dN = ctx.from_numpy(pack(nz, eb))
+    assert unpack(ctx.mul(ctx.inv(dN), dN).to_numpy(), eb) == [1] * n
+    if eb < 16:                                       # unaligned -> scalar path
+        va = eng.DevArray(ctx, dN.t[1:], n - 1)
+        assert unpack(ctx.mul(ctx.inv(va), va).to_numpy(), eb) == [1] * (n - 1)
+
+
 def test_gf2n_table_multiplication(eng, coracle):
     """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
     answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""
