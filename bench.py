@@ -269,6 +269,13 @@ def main():
         # achievable-bandwidth yardstick: the library's streaming copy, 80 MB blocks rotating
         ms_copy = time_launches(lambda s: ctx.copy(s.a.t, s.c.t), sets, reps)
         kern['device_copy'] = dict(roof(2 * eb * n, ms_copy), kernel='k_copy16 (80 MB -> 80 MB, rotating sets)')
+        # second-tier element-wise ops (finfields.py:1278-1281,1424-1458): batched inverse, sqrt = pow by (p+1)/4
+        ms = time_launches(lambda s: ctx.inv(s.a, out=s.c, check_zero=False), sets, 3)
+        kern['inv_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
+                               units_per_s=round(n / (ms * 1e-3), 1))
+        ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
+        kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
+                                units_per_s=round(n / (ms * 1e-3), 1))
         # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
         del sets[1:]
         torch.cuda.empty_cache()

@@ -31,6 +31,9 @@ int ffgpu_sbox_build_lut(const void* gf2p8_policy, const uint8_t* rows8, uint8_t
 int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
+int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
+int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable, int device, const void* a,
+                              const void* b, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, const void* b, void* out, size_t n,
                              hipStream_t st);
 
@@ -44,6 +47,8 @@ struct ffgpu_ctx {
     uint64_t rng_r[2];  // 2^W mod p for the keystream sampler
     int gf8_tab_min;    // GF(2^n<=8): arrays of at least this many elements multiply through LDS tables
     alignas(16) unsigned char gf8_tables[1536];
+    int gf2w_limbs;     // GF(2^n), 9 <= n <= 128: 1 or 2 limbs -> windowed multiplication kernel
+    alignas(16) unsigned char gf2w_rtable[256];
     // last S-box table built for this context (depends only on rows8, b)
     uint8_t sbox_key[9];
     int sbox_valid;
@@ -186,6 +191,11 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     c->elem_bytes = pb.elem_bytes;
     c->policy_kind = pb.kind;
     rng_const(pb, c->rng_r);
+    c->gf2w_limbs = 0;
+    if ((pb.kind == POL_GF2W64 || pb.kind == POL_GF2W128) && !getenv("FFGPU_GF2W_BITSERIAL")) {
+        c->gf2w_limbs = pb.kind == POL_GF2W128 ? 2 : 1;
+        ffgpu_gf2w_build_rtable(c->policy, c->gf2w_limbs, c->gf2w_rtable);
+    }
     c->gf8_tab_min = 0;
     if (pb.kind == POL_GF2P8 && ffgpu_gf8_build_tables(c->policy, c->gf8_tables) == 0) {
         const char* e = getenv("FFGPU_GF8_TABLE_MIN");
@@ -271,6 +281,11 @@ int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
         DeviceGuard g(ctx->device);
         return launch_status(ffgpu_launch_gf8_mul_tab(ctx->gf8_tables, ctx->device, a, b, out, n,
                                                       (hipStream_t)stream));
+    }
+    if (ctx && ctx->gf2w_limbs && n && a && b && out) {
+        DeviceGuard g(ctx->device);
+        return launch_status(ffgpu_launch_gf2w_mul_win(ctx->policy, ctx->gf2w_limbs, ctx->gf2w_rtable, ctx->device,
+                                                       a, b, out, n, (hipStream_t)stream));
     }
     return do_ew2(ctx, OP_MUL, a, b, out, n, stream);
 }
