@@ -6,13 +6,13 @@
 // RFC 8439 / DJB ChaCha, 20 rounds by default) computed in registers by the thread that
 // consumes them, keyed per call with 256 bits from the host's CSPRNG.
 //
-// Keystream -> field element ("sample"): W + 64 uniform bits reduced mod p (bias < 2^-64,
-// the same idea as thresha.PRF's 16 extra bytes, thresha.py:234-236); exact for GF(2^n).
+// Keystream -> field element ("sample"): see the Sampler<> specialisations below (rejection
+// sampling for pseudo-Mersenne primes, W+64-bit wide samples for generic moduli, masks for GF(2^n)).
 //
 // Public layout (what tests/oracle reproduce): the thread that owns 16-byte pack i of an
-// array draws B = ceil(EPV*t*S/64) consecutive 64-byte blocks with block counters
-// i*B .. i*B+B-1; sample number (j*EPV + e) of those blocks (S bytes each, in keystream
-// order) is the coefficient C[j][i*EPV + e]  (j < t rows, e < EPV elements per pack).
+// array draws B = ceil((WPP*t + SPARE)*S/64) consecutive 64-byte blocks with block counters
+// i*B .. i*B+B-1; primary sample number (j*WPP + q) (S bytes each, in keystream order) is the
+// coefficient word C[j][i*WPP + q]  (j < t rows, q < WPP words per pack); spares follow.
 // Tail elements past the last full pack are drawn the same way with the pack index they
 // would have had (EPV consecutive elements always share blocks).
 #pragma once
@@ -59,30 +59,48 @@ FF_HD void chacha_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint3
     out[12] = x12 + w12; out[13] = x13 + w13; out[14] = x14 + w14; out[15] = x15 + w15;
 }
 
-// Per-policy sampling: S = bytes of keystream per sample, sample(f, R, words) -> canonical word.
-// R = 2^W mod p (W = 32 for RC32, 64 for the one-limb and 128 for the two-limb prime policies),
-// computed once on the host (policy_build.hpp rng_const).
+// Per-policy sampling.  S = bytes of keystream per primary sample, SPARE = extra samples per pack.
+//   * pseudo-Mersenne primes p = 2^k - c (PM64 / PM128, every default MPyC prime): rejection
+//     sampling.  Primary sample = k keystream bits; it is >= p with probability c/2^k (2^-56 for
+//     2^64-189, 2^-61 for 2^61-1), in which case the pack's first spare is used, then the second
+//     (conditionally reduced).  Residual bias <= (c/2^k)^3, below 2^-90 for every admissible c.
+//     Half the keystream of the wide-sample method.
+//   * generic moduli (RC64 / RC32 / MONT128): W + 64 uniform bits reduced mod p (bias < 2^-64, the
+//     same idea as thresha.PRF's 16 extra bytes, thresha.py:234-236).  R = 2^W mod p comes from
+//     the host (policy_build.hpp rng_const).
+//   * GF(2^n): exact (mask to n bits).
+// sample(f, R0, R1, w, spare) -> canonical word; `spare` points at the SPARE spare samples.
 template <class F>
 struct Sampler;
 
-template <class F>
-struct SamplerPrime64 {
-    enum { S = 16 };
-    static FF_HD uint64_t sample(const F& f, uint64_t R, uint64_t, const uint32_t* w) {
+template <bool K64, bool C1>
+struct Sampler<PM64<K64, C1> > {
+    enum { S = 8, SPARE = 2 };
+    typedef PM64<K64, C1> F;
+    static FF_HD uint64_t sample(const F& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t* spare) {
+        uint64_t v = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & f.mask;
+        if (v >= f.p) {
+            v = ((uint64_t)spare[0] | ((uint64_t)spare[1] << 32)) & f.mask;
+            if (v >= f.p) v = f.csub(((uint64_t)spare[2] | ((uint64_t)spare[3] << 32)) & f.mask);
+        }
+        return v;
+    }
+};
+
+template <>
+struct Sampler<RC64> {
+    enum { S = 16, SPARE = 0 };
+    static FF_HD uint64_t sample(const RC64& f, uint64_t R, uint64_t, const uint32_t* w, const uint32_t*) {
         uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
         uint64_t hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
         return f.add(f.mul(f.reduce_raw(hi), R), f.reduce_raw(lo));
     }
 };
-template <bool A, bool B>
-struct Sampler<PM64<A, B> > : SamplerPrime64<PM64<A, B> > {};
-template <>
-struct Sampler<RC64> : SamplerPrime64<RC64> {};
 
 template <>
 struct Sampler<RC32> {
-    enum { S = 16 };  // 96 bits used, 32 skipped (keeps samples 16-byte aligned in the block)
-    static FF_HD uint32_t sample(const RC32& f, uint64_t R, uint64_t, const uint32_t* w) {
+    enum { S = 16, SPARE = 0 };  // 96 bits used, 32 skipped (keeps samples 16-byte aligned in the block)
+    static FF_HD uint32_t sample(const RC32& f, uint64_t R, uint64_t, const uint32_t* w, const uint32_t*) {
         uint32_t r = f.reduce_raw(w[2]);
         r = f.add(f.mul(r, (uint32_t)R), f.reduce_raw(w[1]));
         r = f.add(f.mul(r, (uint32_t)R), f.reduce_raw(w[0]));
@@ -90,10 +108,29 @@ struct Sampler<RC32> {
     }
 };
 
-template <class F>
-struct SamplerPrime128 {
-    enum { S = 32 };
-    static FF_HD u128e sample(const F& f, uint64_t Rlo, uint64_t Rhi, const uint32_t* w) {
+template <bool K128>
+struct Sampler<PM128<K128> > {
+    enum { S = 16, SPARE = 2 };
+    typedef PM128<K128> F;
+    static FF_HD ff_u128 get(const F& f, const uint32_t* w) {
+        uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        uint64_t hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        return ff_make128(hi, lo) & f.M();
+    }
+    static FF_HD u128e sample(const F& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t* spare) {
+        ff_u128 v = get(f, w);
+        if (v >= f.P()) {
+            v = get(f, spare);
+            if (v >= f.P()) v = f.csub(get(f, spare + 4));
+        }
+        return F::E(v);
+    }
+};
+
+template <>
+struct Sampler<MONT128> {
+    enum { S = 32, SPARE = 0 };
+    static FF_HD u128e sample(const MONT128& f, uint64_t Rlo, uint64_t Rhi, const uint32_t* w, const uint32_t*) {
         u128e lo, hi, R;
         lo.lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
         lo.hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
@@ -104,27 +141,25 @@ struct SamplerPrime128 {
         return f.add(f.mul(f.reduce_raw(hi), R), f.reduce_raw(lo));
     }
 };
-template <bool A>
-struct Sampler<PM128<A> > : SamplerPrime128<PM128<A> > {};
-template <>
-struct Sampler<MONT128> : SamplerPrime128<MONT128> {};
 
 template <>
 struct Sampler<GF2P8> {
-    enum { S = 4 };  // one 32-bit word = 4 packed elements, masked to n bits each
-    static FF_HD uint32_t sample(const GF2P8& f, uint64_t, uint64_t, const uint32_t* w) { return w[0] & f.emask; }
+    enum { S = 4, SPARE = 0 };  // one 32-bit word = 4 packed elements, masked to n bits each
+    static FF_HD uint32_t sample(const GF2P8& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t*) {
+        return w[0] & f.emask;
+    }
 };
 template <>
 struct Sampler<GF2W64> {
-    enum { S = 8 };
-    static FF_HD uint64_t sample(const GF2W64& f, uint64_t, uint64_t, const uint32_t* w) {
+    enum { S = 8, SPARE = 0 };
+    static FF_HD uint64_t sample(const GF2W64& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t*) {
         return ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & f.emask;
     }
 };
 template <>
 struct Sampler<GF2W128> {
-    enum { S = 16 };
-    static FF_HD u128e sample(const GF2W128& f, uint64_t, uint64_t, const uint32_t* w) {
+    enum { S = 16, SPARE = 0 };
+    static FF_HD u128e sample(const GF2W128& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t*) {
         u128e r;
         r.lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & f.emask_lo;
         r.hi = ((uint64_t)w[2] | ((uint64_t)w[3] << 32)) & f.emask_hi;
@@ -132,27 +167,26 @@ struct Sampler<GF2W128> {
     }
 };
 
-// Draw the T*WPP words (WPP = words per pack) owned by pack `pack`: c[j][q], j < T, q < WPP.
-// Sample index within the thread's blocks is j*WPP + q.
+// Draw the T*WPP words owned by pack `pack`: c[j][q], j < T, q < WPP.  Sample index within the
+// pack's keystream is j*WPP + q; the SPARE spare samples follow the NS primary ones.
 template <class F, int T, int WPP>
 FF_HD void rng_draw_pack(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1, uint64_t pack,
                          typename F::word c[][WPP]) {
     typedef Sampler<F> Smp;
-    constexpr int SPB = 64 / Smp::S;                   // samples per block
-    constexpr int NS = T * WPP;                         // samples per pack
-    constexpr int B = (NS + SPB - 1) / SPB;             // blocks per pack
+    constexpr int NS = T * WPP;                                   // primary samples per pack
+    constexpr int BYTES = (NS + Smp::SPARE) * Smp::S;
+    constexpr int B = (BYTES + 63) / 64;                          // blocks per pack
+    uint32_t ks[16 * B];
     uint64_t ctr0 = pack * (uint64_t)B;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        uint32_t blk[16];
         uint64_t ctr = ctr0 + (uint64_t)b;
-        chacha_block(rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk.nonce[0], rk.nonce[1], (int)rk.rounds, blk);
-#pragma unroll
-        for (int sidx = 0; sidx < SPB; ++sidx) {
-            int sn = b * SPB + sidx;
-            if (sn < NS) c[sn / WPP][sn % WPP] = Smp::sample(f, R0, R1, blk + sidx * (Smp::S / 4));
-        }
+        chacha_block(rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk.nonce[0], rk.nonce[1], (int)rk.rounds,
+                     ks + 16 * b);
     }
+    const uint32_t* spare = ks + NS * (Smp::S / 4);
+#pragma unroll
+    for (int sn = 0; sn < NS; ++sn) c[sn / WPP][sn % WPP] = Smp::sample(f, R0, R1, ks + sn * (Smp::S / 4), spare);
 }
 
 }  // namespace ffgpu

@@ -239,28 +239,28 @@ void orc_chacha_block(const uint32_t key[8], const uint32_t w12_15[4], int round
     for (int i = 0; i < 16; ++i) out[i] = st[i] + init[i];
 }
 
-/* one sample from S bytes of keystream (little-endian words) */
-static u128 orc_sample(const orc_field* f, const uint32_t* w) {
-    const int eb = f->eb;
-    if (f->binary) {
-        if (eb == 1) return (u128)(w[0]) ; /* caller masks per byte */
-        if (eb == 8) return (((u128)w[1] << 32) | w[0]) & f->mask;
-        return (((u128)w[3] << 96) | ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0]) & f->mask;
+/* pseudo-Mersenne p = 2^k - c with c < 2^31 (and, below 2^64, the PM64 admissibility rule of
+ * mpyc_amd/csrc/policy_build.hpp): these fields are sampled by rejection, all others wide. */
+static int orc_is_pm(const orc_field* f, int* kbits) {
+    if (f->binary) return 0;
+    u128 p = f->p;
+    int k = 0;
+    while (k < 128 && (p >> k) > 0) ++k;   /* bit length */
+    if (k < 33) return 0;
+    u128 c = (k == 128) ? (u128)0 - p : (((u128)1) << k) - p;
+    *kbits = k;
+    if (k <= 64) {
+        int cb = (k - 1) / 2 < 31 ? (k - 1) / 2 : 31;
+        if (k == 64 && c == 1) return 0;
+        return c < (((u128)1) << cb);
     }
-    if (eb == 4) {
-        u128 v = ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0];
-        return v % f->p;
-    }
-    if (eb == 8) {
-        u128 lo = ((u128)w[1] << 32) | w[0], hi = ((u128)w[3] << 32) | w[2];
-        u128 R = (((u128)1) << 64) % f->p;
-        return (mulmod(hi % f->p, R, f->p) + lo % f->p) % f->p;
-    }
-    u128 lo = ((u128)w[3] << 96) | ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0];
-    u128 hi = ((u128)w[7] << 96) | ((u128)w[6] << 64) | ((u128)w[5] << 32) | w[4];
-    u128 R = 1;
-    for (int i = 0; i < 128; ++i) R = addmod(R, R, f->p);   /* 2^128 mod p */
-    return addmod(mulmod(hi % f->p, R, f->p), lo % f->p, f->p);
+    return c < (((u128)1) << 31);
+}
+
+static u128 ld_words(const uint32_t* w, int nwords) {
+    u128 v = 0;
+    for (int i = nwords - 1; i >= 0; --i) v = (v << 32) | w[i];
+    return v;
 }
 
 /* coefficient matrix (t, n), row stride cstride elements, exactly as the device draws it */
@@ -270,30 +270,39 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
     const int EPV = 16 / eb;                         /* elements per 16-byte pack */
     const int packed = (f->binary && eb == 1);       /* GF(2^n<=8): a word holds 4 elements */
     const int WPP = packed ? 4 : EPV;                /* sampled words per pack */
-    const int S = packed ? 4 : (f->binary ? eb : (eb == 16 ? 32 : 16));
-    const int SPB = 64 / S;
+    int kbits = 0;
+    const int pm = orc_is_pm(f, &kbits);
+    const int S = packed ? 4 : (f->binary ? eb : (pm ? eb : (eb == 16 ? 32 : 16)));
+    const int SPARE = pm ? 2 : 0;
+    const u128 kmask = kbits >= 128 ? ~(u128)0 : ((((u128)1) << kbits) - 1);
     uint32_t key[8];
     memcpy(key, key32, 32);
     if (rounds == 0) rounds = 20;
     const size_t npacks = (n + EPV - 1) / EPV;
     const int rows_per_draw = t <= 4 ? t : 1;
     const int draws = t <= 4 ? 1 : t;
+    u128 R = 0;
+    if (!f->binary && !pm && eb >= 8) {              /* 2^W mod p for the wide samples */
+        R = 1;
+        for (int i = 0; i < 8 * eb; ++i) R = addmod(R, R, f->p);
+    }
     for (int d = 0; d < draws; ++d) {
         const int T = rows_per_draw;
         const int NS = T * WPP;
-        const int B = (NS + SPB - 1) / SPB;
+        const int B = ((NS + SPARE) * S + 63) / 64;
         uint32_t n0 = (uint32_t)nonce, n1 = (uint32_t)(nonce >> 32);
         if (t > 4) n1 += (uint32_t)(d + 1);
         for (size_t i = 0; i < npacks; ++i) {
-            uint32_t ks[16 * 8];
+            uint32_t ks[16 * 16];
             for (int b = 0; b < B; ++b) {
                 uint64_t ctr = (uint64_t)i * B + b;
                 uint32_t w[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), n0, n1};
                 orc_chacha_block(key, w, rounds, ks + 16 * b);
             }
+            const uint32_t* spare = ks + NS * (S / 4);
             for (int sn = 0; sn < NS; ++sn) {
                 int j = sn / WPP, q = sn % WPP;
-                const uint32_t* w = ks + 16 * (sn / SPB) + (sn % SPB) * (S / 4);
+                const uint32_t* w = ks + sn * (S / 4);
                 int row = t > 4 ? d : j;
                 if (packed) {
                     uint32_t word = w[0] & (uint32_t)(0x01010101u * (uint32_t)f->mask);
@@ -301,10 +310,31 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
                         size_t e = i * EPV + (size_t)q * 4 + b_;
                         if (e < n) st(out, (size_t)row * cstride + e, eb, (word >> (8 * b_)) & 0xff);
                     }
-                } else {
-                    size_t e = i * EPV + (size_t)q;
-                    if (e < n) st(out, (size_t)row * cstride + e, eb, orc_sample(f, w));
+                    continue;
                 }
+                u128 v;
+                if (f->binary) {
+                    v = ld_words(w, eb / 4) & f->mask;
+                } else if (pm) {
+                    v = ld_words(w, eb / 4) & kmask;
+                    if (v >= f->p) {
+                        v = ld_words(spare, eb / 4) & kmask;
+                        if (v >= f->p) {
+                            v = ld_words(spare + eb / 4, eb / 4) & kmask;
+                            if (v >= f->p) v -= f->p;
+                        }
+                    }
+                } else if (eb == 4) {
+                    v = ld_words(w, 3) % f->p;                      /* 96 bits */
+                } else if (eb == 8) {
+                    u128 lo = ld_words(w, 2), hi = ld_words(w + 2, 2);
+                    v = (mulmod(hi % f->p, R, f->p) + lo % f->p) % f->p;
+                } else {
+                    u128 lo = ld_words(w, 4), hi = ld_words(w + 4, 4);
+                    v = addmod(mulmod(hi % f->p, R, f->p), lo % f->p, f->p);
+                }
+                size_t e = i * EPV + (size_t)q;
+                if (e < n) st(out, (size_t)row * cstride + e, eb, v);
             }
         }
     }

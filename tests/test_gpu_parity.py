@@ -340,6 +340,27 @@ def test_device_rng(eng, coracle, modulus, binary):
             assert (ctx.recombine([sh.row(0), sh.row(1)], lam).to_numpy() == S).all()
 
 
+def test_device_rng_rejection_branch(eng, coracle):
+    """GPU vs oracle on the pseudo-Mersenne prime with the highest admissible rejection rate
+    (p = 2^33 - c, c ~ 2^16): ~2^-17 of the samples take the spare path."""
+    from mpyc_amd.finfields import is_prime
+    c = 65535
+    while not is_prime(2**33 - c):
+        c -= 2
+    p = 2**33 - c
+    ctx = ctx_for(eng, p, False)
+    assert ctx.reduction == 'pseudo-mersenne'
+    cf = coracle.CField(p)
+    n = 1 << 20
+    for t in (1, 3):
+        C = ctx.rng_coeffs(KEY, 5, t, n, rounds=8)
+        assert (C.to_numpy() == coracle.rng_coeffs(cf, KEY, 5, 8, t, n)).all()
+    S = rand_np(po.Field(p), 8, n, 5)
+    dS = ctx.from_numpy(S)
+    got = ctx.split_rng(dS, 3, 7, key=KEY, nonce=5, rounds=8)
+    assert (got.to_numpy() == ctx.split(dS, ctx.rng_coeffs(KEY, 5, 3, n, rounds=8), 3, 7).to_numpy()).all()
+
+
 def test_many_rows_and_outputs(eng, coracle):
     """k > 9 rows (generic kernel), w > 8 outputs, t > 4 (generic split)."""
     for modulus, binary in [(P64, False), (0x11b, True), (P128, False)]:

@@ -57,17 +57,55 @@ def test_sampler_and_layout_match_oracle(hostcheck, coracle, golden_fields):
             assert all(0 <= v < F.order for v in vals), name
 
 
-def test_sampler_is_wide_sample_mod_p(hostcheck, coracle):
-    """First coefficient of the first pack for P64: (128 keystream bits) mod p, by hand."""
+def test_sampler_by_hand(hostcheck, coracle):
+    """First coefficients of the first pack, by hand: P64 (pseudo-Mersenne -> rejection sampling: the
+    64 keystream bits themselves unless >= p) and a generic 63-bit prime (128 bits mod p)."""
     from oracle import pyoracle as po
-    p = 2**64 - 189
-    F = po.Field(p)
     blk = coracle.chacha_block(KEY, [0, 0, 5, 0], 20)
+    p = 2**64 - 189
+    got = hc_coeffs(hostcheck, po.Field(p), KEY, 5, 20, 1, 2)
+    w0, w1 = blk[0] | (blk[1] << 32), blk[2] | (blk[3] << 32)
+    assert w0 < p and w1 < p                       # (true for this key; rejection has probability 2^-56)
+    assert int(got[0, 0]) == w0 and int(got[0, 1]) == w1
+    g = 6616326157076047771
+    got = hc_coeffs(hostcheck, po.Field(g), KEY, 5, 20, 1, 2)
     wide = blk[0] | (blk[1] << 32) | (blk[2] << 64) | (blk[3] << 96)
-    got = hc_coeffs(hostcheck, F, KEY, 5, 20, 1, 2)
-    assert int(got[0, 0]) == wide % p
+    assert int(got[0, 0]) == wide % g
     wide2 = blk[4] | (blk[5] << 32) | (blk[6] << 64) | (blk[7] << 96)
-    assert int(got[0, 1]) == wide2 % p
+    assert int(got[0, 1]) == wide2 % g
+
+
+def test_rejection_branch(hostcheck, coracle):
+    """Rejection is rare for the default primes (2^-56), so exercise the branch on an admissible
+    pseudo-Mersenne prime with the largest possible c: p = 2^33 - c, c just below 2^16 (rejection
+    probability ~2^-17 per sample -> dozens of hits in 2^21 samples, including spare re-use)."""
+    from mpyc_amd.finfields import is_prime
+    from oracle import pyoracle as po
+    c = 65535
+    while not is_prime(2**33 - c):
+        c -= 2
+    p = 2**33 - c
+    assert c > 60000
+    F = po.Field(p)
+    cf = coracle.CField(p)
+    n = 1 << 20
+    got = hc_coeffs(hostcheck, F, KEY, 123, 8, 2, n)
+    want = coracle.rng_coeffs(cf, KEY, 123, 8, 2, n)
+    assert (got == want).all()
+    assert int(got.max()) < p
+    # count how many primary samples were rejected, from the raw keystream (pack = 2 elements, t = 2:
+    # 4 primary words + 2 spares = 48 bytes -> 1 block per pack)
+    hits = 0
+    for i in range(0, 4096):
+        blk = coracle.chacha_block(KEY, [i, 0, 123, 0], 8)
+        for sn in range(4):
+            v = (blk[2 * sn] | (blk[2 * sn + 1] << 32)) & (2**33 - 1)
+            hits += v >= p
+    expected = 4096 * 4 * c / 2**33
+    assert hits >= 0 and abs(hits - expected) < 6 * max(1.0, expected) ** 0.5 + 3
+    for q in (2**61 - 1, 2**64 - 189, 2**40 - 87, 2**127 - 1, 2**128 - 173, 2**96 - 17):
+        got = hc_coeffs(hostcheck, po.Field(q), KEY, 77, 20, 3, 4099)
+        assert (got == coracle.rng_coeffs(coracle.CField(q), KEY, 77, 20, 3, 4099)).all(), q
 
 
 def test_uniformity_smoke(hostcheck):
