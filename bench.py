@@ -8,7 +8,11 @@ m=3, t=1:
     c      = a * b                      n mod-muls        (finfields.py:1105-1112)
     shares = np_random_split(c, t, m)   n share gens      (thresha.py:47-64, coefficients supplied)
     y      = np_recombine(2t+1 rows)    n recombinations  (thresha.py:119-132)
-=> 3n field-ops per step (one op = one element through one stage).  Inputs are resident in
+=> 3n field-ops per step (one op = one element through one stage).  The first two stages run as
+ONE kernel (ffgpu_mul_split): the product is formed in registers and goes straight into share
+generation, exactly what mpyc_amd.finfields does for `a * b` followed by np_random_split (deferred
+product); c itself is never written to HBM.  The unfused three-kernel step is timed as well and
+reported as `unfused` (and each kernel separately under `kernels`).  Inputs are resident in
 HBM before the timed region; several independent buffer sets are rotated so that no launch
 finds its operands in the 256 MiB Infinity Cache.
 
@@ -193,7 +197,15 @@ def main():
     def f_rec(s):
         s.rec()
 
+    def f_fused(s):
+        ctx.split(s.a, s.coef, t, m, out=s.shares, mul_by=s.b)
+
     def step(i):
+        s = sets[i % len(sets)]
+        f_fused(s)          # c = a*b in registers -> shares  (never written)
+        f_rec(s)            # shares -> y
+
+    def step_unfused(i):
         s = sets[i % len(sets)]
         f_mul(s)
         f_split(s)
@@ -209,8 +221,11 @@ def main():
     # parity guard inside the bench: recombining the fresh shares gives back a*b
     torch.cuda.synchronize()
     s0 = sets[(args.warmup - 1) % len(sets)] if args.warmup else None
-    if s0 is not None and not torch.equal(s0.y.t, s0.c.t):
-        raise SystemExit('bench parity check failed: recombine(split(a*b)) != a*b')
+    if s0 is not None:
+        f_mul(s0)
+        torch.cuda.synchronize()
+        if not torch.equal(s0.y.t, s0.c.t):
+            raise SystemExit('bench parity check failed: recombine(split(a*b)) != a*b')
 
     barrier()
     t0 = time.perf_counter()
@@ -223,6 +238,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same work as three separate kernels (c materialised), for reference
+    for i in range(min(args.warmup, 3)):
+        step_unfused(i)
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step_unfused(i)
+    barrier()
+    elapsed_unfused = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed_unfused], dtype=torch.float64, device=ctx.torch_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_unfused = float(tt.item())
+
     ops_total = 3.0 * n * world * args.steps
     value = ops_total / elapsed
     out = {
@@ -232,10 +261,15 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64',
         'data': 'synthetic',
         'config': {'workload': 'configs[1]: SecFld(GF(2^61-1)) array, 10^7 elements per GPU; step = '
-                               'modmul + np_random_split(m=3,t=1, coefficients supplied) + np_recombine(k=3)',
+                               'modmul + np_random_split(m=3,t=1, coefficients supplied) + np_recombine(k=3); '
+                               'modmul is fused into the share-generation kernel (product never written to HBM)',
                    'n_per_gpu': n, 'prime': '2^61-1', 'm': m, 't': t, 'k': k, 'field_ops_per_step': 3 * n,
                    'buffer_sets': args.sets, 'parallelism': f'element-sharded x{world}, no collective'},
     }
+
+    out['unfused'] = {'value': round(ops_total / elapsed_unfused, 1), 'unit': 'field-ops/s',
+                      'ms_per_step': round(elapsed_unfused / args.steps * 1e3, 5),
+                      'note': 'same step as three kernels (mul, split, recombine) with c written to HBM'}
 
     if rank == 0 and not args.no_extras:
         eb = 8
@@ -259,11 +293,9 @@ def main():
             kern[f'split_rng_p61_m3t1_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                                               units_per_s=round(n / (ms * 1e-3), 1))
         # fused local product + share generation (c never written)
-        def f_fused(s):
-            ctx.split(s.a, s.coef, t, m, out=s.shares, mul_by=s.b)
         ms = time_launches(f_fused, sets, reps)
         bpu = (2 + t + m) * eb
-        kern['mul_split_fused_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,1,fused>',
+        kern['mul_split_fused_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,T=1,fused mul,nt,lazy>',
                                                 algorithmic_bytes_per_unit=bpu,
                                                 units_per_s=round(n / (ms * 1e-3), 1))
         # achievable-bandwidth yardstick: the library's streaming copy, 80 MB blocks rotating
@@ -379,7 +411,7 @@ def main():
             del bufs
             torch.cuda.empty_cache()
         # dominant kernel of the timed step = the one with the largest share of step time
-        step_kernels = ['mul_p61', 'split_p61_m3t1', 'recombine_p61_k3']
+        step_kernels = ['mul_split_fused_p61_m3t1', 'recombine_p61_k3']
         dom = max(step_kernels, key=lambda q: kern[q]['ms_per_launch'])
         out['roofline'] = dict({kk_: vv for kk_, vv in kern[dom].items()
                                 if kk_ in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')},
@@ -391,11 +423,12 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
-            names = {'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
-                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true>',
+            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, true, false>',
+                     'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
+                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true, false>',
                      'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
                      'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
-                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true>',
+                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true, false>',
                      'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
                      'device_copy': 'k_copy16'}
             for q, kn in names.items():

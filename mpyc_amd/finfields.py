@@ -396,6 +396,8 @@ def _scalar_value(x):
 
 
 _ctx_cache = {}
+_pending_products = []     # weakrefs to FieldArrays holding an unmaterialised product
+lazy_products = True     # defer `a * b` so that a following np_random_split fuses it (see FieldArray._dev)
 
 
 def _context(field, device: Optional[int] = None) -> FieldContext:
@@ -420,7 +422,7 @@ class FieldArray:
     of ints (any integer dtype or object), another FieldArray, or an engine DevArray; with
     check=True inputs are reduced into canonical form (negative ints wrap Python-style)."""
 
-    __slots__ = ('_dev', '_shape', '_cache')
+    __slots__ = ('_devv', '_shape', '_cache', '_lazy', '__weakref__')
     field = None            # set per field by GF()
     __array_priority__ = 100
 
@@ -472,10 +474,51 @@ class FieldArray:
             flat = flat.astype(object)
         return flat % p
 
+    # ---- deferred element-wise product ----------------------------------------------------
+    # `a * b` on equal-shape arrays is recorded, not launched: if the next thing that happens to it is
+    # share generation (the reference's np_multiply -> _reshare, runtime.py:1134-1138) the product is
+    # fused into the split kernel and never written to HBM (ffgpu_mul_split).  Any other use
+    # materialises it with the ordinary mul kernel.
+    @property
+    def _dev(self) -> DevArray:
+        if self._devv is None:
+            a, b = self._lazy
+            self._devv = a.ctx.mul(a, b)
+            self._lazy = None
+        return self._devv
+
+    @_dev.setter
+    def _dev(self, v):
+        self._devv = v
+        self._lazy = None
+
+    @staticmethod
+    def _flush_products_reading(dev: DevArray):
+        """An in-place update of `dev` is about to happen: materialise every pending product that still
+        reads that buffer, so that deferred evaluation never observes the later mutation."""
+        if not _pending_products:
+            return
+        ptr = dev.t.data_ptr()
+        alive = []
+        for ref in _pending_products:
+            arr = ref()
+            if arr is None or arr._devv is not None:
+                continue
+            lz = arr._lazy
+            if lz[0].t.data_ptr() == ptr or lz[1].t.data_ptr() == ptr:
+                arr._dev            # noqa: B018  (property access materialises)
+            else:
+                alive.append(ref)
+        _pending_products[:] = alive
+
+    def _take_lazy_product(self):
+        """(a, b) device operands if this array is an unmaterialised product, else None."""
+        return self._lazy if self._devv is None else None
+
     # ---- representation --------------------------------------------------------------
     @property
     def ctx(self) -> FieldContext:
-        return self._dev.ctx
+        return (self._lazy[0] if self._devv is None else self._devv).ctx
 
     @property
     def value(self) -> np.ndarray:
@@ -525,10 +568,28 @@ class FieldArray:
         o._dev, o._shape, o._cache = dev, tuple(shape), None
         return o
 
+    @classmethod
+    def _wrap_lazy_product(cls, a: DevArray, b: DevArray, shape) -> 'FieldArray':
+        o = cls.__new__(cls)
+        o._devv, o._lazy, o._shape, o._cache = None, (a, b), tuple(shape), None
+        import weakref
+        if len(_pending_products) > 64:      # drop dead / materialised entries now and then
+            _pending_products[:] = [r for r in _pending_products if r() is not None and r()._devv is None]
+        _pending_products.append(weakref.ref(o))
+        return o
+
     def copy(self):
         return self._wrap(self._dev.clone(), self._shape)
 
     def reshape(self, *shape):
+        if self._devv is None and self._lazy is not None:
+            # keep the product deferred through the "in-place flatten" the runtime does before sharing
+            o = self._wrap_lazy_product(self._lazy[0], self._lazy[1], self._shape)
+            o._shape = self._reshape_shape(shape)
+            return o
+        return self._wrap(self._dev, self._reshape_shape(shape))                # view: same device data
+
+    def _reshape_shape(self, shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
         n = self.size
@@ -537,7 +598,7 @@ class FieldArray:
             shape = tuple(n // known if s == -1 else s for s in shape)
         if int(np.prod(shape, dtype=np.int64)) != n:
             raise ValueError(f'cannot reshape array of size {n} into shape {shape}')
-        return self._wrap(self._dev, shape)                                   # view: same device data
+        return tuple(shape)
 
     def flatten(self):
         return self._wrap(self._dev.clone(), (self.size,))
@@ -575,6 +636,7 @@ class FieldArray:
         elif not isinstance(value, FieldArray):
             value = cls(value)
         src = value._limb_view()
+        self._flush_products_reading(self._dev)
         t = self._limb_view()
         if self.ctx.elem_bytes == 16:
             key = key if isinstance(key, tuple) else (key,)
@@ -636,6 +698,8 @@ class FieldArray:
             return NotImplemented
         ctx = self.ctx
         kind, o = opd
+        if inplace:
+            self._flush_products_reading(self._dev)
         if kind == 'scalar':
             fn = reflected_scalar_op or scalar_op
             res = fn(ctx, self._dev, o, self._dev if inplace else None)
@@ -679,6 +743,9 @@ class FieldArray:
         return self._binop(other, FieldContext.sub, sub_scalar, inplace=True)
 
     def __mul__(self, other):
+        if isinstance(other, FieldArray) and other.field is type(self).field and other._shape == self._shape \
+                and self.size > 1 and lazy_products:
+            return self._wrap_lazy_product(self._dev, other._dev, self._shape)
         return self._binop(other, FieldContext.mul, FieldContext.mul_scalar)
 
     __rmul__ = __mul__

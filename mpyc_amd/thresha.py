@@ -50,11 +50,16 @@ def _as_field_array(field, s) -> FieldArray:
 def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
     ctx = S.ctx
     n = S.size
-    dev = S.device_array if S.ndim == 1 else S.reshape(-1).device_array
+    lazy = S._take_lazy_product()          # unmaterialised a*b: fuse the product into the split kernel
+    if lazy is not None:
+        dev, mul_by = lazy
+    else:
+        dev, mul_by = (S.device_array if S.ndim == 1 else S.reshape(-1).device_array), None
     if t == 0 or n == 0:
-        return ctx.split(dev, None, 0, m)
+        return ctx.split(dev, None, 0, m, mul_by=mul_by)
     if randbelow is None:
-        return ctx.split_rng(dev, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds)
+        return ctx.split_rng(dev, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds,
+                             mul_by=mul_by)
     order = field.order
     draws = [randbelow(order) for _ in range(t * n)]
     if np_convention:
@@ -67,7 +72,7 @@ def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
     C = ctx.empty_matrix(t, n)
     for j in range(t):
         C.row(j).t.copy_(ctx.from_numpy(ints_to_np(rows[j], eb)).t)
-    return ctx.split(dev, C, t, m)
+    return ctx.split(dev, C, t, m, mul_by=mul_by)
 
 
 class ShareMatrix:

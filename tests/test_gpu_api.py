@@ -225,3 +225,45 @@ def test_sqrt_and_is_sqr(api):
     assert ints(r * r) == list(range(256))
     with pytest.raises(ZeroDivisionError):
         x.sqrt(INV=True)
+
+
+def test_lazy_product_fuses_into_split_and_stays_correct(api):
+    """a * b is deferred; np_random_split consumes it through the fused mul_split kernel; any other use
+    (or an in-place update of an operand) materialises it first.  Results are identical either way."""
+    finfields, gfpx, thresha = api
+    F = finfields.GF(2**61 - 1)
+    p = F.modulus
+    rng = random.Random(4)
+    n = 5000
+    a = [rng.randrange(p) for _ in range(n)]
+    b = [rng.randrange(p) for _ in range(n)]
+    prod = [x * y % p for x, y in zip(a, b)]
+    A, B = F.array(a), F.array(b)
+    C = A * B
+    assert C._take_lazy_product() is not None                 # nothing launched yet
+    draws = [rng.randrange(p) for _ in range(n)]
+    try:
+        it = iter(draws)
+        thresha.randbelow = lambda bound: next(it)
+        sh = thresha.np_random_split(F, C.reshape(-1), 1, 3)   # fused: product never written
+        it = iter(draws)
+        finfields.lazy_products = False
+        sh_ref = thresha.np_random_split(F, A * B, 1, 3)
+    finally:
+        thresha.randbelow = None
+        finfields.lazy_products = True
+    for i in range(3):
+        assert ints(sh[i]) == ints(sh_ref[i]) == [(c + d * (i + 1)) % p for c, d in zip(prod, draws)]
+    y = thresha.np_recombine(F, [(1, sh[0]), (2, sh[1])])
+    assert ints(y) == prod
+    # any other use materialises
+    D = A * B
+    assert ints(D + 0) == prod and D._take_lazy_product() is None
+    # in-place update of an operand after the product was formed must not leak into it
+    E = A * B
+    A += 1
+    assert ints(E) == prod
+    assert ints(A) == [(x + 1) % p for x in a]
+    G = A * B
+    B[0] = 5
+    assert ints(G)[0] == (a[0] + 1) * b[0] % p

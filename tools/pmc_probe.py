@@ -25,6 +25,7 @@ for P, t, m in ((bench.P61, 1, 3), (bench.P64, 3, 7)):
             ctx.copy(s.a.t, s.y.t)
             ctx.mul(s.a, s.b, out=s.c)
             ctx.split(s.c, s.coef, t, m, out=s.shares)
+            ctx.split(s.a, s.coef, t, m, out=s.shares, mul_by=s.b)
             s.rec()
     torch.cuda.synchronize()
     assert torch.equal(sets[0].y.t, sets[0].c.t)
