@@ -179,6 +179,19 @@ int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint
 int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda,
                     int k, int w, void* out, size_t out_stride, size_t n, void* stream);
 
+/* ---- pseudorandom secret sharing: combination step ----------------------- */
+/* out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * weights[s][j]   (mod modulus)
+ * host_streams: HOST array of ks DEVICE pointers to the raw SHAKE128 output of subset s
+ * (n*d*l bytes each; the XOF is sequential per key and is computed on the host with hashlib, as in
+ * thresha.PRF.__call__, thresha.py:238-266).  draw = l-byte little-endian chunk reduced into
+ * range(bound): mask_bits == 0 -> bound is the field order (wide reduction, l = byte_length + 16),
+ * mask_bits = b > 0 -> bound = 2^b (runtime.py:4062-4076 rounds bounds to powers of two).
+ * host_weights: (ks, d) canonical 2-limb scalars f_S(i) * (i+1)^power from _f_S_i (thresha.py:135-141).
+ * replaces: thresha.py:163-173 np_pseudorandom_share (d = 1), :201-217 np_pseudorandom_share_0,
+ * and the list versions :144-160, :176-198.                                                    */
+int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
+                       const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream);
+
 /* ---- GF(2^8) S-box layer (local / public values) ----------------------- */
 /* out[h] = A * bits(in[h]^254) + B packed back to a byte, with the 8x8 GF(2)
  * matrix given as 8 row bytes (bit c of host_rows8[r] = A[r][c]) and B as a byte.

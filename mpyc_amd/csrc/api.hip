@@ -463,6 +463,20 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
                                              out_stride, n, (hipStream_t)stream));
 }
 
+int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
+                       const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(ks >= 1 && d >= 1 && l >= 1 && l <= 64 && mask_bits >= 0 && mask_bits <= 128);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(host_streams && host_weights && out);
+    for (int s = 0; s < ks; ++s) ARGCHK(host_streams[s]);
+    // limb radix constant for the wide reduction: 2^(8*elem_bytes) mod p (prime policies)
+    uint64_t r2[2] = {ctx->rng_r[0], ctx->rng_r[1]};
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->prss(ctx->policy, ctx->device, host_streams, ks, d, l, mask_bits, host_weights,
+                                        r2, accumulate, out, n, (hipStream_t)stream));
+}
+
 int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b, void* out,
                      size_t n, void* stream) {
     ARGCHK(ctx && host_rows8);

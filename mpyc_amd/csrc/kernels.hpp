@@ -587,6 +587,98 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
     if (anyzero && flag) atomicOr(flag, 1);
 }
 
+
+// ---- PRSS combination (thresha.py:163-173, 201-217) ---------------------------------------------
+// out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * W[s][j]
+// draw_s[i] = the i-th l-byte little-endian chunk of subset s's SHAKE128 output, reduced into
+// range(bound) as thresha.PRF.__call__ does (thresha.py:238-266): `% order` (wide reduction,
+// l = byte_length + len(key)) or, for a power-of-two bound, a mask.  The XOF itself is sequential
+// per key and stays on the host (hashlib); its raw bytes are uploaded once and never boxed.
+enum { PRSS_MAXW = 96, PRSS_MAXS = 48 };
+template <class F>
+struct PrssArgs {
+    const uint8_t* streams[PRSS_MAXS];
+    typename F::word w[PRSS_MAXW];   // (ks, d) prepared weights f_S(i) * x^(power)
+    uint64_t r0, r1;                 // 2^(limb bits) mod p
+    int ks, d, l, mask_bits, accumulate;
+};
+
+template <class F>
+__device__ __forceinline__ typename F::word prss_draw(const F& f, const PrssArgs<F>& pa, const uint8_t* p) {
+    typedef typename F::word W;
+    constexpr int LB = F::EPW > 1 ? 1 : (int)sizeof(W);   // limb bytes of one element
+    const int l = pa.l;
+    auto limb = [&](int off, int nbytes) -> W {           // little-endian bytes [off, off+nbytes) as a word
+        if constexpr (LB == 16) {
+            uint64_t lo = 0, hi = 0;
+            for (int b = 0; b < nbytes && b < 8; ++b) lo |= (uint64_t)p[off + b] << (8 * b);
+            for (int b = 8; b < nbytes; ++b) hi |= (uint64_t)p[off + b] << (8 * (b - 8));
+            W w;
+            w.lo = lo;
+            w.hi = hi;
+            return w;
+        } else {
+            uint64_t v = 0;
+            for (int b = 0; b < nbytes; ++b) v |= (uint64_t)p[off + b] << (8 * b);
+            return (W)v;
+        }
+    };
+    if (pa.mask_bits > 0 || l <= LB) {
+        // power-of-two bound (or a draw no wider than an element): mask / plain reduction
+        W v = limb(0, l < LB ? l : LB);
+        if (pa.mask_bits > 0) {
+            if constexpr (LB == 16) {
+                int mb = pa.mask_bits;
+                if (mb < 64) { v.lo &= (1ull << mb) - 1; v.hi = 0; }
+                else if (mb < 128) v.hi &= (1ull << (mb - 64)) - 1;
+            } else {
+                if (pa.mask_bits < 8 * LB) v = (W)((uint64_t)v & ((1ull << pa.mask_bits) - 1));
+            }
+            return v;            // < bound <= order: canonical
+        }
+        return f.reduce_raw(v);
+    }
+    // wide value mod order, limb by limb from the top: r = r * 2^(8 LB) + limb
+    W R;
+    if constexpr (LB == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
+    int top = (l - 1) / LB * LB;
+    W r = f.reduce_raw(limb(top, l - top));
+    for (int off = top - LB; off >= 0; off -= LB) r = f.add(f.mul(r, R), f.reduce_raw(limb(off, LB)));
+    return r;
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_prss(F f, PrssArgs<F> pa, typename F::elem* __restrict__ out, size_t n) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t h = gid; h < n; h += gsz) {
+        typename F::acc acc;
+        f.acc_zero(acc);
+        W total;
+        bool have = false;
+        int cnt = 0;
+        for (int s = 0; s < pa.ks; ++s) {
+            const uint8_t* base = pa.streams[s] + (h * (size_t)pa.d) * (size_t)pa.l;
+            for (int j = 0; j < pa.d; ++j) {
+                W x = prss_draw(f, pa, base + (size_t)j * pa.l);
+                f.acc_mac(acc, pa.w[s * pa.d + j], x);
+                if (++cnt == 192) {                 // keep the lazy accumulator inside its headroom
+                    W part = f.acc_reduce(acc);
+                    total = have ? f.add(total, part) : part;
+                    have = true;
+                    f.acc_zero(acc);
+                    cnt = 0;
+                }
+            }
+        }
+        W r = f.acc_reduce(acc);
+        if (have) r = f.add(total, r);
+        if (pa.accumulate) r = f.add(r, ld_elem<F>(out, h));
+        st_elem<F>(out, h, r);
+    }
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -624,6 +716,8 @@ struct FieldOps {
     int (*pow)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, hipStream_t st);
     int (*inv)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
                hipStream_t st);
+    int (*prss)(const void* F, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
+                const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
 };
 
 // canonical 2-limb host scalar -> policy word (broadcast for packed fields)
@@ -925,8 +1019,28 @@ struct Launchers {
         return 0;
     }
 
+    static int prss(const void* Fp, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
+                    const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n,
+                    hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        if (ks < 1 || d < 1 || l < 1 || ks > PRSS_MAXS || ks * d > PRSS_MAXW) return 2;
+        PrssArgs<F> pa;
+        memset(&pa, 0, sizeof(pa));
+        for (int s = 0; s < ks; ++s) pa.streams[s] = (const uint8_t*)streams[s];
+        for (int i = 0; i < ks * d; ++i)
+            pa.w[i] = f.prep(word_from_limbs<F>(f, weights2[2 * i], weights2[2 * i + 1]));
+        pa.r0 = r2[0];
+        pa.r1 = r2[1];
+        pa.ks = ks; pa.d = d; pa.l = l; pa.mask_bits = mask_bits; pa.accumulate = accumulate;
+        unsigned grid = grid_for(n, lc);
+        hipLaunchKernelGGL((k_prss<F>), dim3(grid), dim3(BLOCK), 0, st, f, pa, (E*)out, n);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &prss};
         return &ops;
     }
 };

@@ -361,6 +361,28 @@ class FieldContext:
             return keep[1]
         return launch
 
+    def prss_combine(self, streams: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int,
+                     mask_bits: int = 0, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
+        """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs
+        (host bytes, n*d*l each), uploaded as-is (thresha.py:163-173, 201-217)."""
+        ks = len(streams)
+        if len(weights) != ks * d:
+            raise ValueError('need ks*d weights')
+        out = out or self.empty(n)
+        devs = []
+        for sbytes in streams:
+            if len(sbytes) < n * d * l:
+                raise ValueError('XOF stream too short')
+            a = np.frombuffer(sbytes, dtype=np.uint8, count=n * d * l)
+            devs.append(torch.from_numpy(a.copy()).to(self.torch_device))
+        ptrs = (ctypes.c_void_p * ks)(*[t.data_ptr() for t in devs])
+        w = (ctypes.c_uint64 * (2 * ks * d))()
+        for i, v in enumerate(weights):
+            w[2 * i], w[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        _ffi.check(self._L.ffgpu_prss_combine(self._h, ptrs, ks, d, l, mask_bits, w, int(accumulate), out.ptr, n,
+                                              self._stream()), 'prss_combine')
+        return out
+
     def sbox(self, x: DevArray, rows8: Sequence[int], b: int, out=None):
         out = out or self.empty(x.n)
         r = (ctypes.c_uint8 * 8)(*rows8)

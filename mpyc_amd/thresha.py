@@ -20,13 +20,16 @@ from __future__ import annotations
 
 import functools
 import secrets
+from hashlib import shake_128
+from math import prod
 
 import numpy as np
 
 from .engine import DevArray, DevMatrix
 from .finfields import FieldArray, FiniteFieldElement, _context, _fops, _matrix_to_array, _scalar_value
 
-__all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector']
+__all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector',
+           'pseudorandom_share', 'pseudorandom_share_zero', 'np_pseudorandom_share', 'np_pseudorandom_share_0', 'PRF']
 
 randbelow = None      # parity hook: callable(order) -> int, else device CSPRNG
 rng_rounds = 20       # ChaCha rounds of the device CSPRNG (20, 12 or 8)
@@ -204,3 +207,117 @@ def recombine(field, points, x_rs=0):
             return [ops.box(v) for v in row]
         return row
     return conv(vals) if not isinstance(x_rs, list) else [conv(r) for r in vals]
+
+
+# --------------------------------------------------------------------------------------------
+# Pseudorandom secret sharing (thresha.py:135-266).  The SHAKE128 XOF is sequential per key, so it
+# runs on the host (hashlib); its raw output is uploaded and everything per element -- wide
+# reduction of each l-byte draw, multiplication by f_S(i) (and the powers of i+1 for zero
+# sharings), summation over the subsets -- is one kernel (ffgpu_prss_combine).
+# --------------------------------------------------------------------------------------------
+class PRF:
+    """A pseudorandom function determined by a key and a public bound (thresha.py:220-266)."""
+
+    def __init__(self, key, bound):
+        self.key = key
+        self.max = bound
+        self.byte_length = ((bound - 1).bit_length() + 7) // 8
+        if bound & (bound - 1):                       # not a power of 2: extra bytes against bias (:235-236)
+            self.byte_length += len(self.key)
+
+    def raw(self, s, n):
+        """The n*l raw XOF bytes the reference chops into draws (thresha.py:255)."""
+        return shake_128(self.key + s).digest(n * self.byte_length) if n and self.byte_length else b''
+
+    def __call__(self, s, n=None):
+        if isinstance(n, tuple):
+            shape, n = n, prod(n)
+        else:
+            shape = None
+        n_ = 1 if n is None else n
+        l, bound = self.byte_length, self.max
+        if n_ == 0:
+            x = []
+        elif not l:
+            x = [0] * n_
+        else:
+            dk = self.raw(s, n_)
+            x = [int.from_bytes(dk[i:i + l], 'little') % bound for i in range(0, n_ * l, l)]
+        if shape is not None:
+            return np.fromiter(x, object, count=n_).reshape(shape)
+        return x[0] if n is None else x
+
+
+@functools.lru_cache(maxsize=None)
+def _f_S_i(field, m, i, S):
+    """f_S(i+1) for the polynomial with f_S(0) = 1 and f_S(j+1) = 0 for all parties j outside S
+    (thresha.py:135-141), as a canonical scalar."""
+    ops = _fops(field)
+    xs = (0,) + tuple(x + 1 for x in range(m) if x not in S)
+    return _recombination_vector(field, xs, i + 1)[0]       # only the point at x = 0 carries a 1
+
+
+def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
+    ops = _fops(field)
+    ctx = _context(field)
+    items = list(prfs.items())
+    first = items[0][1]
+    bound, l = first.max, first.byte_length
+    if any(prf.max != bound for _, prf in items):
+        raise ValueError('all PRFs must share one bound')
+    if bound & (bound - 1) == 0:
+        mask_bits = bound.bit_length() - 1
+    elif bound == ops.order:
+        mask_bits = 0
+    else:
+        raise NotImplementedError('PRF bound must be the field order or a power of two (runtime.py:4062-4076)')
+    out = ctx.empty(n)
+    if n == 0:
+        return out
+    if l == 0 or (mask_bits == 0 and bound & (bound - 1) == 0):   # bound == 1: all draws are 0
+        return ctx.mul_scalar(ctx.from_ints([0] * n), 0)
+    d = (m - len(items[0][0])) if zero else 1
+    i1 = ops.reduce_int(i + 1)
+    streams, weights = [], []
+    for S, prf in items:
+        f = _f_S_i(field, m, i, S)
+        streams.append(prf.raw(uci, n * d))
+        for j in range(d):
+            if not zero:
+                weights.append(f)
+            else:
+                # np path: draw j multiplies (i+1)^(j+1) (thresha.py:209); list path: Horner, draw j
+                # multiplies (i+1)^(d-j) (thresha.py:193-195)
+                power = j + 1 if np_convention else d - j
+                w = f
+                for _ in range(power):
+                    w = ops.mul(w, i1)
+                weights.append(w)
+    # kernel argument limits: 48 streams / 96 weights per launch
+    per = max(1, min(48, 96 // d))
+    first_launch = True
+    for k0 in range(0, len(streams), per):
+        ctx.prss_combine(streams[k0:k0 + per], d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits=mask_bits,
+                         out=out, accumulate=not first_launch)
+        first_launch = False
+    return out
+
+
+def np_pseudorandom_share(field, m, i, prfs, uci, n):
+    """Pseudorandom Shamir shares for party i of n random numbers (thresha.py:163-173)."""
+    return field.array._wrap(_prss_device(field, m, i, prfs, uci, n, False, True), (n,))
+
+
+def np_pseudorandom_share_0(field, m, i, prfs, uci, n):
+    """Pseudorandom Shamir shares for party i of n sharings of 0 (thresha.py:201-217)."""
+    return field.array._wrap(_prss_device(field, m, i, prfs, uci, n, True, True), (n,))
+
+
+def pseudorandom_share(field, m, i, prfs, uci, n):
+    """List version (thresha.py:144-160): list of field elements."""
+    return [field(v) for v in _prss_device(field, m, i, prfs, uci, n, False, False).to_ints()]
+
+
+def pseudorandom_share_zero(field, m, i, prfs, uci, n):
+    """List version (thresha.py:176-198)."""
+    return [field(v) for v in _prss_device(field, m, i, prfs, uci, n, True, False).to_ints()]

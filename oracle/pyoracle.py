@@ -284,3 +284,60 @@ def sbox(x: Iterable[int], rows8: Sequence[int] = None, b: int = None) -> List[i
             y |= (bin(iv & rows8[r]).count('1') & 1) << r
         out.append(y ^ b)
     return out
+
+
+# --------------------------------------------------------------------------
+# Pseudorandom secret sharing (thresha.py:135-266)
+# --------------------------------------------------------------------------
+def prf_values(key: bytes, bound: int, s: bytes, n: int) -> List[int]:
+    """thresha.PRF.__call__ (thresha.py:238-266): n values in range(bound) from SHAKE128(key+s)."""
+    from hashlib import shake_128
+    l = ((bound - 1).bit_length() + 7) // 8
+    if bound & (bound - 1):
+        l += len(key)
+    if n == 0:
+        return []
+    if l == 0:
+        return [0] * n
+    dk = shake_128(key + s).digest(n * l)
+    return [int.from_bytes(dk[i:i + l], 'little') % bound for i in range(0, n * l, l)]
+
+
+def f_S_i(F: Field, m: int, i: int, S) -> int:
+    """thresha.py:135-141: value at x = i+1 of the polynomial that is 1 at 0 and 0 at every party
+    outside S (reduced; the reference keeps the unreduced integer, congruent)."""
+    pts = [(0, [1])] + [(x + 1, [0]) for x in range(m) if x not in S]
+    return reduce(F, recombine_unreduced(F, pts, i + 1)[0])
+
+
+def np_pseudorandom_share(F: Field, m: int, i: int, keys: dict, bound: int, uci: bytes, n: int) -> List[int]:
+    """thresha.py:163-173."""
+    out = [0] * n
+    for S, key in keys.items():
+        f = f_S_i(F, m, i, S)
+        prl = prf_values(key, bound, uci, n)
+        for h in range(n):
+            out[h] = add(F, out[h], mul(F, reduce(F, prl[h]), f))
+    return out
+
+
+def np_pseudorandom_share_0(F: Field, m: int, i: int, keys: dict, bound: int, uci: bytes, n: int,
+                            list_convention: bool = False) -> List[int]:
+    """thresha.py:201-217 (np: draw j of secret h multiplies (i+1)^(j+1)); with list_convention the
+    Horner order of thresha.py:176-198 (draw j multiplies (i+1)^(d-j))."""
+    d = m - len(next(iter(keys)))
+    i1 = reduce(F, i + 1)
+    out = [0] * n
+    for S, key in keys.items():
+        f = f_S_i(F, m, i, S)
+        prl = prf_values(key, bound, uci, n * d)
+        for h in range(n):
+            acc = 0
+            for j in range(d):
+                power = d - j if list_convention else j + 1
+                w = 1
+                for _ in range(power):
+                    w = mul(F, w, i1)
+                acc = add(F, acc, mul(F, reduce(F, prl[h * d + j]), w))
+            out[h] = add(F, out[h], mul(F, acc, f))
+    return out

@@ -252,5 +252,51 @@ def main():
           {f: os.path.getsize(os.path.join(OUT, f)) for f in ('fields.json', 'sbox.json', 'convention.json')})
 
 
+
+def prss_cases():
+    """PRSS golden vectors (thresha.py:135-266): PRF outputs and every party's shares."""
+    from itertools import combinations
+    out = {}
+    key0 = int('0x00112233445566778899aabbccddeeff', 16).to_bytes(16, byteorder='little')   # tests/test_thresha.py:43
+    uci = 'test uci'.encode()
+    n = 9
+    for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P128', finfields.GF(P128)),
+                    ('P80', finfields.GF(P80)), ('GF19', finfields.GF(19)), ('P63G', finfields.GF(P63G)),
+                    ('P128G', finfields.GF(P128G)), ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))),
+                    ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
+        case = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int), 'uci': uci.hex(), 'n': n,
+                'settings': []}
+        for (m, t) in ((1, 0), (3, 1), (5, 2), (4, 1)):
+            if m >= F.order:
+                continue
+            for bound in (F.order, 1 << max(1, (F.order - 1).bit_length() - 3)):
+                subsets = list(combinations(range(m), m - t))
+                keys = {S: bytes((b + 17 * k) & 0xff for b in key0) for k, S in enumerate(subsets)}
+                setting = {'m': m, 't': t, 'bound': hx(bound), 'keys': {','.join(map(str, S)): k.hex() for S, k in keys.items()},
+                           'prf0': hxl(thresha.PRF(keys[subsets[0]], bound)(uci, n)), 'parties': []}
+                for i in range(m):
+                    prfs = {S: thresha.PRF(k, bound) for S, k in keys.items() if i in S}
+                    sh = thresha.np_pseudorandom_share(F, m, i, prfs, uci, n)
+                    sh_l = thresha.pseudorandom_share(F, m, i, prfs, uci, n)
+                    assert [int(v) for v in sh.value] == [int(v.value) for v in sh_l]
+                    party = {'share': hxl(int(v) for v in sh.value)}
+                    if bound == F.order and t > 0:
+                        z = thresha.np_pseudorandom_share_0(F, m, i, prfs, uci, n)
+                        zl = thresha.pseudorandom_share_zero(F, m, i, prfs, uci, n)
+                        party['zero_np'] = hxl(int(v) for v in z.value)
+                        party['zero_list'] = hxl(int(v.value) for v in zl)
+                    setting['parties'].append(party)
+                # the shares of all parties are a degree-t sharing of sum_S prl_S (resp. of 0)
+                pts = [(i + 1, [int(x, 16) for x in setting['parties'][i]['share']]) for i in range(t + 1)]
+                sec = thresha.recombine(F, pts)
+                setting['secret'] = hxl(int(F(int(v)).value) for v in sec)
+                case['settings'].append(setting)
+        out[name] = case
+    with open(os.path.join(OUT, 'prss.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote prss.json', os.path.getsize(os.path.join(OUT, 'prss.json')))
+
+
 if __name__ == '__main__':
     main()
+    prss_cases()

@@ -267,3 +267,52 @@ def test_lazy_product_fuses_into_split_and_stays_correct(api):
     G = A * B
     B[0] = 5
     assert ints(G)[0] == (a[0] + 1) * b[0] % p
+
+
+def test_prss_matches_reference(api):
+    """np_pseudorandom_share / _0 and the list versions against golden vectors from the reference
+    (every party, several (m, t), bound = field order and a power of two); tests/test_thresha.py:56-86."""
+    import json, os
+    finfields, gfpx, thresha = api
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'prss.json')) as fh:
+        gold = json.load(fh)
+    for name, case in gold.items():
+        mod = int(case['modulus'], 16)
+        F = finfields.GF(gfpx.BinaryPolynomial(mod)) if case['binary'] else finfields.GF(mod)
+        uci, n = bytes.fromhex(case['uci']), case['n']
+        for st in case['settings']:
+            m, t, bound = st['m'], st['t'], int(st['bound'], 16)
+            keys = {tuple(int(x) for x in k.split(',')): bytes.fromhex(v) for k, v in st['keys'].items()}
+            first = next(iter(keys))
+            assert [int(v) for v in thresha.PRF(keys[first], bound)(uci, n)] == unhex(st['prf0'])
+            for i, party in enumerate(st['parties']):
+                prfs = {S: thresha.PRF(k, bound) for S, k in keys.items() if i in S}
+                sh = thresha.np_pseudorandom_share(F, m, i, prfs, uci, n)
+                assert isinstance(sh, F.array) and ints(sh) == unhex(party['share']), (name, m, i)
+                assert [int(v.value) for v in thresha.pseudorandom_share(F, m, i, prfs, uci, n)] == unhex(party['share'])
+                if 'zero_np' in party:
+                    assert ints(thresha.np_pseudorandom_share_0(F, m, i, prfs, uci, n)) == unhex(party['zero_np'])
+                    assert [int(v.value) for v in thresha.pseudorandom_share_zero(F, m, i, prfs, uci, n)] == \
+                        unhex(party['zero_list'])
+    # reference KATs for the PRF (tests/test_thresha.py:42-54)
+    key = int('0x00112233445566778899aabbccddeeff', 16).to_bytes(16, byteorder='little')
+    assert thresha.PRF(key, 1)(b'test') == 0
+    y = thresha.PRF(key, 100)(b'')
+    assert 0 <= y < 100 and y == thresha.PRF(key, 100)(b'')
+    # larger batch: round trip across parties for m = 3, t = 1 over P61 (shares of a common secret)
+    F = finfields.GF(2**61 - 1)
+    n = 20000
+    ks = {(0, 1): b'k01' * 6, (0, 2): b'k02' * 6, (1, 2): b'k12' * 6}
+    shares = []
+    for i in range(3):
+        prfs = {S: thresha.PRF(k[:16], F.order) for S, k in ks.items() if i in S}
+        shares.append(thresha.np_pseudorandom_share(F, 3, i, prfs, b'uci-1', n))
+    a = thresha.np_recombine(F, [(1, shares[0]), (2, shares[1])])
+    b = thresha.np_recombine(F, [(2, shares[1]), (3, shares[2])])
+    assert ints(a) == ints(b)
+    zs = []
+    for i in range(3):
+        prfs = {S: thresha.PRF(k[:16], F.order) for S, k in ks.items() if i in S}
+        zs.append(thresha.np_pseudorandom_share_0(F, 3, i, prfs, b'uci-2', n))
+    z = thresha.np_recombine(F, [(1, zs[0]), (2, zs[1]), (3, zs[2])])
+    assert ints(z) == [0] * n
