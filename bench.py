@@ -308,6 +308,18 @@ def main():
         ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
         kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
                                 units_per_s=round(n / (ms * 1e-3), 1))
+        # dense product over GF(2^61-1) (finfields.py:1126-1135; the author's np_bnnmnist bottleneck)
+        for dim in (2048, 4096):
+            from mpyc_amd.engine import DevArray
+            Am = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
+            Bm = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
+            Cm = ctx.empty(dim * dim)
+            ms = time_launches(lambda s: ctx.matmul(Am, Bm, dim, dim, dim, out=Cm), [0], 2)
+            macs = float(dim) ** 3
+            kern[f'matmul_p61_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'integer ALU', 'unit': 'GMAC/s',
+                                         'achieved': round(macs / (ms * 1e-3) / 1e9, 1),
+                                         'frac': 0.0, 'units_per_s': round(macs / (ms * 1e-3), 1)}
+            del Am, Bm, Cm
         # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
         del sets[1:]
         torch.cuda.empty_cache()

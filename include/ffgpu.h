@@ -179,6 +179,14 @@ int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint
 int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_lambda,
                     int k, int w, void* out, size_t out_stride, size_t n, void* stream);
 
+/* ---- dense matrix product ---------------------------------------------- */
+/* C (M x N) = A (M x K) @ B (K x N) over the field, row-major with leading dimensions lda/ldb/ldc in
+ * ELEMENTS.  Products are accumulated unreduced and reduced once per 192 terms.
+ * replaces: finfields.py:1126-1146 (__matmul__: object matmul then one `%`), the local product of
+ * runtime.py:2481-2541 np_matmul (A @ B at :2531).                                             */
+int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
+                 size_t M, size_t K, size_t N, void* stream);
+
 /* ---- pseudorandom secret sharing: combination step ----------------------- */
 /* out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * weights[s][j]   (mod modulus)
  * host_streams: HOST array of ks DEVICE pointers to the raw SHAKE128 output of subset s

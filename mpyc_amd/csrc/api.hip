@@ -463,6 +463,17 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
                                              out_stride, n, (hipStream_t)stream));
 }
 
+int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
+                 size_t M, size_t K, size_t N, void* stream) {
+    ARGCHK(ctx);
+    if (M == 0 || N == 0) return FFGPU_OK;
+    ARGCHK(C && ldc >= N && M < (1u << 30) && N < (1u << 30) && K < (1u << 30));
+    ARGCHK(K == 0 || (A && B && lda >= K && ldb >= N));
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N,
+                                          (hipStream_t)stream));
+}
+
 int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
                        const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream) {
     ARGCHK(ctx);

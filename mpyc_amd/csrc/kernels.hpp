@@ -679,6 +679,139 @@ __global__ __launch_bounds__(BLOCK) void k_prss(F f, PrssArgs<F> pa, typename F:
     }
 }
 
+
+// ---- dense matrix product C = A @ B over the field (finfields.py:1126-1135, runtime.py:2531) -----
+// Classic LDS-tiled product, but the inner operation is the field's lazily reduced multiply-
+// accumulate (acc_mac: 128/256-bit products summed unreduced, one reduction per FLUSH products), so
+// the cost per MAC is the 4 (16) v_mad_u64_u32 of the product plus carry adds.  Integer-ALU bound.
+// Workgroup 16x16 threads, tile 64 x 64 (one-limb fields: 4x4 per thread) or 32 x 32 (two-limb:
+// 2x2 per thread), K step 16 staged through LDS; A is stored transposed in LDS so that both operand
+// reads are row-contiguous.  Ragged edges are zero-filled on load and masked on store.
+template <class W>
+__device__ __forceinline__ W ff_keep_if(W v, bool ok) {
+    if constexpr (sizeof(W) == 16) {
+        v.lo = ok ? v.lo : 0;
+        v.hi = ok ? v.hi : 0;
+        return v;
+    } else {
+        return ok ? v : (W)0;
+    }
+}
+
+template <class F, int TM, int TN>
+__global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                   const typename F::elem* __restrict__ B, size_t ldb,
+                                                   typename F::elem* __restrict__ C, size_t ldc, int M, int K, int N) {
+    typedef typename F::word W;
+    static_assert(F::EPW == 1, "packed fields use the byte-wise instantiation");
+    constexpr int BK = 16, BM = 16 * TM, BN = 16 * TN, FLUSH = 192;
+    __shared__ W As[BK][BM + 1];
+    __shared__ W Bs[BK][BN + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    typename F::acc acc[TM][TN];
+    W tot[TM][TN];
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.acc_zero(acc[i][j]);
+    int since = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // stage A (BM x BK) transposed and B (BK x BN)
+        for (int idx = threadIdx.x; idx < BM * BK; idx += BLOCK) {
+            int mm = idx / BK, kk = idx % BK;
+            int gm = m0 + mm, gk = k0 + kk;
+            const bool ok = gm < M && gk < K;      // out-of-range: read element 0, then zero it
+            As[kk][mm] = ff_keep_if<W>(f.prep(A[ok ? (size_t)gm * lda + gk : 0]), ok);
+        }
+        for (int idx = threadIdx.x; idx < BK * BN; idx += BLOCK) {
+            int kk = idx / BN, nn = idx % BN;
+            int gk = k0 + kk, gn = n0 + nn;
+            const bool ok = gk < K && gn < N;
+            Bs[kk][nn] = ff_keep_if<W>(B[ok ? (size_t)gk * ldb + gn : 0], ok);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < BK; ++kk) {
+            W a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) f.acc_mac(acc[i][j], a[i], b[j]);
+        }
+        __syncthreads();
+        since += BK;
+        if (since >= FLUSH) {   // keep the unreduced accumulators inside their headroom (2^8 products)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    W part = f.acc_reduce(acc[i][j]);
+                    tot[i][j] = have ? f.add(tot[i][j], part) : part;
+                    f.acc_zero(acc[i][j]);
+                }
+            have = true;
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
+            if (gm < M && gn < N) {
+                W r = f.acc_reduce(acc[i][j]);
+                if (have) r = f.add(tot[i][j], r);
+                C[(size_t)gm * ldc + gn] = r;
+            }
+        }
+}
+
+// GF(2^n <= 8): one element per byte, computed element-wise (word = one element in the low byte)
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_matmul_bytes(F f, const uint8_t* __restrict__ A, size_t lda,
+                                                         const uint8_t* __restrict__ B, size_t ldb,
+                                                         uint8_t* __restrict__ C, size_t ldc, int M, int K, int N) {
+    constexpr int BK = 16, BM = 32, BN = 32;
+    __shared__ uint8_t As[BK][BM + 4];
+    __shared__ uint8_t Bs[BK][BN + 4];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    uint32_t acc[2][2] = {{0, 0}, {0, 0}};
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        for (int idx = threadIdx.x; idx < BM * BK; idx += BLOCK) {
+            int mm = idx / BK, kk = idx % BK;
+            int gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0;
+        }
+        for (int idx = threadIdx.x; idx < BK * BN; idx += BLOCK) {
+            int kk = idx / BN, nn = idx % BN;
+            int gk = k0 + kk, gn = n0 + nn;
+            Bs[kk][nn] = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : 0;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < BK; ++kk) {
+            // pack the 2x2 products of this thread into one SWAR word: bytes (a0b0, a0b1, a1b0, a1b1)
+            uint32_t a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
+            uint32_t av = a0 | (a0 << 8) | (a1 << 16) | (a1 << 24);
+            uint32_t bv = b0 | (b1 << 8) | (b0 << 16) | (b1 << 24);
+            acc[0][0] ^= f.mul(av, bv);
+        }
+        __syncthreads();
+    }
+    uint32_t r = acc[0][0];
+    int gm0 = m0 + ty, gm1 = m0 + ty + 16, gn0 = n0 + tx, gn1 = n0 + tx + 16;
+    if (gm0 < M && gn0 < N) C[(size_t)gm0 * ldc + gn0] = (uint8_t)(r & 0xff);
+    if (gm0 < M && gn1 < N) C[(size_t)gm0 * ldc + gn1] = (uint8_t)((r >> 8) & 0xff);
+    if (gm1 < M && gn0 < N) C[(size_t)gm1 * ldc + gn0] = (uint8_t)((r >> 16) & 0xff);
+    if (gm1 < M && gn1 < N) C[(size_t)gm1 * ldc + gn1] = (uint8_t)(r >> 24);
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -716,6 +849,8 @@ struct FieldOps {
     int (*pow)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, hipStream_t st);
     int (*inv)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
                hipStream_t st);
+    int (*matmul)(const void* F, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
+                  size_t ldc, int M, int K, int N, hipStream_t st);
     int (*prss)(const void* F, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
                 const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
 };
@@ -1019,6 +1154,25 @@ struct Launchers {
         return 0;
     }
 
+    static int matmul(const void* Fp, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
+                      size_t ldc, int M, int K, int N, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        if constexpr (F::EPW > 1) {
+            dim3 grid((N + 31) / 32, (M + 31) / 32);
+            hipLaunchKernelGGL((k_matmul_bytes<F>), grid, dim3(BLOCK), 0, st, f, (const uint8_t*)A, lda,
+                               (const uint8_t*)B, ldb, (uint8_t*)C, ldc, M, K, N);
+        } else if constexpr (sizeof(W) == 16) {
+            dim3 grid((N + 31) / 32, (M + 31) / 32);
+            hipLaunchKernelGGL((k_matmul<F, 2, 2>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B, ldb,
+                               (E*)C, ldc, M, K, N);
+        } else {
+            dim3 grid((N + 63) / 64, (M + 63) / 64);
+            hipLaunchKernelGGL((k_matmul<F, 4, 4>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B, ldb,
+                               (E*)C, ldc, M, K, N);
+        }
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
     static int prss(const void* Fp, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
                     const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n,
                     hipStream_t st) {
@@ -1040,7 +1194,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &prss};
         return &ops;
     }
 };

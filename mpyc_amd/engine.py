@@ -361,6 +361,14 @@ class FieldContext:
             return keep[1]
         return launch
 
+    def matmul(self, A: DevArray, B: DevArray, M: int, K: int, N: int, out: Optional[DevArray] = None) -> DevArray:
+        """C (M, N) = A (M, K) @ B (K, N): contiguous row-major operands (finfields.py:1126-1135)."""
+        if A.n != M * K or B.n != K * N:
+            raise ValueError('matmul: operand sizes do not match the shapes')
+        out = out or self.empty(M * N)
+        _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
+        return out
+
     def prss_combine(self, streams: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int,
                      mask_bits: int = 0, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
         """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs

@@ -839,8 +839,8 @@ class FieldArray:
         A2 = A.reshape(1, -1) if vec else A
         if A2.ndim != 2 or A2.shape[1] != self._shape[0]:
             raise ValueError('matmul: shape mismatch')
-        if A2.size > 4096:
-            raise NotImplementedError('dense modular matmul is not on the accelerated path yet')
+        if A2.size > 4096 or isinstance(other, FieldArray):
+            return (other if isinstance(other, FieldArray) else type(self)(other)).__matmul__(self)
         ops = _fops(F)
         lam = [ops.reduce_int(int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v)))
                for v in A2.reshape(-1)]
@@ -854,7 +854,24 @@ class FieldArray:
         return _matrix_to_array(type(self), out)
 
     def __matmul__(self, other):
-        raise NotImplementedError('array @ x is only accelerated with the small operand on the left')
+        """Matrix product over the field on the device (finfields.py:1126-1135): 1-D / 2-D operands
+        with NumPy's matmul shape rules; the right operand may be anything the ctor accepts."""
+        cls = type(self)
+        if not isinstance(other, FieldArray):
+            other = cls(other)
+        elif other.field is not cls.field:
+            raise TypeError('arrays over different fields')
+        if self.ndim not in (1, 2) or other.ndim not in (1, 2):
+            raise NotImplementedError('matmul of arrays with more than 2 dimensions is not accelerated')
+        M, K = (1, self._shape[0]) if self.ndim == 1 else self._shape
+        K2, N = (other._shape[0], 1) if other.ndim == 1 else other._shape
+        if K != K2:
+            raise ValueError(f'matmul: shapes {self._shape} and {other._shape} not aligned')
+        out = self.ctx.matmul(self._dev, other._dev, M, K, N)
+        if self.ndim == 1 and other.ndim == 1:
+            return cls.field(out.to_ints()[0])
+        shape = (N,) if self.ndim == 1 else (M,) if other.ndim == 1 else (M, N)
+        return self._wrap(out, shape)
 
     # ---- comparisons (finfields.py:1031-1043) --------------------------------------------------
     def _zero_mask(self):

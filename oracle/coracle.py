@@ -111,6 +111,15 @@ def rng_coeffs(cf: 'CField', key32: bytes, nonce: int, rounds: int, t: int, n: i
     return out
 
 
+def matmul(cf: 'CField', A: np.ndarray, B: np.ndarray, M: int, K: int, N: int) -> np.ndarray:
+    A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    shape = (M * N, 2) if cf.eb == 16 else (M * N,)
+    C = np.zeros(shape, dtype=A.dtype)
+    lib().orc_matmul(cf._buf, A.ctypes.data_as(ctypes.c_void_p), B.ctypes.data_as(ctypes.c_void_p),
+                     C.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(M), ctypes.c_size_t(K), ctypes.c_size_t(N))
+    return C
+
+
 def sbox(x: np.ndarray, rows8, b: int) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.uint8)
     out = np.empty_like(x)

@@ -186,6 +186,22 @@ int orc_recombine(const orc_field* f, const unsigned char* const* rows, const ui
     return 0;
 }
 
+/* C (M,N) = A (M,K) @ B (K,N): finfields.py:1126-1135 (object matmul, then one `%`) */
+int orc_matmul(const orc_field* f, const unsigned char* A, const unsigned char* B, unsigned char* C, size_t M,
+               size_t K, size_t N) {
+    const int eb = f->eb;
+    long long i;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (i = 0; i < (long long)M; ++i)
+        for (size_t j = 0; j < N; ++j) {
+            u128 acc = 0;
+            for (size_t k = 0; k < K; ++k)
+                acc = f_add(f, acc, f_mul(f, ld(A, (size_t)i * K + k, eb), ld(B, k * N + j, eb)));
+            st(C, (size_t)i * N + j, eb, acc);
+        }
+    return 0;
+}
+
 int orc_sbox(const unsigned char* in, const uint8_t* rows8, uint8_t b, unsigned char* out, size_t n) {
     orc_field f;
     uint64_t mod = 0x11b;

@@ -297,6 +297,32 @@ def prss_cases():
     print('wrote prss.json', os.path.getsize(os.path.join(OUT, 'prss.json')))
 
 
+def matmul_cases():
+    """F.array @ F.array from the reference (finfields.py:1126-1135; tests/test_finfields.py:389-404)."""
+    out = {}
+    for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P127', finfields.GF(P127)),
+                    ('P128', finfields.GF(P128)), ('P128G', finfields.GF(P128G)), ('P63G', finfields.GF(P63G)),
+                    ('GF19', finfields.GF(19)), ('P31', finfields.GF(P31)),
+                    ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))), ('GF2_64', finfields.GF(GF2X(BINARIES['GF2_64']))),
+                    ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
+        q = F.order
+        cases = []
+        for (M, K, N) in ((1, 1, 1), (5, 7, 3), (3, 1, 4), (2, 20, 2)):
+            A = [[rng.randrange(q) for _ in range(K)] for _ in range(M)]
+            B = [[rng.randrange(q) for _ in range(N)] for _ in range(K)]
+            A[0][0] = q - 1
+            B[0][0] = q - 1
+            C = F.array(A) @ F.array(B)
+            v = (F.array(A[0]) @ F.array(B)).value          # 1-D @ 2-D
+            cases.append({'M': M, 'K': K, 'N': N, 'A': [hxl(r) for r in A], 'B': [hxl(r) for r in B],
+                          'C': [hxl(int(x) for x in r) for r in C.value], 'row0': hxl(int(x) for x in v)})
+        out[name] = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int), 'cases': cases}
+    with open(os.path.join(OUT, 'matmul.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote matmul.json', os.path.getsize(os.path.join(OUT, 'matmul.json')))
+
+
 if __name__ == '__main__':
     main()
     prss_cases()
+    matmul_cases()

@@ -316,3 +316,25 @@ def test_prss_matches_reference(api):
         zs.append(thresha.np_pseudorandom_share_0(F, 3, i, prfs, b'uci-2', n))
     z = thresha.np_recombine(F, [(1, zs[0]), (2, zs[1]), (3, zs[2])])
     assert ints(z) == [0] * n
+
+
+def test_matmul_operator(api):
+    """tests/test_finfields.py:389-404: `@` on arrays over the 2^127-1 prime vs NumPy object ints."""
+    finfields, gfpx, _ = api
+    p = 2**127 - 1
+    F = finfields.GF(p)
+    rng = random.Random(11)
+    A = [[rng.randrange(p) for _ in range(6)] for _ in range(4)]
+    B = [[rng.randrange(p) for _ in range(5)] for _ in range(6)]
+    want = (np.array(A, dtype=object) @ np.array(B, dtype=object)) % p
+    C = F.array(A) @ F.array(B)
+    assert C.shape == (4, 5) and [[int(v) for v in r] for r in C.value] == [[int(v) for v in r] for r in want]
+    v = F.array(A[1]) @ F.array(B)
+    assert v.shape == (5,) and ints(v) == [int(x) for x in want[1]]
+    w = F.array(A) @ F.array([r[2] for r in B])
+    assert w.shape == (4,) and ints(w) == [int(x) for x in want[:, 2]]
+    d = F.array(A[0]) @ F.array([r[0] for r in B])
+    assert isinstance(d, F) and int(d.value) == int(want[0, 0])
+    assert ints(F.array(A) @ np.array(B, dtype=object)) == [int(x) for x in want.reshape(-1)]
+    with pytest.raises(ValueError):
+        F.array(A) @ F.array(A)

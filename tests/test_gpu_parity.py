@@ -273,6 +273,43 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
         assert unpack(ctx.mul(ctx.inv(va), va).to_numpy(), eb) == [1] * (n - 1)
 
 
+def test_matmul(eng, coracle):
+    """Dense product over the field (finfields.py:1126-1135): golden matrices from the reference,
+    then ragged / large-K shapes against the oracle (K > 192 exercises the accumulator flush)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'matmul.json')) as fh:
+        gold = json.load(fh)
+    for name, case in gold.items():
+        mod = int(case['modulus'], 16)
+        ctx = ctx_for(eng, mod, case['binary'])
+        eb = ctx.elem_bytes
+        for c in case['cases']:
+            M, K, N = c['M'], c['K'], c['N']
+            A = pack([int(v, 16) for r in c['A'] for v in r], eb)
+            B = pack([int(v, 16) for r in c['B'] for v in r], eb)
+            got = unpack(ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy(), eb)
+            assert got == [int(v, 16) for r in c['C'] for v in r], (name, M, K, N)
+    for modulus, binary in [(P61, False), (P64, False), (P128, False), (6616326157076047771, False), (2**31 - 1, False),
+                            (258797994007609146293811961253269568351, False), (0x11b, True), ((1 << 64) | 0x1b, True),
+                            ((1 << 128) | 0x87, True)]:
+        F = po.Field(modulus, binary)
+        ctx = ctx_for(eng, modulus, binary)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, binary)
+        slow = eb == 16
+        for (M, K, N) in [(1, 1, 1), (64, 64, 64), (70, 130, 65), (3, 500, 5), (33, 17, 129)] if not slow else \
+                [(1, 1, 1), (33, 40, 35), (3, 300, 5)]:
+            A, B = rand_np(F, eb, M * K, 81), rand_np(F, eb, K * N, 82)
+            if not binary:
+                A[:K] = pack([F.order - 1] * K, eb)             # worst-case accumulation in row 0
+                B[::N] = pack([F.order - 1] * K, eb)            # ... column 0
+            got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A, B, M, K, N)
+            coracle.set_threads(1)
+            assert (got == want).all(), (hex(modulus), M, K, N)
+
+
 def test_gf2n_table_multiplication(eng, coracle):
     """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
     answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""
