@@ -118,6 +118,29 @@ class DevMatrix:
         return [np_to_ints(a[i], self.ctx.elem_bytes) for i in range(self.rows)]
 
 
+class CapturedLaunches:
+    """A fixed sequence of engine calls captured into a HIP graph (through torch.cuda.CUDAGraph, which
+    captures every launch issued on the capture stream -- including libffgpu's, since the engine always
+    launches on torch's current stream).  For launch-bound work: a gate on a few thousand elements is
+    three kernels of ~3 us each, dominated by per-launch host cost when issued one by one.
+    The captured kernels read and write the SAME device buffers on every replay: refresh inputs with
+    tensor.copy_() into those buffers, then replay()."""
+
+    def __init__(self, fn, warmup: int = 2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+
+    def replay(self):
+        self.graph.replay()
+
+
 class FieldContext:
     """One finite field on one GPU.  modulus: prime p, or (binary=True) the bit pattern of the
     irreducible polynomial.  Mirrors what finfields.GF(modulus) fixes for an array type

@@ -273,6 +273,34 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
         assert unpack(ctx.mul(ctx.inv(va), va).to_numpy(), eb) == [1] * (n - 1)
 
 
+def test_hip_graph_capture_of_a_gate(eng, coracle):
+    """A gate (fused local product + share generation, then recombination) captured once into a HIP graph
+    and replayed on fresh inputs gives the same bits as eager launches."""
+    F = po.Field(P61)
+    ctx = ctx_for(eng, P61, False)
+    cf = coracle.CField(P61)
+    n, t, m = 4096, 1, 3
+    a, b = ctx.from_numpy(rand_np(F, 8, n, 1)), ctx.from_numpy(rand_np(F, 8, n, 2))
+    coef = ctx.matrix_from_numpy(rand_np(F, 8, n, 3).reshape(1, n))
+    shares, y = ctx.empty_matrix(m, n), ctx.empty(n)
+    lam = po.recombination_vector(F, [1, 2, 3], 0)
+    rec = ctx.recombine_plan([shares.row(j) for j in range(3)], lam, y)
+
+    def gate():
+        ctx.split(a, coef, t, m, out=shares, mul_by=b)
+        rec()
+
+    g = eng.CapturedLaunches(gate)
+    for seed in (10, 11, 12):
+        A, B = rand_np(F, 8, n, seed), rand_np(F, 8, n, seed + 100)
+        a.t.copy_(ctx.from_numpy(A).t)
+        b.t.copy_(ctx.from_numpy(B).t)
+        y.t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (y.to_numpy() == cf.ew(coracle.MUL, A, B)).all(), seed
+
+
 def test_matmul(eng, coracle):
     """Dense product over the field (finfields.py:1126-1135): golden matrices from the reference,
     then ragged / large-K shapes against the oracle (K > 192 exercises the accumulator flush)."""
