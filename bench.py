@@ -301,142 +301,168 @@ def main():
         # achievable-bandwidth yardstick: the library's streaming copy, 80 MB blocks rotating
         ms_copy = time_launches(lambda s: ctx.copy(s.a.t, s.c.t), sets, reps)
         kern['device_copy'] = dict(roof(2 * eb * n, ms_copy), kernel='k_copy16 (80 MB -> 80 MB, rotating sets)')
-        # second-tier element-wise ops (finfields.py:1278-1281,1424-1458): batched inverse, sqrt = pow by (p+1)/4
-        ms = time_launches(lambda s: ctx.inv(s.a, out=s.c, check_zero=False), sets, 3)
-        kern['inv_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
-                               units_per_s=round(n / (ms * 1e-3), 1))
-        ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
-        kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
-                                units_per_s=round(n / (ms * 1e-3), 1))
-        # launch-bound regime: the same gate on 4096 elements, eager vs captured in a HIP graph
-        from mpyc_amd.engine import CapturedLaunches
-        small = StepData(ctx, 4096, t, m, gen)
-        small.rec = ctx.recombine_plan([small.shares.row(j) for j in range(k)], lam, small.y)
+        def optional_measurements():
+            """Everything beyond the step's own kernels; a failure here must not cost the headline line."""
+            # second-tier element-wise ops (finfields.py:1278-1281,1424-1458): batched inverse, sqrt = pow by (p+1)/4
+            ms = time_launches(lambda s: ctx.inv(s.a, out=s.c, check_zero=False), sets, 3)
+            kern['inv_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
+                                   units_per_s=round(n / (ms * 1e-3), 1))
+            ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
+            kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
+                                    units_per_s=round(n / (ms * 1e-3), 1))
+            # launch-bound regime: the same gate on 4096 elements, eager vs captured in a HIP graph
+            from mpyc_amd.engine import CapturedLaunches
+            small = StepData(ctx, 4096, t, m, gen)
+            small.rec = ctx.recombine_plan([small.shares.row(j) for j in range(k)], lam, small.y)
 
-        def small_gate():
-            ctx.split(small.a, small.coef, t, m, out=small.shares, mul_by=small.b)
-            small.rec()
-        ms_eager = time_launches(lambda s: small_gate(), [0], 200)
-        cg = CapturedLaunches(small_gate)
-        ms_graph = time_launches(lambda s: cg.replay(), [0], 200)
-        kern['gate_p61_n4096_eager_vs_graph'] = {'ms_per_launch': round(ms_eager, 5), 'ms_per_replay': round(ms_graph, 5),
-                                                 'achieved': 0.0, 'frac': 0.0, 'unit': 'us',
-                                                 'units_per_s': round(4096 / (ms_graph * 1e-3), 1)}
-        # dense product over GF(2^61-1) (finfields.py:1126-1135; the author's np_bnnmnist bottleneck)
-        for dim in (2048, 4096):
-            from mpyc_amd.engine import DevArray
-            Am = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
-            Bm = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
-            Cm = ctx.empty(dim * dim)
-            ms = time_launches(lambda s: ctx.matmul(Am, Bm, dim, dim, dim, out=Cm), [0], 2)
-            macs = float(dim) ** 3
-            kern[f'matmul_p61_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'integer ALU', 'unit': 'GMAC/s',
-                                         'achieved': round(macs / (ms * 1e-3) / 1e9, 1),
-                                         'frac': 0.0, 'units_per_s': round(macs / (ms * 1e-3), 1)}
-            del Am, Bm, Cm
-        # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
-        del sets[1:]
-        torch.cuda.empty_cache()
-        ctx64 = FieldContext(P64, device=local_rank)
-        t2, m2 = 3, 7
-        sets64 = [StepData(ctx64, n, t2, m2, gen) for _ in range(3)]
-        ms = time_launches(lambda s: ctx64.mul(s.a, s.b, out=s.c), sets64, reps)
-        kern['mul_p64'] = dict(roof(3 * eb * n, ms), algorithmic_bytes_per_unit=3 * eb,
-                               units_per_s=round(n / (ms * 1e-3), 1))
-        ms = time_launches(lambda s: ctx64.split(s.a, s.coef, t2, m2, out=s.shares), sets64, reps)
-        bpu = (1 + t2 + m2) * eb
-        kern['split_p64_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
-                                      units_per_s=round(n / (ms * 1e-3), 1))
-        # production mode: coefficients from the on-device CSPRNG (never in HBM): 8 read + 56 written
-        key = bytes(range(32))
-        for rounds in (20, 12, 8):
-            ms = time_launches(lambda s: ctx64.split_rng(s.a, t2, m2, key=key, nonce=7, rounds=rounds, out=s.shares),
-                               sets64, reps)
-            bpu = (1 + m2) * eb
-            kern[f'split_rng_p64_m7t3_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
-                                                              units_per_s=round(n / (ms * 1e-3), 1))
-        F64 = po.Field(P64)
-        for kk in (t2 + 1, 2 * t2 + 1):
-            lam64 = po.recombination_vector(F64, list(range(1, kk + 1)), 0)
-            for s in sets64:
-                s.rec = ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y)
-            ms = time_launches(lambda s: s.rec(), sets64, reps)
-            bpu = (kk + 1) * eb
-            kern[f'recombine_p64_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
-                                                units_per_s=round(n / (ms * 1e-3), 1))
-        # configs[3] shape on ONE GPU: 128-bit prime (two limbs), gate = mul + split(m=7,t=3) + recombine(k=7)
-        del sets64[:]
-        torch.cuda.empty_cache()
-        P128 = 2**128 - 173
-        ctx128 = FieldContext(P128, device=local_rank)
-        F128 = po.Field(P128)
-
-        def u128_rows(rows):
-            x = torch.randint(-2**63, 2**63 - 1, (rows, n, 2), dtype=torch.int64, device=ctx.torch_device,
-                              generator=gen)
-            # canonical: (hi,lo) >= p only if hi == 2^64-1 and lo >= 2^64-173: fold those few
-            bad = (x[..., 1] == -1) & (x[..., 0] < 0) & (x[..., 0] >= -173)
-            x[..., 0] = torch.where(bad, x[..., 0] + 173, x[..., 0])
-            x[..., 1] = torch.where(bad, torch.zeros_like(x[..., 1]), x[..., 1])
-            return x
-
-        class Set128:
-            def __init__(s):
+            def small_gate():
+                ctx.split(small.a, small.coef, t, m, out=small.shares, mul_by=small.b)
+                small.rec()
+            ms_eager = time_launches(lambda s: small_gate(), [0], 200)
+            cg = CapturedLaunches(small_gate)
+            ms_graph = time_launches(lambda s: cg.replay(), [0], 200)
+            kern['gate_p61_n4096_eager_vs_graph'] = {'ms_per_launch': round(ms_eager, 5), 'ms_per_replay': round(ms_graph, 5),
+                                                     'achieved': 0.0, 'frac': 0.0, 'unit': 'us',
+                                                     'units_per_s': round(4096 / (ms_graph * 1e-3), 1)}
+            # dense product over GF(2^61-1) (finfields.py:1126-1135; the author's np_bnnmnist bottleneck)
+            for dim in (2048, 4096):
                 from mpyc_amd.engine import DevArray
-                ab = u128_rows(2)
-                s.a, s.b = DevArray(ctx128, ab[0], n), DevArray(ctx128, ab[1], n)
-                s.c = ctx128.empty(n)
-                s.coef = ctx128.empty_matrix(t2, n)
-                cf_ = u128_rows(t2)
-                for j in range(t2):
-                    s.coef.row(j).t.copy_(cf_[j])
-                s.shares = ctx128.empty_matrix(m2, n)
-                s.y = ctx128.empty(n)
-                s.rec = None
-        sets128 = [Set128() for _ in range(2)]
-        eb2 = 16
-        ms = time_launches(lambda s: ctx128.mul(s.a, s.b, out=s.c), sets128, reps)
-        kern['mul_p128'] = dict(roof(3 * eb2 * n, ms), algorithmic_bytes_per_unit=3 * eb2,
-                                units_per_s=round(n / (ms * 1e-3), 1))
-        ms = time_launches(lambda s: ctx128.split(s.c, s.coef, t2, m2, out=s.shares), sets128, reps)
-        bpu = (1 + t2 + m2) * eb2
-        kern['split_p128_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
-                                       units_per_s=round(n / (ms * 1e-3), 1))
-        lam128 = po.recombination_vector(F128, list(range(1, 2 * t2 + 2)), 0)
-        for s in sets128:
-            s.rec = ctx128.recombine_plan([s.shares.row(j) for j in range(2 * t2 + 1)], lam128, s.y)
-        ms = time_launches(lambda s: s.rec(), sets128, reps)
-        bpu = (2 * t2 + 2) * eb2
-        kern['recombine_p128_k7'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
-                                         units_per_s=round(n / (ms * 1e-3), 1))
-        if not torch.equal(sets128[0].y.t, sets128[0].c.t):
-            raise SystemExit('bench parity check failed for P128 gate')
-        gate_ms = sum(kern[q]['ms_per_launch'] for q in ('mul_p128', 'split_p128_m7t3', 'recombine_p128_k7'))
-        kern['gate_p128_m7t3'] = {'gates_per_s': round(n / (gate_ms * 1e-3), 1), 'algorithmic_bytes_per_unit': 352,
-                                  'achieved': round(352 * n / (gate_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
-                                  'frac': round(352 * n / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  'ms_per_launch': round(gate_ms, 5)}
-        # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
-        del sets128[:]
-        torch.cuda.empty_cache()
-        ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
-        rows8, b8 = po.aes_affine_rows()
-        for n8 in (1_000_000, 1_000_000_000):
-            from mpyc_amd.engine import DevArray
-            bufs = []
-            for _ in range(3 if n8 > 10**8 else 8):
-                x = torch.randint(0, 256, (3, n8), dtype=torch.uint8, device=ctx.torch_device, generator=gen)
-                bufs.append((DevArray(ctx8, x[0], n8), DevArray(ctx8, x[1], n8), DevArray(ctx8, x[2], n8)))
-            tag = '1e6' if n8 == 1_000_000 else '1e9'
-            ms = time_launches(lambda s: ctx8.mul(s[0], s[1], out=s[2]), bufs, reps if n8 < 10**8 else 3)
-            kern[f'gf256_mul_{tag}'] = dict(roof(3 * n8, ms), algorithmic_bytes_per_unit=3,
-                                            units_per_s=round(n8 / (ms * 1e-3), 1))
-            ms = time_launches(lambda s: ctx8.sbox(s[0], rows8, b8, out=s[2]), bufs, reps if n8 < 10**8 else 3)
-            kern[f'gf256_sbox_{tag}'] = dict(roof(2 * n8, ms), algorithmic_bytes_per_unit=2,
-                                             units_per_s=round(n8 / (ms * 1e-3), 1))
-            del bufs
+                Am = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
+                Bm = DevArray(ctx, uniform_field(gen, dim * dim, P61, ctx.torch_device), dim * dim)
+                Cm = ctx.empty(dim * dim)
+                ms = time_launches(lambda s: ctx.matmul(Am, Bm, dim, dim, dim, out=Cm), [0], 2)
+                macs = float(dim) ** 3
+                kern[f'matmul_p61_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'integer ALU', 'unit': 'GMAC/s',
+                                             'achieved': round(macs / (ms * 1e-3) / 1e9, 1),
+                                             'frac': 0.0, 'units_per_s': round(macs / (ms * 1e-3), 1)}
+                del Am, Bm, Cm
+            # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
+            del sets[1:]
             torch.cuda.empty_cache()
-        # dominant kernel of the timed step = the one with the largest share of step time
+            ctx64 = FieldContext(P64, device=local_rank)
+            t2, m2 = 3, 7
+            sets64 = [StepData(ctx64, n, t2, m2, gen) for _ in range(3)]
+            ms = time_launches(lambda s: ctx64.mul(s.a, s.b, out=s.c), sets64, reps)
+            kern['mul_p64'] = dict(roof(3 * eb * n, ms), algorithmic_bytes_per_unit=3 * eb,
+                                   units_per_s=round(n / (ms * 1e-3), 1))
+            ms = time_launches(lambda s: ctx64.split(s.a, s.coef, t2, m2, out=s.shares), sets64, reps)
+            bpu = (1 + t2 + m2) * eb
+            kern['split_p64_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                          units_per_s=round(n / (ms * 1e-3), 1))
+            # production mode: coefficients from the on-device CSPRNG (never in HBM): 8 read + 56 written
+            key = bytes(range(32))
+            for rounds in (20, 12, 8):
+                ms = time_launches(lambda s: ctx64.split_rng(s.a, t2, m2, key=key, nonce=7, rounds=rounds, out=s.shares),
+                                   sets64, reps)
+                bpu = (1 + m2) * eb
+                kern[f'split_rng_p64_m7t3_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                                  units_per_s=round(n / (ms * 1e-3), 1))
+            F64 = po.Field(P64)
+            for kk in (t2 + 1, 2 * t2 + 1):
+                lam64 = po.recombination_vector(F64, list(range(1, kk + 1)), 0)
+                for s in sets64:
+                    s.rec = ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y)
+                ms = time_launches(lambda s: s.rec(), sets64, reps)
+                bpu = (kk + 1) * eb
+                kern[f'recombine_p64_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                    units_per_s=round(n / (ms * 1e-3), 1))
+            # generic (non pseudo-Mersenne) primes: reciprocal / Montgomery reductions, u32 storage
+            from mpyc_amd.engine import DevArray as _DA
+            for label, modulus in (('rc64_generic63', 6616326157076047771), ('rc32_p31', 2**31 - 1),
+                                   ('mont128_generic', 258797994007609146293811961253269568351)):
+                cg_ = FieldContext(modulus, device=local_rank)
+                ebg = cg_.elem_bytes
+                bufs = []
+                for _ in range(3):
+                    if ebg == 16:
+                        x = torch.randint(0, 2**62, (3, n, 2), dtype=torch.int64, device=ctx.torch_device, generator=gen)
+                    elif ebg == 8:
+                        x = torch.randint(0, 2**62, (3, n), dtype=torch.int64, device=ctx.torch_device, generator=gen)
+                    else:
+                        x = torch.randint(0, 2**31 - 1, (3, n), dtype=torch.int32, device=ctx.torch_device, generator=gen)
+                    bufs.append(tuple(_DA(cg_, x[i], n) for i in range(3)))
+                ms = time_launches(lambda s: cg_.mul(s[0], s[1], out=s[2]), bufs, reps)
+                kern[f'mul_{label}'] = dict(roof(3 * ebg * n, ms), algorithmic_bytes_per_unit=3 * ebg,
+                                            units_per_s=round(n / (ms * 1e-3), 1))
+                del bufs
+                torch.cuda.empty_cache()
+            # configs[3] shape on ONE GPU: 128-bit prime (two limbs), gate = mul + split(m=7,t=3) + recombine(k=7)
+            del sets64[:]
+            torch.cuda.empty_cache()
+            P128 = 2**128 - 173
+            ctx128 = FieldContext(P128, device=local_rank)
+            F128 = po.Field(P128)
+
+            def u128_rows(rows):
+                x = torch.randint(-2**63, 2**63 - 1, (rows, n, 2), dtype=torch.int64, device=ctx.torch_device,
+                                  generator=gen)
+                # canonical: (hi,lo) >= p only if hi == 2^64-1 and lo >= 2^64-173: fold those few
+                bad = (x[..., 1] == -1) & (x[..., 0] < 0) & (x[..., 0] >= -173)
+                x[..., 0] = torch.where(bad, x[..., 0] + 173, x[..., 0])
+                x[..., 1] = torch.where(bad, torch.zeros_like(x[..., 1]), x[..., 1])
+                return x
+
+            class Set128:
+                def __init__(s):
+                    from mpyc_amd.engine import DevArray
+                    ab = u128_rows(2)
+                    s.a, s.b = DevArray(ctx128, ab[0], n), DevArray(ctx128, ab[1], n)
+                    s.c = ctx128.empty(n)
+                    s.coef = ctx128.empty_matrix(t2, n)
+                    cf_ = u128_rows(t2)
+                    for j in range(t2):
+                        s.coef.row(j).t.copy_(cf_[j])
+                    s.shares = ctx128.empty_matrix(m2, n)
+                    s.y = ctx128.empty(n)
+                    s.rec = None
+            sets128 = [Set128() for _ in range(2)]
+            eb2 = 16
+            ms = time_launches(lambda s: ctx128.mul(s.a, s.b, out=s.c), sets128, reps)
+            kern['mul_p128'] = dict(roof(3 * eb2 * n, ms), algorithmic_bytes_per_unit=3 * eb2,
+                                    units_per_s=round(n / (ms * 1e-3), 1))
+            ms = time_launches(lambda s: ctx128.split(s.c, s.coef, t2, m2, out=s.shares), sets128, reps)
+            bpu = (1 + t2 + m2) * eb2
+            kern['split_p128_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                           units_per_s=round(n / (ms * 1e-3), 1))
+            lam128 = po.recombination_vector(F128, list(range(1, 2 * t2 + 2)), 0)
+            for s in sets128:
+                s.rec = ctx128.recombine_plan([s.shares.row(j) for j in range(2 * t2 + 1)], lam128, s.y)
+            ms = time_launches(lambda s: s.rec(), sets128, reps)
+            bpu = (2 * t2 + 2) * eb2
+            kern['recombine_p128_k7'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                             units_per_s=round(n / (ms * 1e-3), 1))
+            if not torch.equal(sets128[0].y.t, sets128[0].c.t):
+                raise SystemExit('bench parity check failed for P128 gate')
+            gate_ms = sum(kern[q]['ms_per_launch'] for q in ('mul_p128', 'split_p128_m7t3', 'recombine_p128_k7'))
+            kern['gate_p128_m7t3'] = {'gates_per_s': round(n / (gate_ms * 1e-3), 1), 'algorithmic_bytes_per_unit': 352,
+                                      'achieved': round(352 * n / (gate_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
+                                      'frac': round(352 * n / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      'ms_per_launch': round(gate_ms, 5)}
+            # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
+            del sets128[:]
+            torch.cuda.empty_cache()
+            ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
+            rows8, b8 = po.aes_affine_rows()
+            for n8 in (1_000_000, 1_000_000_000):
+                from mpyc_amd.engine import DevArray
+                bufs = []
+                for _ in range(3 if n8 > 10**8 else 8):
+                    x = torch.randint(0, 256, (3, n8), dtype=torch.uint8, device=ctx.torch_device, generator=gen)
+                    bufs.append((DevArray(ctx8, x[0], n8), DevArray(ctx8, x[1], n8), DevArray(ctx8, x[2], n8)))
+                tag = '1e6' if n8 == 1_000_000 else '1e9'
+                ms = time_launches(lambda s: ctx8.mul(s[0], s[1], out=s[2]), bufs, reps if n8 < 10**8 else 3)
+                kern[f'gf256_mul_{tag}'] = dict(roof(3 * n8, ms), algorithmic_bytes_per_unit=3,
+                                                units_per_s=round(n8 / (ms * 1e-3), 1))
+                ms = time_launches(lambda s: ctx8.sbox(s[0], rows8, b8, out=s[2]), bufs, reps if n8 < 10**8 else 3)
+                kern[f'gf256_sbox_{tag}'] = dict(roof(2 * n8, ms), algorithmic_bytes_per_unit=2,
+                                                 units_per_s=round(n8 / (ms * 1e-3), 1))
+                del bufs
+                torch.cuda.empty_cache()
+            # dominant kernel of the timed step = the one with the largest share of step time
+        try:
+            optional_measurements()
+        except Exception as exc:          # noqa: BLE001 -- report, keep the main result
+            out['extras_error'] = f'{type(exc).__name__}: {exc}'
         step_kernels = ['mul_split_fused_p61_m3t1', 'recombine_p61_k3']
         dom = max(step_kernels, key=lambda q: kern[q]['ms_per_launch'])
         out['roofline'] = dict({kk_: vv for kk_, vv in kern[dom].items()
