@@ -192,9 +192,24 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     c->policy_kind = pb.kind;
     rng_const(pb, c->rng_r);
     c->gf2w_limbs = 0;
-    if ((pb.kind == POL_GF2W64 || pb.kind == POL_GF2W128) && !getenv("FFGPU_GF2W_BITSERIAL")) {
-        c->gf2w_limbs = pb.kind == POL_GF2W128 ? 2 : 1;
-        ffgpu_gf2w_build_rtable(c->policy, c->gf2w_limbs, c->gf2w_rtable);
+    if (pb.kind == POL_GF2W64 || pb.kind == POL_GF2W128) {
+        // sparse moduli (all MPyC defaults) multiply in registers through the integer multiplier
+        // (fields.hpp ff_clmul*); dense moduli use the 4-bit window kernel with LDS tables
+        bool in_regs;
+        if (pb.kind == POL_GF2W128) {
+            GF2W128 f;
+            memcpy(&f, pb.bytes, sizeof(f));
+            in_regs = (f.fast & 1) != 0;
+        } else {
+            GF2W64 f;
+            memcpy(&f, pb.bytes, sizeof(f));
+            in_regs = f.n <= 32 || (f.fast & 1) != 0;
+        }
+        if (getenv("FFGPU_GF2W_WINDOW")) in_regs = false;
+        if (!in_regs) {
+            c->gf2w_limbs = pb.kind == POL_GF2W128 ? 2 : 1;
+            ffgpu_gf2w_build_rtable(c->policy, c->gf2w_limbs, c->gf2w_rtable);
+        }
     }
     c->gf8_tab_min = 0;
     if (pb.kind == POL_GF2P8 && ffgpu_gf8_build_tables(c->policy, c->gf8_tables) == 0) {

@@ -794,8 +794,56 @@ struct GF2P8 {
     FF_HD uint32_t acc_reduce(const acc& s) const { return s.a; }
 };
 
+
 // ---------------------------------------------------------------------------
-// GF2W64 / GF2W128: GF(2^n) for 9 <= n <= 64 / 65 <= n <= 128, limb shift-xor.
+// Carry-less multiplication through the integer multiplier.  gfx950 has no
+// clmul instruction; a shift-xor loop costs ~25 VALU ops per BIT.  Instead the
+// operands are split into four "every 4th bit" masks: in the integer product of
+// two such masks every 4-bit slot receives at most 8 partial products, so
+// nothing carries between slots and bit 0 of a slot is the GF(2) sum.  16
+// v_mad_u64_u32 + ~46 logic ops give a 32x32 -> 64 carry-less product;
+// Karatsuba (3 products per doubling) builds 64x64 and 128x128 from it.
+// ---------------------------------------------------------------------------
+FF_HD uint64_t ff_clmul32(uint32_t x, uint32_t y) {
+    const uint32_t x0 = x & 0x11111111u, x1 = x & 0x22222222u, x2 = x & 0x44444444u, x3 = x & 0x88888888u;
+    const uint32_t y0 = y & 0x11111111u, y1 = y & 0x22222222u, y2 = y & 0x44444444u, y3 = y & 0x88888888u;
+    uint64_t z0 = ((uint64_t)x0 * y0) ^ ((uint64_t)x1 * y3) ^ ((uint64_t)x2 * y2) ^ ((uint64_t)x3 * y1);
+    uint64_t z1 = ((uint64_t)x0 * y1) ^ ((uint64_t)x1 * y0) ^ ((uint64_t)x2 * y3) ^ ((uint64_t)x3 * y2);
+    uint64_t z2 = ((uint64_t)x0 * y2) ^ ((uint64_t)x1 * y1) ^ ((uint64_t)x2 * y0) ^ ((uint64_t)x3 * y3);
+    uint64_t z3 = ((uint64_t)x0 * y3) ^ ((uint64_t)x1 * y2) ^ ((uint64_t)x2 * y1) ^ ((uint64_t)x3 * y0);
+    return (z0 & 0x1111111111111111ull) | (z1 & 0x2222222222222222ull) | (z2 & 0x4444444444444444ull) |
+           (z3 & 0x8888888888888888ull);
+}
+// 64 x 64 -> 128 (hi, lo)
+FF_HD void ff_clmul64(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t z0 = ff_clmul32(a0, b0);
+    const uint64_t z2 = ff_clmul32(a1, b1);
+    const uint64_t z1 = ff_clmul32(a0 ^ a1, b0 ^ b1) ^ z0 ^ z2;
+    lo = z0 ^ (z1 << 32);
+    hi = z2 ^ (z1 >> 32);
+}
+// 128 x 128 -> 256 as four limbs p[0..3]
+FF_HD void ff_clmul128(uint64_t alo, uint64_t ahi, uint64_t blo, uint64_t bhi, uint64_t p[4]) {
+    uint64_t z0h, z0l, z2h, z2l, z1h, z1l;
+    ff_clmul64(alo, blo, z0h, z0l);
+    ff_clmul64(ahi, bhi, z2h, z2l);
+    ff_clmul64(alo ^ ahi, blo ^ bhi, z1h, z1l);
+    z1l ^= z0l ^ z2l;
+    z1h ^= z0h ^ z2h;
+    p[0] = z0l;
+    p[1] = z0h ^ z1l;
+    p[2] = z2l ^ z1h;
+    p[3] = z2h;
+}
+
+// ---------------------------------------------------------------------------
+// GF2W64 / GF2W128: GF(2^n) for 9 <= n <= 64 / 65 <= n <= 128.
+// mul: carry-less product (above) + reduction.  For moduli x^n + r(x) with a
+// short r (r < 2^28: every default MPyC irreducible, e.g. x^128+x^7+x^2+x+1) the
+// high part is folded down with one shift-xor per set bit of r (`fast`, nfold
+// passes); other moduli take the bit-serial loop.  n <= 32 reduces bit-serially
+// (at most 31 steps on a 64-bit product).
 // ---------------------------------------------------------------------------
 struct GF2W64 {
     typedef uint64_t elem;
@@ -804,7 +852,7 @@ struct GF2W64 {
     uint64_t red;   // modulus without leading term
     uint64_t emask; // 2^n - 1
     uint32_t n;
-    uint32_t pad_;
+    uint32_t fast;   // bit 0: sparse modulus (fold reduction); bits 8..15: number of fold passes
     struct acc {
         uint64_t a;
     };
@@ -832,12 +880,32 @@ struct GF2W64 {
         for (int i = 63; i >= 0; --i) r = xtime(r) ^ ((a >> i) & 1);
         return r;
     }
-    FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
+    FF_HD uint64_t mul_bitserial(uint64_t a, uint64_t b) const {
         uint64_t c = 0;
         for (int i = (int)n - 1; i >= 0; --i) {
             c = xtime(c) ^ ((0 - ((b >> i) & 1)) & a);
         }
         return c;
+    }
+    FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
+        if (n <= 32) {
+            // 64-bit product, then long division by f = x^n + red from the top
+            uint64_t pr = ff_clmul32((uint32_t)a, (uint32_t)b);
+            const uint64_t fm = red | (1ull << n);
+            for (int i = 2 * (int)n - 2; i >= (int)n; --i) pr ^= (0 - ((pr >> i) & 1)) & (fm << (i - (int)n));
+            return pr;
+        }
+        if (!(fast & 1)) return mul_bitserial(a, b);
+        uint64_t hi, lo;
+        ff_clmul64(a, b, hi, lo);
+        ff_u128 t = ff_make128(hi, lo);
+        const int folds = (int)((fast >> 8) & 0xff);
+        for (int it = 0; it < folds; ++it) {
+            uint64_t h = (uint64_t)(t >> n);          // excess part (< 2^63)
+            t &= (ff_u128)emask;
+            for (uint64_t rr = red; rr; rr &= rr - 1) t ^= (ff_u128)h << __builtin_ctzll(rr);
+        }
+        return ff_lo(t);
     }
     FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
         // x < 2^32 public; degree of X(x) < 32
@@ -862,7 +930,7 @@ struct GF2W128 {
     uint64_t red_lo, red_hi;      // modulus without leading term
     uint64_t emask_lo, emask_hi;  // 2^n - 1
     uint32_t n;                   // 65..128
-    uint32_t pad_;
+    uint32_t fast;                // 1: modulus x^n + r, r < 2^28 (two-pass fold), else bit-serial
     struct acc {
         uint64_t lo, hi;
     };
@@ -914,6 +982,46 @@ struct GF2W128 {
         return r;
     }
     FF_HD u128e mul(const u128e& a, const u128e& b) const {
+        if (!(fast & 1)) return mul_bitserial(a, b);
+        uint64_t p[4];
+        ff_clmul128(a.lo, a.hi, b.lo, b.hi, p);
+        const uint32_t r = (uint32_t)red_lo;
+        // H = P >> n (two limbs), L = P & mask;  T = L ^ H*r  (three limbs, H*r < 2^(n+27))
+        uint64_t h0, h1;
+        if (n == 128) {
+            h0 = p[2];
+            h1 = p[3];
+        } else {
+            const uint32_t sh = n - 64;       // 1..63
+            h0 = (p[1] >> sh) | (p[2] << (64 - sh));
+            h1 = (p[2] >> sh) | (p[3] << (64 - sh));
+        }
+        uint64_t t0 = p[0] & emask_lo, t1 = p[1] & emask_hi, t2 = 0;
+        for (uint32_t rr = r; rr; rr &= rr - 1) {
+            const int j = __builtin_ctz(rr);           // 0..27, wave-uniform
+            t0 ^= h0 << j;
+            t1 ^= (h1 << j) | (j ? (h0 >> (64 - j)) : 0);
+            t2 ^= j ? (h1 >> (64 - j)) : 0;
+        }
+        // second pass: what stuck out above bit n is < 2^27
+        uint64_t h2;
+        if (n == 128) {
+            h2 = t2;
+        } else {
+            const uint32_t sh = n - 64;
+            h2 = (t1 >> sh) | (t2 << (64 - sh));
+            t1 &= emask_hi;
+        }
+        for (uint32_t rr = r; rr; rr &= rr - 1) {
+            const int j = __builtin_ctz(rr);
+            t0 ^= h2 << j;                             // h2 * r < 2^54 < 2^n: stays in limb 0
+        }
+        u128e out;
+        out.lo = t0;
+        out.hi = t1;
+        return out;
+    }
+    FF_HD u128e mul_bitserial(const u128e& a, const u128e& b) const {
         uint64_t lo = 0, hi = 0;
         for (int i = (int)n - 1; i >= 64; --i) {
             xtime(lo, hi);

@@ -162,7 +162,18 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
         f.n = (uint32_t)deg;
         f.emask = deg == 64 ? ~0ull : ((1ull << deg) - 1);
         f.red = deg == 64 ? m0 : (m0 ^ (1ull << deg));
-        f.pad_ = 0;
+        f.fast = 0;
+        if (deg > 32 && f.red && f.red < (1ull << 28)) {
+            // fold passes until nothing sticks out above bit n: excess e -> max(0, e + deg(r) - n)
+            int rdeg = 63 - __builtin_clzll(f.red);
+            int e = deg - 1, folds = 0;
+            while (e > 0 && folds < 16) {
+                e = e + rdeg - deg;
+                if (e < 0) e = 0;
+                ++folds;
+            }
+            if (e == 0) f.fast = 1u | ((uint32_t)folds << 8);
+        }
         store_policy(c, f, POL_GF2W64, PB_RED_WIDE);
         return PB_OK;
     }
@@ -172,7 +183,7 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
     f.red_hi = deg == 128 ? m1 : (m1 ^ (1ull << (deg - 64)));
     f.emask_lo = ~0ull;
     f.emask_hi = deg == 128 ? ~0ull : ((1ull << (deg - 64)) - 1);
-    f.pad_ = 0;
+    f.fast = (f.red_hi == 0 && f.red_lo != 0 && f.red_lo < (1ull << 28)) ? 1u : 0u;
     store_policy(c, f, POL_GF2W128, PB_RED_WIDE);
     return PB_OK;
 }

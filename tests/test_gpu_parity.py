@@ -273,6 +273,33 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
         assert unpack(ctx.mul(ctx.inv(va), va).to_numpy(), eb) == [1] * (n - 1)
 
 
+def test_binary_fields_dense_and_small(eng, coracle):
+    """GF(2^n) multiplication paths: in-register carry-less product + fold (sparse moduli), 4-bit
+    window LDS kernel (dense moduli), long division (n <= 32) -- all against the oracle; plus the
+    gate identity recombine(split(a*b)) == a*b on a dense 128-bit modulus."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    mods = [int(BinaryPolynomial.next_irreducible((1 << 64) | (1 << 45))),
+            int(BinaryPolynomial.next_irreducible((1 << 128) | (1 << 100))),
+            int(BinaryPolynomial.next_irreducible(1 << 9)), int(BinaryPolynomial.next_irreducible(1 << 32)),
+            int(BinaryPolynomial.next_irreducible(1 << 33)), int(BinaryPolynomial.next_irreducible(1 << 127))]
+    for mod in mods:
+        F = po.Field(mod, True)
+        ctx = ctx_for(eng, mod, True)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(mod, True)
+        n = 20011
+        A, B = rand_np(F, eb, n, 91), rand_np(F, eb, n, 92)
+        dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+        want = cf.ew(coracle.MUL, A, B)
+        assert (ctx.mul(dA, dB).to_numpy() == want).all(), hex(mod)
+        t, m = 2, 5
+        Cn = rand_np(F, eb, t * n, 93).reshape((t, n, 2) if eb == 16 else (t, n))
+        sh = ctx.split(dA, ctx.matrix_from_numpy(Cn), t, m, mul_by=dB)
+        xs = [2, 4, 5, 1, 3]
+        rec = ctx.recombine([sh.row(x - 1) for x in xs], po.recombination_vector(F, xs, 0))
+        assert (rec.to_numpy() == want).all(), hex(mod)
+
+
 def test_hip_graph_capture_of_a_gate(eng, coracle):
     """A gate (fused local product + share generation, then recombination) captured once into a HIP graph
     and replayed on fresh inputs gives the same bits as eager launches."""

@@ -162,3 +162,25 @@ def test_lazy_share_accumulator(hostcheck, golden_fields):
                 assert got == want, (name, t, m, party)
                 checked += 1
     assert checked > 50
+
+
+def test_dense_binary_moduli_take_the_bitserial_path(hostcheck):
+    """GF(2^n) moduli whose low part r(x) is not short (>= 2^28) do not use the fold reduction;
+    n <= 32 uses long division of the 64-bit carry-less product.  All against the bit-level oracle."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    mods = [int(BinaryPolynomial.next_irreducible((1 << 64) | (1 << 45))),       # dense, one limb
+            int(BinaryPolynomial.next_irreducible((1 << 100) | (1 << 70))),      # dense, two limbs
+            int(BinaryPolynomial.next_irreducible((1 << 128) | (1 << 100))),
+            int(BinaryPolynomial.next_irreducible(1 << 9)), int(BinaryPolynomial.next_irreducible(1 << 31)),
+            int(BinaryPolynomial.next_irreducible(1 << 32)), int(BinaryPolynomial.next_irreducible(1 << 33)),
+            int(BinaryPolynomial.next_irreducible((1 << 40) | (1 << 27))),       # r just below 2^28: fold x several passes
+            int(BinaryPolynomial.next_irreducible(1 << 65)), int(BinaryPolynomial.next_irreducible(1 << 127))]
+    for mod in mods:
+        F = po.Field(mod, True)
+        ev = edge_values(F) + rand_values(F, 10, 1)
+        a, b = cross(ev)
+        got, _ = run(hostcheck, F, HC_MUL, a, b)
+        assert got == po.vec(po.mul, F, a, b), hex(mod)
+        a, b = rand_values(F, 1500, 2), rand_values(F, 1500, 3)
+        got, _ = run(hostcheck, F, HC_MUL, a, b)
+        assert got == po.vec(po.mul, F, a, b), hex(mod)
