@@ -771,10 +771,13 @@ struct GF2P8 {
     }
     // y * X(x) + c where X(x) is the polynomial with bit pattern x (< 2^n)
     FF_HD uint32_t muladd_small(uint32_t y, uint32_t x, uint32_t cadd) const {
-        uint32_t c = 0;
-        for (int i = (int)n - 1; i >= 0; --i) {
+        // x < 2^n is wave-uniform (a party's x-coordinate, usually < 8): Horner over ITS bits only,
+        // starting at its top set bit (scalar branches)
+        if (x == 0) return cadd;
+        uint32_t c = y;
+        for (int i = 30 - __builtin_clz(x); i >= 0; --i) {
             c = xtime(c);
-            if ((x >> i) & 1) c ^= y;        // x is wave-uniform: scalar branch
+            if ((x >> i) & 1) c ^= y;
         }
         return c ^ cadd;
     }
@@ -783,9 +786,10 @@ struct GF2P8 {
     // lam: single element broadcast to the 4 bytes by the host
     FF_HD void acc_mac(acc& s, uint32_t lam, uint32_t x) const {
         // lam is wave-uniform: multiply x by the constant via scalar-branch Horner
-        uint32_t c = 0;
         uint32_t l = lam & 0xffu;
-        for (int i = (int)n - 1; i >= 0; --i) {
+        if (l == 0) return;
+        uint32_t c = x;
+        for (int i = 30 - __builtin_clz(l); i >= 0; --i) {
             c = xtime(c);
             if ((l >> i) & 1) c ^= x;
         }
@@ -908,10 +912,10 @@ struct GF2W64 {
         return ff_lo(t);
     }
     FF_HD uint64_t muladd_small(uint64_t y, uint32_t x, uint64_t cadd) const {
-        // x < 2^32 public; degree of X(x) < 32
-        uint64_t c = 0;
-        int top = n < 32 ? (int)n - 1 : 31;
-        for (int i = top; i >= 0; --i) {
+        // x < min(2^32, 2^n) public and wave-uniform: Horner over its bits from the top set one
+        if (x == 0) return cadd;
+        uint64_t c = y;
+        for (int i = 30 - __builtin_clz(x); i >= 0; --i) {
             c = xtime(c);
             if ((x >> i) & 1) c ^= y;
         }
@@ -1041,8 +1045,9 @@ struct GF2W128 {
         return r;
     }
     FF_HD u128e muladd_small(const u128e& y, uint32_t x, const u128e& cadd) const {
-        uint64_t lo = 0, hi = 0;
-        for (int i = 31; i >= 0; --i) {
+        if (x == 0) return cadd;
+        uint64_t lo = y.lo, hi = y.hi;
+        for (int i = 30 - __builtin_clz(x); i >= 0; --i) {
             xtime(lo, hi);
             if ((x >> i) & 1) {
                 lo ^= y.lo;
