@@ -239,14 +239,28 @@ struct RC64 {
 
 
     // (u1:u0) mod d, requires u1 < d
-    enum { HAS_SACC = 0 };
+    // lazily reduced share generation (see PM64): T = hi*2^64 + lo < (t+1) * 2^32 * p
+    enum { HAS_SACC = 1 };
     struct sacc {
-        uint64_t v;
+        uint64_t lo, hi;
     };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, uint64_t sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, uint64_t, uint32_t) const {}
-    FF_HD uint64_t sacc_reduce(const sacc& a) const { return a.v; }
+    FF_HD bool sacc_ok(int t, int m) const {
+        double pw = 1.0;
+        for (int j = 0; j < t; ++j) pw *= (double)m;
+        return t >= 2 && pw < 4294967296.0 && t < 65536;   // t = 1: one Horner step is cheaper (measured)
+    }
+    FF_HD void sacc_init(sacc& a, uint64_t sv) const {
+        a.lo = sv;
+        a.hi = 0;
+    }
+    FF_HD void sacc_mac(sacc& a, uint64_t cj, uint32_t xp) const {
+        uint64_t p0 = (uint64_t)(uint32_t)cj * xp;
+        uint64_t p1 = (uint64_t)(uint32_t)(cj >> 32) * xp + (p0 >> 32);
+        uint64_t tl = (p1 << 32) | (uint32_t)p0;
+        a.lo += tl;
+        a.hi += (p1 >> 32) + (a.lo < tl);
+    }
+    FF_HD uint64_t sacc_reduce(const sacc& a) const;   // defined after acc_reduce
     FF_HD uint64_t rem21(uint64_t u1, uint64_t u0) const {
         ff_u128 q = (ff_u128)v * u1 + ff_make128(u1, u0);
         uint64_t q1 = ff_hi(q) + 1;
@@ -299,6 +313,13 @@ struct RC64 {
         return rem21(r1, w0) >> s;
     }
 };
+FF_HD uint64_t RC64::sacc_reduce(const sacc& a) const {
+    acc t;
+    t.a0 = a.lo;
+    t.a1 = a.hi;
+    t.a2 = 0;
+    return acc_reduce(t);   // (T << s) has its top limb below d: T < (t+1) 2^32 p
+}
 
 // ---------------------------------------------------------------------------
 // RC32: arbitrary modulus 2 <= p < 2^32 stored as uint32 (half the HBM bytes of
@@ -318,14 +339,28 @@ struct RC32 {
     FF_HD uint32_t prep(uint32_t cst) const { return cst; }
 
 
-    enum { HAS_SACC = 0 };
+    // lazily reduced share generation: 64-bit terms C_j * x^(j+1) summed in the 96-bit accumulator
+    enum { HAS_SACC = 1 };
     struct sacc {
-        uint32_t v;
+        uint64_t lo;
+        uint32_t hi;
     };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, uint32_t sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, uint32_t, uint32_t) const {}
-    FF_HD uint32_t sacc_reduce(const sacc& a) const { return a.v; }
+    FF_HD bool sacc_ok(int t, int m) const {
+        double pw = 1.0;
+        for (int j = 0; j < t; ++j) pw *= (double)m;
+        return t >= 2 && pw < 4294967296.0 && t < 200;     // carries stay below the accumulator's 2^8 headroom
+    }
+    FF_HD void sacc_init(sacc& a, uint32_t sv) const {
+        a.lo = sv;
+        a.hi = 0;
+    }
+    FF_HD void sacc_mac(sacc& a, uint32_t cj, uint32_t xp) const {
+        uint64_t pr = (uint64_t)cj * xp;
+        uint64_t nn = a.lo + pr;
+        a.hi += nn < pr;
+        a.lo = nn;
+    }
+    FF_HD uint32_t sacc_reduce(const sacc& a) const;   // defined after acc_reduce
     FF_HD uint32_t rem21(uint32_t u1, uint32_t u0) const {
         uint64_t q = (uint64_t)v * u1 + (((uint64_t)u1 << 32) | u0);
         uint32_t q1 = (uint32_t)(q >> 32) + 1;
@@ -380,6 +415,12 @@ struct RC32 {
         return rem21(r1, w0) >> s;
     }
 };
+FF_HD uint32_t RC32::sacc_reduce(const sacc& a) const {
+    acc t;
+    t.lo = a.lo;
+    t.hi = a.hi;
+    return acc_reduce(t);
+}
 
 // ---------------------------------------------------------------------------
 // PM128: prime p = 2^k - c, 65 <= k <= 128, c < 2^31, two 64-bit limbs
