@@ -196,53 +196,69 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     const P* __restrict__ av = reinterpret_cast<const P*>(a);
     const P* __restrict__ bv = reinterpret_cast<const P*>(b);
-    for (size_t i = gid; i < nvec; i += gsz) {
-        P s = ldg<NT>(av + i);
-        P s2;
-        if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
-        W c[TT][P::N];
-        if constexpr (RNG && T > 0) {
-            rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, c);
-        } else {
+    // With the in-kernel CSPRNG a thread serves a GROUP of G adjacent packs from shared keystream
+    // blocks (rng.hpp RngLayout); without it G = 1 and this is the plain one-pack-per-thread loop.
+    constexpr int G = (RNG && T > 0) ? RngLayout<F, TT, P::N>::G : 1;
+    constexpr int EPV_ = P::N * F::EPW;
+    const size_t npacks_all = (n + EPV_ - 1) / EPV_;               // the layout is defined over ALL packs of n
+    const size_t ngroups = (RNG && T > 0) ? (npacks_all + G - 1) / G : nvec;
+    for (size_t ig = gid; ig < ngroups; ig += gsz) {
+        W cg[G][TT][P::N];
+        if constexpr (RNG && T > 0) rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                P t_ = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
+        for (int u = 0; u < G; ++u) {
+            const size_t i = (size_t)u * ngroups + ig;             // stride NG: lanes stay on adjacent packs
+            if (i >= nvec) continue;
+            P s = ldg<NT>(av + i);
+            P s2;
+            if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+            W c[TT][P::N];
+            if constexpr (RNG && T > 0) {
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
-            }
-        }
-        if constexpr (FUSE_MUL) {
+                for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
-        }
-        for (int party = 1; party <= m; ++party) {
-            P y;
-            if constexpr (T == 0) {
-                y = s;
-            } else if constexpr (LAZY) {
-                // public powers x^(j+1): wave-uniform, scalar unit
-                uint32_t xp[TT];
-                xp[0] = (uint32_t)party;
-#pragma unroll
-                for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) {
-                    typename F::sacc acc;
-                    f.sacc_init(acc, s.w[q]);
-#pragma unroll
-                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
-                    y.w[q] = f.sacc_reduce(acc);
-                }
+                    for (int q = 0; q < P::N; ++q) c[j][q] = cg[u][j][q];
             } else {
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) {
-                    W acc = c[T - 1][q];
+                for (int j = 0; j < T; ++j) {
+                    P t_ = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
 #pragma unroll
-                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
-                    y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
+                    for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
                 }
             }
-            stg<NT>(reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride) + i, y);
+            if constexpr (FUSE_MUL) {
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
+            }
+            for (int party = 1; party <= m; ++party) {
+                P y;
+                if constexpr (T == 0) {
+                    y = s;
+                } else if constexpr (LAZY) {
+                    // public powers x^(j+1): wave-uniform, scalar unit
+                    uint32_t xp[TT];
+                    xp[0] = (uint32_t)party;
+#pragma unroll
+                    for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
+#pragma unroll
+                    for (int q = 0; q < P::N; ++q) {
+                        typename F::sacc acc;
+                        f.sacc_init(acc, s.w[q]);
+#pragma unroll
+                        for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
+                        y.w[q] = f.sacc_reduce(acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < P::N; ++q) {
+                        W acc = c[T - 1][q];
+#pragma unroll
+                        for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
+                        y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
+                    }
+                }
+                stg<NT>(reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride) + i, y);
+            }
         }
     }
     // scalar tail: elements past the last full pack (or everything, if pointers are unaligned)
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
         W c[TT];
         if constexpr (RNG && T > 0) {
             W cc[TT][P::N];
-            rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)(e / EPV), cc);
+            rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)(e / EPV), (uint64_t)((n + EPV - 1) / EPV), cc);
             const int q = (int)((e % EPV) / F::EPW);
 #pragma unroll
             for (int j = 0; j < T; ++j) {
@@ -292,28 +308,40 @@ __global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __r
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     const size_t npacks = (n + EPV - 1) / EPV;
-    for (size_t i = gid; i < npacks; i += gsz) {
-        W c[T][P::N];
-        rng_draw_pack<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, c);
-        if (i < nvec) {
+    constexpr int G = RngLayout<F, T, P::N>::G;
+    const size_t ngroups = (npacks + G - 1) / G;
+    for (size_t ig = gid; ig < ngroups; ig += gsz) {
+        W cg[G][T][P::N];
+        rng_draw_group<F, T, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
+        for (int u = 0; u < G; ++u) {
+            const size_t i = (size_t)u * ngroups + ig;
+            if (i >= npacks) continue;
+            if (i < nvec) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                P t_;
+                for (int j = 0; j < T; ++j) {
+                    P t_;
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) t_.w[q] = c[j][q];
-                stg<true>(reinterpret_cast<P*>(coef + (size_t)j * cstride) + i, t_);
-            }
-        } else {
-            for (int j = 0; j < T; ++j)
-                for (int q = 0; q < P::N; ++q)
-                    for (int b_ = 0; b_ < F::EPW; ++b_) {
-                        size_t e = i * EPV + (size_t)q * F::EPW + b_;
-                        if (e < n) {
-                            W v = c[j][q];
-                            if constexpr (F::EPW > 1) v = (W)((v >> (8 * b_)) & 0xffu);
-                            st_elem<F>(coef + (size_t)j * cstride, e, v);
-                        }
+                    for (int q = 0; q < P::N; ++q) {
+                        W v = cg[0][j][q];
+#pragma unroll
+                        for (int uu = 1; uu < G; ++uu) v = (uu == u) ? cg[uu][j][q] : v;
+                        t_.w[q] = v;
                     }
+                    stg<true>(reinterpret_cast<P*>(coef + (size_t)j * cstride) + i, t_);
+                }
+            } else {
+                for (int j = 0; j < T; ++j)
+                    for (int q = 0; q < P::N; ++q)
+                        for (int b_ = 0; b_ < F::EPW; ++b_) {
+                            size_t e = i * EPV + (size_t)q * F::EPW + b_;
+                            if (e < n) {
+                                W v = cg[0][j][q];
+                                for (int uu = 1; uu < G; ++uu) v = (uu == u) ? cg[uu][j][q] : v;
+                                if constexpr (F::EPW > 1) v = (W)((v >> (8 * b_)) & 0xffu);
+                                st_elem<F>(coef + (size_t)j * cstride, e, v);
+                            }
+                        }
+            }
         }
     }
 }
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
             RngArgs rj = ra;
             rj.rk.nonce[1] += (uint32_t)(j + 1);
             W cc[1][P::N];
-            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)(e / EPV), cc);
+            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)(e / EPV), (uint64_t)((n + EPV - 1) / EPV), cc);
             const int q = (int)((e % EPV) / F::EPW);
             W v = cc[0][0];
 #pragma unroll
@@ -372,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_rng_coeffs_any(F f, typename F::elem*
             RngArgs rj = ra;
             rj.rk.nonce[1] += (uint32_t)(j + 1);
             W cc[1][P::N];
-            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)i, cc);
+            rng_draw_pack<F, 1, P::N>(f, rj.rk, rj.r0, rj.r1, (uint64_t)i, (uint64_t)npacks, cc);
             for (int q = 0; q < P::N; ++q)
                 for (int b_ = 0; b_ < F::EPW; ++b_) {
                     size_t e = i * EPV + (size_t)q * F::EPW + b_;
@@ -1000,7 +1028,8 @@ struct Launchers {
                    ((ostride * sizeof(E)) % 16 == 0 || m <= 1) &&
                    (RNG || t == 0 || (aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1)));
         size_t nvec = vec ? n / EPV : 0;
-        unsigned grid = grid_for(nvec ? nvec : n, lc);
+        // RNG kernels serve up to 4 packs per thread (RngLayout::G); a slightly larger grid is harmless
+        unsigned grid = grid_for(nvec ? (RNG ? (n / EPV + 2) / 2 : nvec) : n, lc);
         bool nt = lc.nt != 0;
         switch (t) {
             case 0: go_split<0, FUSE, false>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;

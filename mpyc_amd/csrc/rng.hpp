@@ -9,12 +9,10 @@
 // Keystream -> field element ("sample"): see the Sampler<> specialisations below (rejection
 // sampling for pseudo-Mersenne primes, W+64-bit wide samples for generic moduli, masks for GF(2^n)).
 //
-// Public layout (what tests/oracle reproduce): the thread that owns 16-byte pack i of an
-// array draws B = ceil((WPP*t + SPARE)*S/64) consecutive 64-byte blocks with block counters
-// i*B .. i*B+B-1; primary sample number (j*WPP + q) (S bytes each, in keystream order) is the
-// coefficient word C[j][i*WPP + q]  (j < t rows, q < WPP words per pack); spares follow.
+// Public layout (what tests/oracle reproduce): see RngLayout below -- groups of G adjacent 16-byte
+// packs share B consecutive 64-byte blocks; samples are S bytes each in keystream order.
 // Tail elements past the last full pack are drawn the same way with the pack index they
-// would have had (EPV consecutive elements always share blocks).
+// would have had.
 #pragma once
 #include <stdint.h>
 #include "fields.hpp"
@@ -167,26 +165,68 @@ struct Sampler<GF2W128> {
     }
 };
 
-// Draw the T*WPP words owned by pack `pack`: c[j][q], j < T, q < WPP.  Sample index within the
-// pack's keystream is j*WPP + q; the SPARE spare samples follow the NS primary ones.
+// ---- keystream layout ---------------------------------------------------------------------------
+// G packs (a "group") share B consecutive blocks: block counters group*B .. group*B+B-1.  With
+// NG = ceil(npacks / G) groups, group g serves the packs g, g + NG, g + 2 NG, ... (a stride of NG, so
+// that neighbouring lanes still touch neighbouring packs: every load stays fully coalesced); primary
+// sample (u*NS + j*WPP + q) belongs to pack g + u*NG, row j, word q; the SPARE spare samples follow
+// the G*NS primary ones.  G in {1,2,3,4} is the value that wastes the least keystream
+// (fewest blocks per pack, smallest G on ties) -- e.g. 64-bit pseudo-Mersenne primes: t=1 -> G=3
+// (6 samples + 2 spares = one block for three packs), t=3 -> G=1 (exactly one block per pack).
 template <class F, int T, int WPP>
-FF_HD void rng_draw_pack(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1, uint64_t pack,
-                         typename F::word c[][WPP]) {
+struct RngLayout {
     typedef Sampler<F> Smp;
-    constexpr int NS = T * WPP;                                   // primary samples per pack
-    constexpr int BYTES = (NS + Smp::SPARE) * Smp::S;
-    constexpr int B = (BYTES + 63) / 64;                          // blocks per pack
-    uint32_t ks[16 * B];
-    uint64_t ctr0 = pack * (uint64_t)B;
+    enum { S = Smp::S, SPARE = Smp::SPARE, NS = T * WPP };
+    static constexpr int blocks(int g) { return ((g * NS + SPARE) * S + 63) / 64; }
+    static constexpr int best() {
+        int bg = 1;
+        for (int g = 2; g <= 4; ++g)
+            if (blocks(g) * bg < blocks(bg) * g) bg = g;
+        return bg;
+    }
+    enum { G = best(), B = blocks(best()) };
+};
+
+// draw all coefficients of group `group`: c[u][j][q]
+template <class F, int T, int WPP>
+FF_HD void rng_draw_group(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1, uint64_t group,
+                          typename F::word c[][T][WPP]) {
+    typedef RngLayout<F, T, WPP> L;
+    typedef Sampler<F> Smp;
+    uint32_t ks[16 * L::B];
+    const uint64_t ctr0 = group * (uint64_t)L::B;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-        uint64_t ctr = ctr0 + (uint64_t)b;
+    for (int b = 0; b < L::B; ++b) {
+        const uint64_t ctr = ctr0 + (uint64_t)b;
         chacha_block(rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk.nonce[0], rk.nonce[1], (int)rk.rounds,
                      ks + 16 * b);
     }
-    const uint32_t* spare = ks + NS * (Smp::S / 4);
+    const uint32_t* spare = ks + L::G * L::NS * (Smp::S / 4);
 #pragma unroll
-    for (int sn = 0; sn < NS; ++sn) c[sn / WPP][sn % WPP] = Smp::sample(f, R0, R1, ks + sn * (Smp::S / 4), spare);
+    for (int u = 0; u < L::G; ++u)
+#pragma unroll
+        for (int sn = 0; sn < L::NS; ++sn)
+            c[u][sn / WPP][sn % WPP] = Smp::sample(f, R0, R1, ks + (u * L::NS + sn) * (Smp::S / 4), spare);
+}
+
+// coefficients of ONE pack (scalar tails, unaligned inputs): draws the pack's group and selects
+template <class F, int T, int WPP>
+FF_HD void rng_draw_pack(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1, uint64_t pack, uint64_t npacks,
+                         typename F::word c[][WPP]) {
+    typedef RngLayout<F, T, WPP> L;
+    typename F::word g[L::G][T][WPP];
+    const uint64_t ng = (npacks + L::G - 1) / L::G;
+    rng_draw_group<F, T, WPP>(f, rk, R0, R1, pack % ng, g);
+    const int u = (int)(pack / ng);
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int q = 0; q < WPP; ++q) {
+            typename F::word v = g[0][j][q];
+#pragma unroll
+            for (int uu = 1; uu < L::G; ++uu) v = (uu == u) ? g[uu][j][q] : v;
+            c[j][q] = v;
+        }
 }
 
 }  // namespace ffgpu

@@ -305,52 +305,63 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
     for (int d = 0; d < draws; ++d) {
         const int T = rows_per_draw;
         const int NS = T * WPP;
-        const int B = ((NS + SPARE) * S + 63) / 64;
+        /* group size: G in 1..4 with the fewest blocks per pack (smallest G on ties) */
+        int G = 1;
+        for (int g = 2; g <= 4; ++g) {
+            int bg = ((g * NS + SPARE) * S + 63) / 64, bG = ((G * NS + SPARE) * S + 63) / 64;
+            if (bg * G < bG * g) G = g;
+        }
+        const int B = ((G * NS + SPARE) * S + 63) / 64;
         uint32_t n0 = (uint32_t)nonce, n1 = (uint32_t)(nonce >> 32);
         if (t > 4) n1 += (uint32_t)(d + 1);
-        for (size_t i = 0; i < npacks; ++i) {
-            uint32_t ks[16 * 16];
+        const size_t ngroups = (npacks + G - 1) / G;
+        for (size_t grp = 0; grp < ngroups; ++grp) {
+            uint32_t ks[16 * 32];
             for (int b = 0; b < B; ++b) {
-                uint64_t ctr = (uint64_t)i * B + b;
+                uint64_t ctr = (uint64_t)grp * B + b;
                 uint32_t w[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), n0, n1};
                 orc_chacha_block(key, w, rounds, ks + 16 * b);
             }
-            const uint32_t* spare = ks + NS * (S / 4);
-            for (int sn = 0; sn < NS; ++sn) {
-                int j = sn / WPP, q = sn % WPP;
-                const uint32_t* w = ks + sn * (S / 4);
-                int row = t > 4 ? d : j;
-                if (packed) {
-                    uint32_t word = w[0] & (uint32_t)(0x01010101u * (uint32_t)f->mask);
-                    for (int b_ = 0; b_ < 4; ++b_) {
-                        size_t e = i * EPV + (size_t)q * 4 + b_;
-                        if (e < n) st(out, (size_t)row * cstride + e, eb, (word >> (8 * b_)) & 0xff);
-                    }
-                    continue;
-                }
-                u128 v;
-                if (f->binary) {
-                    v = ld_words(w, eb / 4) & f->mask;
-                } else if (pm) {
-                    v = ld_words(w, eb / 4) & kmask;
-                    if (v >= f->p) {
-                        v = ld_words(spare, eb / 4) & kmask;
-                        if (v >= f->p) {
-                            v = ld_words(spare + eb / 4, eb / 4) & kmask;
-                            if (v >= f->p) v -= f->p;
+            const uint32_t* spare = ks + G * NS * (S / 4);
+            for (int u = 0; u < G; ++u) {
+                size_t i = (size_t)u * ngroups + grp;   /* pack index: group g serves g, g+NG, g+2NG, ... */
+                if (i >= npacks) continue;
+                for (int sn = 0; sn < NS; ++sn) {
+                    int j = sn / WPP, q = sn % WPP;
+                    const uint32_t* w = ks + (u * NS + sn) * (S / 4);
+                    int row = t > 4 ? d : j;
+                    if (packed) {
+                        uint32_t word = w[0] & (uint32_t)(0x01010101u * (uint32_t)f->mask);
+                        for (int b_ = 0; b_ < 4; ++b_) {
+                            size_t e = i * EPV + (size_t)q * 4 + b_;
+                            if (e < n) st(out, (size_t)row * cstride + e, eb, (word >> (8 * b_)) & 0xff);
                         }
+                        continue;
                     }
-                } else if (eb == 4) {
-                    v = ld_words(w, 3) % f->p;                      /* 96 bits */
-                } else if (eb == 8) {
-                    u128 lo = ld_words(w, 2), hi = ld_words(w + 2, 2);
-                    v = (mulmod(hi % f->p, R, f->p) + lo % f->p) % f->p;
-                } else {
-                    u128 lo = ld_words(w, 4), hi = ld_words(w + 4, 4);
-                    v = addmod(mulmod(hi % f->p, R, f->p), lo % f->p, f->p);
+                    u128 v;
+                    if (f->binary) {
+                        v = ld_words(w, eb / 4) & f->mask;
+                    } else if (pm) {
+                        v = ld_words(w, eb / 4) & kmask;
+                        if (v >= f->p) {
+                            v = ld_words(spare, eb / 4) & kmask;
+                            if (v >= f->p) {
+                                v = ld_words(spare + eb / 4, eb / 4) & kmask;
+                                if (v >= f->p) v -= f->p;
+                            }
+                        }
+                    } else if (eb == 4) {
+                        v = ld_words(w, 3) % f->p;                      /* 96 bits */
+                    } else if (eb == 8) {
+                        u128 lo = ld_words(w, 2), hi = ld_words(w + 2, 2);
+                        v = (mulmod(hi % f->p, R, f->p) + lo % f->p) % f->p;
+                    } else {
+                        u128 lo = ld_words(w, 4), hi = ld_words(w + 4, 4);
+                        v = addmod(mulmod(hi % f->p, R, f->p), lo % f->p, f->p);
+                    }
+                    size_t e = i * EPV + (size_t)q;
+                    if (e < n) st(out, (size_t)row * cstride + e, eb, v);
                 }
-                size_t e = i * EPV + (size_t)q;
-                if (e < n) st(out, (size_t)row * cstride + e, eb, v);
             }
         }
     }

@@ -142,7 +142,7 @@ static void draw_rows(const PolicyBlob& pb, const RngKey& rk, unsigned char* out
     size_t npacks = (n + EPV - 1) / EPV;
     for (size_t i = 0; i < npacks; ++i) {
         typename F::word c[T][WPP];
-        rng_draw_pack<F, T, WPP>(f, rk, R[0], R[1], (uint64_t)i, c);
+        rng_draw_pack<F, T, WPP>(f, rk, R[0], R[1], (uint64_t)i, (uint64_t)npacks, c);
         for (int j = 0; j < T; ++j)
             for (int q = 0; q < WPP; ++q)
                 for (int b = 0; b < F::EPW; ++b) {

@@ -94,7 +94,7 @@ def test_rejection_branch(hostcheck, coracle):
     assert (got == want).all()
     assert int(got.max()) < p
     # count how many primary samples were rejected, from the raw keystream (pack = 2 elements, t = 2:
-    # 4 primary words + 2 spares = 48 bytes -> 1 block per pack)
+    # 4 primary words + 2 spares = 48 bytes -> G = 1, one block per pack)
     hits = 0
     for i in range(0, 4096):
         blk = coracle.chacha_block(KEY, [i, 0, 123, 0], 8)
