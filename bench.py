@@ -166,13 +166,21 @@ def main():
             raise SystemExit('for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    # validation hooks (not used by the driver): run the N>1 control flow on a 1-GPU box
+    force_dev = os.environ.get('FFGPU_BENCH_DEVICE')
+    if force_dev is not None:
+        local_rank = int(force_dev)
+    backend = os.environ.get('FFGPU_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from mpyc_amd.engine import FieldContext
     from oracle import pyoracle as po
@@ -233,8 +241,9 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    red_dev = ctx.torch_device if backend == 'nccl' else 'cpu'
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -248,7 +257,7 @@ def main():
     barrier()
     elapsed_unfused = time.perf_counter() - t1
     if dist is not None:
-        tt = torch.tensor([elapsed_unfused], dtype=torch.float64, device=ctx.torch_device)
+        tt = torch.tensor([elapsed_unfused], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_unfused = float(tt.item())
 
