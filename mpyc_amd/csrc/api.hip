@@ -32,6 +32,8 @@ int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* o
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
+int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
+                                int k, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable, int device, const void* a,
                               const void* b, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, const void* b, void* out, size_t n,
@@ -474,6 +476,18 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
     ARGCHK(host_rows && host_lambda && out && (w == 1 || out_stride >= n));
     for (int j = 0; j < k; ++j) ARGCHK(host_rows[j]);
     DeviceGuard g(ctx->device);
+    // GF(2^n), 9 <= n <= 128 with a sparse modulus: shared nibble tables of the (uniform) Lagrange
+    // coefficients in LDS instead of one full field multiplication per row and element
+    if ((ctx->policy_kind == POL_GF2W64 || ctx->policy_kind == POL_GF2W128) && !ctx->gf2w_limbs && k <= 9 &&
+        n >= 65536 && !getenv("FFGPU_GF2W_REC_PLAIN")) {
+        const int limbs = ctx->policy_kind == POL_GF2W128 ? 2 : 1;
+        int rc = 0;
+        for (int r = 0; r < w && rc == 0; ++r)
+            rc = ffgpu_launch_gf2w_recombine(ctx->policy, limbs, ctx->device, host_rows, host_lambda + 2 * (size_t)r * k,
+                                             k, (char*)out + (size_t)r * out_stride * ctx->elem_bytes, n,
+                                             (hipStream_t)stream);
+        if (rc != 2) return launch_status(rc);
+    }
     return launch_status(ctx->ops->recombine(ctx->policy, ctx->device, host_rows, host_lambda, k, w, out,
                                              out_stride, n, (hipStream_t)stream));
 }

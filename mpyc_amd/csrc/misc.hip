@@ -383,6 +383,138 @@ int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable,
     return 0;
 }
 
+// ---- GF(2^n), 9 <= n <= 128: recombination through shared nibble tables -----------------------------
+// out[h] = sum_j lambda_j * rows[j][h].  The Lagrange coefficients are wave-uniform, and x -> lambda*x
+// is GF(2)-linear, so each workgroup first builds, for every row j, nibble position pos and nibble
+// value v, the entry  T[j][pos][v] = lambda_j * (v * x^(4 pos)) mod f  (K * NPOS * 16 entries, built
+// cooperatively with the in-register carry-less product), and then every element costs NPOS look-ups
+// + xors per row instead of a full field multiplication.  An entry's bank depends only on v (16
+// consecutive 16-byte slots per position), so the data-dependent reads are conflict-free.
+template <int LIMBS, int K>
+struct Gf2wRecArgs {
+    const void* rows[K];
+    uint64_t lam_lo[K], lam_hi[K];
+};
+
+template <int LIMBS, int K>
+__global__ __launch_bounds__(BLOCK) void k_gf2w_recombine_tab(typename Gf2wTraits<LIMBS>::F f, Gf2wRecArgs<LIMBS, K> ra,
+                                                               typename Gf2wTraits<LIMBS>::E* __restrict__ out, size_t n) {
+    typedef Gf2wTraits<LIMBS> Tr;
+    typedef typename Tr::L L;
+    typedef typename Tr::E E;
+    constexpr int NPOS = 16 * LIMBS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    L* T = reinterpret_cast<L*>(smem);                       // [K][NPOS][16]
+    for (int e = threadIdx.x; e < K * NPOS * 16; e += BLOCK) {
+        const int j = e / (NPOS * 16), pos = (e / 16) % NPOS, v = e % 16;
+        uint64_t clo = 0, chi = 0;
+        if (4 * pos < 64) clo = (uint64_t)v << (4 * pos); else chi = (uint64_t)v << (4 * pos - 64);
+        uint64_t rlo, rhi;
+        if constexpr (LIMBS == 2) {
+            // the constant may exceed degree n only if 4*pos+3 >= n: reduce it first
+            u128e c;
+            c.lo = clo;
+            c.hi = chi;
+            if (f.n < 128) c = f.reduce_raw(c);
+            u128e lam;
+            lam.lo = ra.lam_lo[j];
+            lam.hi = ra.lam_hi[j];
+            u128e r = f.mul(lam, c);
+            rlo = r.lo;
+            rhi = r.hi;
+        } else {
+            uint64_t c = f.n < 64 ? f.reduce_raw(clo) : clo;
+            rlo = f.mul(ra.lam_lo[j], c);
+            rhi = 0;
+        }
+        T[e] = Tr::pack(rlo, rhi);
+    }
+    __syncthreads();
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < n; i += gsz) {
+        uint64_t alo = 0, ahi = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            uint64_t xlo, xhi;
+            if constexpr (LIMBS == 2) {
+                u128e x = reinterpret_cast<const u128e*>(ra.rows[j])[i];
+                xlo = x.lo;
+                xhi = x.hi;
+            } else {
+                xlo = reinterpret_cast<const uint64_t*>(ra.rows[j])[i];
+                xhi = 0;
+            }
+            const L* Tj = T + j * NPOS * 16;
+#pragma unroll
+            for (int pos = 0; pos < NPOS; ++pos) {
+                uint32_t v = pos < 16 ? (uint32_t)(xlo >> (4 * pos)) & 15u : (uint32_t)(xhi >> (4 * (pos - 16))) & 15u;
+                uint64_t tlo, thi;
+                Tr::unpack(Tj[pos * 16 + v], tlo, thi);
+                alo ^= tlo;
+                ahi ^= thi;
+            }
+        }
+        if constexpr (LIMBS == 2) {
+            u128e r;
+            r.lo = alo;
+            r.hi = ahi;
+            out[i] = r;
+        } else {
+            out[i] = alo;
+        }
+    }
+}
+
+template <int LIMBS, int K>
+static int launch_gf2w_rec(const void* policy, int device, const void* const* rows, const uint64_t* lam2, void* out,
+                           size_t n, hipStream_t st) {
+    typedef Gf2wTraits<LIMBS> Tr;
+    const typename Tr::F& f = *reinterpret_cast<const typename Tr::F*>(policy);
+    Gf2wRecArgs<LIMBS, K> ra;
+    for (int j = 0; j < K; ++j) {
+        ra.rows[j] = rows[j];
+        ra.lam_lo[j] = lam2[2 * j];
+        ra.lam_hi[j] = lam2[2 * j + 1];
+    }
+    const size_t lds = (size_t)K * 16 * LIMBS * 16 * sizeof(typename Tr::L);
+    LaunchCfg lc = launch_cfg(device);
+    // persistent grid: the table build (2K field multiplications per thread) is amortised over many elements
+    int per_cu = (int)(160 * 1024 / (lds + 256));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    LaunchCfg capped = lc;
+    capped.blocks_per_cu = per_cu;
+    unsigned grid = grid_for(n, capped);
+    if (lds > 48 * 1024) {
+        static bool raised = false;     // per instantiation: allow more than the default dynamic LDS
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gf2w_recombine_tab<LIMBS, K>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((k_gf2w_recombine_tab<LIMBS, K>), dim3(grid), dim3(BLOCK), lds, st, f, ra,
+                       (typename Tr::E*)out, n);
+    FFGPU_CHECK_LAUNCH();
+    return 0;
+}
+
+// k rows (1..9), one output row; limbs selects GF2W64 / GF2W128.  Returns 2 if the shape is not covered.
+int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
+                                int k, void* out, size_t n, hipStream_t st) {
+#define GF2W_REC_CASE(KK)                                                                                        \
+    case KK:                                                                                                     \
+        return limbs == 2 ? launch_gf2w_rec<2, KK>(policy, device, rows, lam2, out, n, st)                       \
+                          : launch_gf2w_rec<1, KK>(policy, device, rows, lam2, out, n, st);
+    switch (k) {
+        GF2W_REC_CASE(1) GF2W_REC_CASE(2) GF2W_REC_CASE(3) GF2W_REC_CASE(4) GF2W_REC_CASE(5)
+        GF2W_REC_CASE(6) GF2W_REC_CASE(7) GF2W_REC_CASE(8) GF2W_REC_CASE(9)
+        default: return 2;
+    }
+#undef GF2W_REC_CASE
+}
+
 __global__ __launch_bounds__(BLOCK) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst,
                                                    size_t nvec) {
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -300,6 +300,32 @@ def test_binary_fields_dense_and_small(eng, coracle):
         assert (rec.to_numpy() == want).all(), hex(mod)
 
 
+def test_wide_binary_recombination_tables(eng, coracle):
+    """GF(2^n), 9 <= n <= 128: recombination of large arrays goes through per-workgroup nibble tables of
+    the Lagrange coefficients (k_gf2w_recombine_tab); same bits as the plain kernel and the oracle."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    for mod in ((1 << 128) | 0x87, (1 << 64) | 0x1b, int(BinaryPolynomial.next_irreducible(1 << 100)),
+                int(BinaryPolynomial.next_irreducible(1 << 33)), int(BinaryPolynomial.next_irreducible(1 << 13))):
+        F = po.Field(mod, True)
+        ctx = ctx_for(eng, mod, True)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(mod, True)
+        n = 70001
+        for k in (1, 3, 7, 9):
+            rows = [rand_np(F, eb, n, 300 + j) for j in range(k)]
+            rng = random.Random(k)
+            lam = [rng.randrange(F.order) for _ in range(k)]
+            lam[0] = F.order - 1
+            got = ctx.recombine([ctx.from_numpy(r) for r in rows], lam).to_numpy()
+            assert (got == cf.recombine(rows, lam)).all(), (hex(mod), k)
+            small = ctx.recombine([ctx.from_numpy(r[:1000]) for r in rows], lam).to_numpy()     # plain kernel
+            assert (small == got[:1000]).all()
+        rows = [rand_np(F, eb, n, 400 + j) for j in range(3)]
+        lam = [random.Random(9).randrange(F.order) for _ in range(6)]
+        out = ctx.recombine([ctx.from_numpy(r) for r in rows], lam, w=2)
+        assert (out.to_numpy() == cf.recombine(rows, lam, w=2)).all()
+
+
 def test_hip_graph_capture_of_a_gate(eng, coracle):
     """A gate (fused local product + share generation, then recombination) captured once into a HIP graph
     and replayed on fresh inputs gives the same bits as eager launches."""
