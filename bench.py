@@ -183,7 +183,11 @@ def main():
             dist.init_process_group(backend)
 
     from mpyc_amd.engine import FieldContext
-    from oracle import pyoracle as po
+    from mpyc_amd import finfields as gff, thresha as gth
+
+    def lagrange(modulus, xs):
+        """Recombination vector at 0 from the product's own host code (thresha.py:67-85 mirror)."""
+        return list(gth._recombination_vector(gff.GF(modulus), tuple(xs), 0))
 
     n, t, m = args.n, 1, 3
     k = 2 * t + 1
@@ -191,7 +195,7 @@ def main():
     gen = torch.Generator(device=ctx.torch_device)
     gen.manual_seed(20260925 + rank)
     sets = [StepData(ctx, n, t, m, gen) for _ in range(args.sets)]
-    lam = po.recombination_vector(po.Field(P61), list(range(1, k + 1)), 0)
+    lam = lagrange(P61, range(1, k + 1))
 
     def f_mul(s):
         ctx.mul(s.a, s.b, out=s.c)
@@ -326,7 +330,7 @@ def main():
             P40 = 2**40 - 87
             ctx40 = FieldContext(P40, device=local_rank)
             small = StepData(ctx40, 4096, t, m, gen)
-            lam40 = po.recombination_vector(po.Field(P40), list(range(1, k + 1)), 0)
+            lam40 = lagrange(P40, range(1, k + 1))
             small.rec = ctx40.recombine_plan([small.shares.row(j) for j in range(k)], lam40, small.y)
 
             def small_gate():
@@ -371,9 +375,8 @@ def main():
                 bpu = (1 + m2) * eb
                 kern[f'split_rng_p64_m7t3_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                                                   units_per_s=round(n / (ms * 1e-3), 1))
-            F64 = po.Field(P64)
             for kk in (t2 + 1, 2 * t2 + 1):
-                lam64 = po.recombination_vector(F64, list(range(1, kk + 1)), 0)
+                lam64 = lagrange(P64, range(1, kk + 1))
                 for s in sets64:
                     s.rec = ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y)
                 ms = time_launches(lambda s: s.rec(), sets64, reps)
@@ -405,7 +408,6 @@ def main():
             torch.cuda.empty_cache()
             P128 = 2**128 - 173
             ctx128 = FieldContext(P128, device=local_rank)
-            F128 = po.Field(P128)
 
             def u128_rows(rows):
                 x = torch.randint(-2**63, 2**63 - 1, (rows, n, 2), dtype=torch.int64, device=ctx.torch_device,
@@ -438,7 +440,7 @@ def main():
             bpu = (1 + t2 + m2) * eb2
             kern['split_p128_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                            units_per_s=round(n / (ms * 1e-3), 1))
-            lam128 = po.recombination_vector(F128, list(range(1, 2 * t2 + 2)), 0)
+            lam128 = lagrange(P128, range(1, 2 * t2 + 2))
             for s in sets128:
                 s.rec = ctx128.recombine_plan([s.shares.row(j) for j in range(2 * t2 + 1)], lam128, s.y)
             ms = time_launches(lambda s: s.rec(), sets128, reps)
@@ -456,7 +458,10 @@ def main():
             del sets128[:]
             torch.cuda.empty_cache()
             ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
-            rows8, b8 = po.aes_affine_rows()
+            # demos/np_aes.py:23-33: A = circulant([1,0,0,0,1,1,1,1]) (row j = first row rolled by j), B = 0x63
+            r_ = [1, 0, 0, 0, 1, 1, 1, 1]
+            rows8 = [sum(r_[(c_ - j_) % 8] << c_ for c_ in range(8)) for j_ in range(8)]
+            b8 = 0x63
             for n8 in (1_000_000, 1_000_000_000):
                 from mpyc_amd.engine import DevArray
                 bufs = []

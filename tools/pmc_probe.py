@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 from mpyc_amd.engine import FieldContext
-from oracle import pyoracle as po
+from mpyc_amd import finfields as gff, gfpx, thresha as gth
 
 torch.cuda.set_device(0)
 n = 10_000_000
@@ -17,7 +17,7 @@ for P, t, m in ((bench.P61, 1, 3), (bench.P64, 3, 7)):
     ctx = FieldContext(P, device=0)
     sets = [bench.StepData(ctx, n, t, m, gen) for _ in range(4)]
     k = 2 * t + 1
-    lam = po.recombination_vector(po.Field(P), list(range(1, k + 1)), 0)
+    lam = list(gth._recombination_vector(gff.GF(P), tuple(range(1, k + 1)), 0))
     for s in sets:
         s.rec = ctx.recombine_plan([s.shares.row(j) for j in range(k)], lam, s.y)
     for rep in range(3):

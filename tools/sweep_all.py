@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mpyc_amd.engine import FieldContext, DevArray
-from oracle import pyoracle as po
+from mpyc_amd import finfields as gff, gfpx, thresha as gth
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
 FAM = [('PM64 2^61-1', 2**61 - 1, False), ('PM64 2^64-189', 2**64 - 189, False), ('RC64 generic', 6616326157076047771, False),
        ('RC32 2^31-1', 2**31 - 1, False), ('PM128 2^128-173', 2**128 - 173, False), ('PM128 2^127-1', 2**127 - 1, False),
@@ -16,7 +16,7 @@ for name, mod, binary in FAM:
     ctx = FieldContext(mod, binary, device=0)
     eb = ctx.elem_bytes
     n = 40_000_000 if eb == 1 else 10_000_000
-    F = po.Field(mod, binary)
+    F = gff.GF(gfpx.BinaryPolynomial(mod)) if binary else gff.GF(mod)
     def rnd(rows):
         if eb == 16:
             x = torch.randint(0, 2**62, (rows, n, 2), dtype=torch.int64, device='cuda:0', generator=gen)
@@ -50,7 +50,7 @@ for name, mod, binary in FAM:
         ms = bench.time_launches(lambda s: ctx.split(sets[0][0], coef, t, m, out=s), sh, 3)
         res.append((f'split m{m}t{t}', (1 + t + m) * eb * n / ms / 1e6))
         k = 2 * t + 1
-        lam = po.recombination_vector(F, list(range(1, k + 1)), 0)
+        lam = list(gth._recombination_vector(F, tuple(range(1, k + 1)), 0))
         outs = [ctx.empty(n) for _ in range(2)]
         plans = [ctx.recombine_plan([sh[i].row(j) for j in range(k)], lam, outs[i]) for i in range(2)]
         ms = bench.time_launches(lambda pl: pl(), plans, 3)
