@@ -187,6 +187,15 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
                  size_t M, size_t K, size_t N, void* stream);
 
+/* ---- reductions ------------------------------------------------------------- */
+/* out[0] = sum_i a[i]*b[i]  (ffgpu_dot)  /  sum_i a[i]  (ffgpu_sum), one field element.
+ * workspace: device scratch of at least FFGPU_REDUCE_WORKSPACE_BYTES bytes (per concurrent call).
+ * replaces: the local part of runtime.py in_prod / np_sum-style reductions (sum(map(mul, x, y)) on
+ * shares, then one reshare) and FiniteFieldArray reductions through __array_function__ (np.sum).    */
+#define FFGPU_REDUCE_WORKSPACE_BYTES (1024 * 16)
+int ffgpu_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream);
+int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t n, void* stream);
+
 /* ---- pseudorandom secret sharing: combination step ----------------------- */
 /* out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * weights[s][j]   (mod modulus)
  * host_streams: HOST array of ks DEVICE pointers to the raw SHAKE128 output of subset s

@@ -503,6 +503,24 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
                                           (hipStream_t)stream));
 }
 
+static int do_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream) {
+    ARGCHK(ctx && out);
+    DeviceGuard g(ctx->device);
+    if (n == 0) {   // empty sum = 0
+        HIPCHK(hipMemsetAsync(out, 0, (size_t)ctx->elem_bytes, (hipStream_t)stream));
+        return FFGPU_OK;
+    }
+    ARGCHK(a && workspace);
+    return launch_status(ctx->ops->dot(ctx->policy, ctx->device, a, b, out, workspace, n, (hipStream_t)stream));
+}
+int ffgpu_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream) {
+    ARGCHK(n == 0 || b);
+    return do_dot(ctx, a, b, out, workspace, n, stream);
+}
+int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t n, void* stream) {
+    return do_dot(ctx, a, nullptr, out, workspace, n, stream);
+}
+
 int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
                        const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream) {
     ARGCHK(ctx);

@@ -841,6 +841,106 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_bytes(F f, const uint8_t* __re
     if (gm1 < M && gn1 < N) C[(size_t)gm1 * ldc + gn1] = (uint8_t)(r >> 24);
 }
 
+
+// ---- reductions: out[0] = sum_i a[i] * b[i]   (b == nullptr: sum_i a[i]) ---------------------------
+// The local part of an inner product of secret-shared vectors (runtime.in_prod: sum(map(mul, x, y))
+// then ONE reshare) and of FieldArray.sum().  Two launches: every workgroup reduces a slice (lazy
+// multiply-accumulate per thread, flushed every 192 terms, then an LDS tree with field additions) into
+// partial[blockIdx]; a single workgroup then folds the partials.
+enum { DOT_MAX_BLOCKS = 1024 };
+
+template <class F>
+__device__ __forceinline__ typename F::word block_reduce_add(const F& f, typename F::word v, typename F::word* sm) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = f.add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+template <class F, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_dot_partial(F f, const typename F::elem* __restrict__ a,
+                                                        const typename F::elem* __restrict__ b,
+                                                        typename F::word* __restrict__ partial, size_t nvec, size_t n) {
+    typedef Pack<typename F::word> P;
+    typedef typename F::word W;
+    __shared__ W sm[BLOCK];
+    const P* __restrict__ av = reinterpret_cast<const P*>(a);
+    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const W one = f.prep(ff_one(f));
+    typename F::acc acc;
+    f.acc_zero(acc);
+    W total = W();
+    bool have = false;
+    int cnt = 0;
+    auto flush = [&]() {
+        W part = f.acc_reduce(acc);
+        total = have ? f.add(total, part) : part;
+        have = true;
+        f.acc_zero(acc);
+        cnt = 0;
+    };
+    for (size_t i = gid; i < nvec; i += gsz) {
+        P x = ldg<true>(av + i);
+        P y;
+        if constexpr (HAS_B) y = ldg<true>(bv + i);
+#pragma unroll
+        for (int q = 0; q < P::N; ++q) {
+            if constexpr (F::EPW > 1) {
+                // packed GF(2^n<=8): four independent byte lanes per word, xor-accumulated
+                if constexpr (HAS_B) acc.a ^= f.mul(x.w[q], y.w[q]); else acc.a ^= x.w[q];
+            } else {
+                if constexpr (HAS_B) f.acc_mac(acc, f.prep(x.w[q]), y.w[q]);
+                else f.acc_mac(acc, one, x.w[q]);
+            }
+        }
+        cnt += P::N;
+        if (cnt >= 192) flush();
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        if constexpr (F::EPW > 1) {
+            if constexpr (HAS_B) acc.a ^= f.mul(ld_elem<F>(a, e), ld_elem<F>(b, e)); else acc.a ^= ld_elem<F>(a, e);
+        } else {
+            if constexpr (HAS_B) f.acc_mac(acc, f.prep(ld_elem<F>(a, e)), ld_elem<F>(b, e));
+            else f.acc_mac(acc, one, ld_elem<F>(a, e));
+        }
+        if (++cnt >= 192) flush();
+    }
+    W r = f.acc_reduce(acc);
+    if (have) r = f.add(total, r);
+    r = block_reduce_add(f, r, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word* __restrict__ partial, int nparts,
+                                                      typename F::elem* __restrict__ out) {
+    typedef typename F::word W;
+    __shared__ W sm[BLOCK];
+    W r = W();
+    bool have = false;
+    for (int i = threadIdx.x; i < nparts; i += BLOCK) {
+        r = have ? f.add(r, partial[i]) : partial[i];
+        have = true;
+    }
+    r = block_reduce_add(f, r, sm);     // threads without a partial contribute the zero word
+    if (threadIdx.x == 0) {
+        if constexpr (F::EPW > 1) {
+            // packed GF(2^n<=8): fold the four byte lanes of the word into one element
+            W w = r;
+            w = (w ^ (w >> 8) ^ (w >> 16) ^ (w >> 24)) & 0xffu;
+            out[0] = (typename F::elem)w;
+        } else {
+            out[0] = r;
+        }
+    }
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -880,6 +980,8 @@ struct FieldOps {
                hipStream_t st);
     int (*matmul)(const void* F, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
                   size_t ldc, int M, int K, int N, hipStream_t st);
+    int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
+               hipStream_t st);
     int (*prss)(const void* F, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
                 const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
 };
@@ -1222,6 +1324,27 @@ struct Launchers {
         FFGPU_CHECK_LAUNCH();
         return 0;
     }
+    static int dot(const void* Fp, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
+                   hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        LaunchCfg lc = launch_cfg(device);
+        bool vec = aligned16(a) && (!b || aligned16(b));
+        size_t nvec = vec ? n / EPV : 0;
+        size_t iters = nvec ? nvec : n;
+        size_t want = (iters + (size_t)BLOCK * 8 - 1) / ((size_t)BLOCK * 8);     // >= 8 packs per thread
+        unsigned grid = (unsigned)(want < 1 ? 1 : want > DOT_MAX_BLOCKS ? DOT_MAX_BLOCKS : want);
+        W* part = (W*)workspace;
+        if (b)
+            hipLaunchKernelGGL((k_dot_partial<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, (const E*)b,
+                               part, nvec, n);
+        else
+            hipLaunchKernelGGL((k_dot_partial<F, false>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, (const E*)a,
+                               part, nvec, n);
+        hipLaunchKernelGGL((k_dot_final<F>), dim3(1), dim3(BLOCK), 0, st, f, (const W*)part, (int)grid, (E*)out);
+        FFGPU_CHECK_LAUNCH();
+        (void)lc;
+        return 0;
+    }
     static int prss(const void* Fp, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
                     const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n,
                     hipStream_t st) {
@@ -1243,7 +1366,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &prss};
         return &ops;
     }
 };

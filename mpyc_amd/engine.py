@@ -392,6 +392,26 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
         return out
 
+    def _workspace(self):
+        ws = getattr(self, '_ws', None)
+        if ws is None:
+            ws = self._ws = torch.empty(1024 * 16, dtype=torch.uint8, device=self.torch_device)
+        return ws
+
+    def dot(self, a: DevArray, b: DevArray) -> DevArray:
+        """sum_i a[i]*b[i] as a 1-element device array (local part of runtime.in_prod)."""
+        if a.n != b.n:
+            raise ValueError('length mismatch')
+        out = self.empty(1)
+        _ffi.check(self._L.ffgpu_dot(self._h, a.ptr, b.ptr, out.ptr, self._workspace().data_ptr(), a.n,
+                                     self._stream()), 'dot')
+        return out
+
+    def sum(self, a: DevArray) -> DevArray:
+        out = self.empty(1)
+        _ffi.check(self._L.ffgpu_sum(self._h, a.ptr, out.ptr, self._workspace().data_ptr(), a.n, self._stream()), 'sum')
+        return out
+
     def prss_combine(self, streams: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int,
                      mask_bits: int = 0, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
         """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs

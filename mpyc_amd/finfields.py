@@ -867,9 +867,10 @@ class FieldArray:
         K2, N = (other._shape[0], 1) if other.ndim == 1 else other._shape
         if K != K2:
             raise ValueError(f'matmul: shapes {self._shape} and {other._shape} not aligned')
-        out = self.ctx.matmul(self._dev, other._dev, M, K, N)
         if self.ndim == 1 and other.ndim == 1:
-            return cls.field(out.to_ints()[0])
+            # inner product: two-stage reduction kernel (the local part of runtime.in_prod)
+            return cls.field(self.ctx.dot(self._dev, other._dev).to_ints()[0])
+        out = self.ctx.matmul(self._dev, other._dev, M, K, N)
         shape = (N,) if self.ndim == 1 else (M,) if other.ndim == 1 else (M, N)
         return self._wrap(out, shape)
 
@@ -911,6 +912,12 @@ class FieldArray:
         if _fops(cls.field).binary:
             return a.unsigned_()
         return a.signed_() if cls.field.is_signed else a.unsigned_()
+
+    def sum(self, axis=None):
+        """Sum of all elements as a field element (np.sum on a field array, finfields.py:766-819)."""
+        if axis is not None:
+            raise NotImplementedError('sum along an axis is not accelerated')
+        return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
 
     def tolist(self):
         return self.unsigned_().tolist()

@@ -326,6 +326,37 @@ def test_wide_binary_recombination_tables(eng, coracle):
         assert (out.to_numpy() == cf.recombine(rows, lam, w=2)).all()
 
 
+@pytest.mark.parametrize('modulus,binary', FIELDS)
+def test_dot_and_sum_reductions(eng, modulus, binary):
+    """Two-stage reduction kernels: inner product and sum, vs Python integers / the GF(2^n) oracle."""
+    F = po.Field(modulus, binary)
+    ctx = ctx_for(eng, modulus, binary)
+    eb = ctx.elem_bytes
+    for n in (0, 1, 2, 17, 255, 4099, 200003 if eb < 16 else 30011):
+        A, B = rand_np(F, eb, n, 501), rand_np(F, eb, n, 502)
+        a, b = unpack(A, eb), unpack(B, eb)
+        dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+        if binary:
+            want_dot, want_sum = 0, 0
+            for x, y in zip(a, b):
+                want_dot ^= po.mul(F, x, y)
+                want_sum ^= x
+        else:
+            want_dot = sum(x * y for x, y in zip(a, b)) % modulus
+            want_sum = sum(a) % modulus
+        assert unpack(ctx.dot(dA, dB).to_numpy(), eb) == [want_dot], (hex(modulus), n)
+        assert unpack(ctx.sum(dA).to_numpy(), eb) == [want_sum], (hex(modulus), n)
+        if eb < 16 and n > 2:
+            va, vb = eng.DevArray(ctx, dA.t[1:], n - 1), eng.DevArray(ctx, dB.t[1:], n - 1)
+            if binary:
+                w = 0
+                for x, y in zip(a[1:], b[1:]):
+                    w ^= po.mul(F, x, y)
+            else:
+                w = sum(x * y for x, y in zip(a[1:], b[1:])) % modulus
+            assert unpack(ctx.dot(va, vb).to_numpy(), eb) == [w]
+
+
 def test_hip_graph_capture_of_a_gate(eng, coracle):
     """A gate (fused local product + share generation, then recombination) captured once into a HIP graph
     and replayed on fresh inputs gives the same bits as eager launches."""
