@@ -919,6 +919,63 @@ class FieldArray:
             raise NotImplementedError('sum along an axis is not accelerated')
         return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
 
+    # ---- NumPy protocol (finfields.py:728-819): data movement on the device limb tensors, arithmetic
+    #      through the kernels; anything not listed raises instead of silently computing on the host ----
+    def __array__(self, dtype=None, copy=None):
+        return np.array(self.value, dtype=object if dtype is None else dtype)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != '__call__' or kwargs.get('out') is not None:
+            return NotImplemented
+        name = ufunc.__name__
+        a = inputs[0]
+        b = inputs[1] if len(inputs) > 1 else None
+        first = isinstance(a, FieldArray)
+        binary = {'add': ('__add__', '__radd__'), 'subtract': ('__sub__', '__rsub__'),
+                  'multiply': ('__mul__', '__rmul__'), 'divide': ('__truediv__', '__rtruediv__'),
+                  'true_divide': ('__truediv__', '__rtruediv__'), 'matmul': ('__matmul__', '__rmatmul__'),
+                  'equal': ('__eq__', '__eq__'), 'not_equal': ('__ne__', '__ne__'),
+                  'left_shift': ('__lshift__', None), 'right_shift': ('__rshift__', None),
+                  'power': ('__pow__', None)}
+        if name in binary:
+            fwd, rev = binary[name]
+            if first:
+                return getattr(a, fwd)(b)
+            if rev is None:
+                return NotImplemented
+            return getattr(b, rev)(a)
+        unary = {'negative': '__neg__', 'positive': '__pos__', 'reciprocal': 'reciprocal', 'sqrt': 'sqrt'}
+        if name in unary:
+            return getattr(a, unary[name])()
+        return NotImplemented
+
+    def __array_function__(self, func, types, args, kwargs):
+        impl = _ARRAY_FUNCTIONS.get(func.__name__)
+        if impl is None:
+            raise NotImplementedError(f'numpy.{func.__name__} is not supported on GPU field arrays')
+        return impl(*args, **kwargs)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def transpose(self, *axes):
+        if len(axes) == 1 and isinstance(axes[0], (tuple, list)):
+            axes = tuple(axes[0])
+        if not axes:
+            axes = tuple(reversed(range(self.ndim)))
+        t = self._limb_view()
+        perm = tuple(axes) + ((self.ndim,) if self.ctx.elem_bytes == 16 else ())
+        return self._from_limb_view(t.permute(*perm))
+
+    def _from_limb_view(self, t):
+        """limb tensor (array shape [+ trailing 2]) -> FieldArray with contiguous device data"""
+        eb = self.ctx.elem_bytes
+        shape = tuple(t.shape[:-1]) if eb == 16 else tuple(t.shape)
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        flat = t.contiguous().view(n, 2) if eb == 16 else t.contiguous().view(n)
+        return self._wrap(DevArray(self.ctx, flat, n), shape)
+
     def tolist(self):
         return self.unsigned_().tolist()
 
@@ -963,3 +1020,49 @@ def _matrix_to_array(cls, mtx: DevMatrix) -> FieldArray:
     else:
         t = mtx.t[:, :mtx.n].contiguous().view(-1)
     return cls._wrap(DevArray(ctx, t, mtx.rows * mtx.n), (mtx.rows, mtx.n))
+
+
+# ---- numpy functions routed through __array_function__ ----------------------------------------------
+def _np_concatenate(arrays, axis=0):
+    arrays = list(arrays)
+    cls = type(next(a for a in arrays if isinstance(a, FieldArray)))
+    arrays = [a if isinstance(a, FieldArray) else cls(a) for a in arrays]
+    if axis is None:
+        arrays, axis = [a.reshape(-1) for a in arrays], 0
+    t = torch.cat([a._limb_view() for a in arrays], dim=axis if axis >= 0 else axis + arrays[0].ndim)
+    return arrays[0]._from_limb_view(t)
+
+
+def _np_stack(arrays, axis=0):
+    arrays = list(arrays)
+    cls = type(next(a for a in arrays if isinstance(a, FieldArray)))
+    arrays = [a if isinstance(a, FieldArray) else cls(a) for a in arrays]
+    nd = arrays[0].ndim + 1
+    t = torch.stack([a._limb_view() for a in arrays], dim=axis if axis >= 0 else axis + nd)
+    return arrays[0]._from_limb_view(t)
+
+
+def _np_roll(a, shift, axis=None):
+    if axis is None:
+        return _np_roll(a.reshape(-1), shift, 0).reshape(a.shape)
+    return a._from_limb_view(torch.roll(a._limb_view(), shift, dims=axis if axis >= 0 else axis + a.ndim))
+
+
+def _np_flip(a, axis=None):
+    dims = tuple(range(a.ndim)) if axis is None else ((axis if axis >= 0 else axis + a.ndim),)
+    return a._from_limb_view(torch.flip(a._limb_view(), dims=dims))
+
+
+_ARRAY_FUNCTIONS = {
+    'shape': lambda a: a.shape, 'ndim': lambda a: a.ndim, 'size': lambda a: a.size,
+    'reshape': lambda a, *shape, **kw: a.reshape(*shape if shape else (kw.get('newshape', kw.get('shape')),)),
+    'ravel': lambda a: a.ravel(), 'copy': lambda a: a.copy(),
+    'transpose': lambda a, axes=None: a.transpose(*([axes] if axes is not None else [])),
+    'concatenate': _np_concatenate, 'stack': _np_stack,
+    'vstack': lambda arrays: _np_concatenate([a.reshape(1, -1) if a.ndim == 1 else a for a in arrays], 0),
+    'hstack': lambda arrays: _np_concatenate(list(arrays), 0 if list(arrays)[0].ndim == 1 else 1),
+    'roll': _np_roll, 'flip': _np_flip,
+    'sum': lambda a, axis=None, **kw: a.sum(axis),
+    'dot': lambda a, b: a @ b, 'matmul': lambda a, b: a @ b,
+    'negative': lambda a: -a, 'add': lambda a, b: a + b, 'subtract': lambda a, b: a - b, 'multiply': lambda a, b: a * b,
+}

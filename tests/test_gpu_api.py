@@ -338,3 +338,56 @@ def test_matmul_operator(api):
     assert ints(F.array(A) @ np.array(B, dtype=object)) == [int(x) for x in want.reshape(-1)]
     with pytest.raises(ValueError):
         F.array(A) @ F.array(A)
+
+
+def test_numpy_protocol(api):
+    """np.* functions and ufuncs on GPU field arrays (finfields.py:728-819 restated): results equal the same
+    NumPy call on plain integer arrays reduced mod p; unsupported functions raise instead of falling back."""
+    finfields, gfpx, _ = api
+    p = 2**61 - 1
+    F = finfields.GF(p)
+    rng = random.Random(21)
+    a = [[rng.randrange(p) for _ in range(5)] for _ in range(3)]
+    b = [[rng.randrange(p) for _ in range(5)] for _ in range(3)]
+    A, B = F.array(a), F.array(b)
+    na, nb = np.array(a, dtype=object), np.array(b, dtype=object)
+
+    def same(x, want):
+        assert isinstance(x, F.array) and x.shape == want.shape, (x.shape, want.shape)
+        assert [int(v) for v in np.asarray(x.value).reshape(-1)] == [int(v) % p for v in want.reshape(-1)]
+
+    same(np.add(A, B), na + nb)
+    same(np.multiply(A, B), na * nb)
+    same(np.subtract(A, B), na - nb)
+    same(np.negative(A), -na)
+    same(np.multiply(3, A), 3 * na)
+    same(np.concatenate((A, B)), np.concatenate((na, nb)))
+    same(np.concatenate((A, B), axis=1), np.concatenate((na, nb), axis=1))
+    same(np.stack((A, B)), np.stack((na, nb)))
+    same(np.stack((A, B), axis=2), np.stack((na, nb), axis=2))
+    same(np.vstack((A[0], B[1])), np.vstack((na[0], nb[1])))
+    same(np.hstack((A[0], B[1])), np.hstack((na[0], nb[1])))
+    same(np.transpose(A), na.T)
+    same(A.T, na.T)
+    same(np.reshape(A, (5, 3)), na.reshape(5, 3))
+    same(np.roll(A, 2, axis=1), np.roll(na, 2, axis=1))
+    same(np.roll(A, 4), np.roll(na, 4))
+    same(np.flip(A, axis=0), np.flip(na, axis=0))
+    same(A.T @ B, na.T @ nb)
+    same(np.matmul(A, B.T), na @ nb.T)
+    assert int(np.sum(A).value) == int(na.sum()) % p
+    assert np.shape(A) == (3, 5) and np.ndim(A) == 2 and np.size(A) == 15
+    assert (np.equal(A, A)).all() and not np.not_equal(A, A).any()
+    assert [int(v) for v in np.asarray(A).reshape(-1)] == [v for row in a for v in row]
+    with pytest.raises(NotImplementedError):
+        np.cumsum(A)
+    G = finfields.GF(2**128 - 173)                      # two-limb elements: trailing limb axis handled
+    q = G.modulus
+    c = [[rng.randrange(q) for _ in range(4)] for _ in range(2)]
+    C = G.array(c)
+    nc = np.array(c, dtype=object)
+    assert [int(v) for v in np.asarray(C.T.value).reshape(-1)] == [int(v) for v in nc.T.reshape(-1)]
+    assert [int(v) for v in np.asarray(np.concatenate((C, C), axis=1).value).reshape(-1)] == \
+        [int(v) for v in np.concatenate((nc, nc), axis=1).reshape(-1)]
+    assert [int(v) for v in np.asarray(np.roll(C, 1, axis=1).value).reshape(-1)] == \
+        [int(v) for v in np.roll(nc, 1, axis=1).reshape(-1)]
