@@ -620,6 +620,30 @@ def test_full_size_share_recombine_p64(eng):
             assert int(col[hh]) == want
 
 
+def test_more_than_2_to_32_elements(eng):
+    """Index arithmetic beyond 32 bits: 2^32 + 1000 GF(2^8) elements (4.3 GB per array).  Checked on
+    the device: the product of the whole array equals the products of its two halves, and spot values."""
+    ctx = ctx_for(eng, 0x11b, True)
+    n = (1 << 32) + 1000
+    g = torch.Generator(device='cuda:0')
+    g.manual_seed(5)
+    a = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda:0', generator=g)
+    b = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda:0', generator=g)
+    A, B = eng.DevArray(ctx, a, n), eng.DevArray(ctx, b, n)
+    full = ctx.mul(A, B)
+    h = (1 << 31) + 16                                   # 16-byte aligned split point above 2^31
+    lo = ctx.mul(eng.DevArray(ctx, a[:h], h), eng.DevArray(ctx, b[:h], h))
+    hi = ctx.mul(eng.DevArray(ctx, a[h:], n - h), eng.DevArray(ctx, b[h:], n - h))
+    assert torch.equal(full.t[:h], lo.t) and torch.equal(full.t[h:], hi.t)
+    F = po.Field(0x11b, True)
+    for i in (0, 1, h - 1, h, (1 << 32) - 1, 1 << 32, n - 1):
+        assert int(full.t[i]) == po.mul(F, int(a[i]), int(b[i])), i
+    s = ctx.split(A, None, 0, 1)                         # copy path (t = 0) over the same range
+    assert torch.equal(s.row(0).t, a)
+    del full, lo, hi, s, a, b
+    torch.cuda.empty_cache()
+
+
 def test_full_size_gate_p128(eng):
     """configs[3] shape on one GPU: 128-bit prime, gate = local product + reshare (m=7,t=3):
     recombining the 2t+1 re-shared rows at x=0 gives a*b."""
