@@ -129,6 +129,16 @@ int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_l
  * replaces: finfields.py:1278-1281 (reciprocal), :1416-1422 (_reciprocal via gmpy2.invert per element). */
 int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero_flag, void* stream);
 
+/* ---- Beaver-triple combination (NOT a reference function; parity UNPINNED) ------------- */
+/* out = z + d*y + e*x (+ d*e if add_de != 0), element-wise: the local step of Beaver multiplication
+ * after d = a - x and e = b - y have been opened ([x],[y],[z] = shares of a triple z = x*y).  add_de:
+ * whether this party adds the public term d*e -- every party under Shamir sharing (a public constant is
+ * shared by the constant polynomial), exactly one party under additive sharing.  MPyC itself multiplies with GRR resharing (runtime.py:603-689) and
+ * has no Beaver triples; this entry point exists because the project brief names
+ * it and is validated only against the textbook identity, not against reference outputs.          */
+int ffgpu_beaver_combine(ffgpu_ctx* ctx, const void* z, const void* x, const void* y, const void* d,
+                         const void* e, int add_de, void* out, size_t n, void* stream);
+
 /* ---- Shamir share generation ------------------------------------------ */
 /* shares[i][h] = secrets[h] + sum_{j<t} coeffs[j][h] * (i+1)^(j+1)  (mod modulus),
  * i = 0..m-1, h = 0..n-1;  coeffs is (t, n) row-major with row stride

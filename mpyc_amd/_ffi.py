@@ -54,6 +54,7 @@ _SIGS = {
     'ffgpu_muladd': [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_pow': [_vp, _vp, _u64p, _int, _vp, _sz, _vp],
     'ffgpu_inv': [_vp, _vp, _vp, _sz, _vp, _vp],
+    'ffgpu_beaver_combine': [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp],
     'ffgpu_split': [_vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_mul_split': [_vp, _vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_rng_coeffs': [_vp, ctypes.c_char_p, ctypes.c_uint64, _int, _int, _vp, _sz, _sz, _vp],

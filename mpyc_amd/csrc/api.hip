@@ -393,6 +393,16 @@ int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero
                                        (hipStream_t)stream));
 }
 
+int ffgpu_beaver_combine(ffgpu_ctx* ctx, const void* z, const void* x, const void* y, const void* d, const void* e,
+                         int add_de, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(z && x && y && d && e && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->beaver(ctx->policy, ctx->device, z, x, y, d, e, out, add_de ? 1 : 0, n,
+                                          (hipStream_t)stream));
+}
+
 static int do_split(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, const void* coeffs,
                     size_t coeff_stride, int t, int m, void* shares, size_t share_stride, size_t n,
                     void* stream) {

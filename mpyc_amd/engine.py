@@ -291,6 +291,13 @@ class FieldContext:
             raise ZeroDivisionError('inverse of 0 does not exist')
         return out
 
+    def beaver_combine(self, z, x, y, d, e, add_de: bool, out=None):
+        """z + d*y + e*x (+ d*e): local step of Beaver multiplication (not a reference function; see ffgpu.h)."""
+        out = out or self.empty(z.n)
+        _ffi.check(self._L.ffgpu_beaver_combine(self._h, z.ptr, x.ptr, y.ptr, d.ptr, e.ptr, int(bool(add_de)), out.ptr,
+                                                z.n, self._stream()), 'beaver_combine')
+        return out
+
     # ---- sharing ----------------------------------------------------------
     def split(self, secrets: DevArray, coeffs: Optional[DevMatrix], t: int, m: int,
               out: Optional[DevMatrix] = None, mul_by: Optional[DevArray] = None) -> DevMatrix:

@@ -357,6 +357,46 @@ def test_dot_and_sum_reductions(eng, modulus, binary):
             assert unpack(ctx.dot(va, vb).to_numpy(), eb) == [w]
 
 
+def test_beaver_combine(eng, coracle):
+    """Beaver multiplication vs GRR resharing on the same inputs: both open to a*b.  (Parity UNPINNED:
+    the reference has no Beaver triples; this checks the textbook identity only.)  Three simulated
+    parties, t = 1, every party's shares on this one GPU."""
+    for modulus in (P61, P128):
+        F = po.Field(modulus)
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus)
+        n, t, m = 5003, 1, 3
+        A, B, X, Y = (rand_np(F, eb, n, s) for s in (601, 602, 603, 604))
+        Z = cf.ew(coracle.MUL, X, Y)
+        def share(V, seed):
+            C = rand_np(F, eb, n, seed).reshape((1, n, 2) if eb == 16 else (1, n))
+            return ctx.split(ctx.from_numpy(V), ctx.matrix_from_numpy(C), t, m)
+        sa, sb, sx, sy, sz = (share(V, 700 + i) for i, V in enumerate((A, B, X, Y, Z)))
+        lam2 = po.recombination_vector(F, [1, 2], 0)
+        # open d = a - x and e = b - y (public)
+        dsh = [ctx.sub(sa.row(i), sx.row(i)) for i in range(m)]
+        esh = [ctx.sub(sb.row(i), sy.row(i)) for i in range(m)]
+        d = ctx.recombine(dsh[:2], lam2)
+        e = ctx.recombine(esh[:2], lam2)
+        assert (d.to_numpy() == cf.ew(coracle.SUB, A, X)).all()
+        # every party combines locally; party 0 adds the public d*e term ... as a SHARE of a public value the
+        # constant polynomial d*e has the same share for every party, so every party adds it here
+        csh = [ctx.beaver_combine(sz.row(i), sx.row(i), sy.row(i), d, e, True) for i in range(m)]
+        c = ctx.recombine(csh[:2], lam2)
+        want = cf.ew(coracle.MUL, A, B)
+        assert (c.to_numpy() == want).all(), modulus
+        c23 = ctx.recombine(csh[1:], po.recombination_vector(F, [2, 3], 0))
+        assert (c23.to_numpy() == want).all()
+        # the GRR route on the same shares: local products (degree 2t) recombined from 2t+1 parties
+        prod = [ctx.mul(sa.row(i), sb.row(i)) for i in range(m)]
+        assert (ctx.recombine(prod, po.recombination_vector(F, [1, 2, 3], 0)).to_numpy() == want).all()
+        # add_de = False omits the d*e term
+        nod = ctx.beaver_combine(sz.row(0), sx.row(0), sy.row(0), d, e, False)
+        de = ctx.mul(d, e)
+        assert (ctx.add(nod, de).to_numpy() == csh[0].to_numpy()).all()
+
+
 def test_hip_graph_capture_of_a_gate(eng, coracle):
     """A gate (fused local product + share generation, then recombination) captured once into a HIP graph
     and replayed on fresh inputs gives the same bits as eager launches."""
