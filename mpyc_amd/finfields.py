@@ -453,10 +453,30 @@ class FieldArray:
                 raise TypeError('float values are not field elements')
             flat = np.array([int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v))
                              for v in flat], dtype=object) if flat.size else flat
-        if check and flat.size:
-            flat = self._canonical_host(flat, F)
-        self._dev = ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes)) if flat.size else ctx.empty(0)
+        if not flat.size:
+            self._dev = ctx.empty(0)
+        elif not check:
+            self._dev = ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes))
+        elif self._fits_limbs(flat, ctx.elem_bytes, F):
+            # the usual case: non-negative values that fit the limb width -> upload as they are and let
+            # the device do `value %= modulus` (ffgpu_reduce, finfields.py:724)
+            self._dev = ctx.reduce(ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes)))
+        else:
+            # negative or wider-than-limb Python ints cannot be expressed as limbs: canonicalise those on
+            # the host while marshalling (the reference does the same `%` on the host for every input)
+            self._dev = ctx.from_numpy(ints_to_np(self._canonical_host(flat, F), ctx.elem_bytes))
         self._shape = tuple(shape)
+
+    @staticmethod
+    def _fits_limbs(flat, eb, F):
+        if flat.dtype != object:
+            if flat.dtype.kind == 'u':
+                return flat.dtype.itemsize <= eb
+            if flat.dtype.kind == 'i':
+                return flat.dtype.itemsize <= eb and bool((flat >= 0).all())
+            return False
+        lo, hi = min(flat), max(flat)
+        return lo >= 0 and hi < (1 << (8 * eb))
 
     @staticmethod
     def _canonical_host(flat, F):
