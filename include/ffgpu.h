@@ -197,6 +197,15 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
                  size_t M, size_t K, size_t N, void* stream);
 
+/* ---- small public matrix over the last axis --------------------------------- */
+/* out[i*r + a] = bias[a] + sum_{c<g} M[a][c] * in[i*g + c]  for every group i of g consecutive elements
+ * (r, g <= 16).  host_matrix: (r, g) canonical 2-limb scalars; host_bias: r scalars or NULL.
+ * replaces: finfields.py:1126-1146 `A @ x[..., np.newaxis]` with a public A and trailing axis g
+ * (demos/np_aes.py:40-41: the S-box's GF(2) affine map on the 8 bit-shares of every byte, `+ B`),
+ * and runtime.py:4475-4484 np_from_bits (sum_j x_j * 2^j over the last axis: r = 1).               */
+int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int r, int g,
+                       const void* in, void* out, size_t ngroups, void* stream);
+
 /* ---- reductions ------------------------------------------------------------- */
 /* out[0] = sum_i a[i]*b[i]  (ffgpu_dot)  /  sum_i a[i]  (ffgpu_sum), one field element.
  * workspace: device scratch of at least FFGPU_REDUCE_WORKSPACE_BYTES bytes (per concurrent call).

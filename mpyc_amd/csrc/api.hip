@@ -513,6 +513,17 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
                                           (hipStream_t)stream));
 }
 
+int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int r, int g,
+                       const void* in, void* out, size_t ngroups, void* stream) {
+    ARGCHK(ctx && host_matrix && r >= 1 && g >= 1);
+    if (r > 16 || g > 16) return FFGPU_ENOTSUP;
+    if (ngroups == 0) return FFGPU_OK;
+    ARGCHK(in && out);
+    DeviceGuard gd(ctx->device);
+    return launch_status(ctx->ops->group_matvec(ctx->policy, ctx->device, host_matrix, host_bias, r, g, in, out,
+                                                ngroups, (hipStream_t)stream));
+}
+
 static int do_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream) {
     ARGCHK(ctx && out);
     DeviceGuard g(ctx->device);

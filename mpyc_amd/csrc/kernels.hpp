@@ -975,6 +975,42 @@ __global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word
     }
 }
 
+
+// ---- small public matrix applied to every group of g consecutive elements --------------------------
+// out[i*r + a] = bias[a] + sum_{c<g} M[a][c] * in[i*g + c],   a < r,  i < ngroups   (r, g <= 16)
+// The array-of-structs sibling of k_recombine: finfields `A @ x[..., np.newaxis]` with a public A
+// (demos/np_aes.py:40: the 8x8 GF(2) matrix of the S-box applied to the 8 bit-shares of every byte),
+// and runtime.np_from_bits (runtime.py:4475-4484: sum_j x_j * 2^j over the last axis, r = 1).
+enum { GM_MAX = 16 };
+template <class F>
+struct GroupMatArgs {
+    typename F::word m[GM_MAX * GM_MAX];   // prepared, row-major (r, g)
+    typename F::word bias[GM_MAX];
+    int r, g;
+};
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_group_matvec(F f, GroupMatArgs<F> ga, const typename F::elem* __restrict__ in,
+                                                         typename F::elem* __restrict__ out, size_t ngroups) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < ngroups; i += gsz) {
+        W x[GM_MAX];
+#pragma unroll
+        for (int c = 0; c < GM_MAX; ++c)
+            if (c < ga.g) x[c] = ld_elem<F>(in, i * (size_t)ga.g + c);
+        for (int a = 0; a < ga.r; ++a) {
+            typename F::acc s;
+            f.acc_zero(s);
+#pragma unroll
+            for (int c = 0; c < GM_MAX; ++c)
+                if (c < ga.g) f.acc_mac(s, ga.m[a * ga.g + c], x[c]);
+            st_elem<F>(out, i * (size_t)ga.r + a, f.add(f.acc_reduce(s), ga.bias[a]));
+        }
+    }
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -1016,6 +1052,8 @@ struct FieldOps {
                   size_t ldc, int M, int K, int N, hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
+    int (*group_matvec)(const void* F, int device, const uint64_t* m2, const uint64_t* bias2, int r, int g,
+                        const void* in, void* out, size_t ngroups, hipStream_t st);
     int (*beaver)(const void* F, int device, const void* z, const void* x, const void* y, const void* d, const void* e,
                   void* out, int add_de, size_t n, hipStream_t st);
     int (*prss)(const void* F, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
@@ -1381,6 +1419,26 @@ struct Launchers {
         (void)lc;
         return 0;
     }
+    static int group_matvec(const void* Fp, int device, const uint64_t* m2, const uint64_t* bias2, int r, int g,
+                            const void* in, void* out, size_t ngroups, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        if (r < 1 || g < 1 || r > GM_MAX || g > GM_MAX) return 2;
+        LaunchCfg lc = launch_cfg(device);
+        GroupMatArgs<F> ga;
+        memset(&ga, 0, sizeof(ga));
+        for (int i = 0; i < r * g; ++i) ga.m[i] = f.prep(word_from_limbs<F>(f, m2[2 * i], m2[2 * i + 1]));
+        for (int a = 0; a < r; ++a) {
+            W b = word_from_limbs<F>(f, bias2 ? bias2[2 * a] : 0, bias2 ? bias2[2 * a + 1] : 0);
+            if constexpr (F::EPW > 1) b &= 0xffu;     // one element per word on this (element-wise) path
+            ga.bias[a] = b;
+        }
+        ga.r = r;
+        ga.g = g;
+        unsigned grid = grid_for(ngroups, lc);
+        hipLaunchKernelGGL((k_group_matvec<F>), dim3(grid), dim3(BLOCK), 0, st, f, ga, (const E*)in, (E*)out, ngroups);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
     static int beaver(const void* Fp, int device, const void* z, const void* x, const void* y, const void* d,
                       const void* e, void* out, int add_de, size_t n, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
@@ -1414,7 +1472,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &beaver, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &group_matvec, &beaver, &prss};
         return &ops;
     }
 };

@@ -399,6 +399,26 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
         return out
 
+    def group_matvec(self, x: DevArray, matrix: Sequence[Sequence[int]], bias: Optional[Sequence[int]] = None,
+                     out: Optional[DevArray] = None) -> DevArray:
+        """out[i*r+a] = bias[a] + sum_c matrix[a][c] * x[i*g+c] over groups of g = len(matrix[0]) consecutive
+        elements (public r x g matrix; np_aes affine layer, np_from_bits)."""
+        r, g = len(matrix), len(matrix[0])
+        if x.n % g:
+            raise ValueError('array length is not a multiple of the group size')
+        ng = x.n // g
+        out = out or self.empty(ng * r)
+        m = (ctypes.c_uint64 * (2 * r * g))()
+        for i, v in enumerate(v for row in matrix for v in row):
+            m[2 * i], m[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        b = None
+        if bias is not None:
+            b = (ctypes.c_uint64 * (2 * r))()
+            for i, v in enumerate(bias):
+                b[2 * i], b[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        _ffi.check(self._L.ffgpu_group_matvec(self._h, m, b, r, g, x.ptr, out.ptr, ng, self._stream()), 'group_matvec')
+        return out
+
     def _workspace(self):
         ws = getattr(self, '_ws', None)
         if ws is None:

@@ -881,6 +881,14 @@ class FieldArray:
             other = cls(other)
         elif other.field is not cls.field:
             raise TypeError('arrays over different fields')
+        if (self.ndim == 2 and other.ndim >= 3 and other._shape[-1] == 1 and other._shape[-2] == self._shape[1]
+                and max(self._shape) <= 16):
+            # small public matrix applied along the last axis of a batch: `A @ x[..., np.newaxis]`
+            # (demos/np_aes.py:40) -- one streaming pass, the matrix travels as kernel arguments
+            r, g = self._shape
+            A = [int(v) for v in self._dev.to_ints()]
+            out = self.ctx.group_matvec(other._dev, [A[i * g:(i + 1) * g] for i in range(r)])
+            return self._wrap(out, other._shape[:-2] + (r, 1))
         if self.ndim not in (1, 2) or other.ndim not in (1, 2):
             raise NotImplementedError('matmul of arrays with more than 2 dimensions is not accelerated')
         M, K = (1, self._shape[0]) if self.ndim == 1 else self._shape

@@ -391,3 +391,19 @@ def test_numpy_protocol(api):
         [int(v) for v in np.concatenate((nc, nc), axis=1).reshape(-1)]
     assert [int(v) for v in np.asarray(np.roll(C, 1, axis=1).value).reshape(-1)] == \
         [int(v) for v in np.roll(nc, 1, axis=1).reshape(-1)]
+
+
+def test_small_matrix_over_last_axis(api):
+    """`A @ x[..., np.newaxis]` (demos/np_aes.py:40): public 8x8 matrix over a batch of 8-vectors."""
+    import functools
+    from oracle.pyoracle import Field, mul
+    finfields, gfpx, _ = api
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    rng = random.Random(5)
+    A = [[rng.randrange(256) for _ in range(8)] for _ in range(8)]
+    x = [[rng.randrange(256) for _ in range(8)] for _ in range(300)]
+    y = F.array(A) @ F.array(x).reshape(300, 8, 1)
+    assert y.shape == (300, 8, 1)
+    Fo = Field(0x11b, True)
+    want = [functools.reduce(lambda s, c: s ^ mul(Fo, A[r][c], row[c]), range(8), 0) for row in x for r in range(8)]
+    assert ints(y) == want

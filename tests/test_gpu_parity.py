@@ -357,6 +357,58 @@ def test_dot_and_sum_reductions(eng, modulus, binary):
             assert unpack(ctx.dot(va, vb).to_numpy(), eb) == [w]
 
 
+def test_group_matvec_aes_affine_and_from_bits(eng, golden_sbox):
+    """Small public matrix over the last axis: (1) the AES S-box affine layer applied to SHARES of the
+    8 bits of x^254 followed by np_from_bits equals the S-box table when the 'shares' are the bits
+    themselves (m = 1), and stays linear on random GF(2^8) shares; (2) np_from_bits over a prime field;
+    (3) random matrices vs Python for P61 / P128 / GF(2^8)."""
+    F8 = po.Field(0x11b, True)
+    ctx = ctx_for(eng, 0x11b, True)
+    rows8, b8 = golden_sbox['rows8'], golden_sbox['b']
+    A = [[(rows8[r] >> c) & 1 for c in range(8)] for r in range(8)]
+    Bv = [(b8 >> r) & 1 for r in range(8)]
+    inv = golden_sbox['pow254']
+    bits = [(inv[v] >> j) & 1 for v in range(256) for j in range(8)]            # np_to_bits of x^254, shape (256, 8)
+    y = ctx.group_matvec(ctx.from_numpy(np.array(bits, dtype=np.uint8)), A, Bv)  # A @ bits + B
+    w = ctx.group_matvec(y, [[1 << j for j in range(8)]])                       # np_from_bits
+    assert unpack(w.to_numpy(), 1) == golden_sbox['table']
+    rng = random.Random(31)
+    x = [rng.randrange(256) for _ in range(8 * 5000)]
+    got = unpack(ctx.group_matvec(ctx.from_numpy(np.array(x, dtype=np.uint8)), A, Bv).to_numpy(), 1)
+    want = []
+    for i in range(5000):
+        for r in range(8):
+            acc = Bv[r]
+            for c in range(8):
+                if A[r][c]:
+                    acc ^= x[8 * i + c]
+            want.append(acc)
+    assert got == want
+    for modulus, binary in [(P61, False), (P128, False), (0x11b, True), (2**31 - 1, False)]:
+        F = po.Field(modulus, binary)
+        c2 = ctx_for(eng, modulus, binary)
+        eb = c2.elem_bytes
+        r_, g_, ng = 3, 5, 1203
+        M = [[rng.randrange(F.order) for _ in range(g_)] for _ in range(r_)]
+        bias = [rng.randrange(F.order) for _ in range(r_)]
+        X = rand_np(F, eb, g_ * ng, 611)
+        xs = unpack(X, eb)
+        got = unpack(c2.group_matvec(c2.from_numpy(X), M, bias).to_numpy(), eb)
+        want = []
+        for i in range(ng):
+            for a in range(r_):
+                acc = bias[a]
+                for c in range(g_):
+                    acc = po.add(F, acc, po.mul(F, M[a][c], xs[i * g_ + c]))
+                want.append(acc)
+        assert got == want, hex(modulus)
+        if not binary:                                                        # np_from_bits: sum_j x_j 2^j
+            l = 16
+            bitsv = [rng.randrange(F.order) for _ in range(l * 100)]
+            got = unpack(c2.group_matvec(c2.from_numpy(pack(bitsv, eb)), [[1 << j for j in range(l)]]).to_numpy(), eb)
+            assert got == [sum(bitsv[i * l + j] << j for j in range(l)) % modulus for i in range(100)]
+
+
 def test_beaver_combine(eng, coracle):
     """Beaver multiplication vs GRR resharing on the same inputs: both open to a*b.  (Parity UNPINNED:
     the reference has no Beaver triples; this checks the textbook identity only.)  Three simulated
