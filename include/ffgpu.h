@@ -197,6 +197,19 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
                  size_t M, size_t K, size_t N, void* stream);
 
+/* ---- Gaussian elimination ---------------------------------------------------- */
+/* In place on `batch` row-major (n x ncols) matrices stored back to back (ncols >= n).
+ * mode 0 (solve): (A | B) -> (. | A^-1 B), Gauss-Jordan; the solution occupies columns n..ncols-1.
+ * mode 1 (det):   forward elimination only; det_out[b] = product of the pivots chosen by the reference's
+ *                 rule (first nonzero entry at or below the diagonal; finfields.py:933-947 -- NB the
+ *                 reference does not negate on row swaps, and neither does this), 0 if singular.
+ * dev_singular: `batch` ints in device memory, set to 1 for singular matrices (whose contents are then
+ *               unspecified); the caller raises ZeroDivisionError('no inverse exists') (finfields.py:893).
+ * replaces: finfields.py:872-908 gauss_solve, :910-916 gauss_inv, :918-955 gauss_det
+ *           (np.linalg.solve / inv / det / matrix_power with negative exponent on field arrays).     */
+int ffgpu_gauss(ffgpu_ctx* ctx, void* a, int n, int ncols, size_t batch, int mode, void* det_out,
+                void* dev_singular, void* stream);
+
 /* ---- small public matrix over the last axis --------------------------------- */
 /* out[i*r + a] = bias[a] + sum_{c<g} M[a][c] * in[i*g + c]  for every group i of g consecutive elements
  * (r, g <= 16).  host_matrix: (r, g) canonical 2-limb scalars; host_bias: r scalars or NULL.

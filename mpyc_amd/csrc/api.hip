@@ -363,6 +363,42 @@ int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_l
     return launch_status(ctx->ops->pow(ctx->policy, ctx->device, a, &ex, out, n, (hipStream_t)stream));
 }
 
+// exponent q - 2 for x^-1 = x^(q-2); false for the two-element fields, where x^-1 = x
+static bool inverse_exponent(const ffgpu_ctx* ctx, ExpArgs* ex) {
+    ff_u128 q;
+    if (ctx->kind == FFGPU_PRIME) {
+        q = ff_make128(ctx->modulus[1], ctx->modulus[0]);
+    } else {
+        int deg = ctx->modulus[2] ? 128 : (ctx->modulus[1] ? 64 + (63 - __builtin_clzll(ctx->modulus[1]))
+                                                           : 63 - __builtin_clzll(ctx->modulus[0]));
+        q = deg == 128 ? (ff_u128)0 : ((ff_u128)1 << deg);
+    }
+    ff_u128 e = q - 2;
+    uint64_t el[2] = {ff_lo(e), ff_hi(e)};
+    make_exp(el, 2, ex);
+    if (ex->nbits == 0) {
+        ex->e[0] = 1;
+        ex->nbits = 1;
+        return false;
+    }
+    return true;
+}
+
+int ffgpu_gauss(ffgpu_ctx* ctx, void* a, int n, int ncols, size_t batch, int mode, void* det_out,
+                void* dev_singular, void* stream) {
+    ARGCHK(ctx && n >= 0 && ncols >= n && (mode == 0 || mode == 1));
+    if (batch == 0) return FFGPU_OK;
+    ARGCHK(dev_singular && (mode == 0 || det_out));
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a);
+    DeviceGuard g(ctx->device);
+    ExpArgs ex;
+    inverse_exponent(ctx, &ex);
+    if (hipMemsetAsync(dev_singular, 0, batch * sizeof(int), (hipStream_t)stream) != hipSuccess) return FFGPU_EHIP;
+    return launch_status(ctx->ops->gauss(ctx->policy, ctx->device, a, n, ncols, batch, mode, &ex,
+                                         mode ? det_out : nullptr, (int*)dev_singular, (hipStream_t)stream));
+}
+
 int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero_flag, void* stream) {
     ARGCHK(ctx);
     if (n == 0) return FFGPU_OK;

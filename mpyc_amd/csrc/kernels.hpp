@@ -525,6 +525,11 @@ FF_HD typename F::word ff_one(const F&) {
         return (typename F::word)1;
     }
 }
+template <class F>
+FF_HD typename F::word ff_one_elem(const F& f) {       // one in element 0 only (scalar paths of packed fields)
+    if constexpr (F::EPW == 4) return (typename F::word)1;
+    else return ff_one(f);
+}
 // zero elements are replaced by one (so that products stay invertible); zm remembers where
 template <class F>
 FF_HD typename F::word ff_zero_fix(const F&, typename F::word v, uint32_t& zm) {
@@ -976,6 +981,79 @@ __global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word
 }
 
 
+
+// ---- Gaussian elimination on a batch of (n x ncols) matrices, in place -----------------------------
+// finfields.py:872-955 (gauss_solve / gauss_inv / gauss_det behind np.linalg.solve / inv / det).
+// Two launches per pivot column k, for every matrix of the batch at once:
+//   k_gauss_pivot (one workgroup per matrix): first row x >= k with A[x][k] != 0 -- the reference's pivot
+//     rule, which fixes the swap count and hence its (unsigned) determinant --, swap rows
+//     k and x, scale row k by 1/pivot, det *= pivot; no such row: singular flag (det = 0), matrix skipped;
+//   k_gauss_elim (2-D grid): A[i][j] -= A[i][k] * A[k][j] for j > k and i != k (solve: Gauss-Jordan, the
+//     solution ends up in columns n..ncols-1) or i > k (det).
+// The result of solve/inv is unique, so the elimination order need not follow the reference's LU + back
+// substitution; the determinant follows its pivot rule exactly.
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_gauss_pivot(F f, typename F::elem* __restrict__ A, int n, int ncols, int k,
+                                                        ExpArgs ex, typename F::elem* __restrict__ det,
+                                                        int* __restrict__ sing) {
+    typedef typename F::word W;
+    const size_t b = blockIdx.x;
+    if (sing[b]) return;
+    typename F::elem* M = A + b * (size_t)n * ncols;
+    __shared__ int piv;
+    if (threadIdx.x == 0) piv = n;
+    __syncthreads();
+    for (int i = k + threadIdx.x; i < n; i += BLOCK) {
+        uint32_t zm;
+        ff_zero_fix(f, ld_elem<F>(M, (size_t)i * ncols + k), zm);
+        if (!(zm & 1)) {
+            atomicMin(&piv, i);
+            break;                                   // later rows of this thread are larger
+        }
+    }
+    __syncthreads();
+    const int x = piv;
+    if (x == n) {
+        if (threadIdx.x == 0) {
+            sing[b] = 1;
+            if (det) st_elem<F>(det, b, ld_elem<F>(M, (size_t)k * ncols + k));   // = 0
+        }
+        return;
+    }
+    const W pv = ld_elem<F>(M, (size_t)x * ncols + k);
+    const W inv = ff_pow(f, pv, ex);
+    __syncthreads();                                 // every thread has read the pivot before row x changes
+    for (int j = k + threadIdx.x; j < ncols; j += BLOCK) {
+        W a = ld_elem<F>(M, (size_t)k * ncols + j);
+        W c = ld_elem<F>(M, (size_t)x * ncols + j);
+        if (x != k) st_elem<F>(M, (size_t)x * ncols + j, a);
+        st_elem<F>(M, (size_t)k * ncols + j, j == k ? ff_one_elem(f) : f.mul(c, inv));
+    }
+    if (det && threadIdx.x == 0) st_elem<F>(det, b, k == 0 ? pv : f.mul(ld_elem<F>(det, b), pv));
+}
+
+template <class F, int TI>
+__global__ __launch_bounds__(BLOCK) void k_gauss_elim(F f, typename F::elem* __restrict__ A, int n, int ncols, int k,
+                                                       int lower_only, const int* __restrict__ sing) {
+    typedef typename F::word W;
+    const size_t b = blockIdx.z;
+    if (sing[b]) return;
+    typename F::elem* M = A + b * (size_t)n * ncols;
+    const int j = k + 1 + blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= ncols) return;
+    const int i0 = (lower_only ? k + 1 : 0) + blockIdx.y * TI;
+    const W r = ld_elem<F>(M, (size_t)k * ncols + j);
+#pragma unroll
+    for (int q = 0; q < TI; ++q) {
+        const int i = i0 + q;
+        if (i < n && i != k) {
+            W m = ld_elem<F>(M, (size_t)i * ncols + k);          // wave-uniform address: one broadcast load
+            W a = ld_elem<F>(M, (size_t)i * ncols + j);
+            st_elem<F>(M, (size_t)i * ncols + j, f.sub(a, f.mul(m, r)));
+        }
+    }
+}
+
 // ---- small public matrix applied to every group of g consecutive elements --------------------------
 // out[i*r + a] = bias[a] + sum_{c<g} M[a][c] * in[i*g + c],   a < r,  i < ngroups   (r, g <= 16)
 // The array-of-structs sibling of k_recombine: finfields `A @ x[..., np.newaxis]` with a public A
@@ -1052,6 +1130,8 @@ struct FieldOps {
                   size_t ldc, int M, int K, int N, hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
+    int (*gauss)(const void* F, int device, void* A, int n, int ncols, size_t batch, int det_mode, const ExpArgs* ex,
+                 void* det, int* sing, hipStream_t st);
     int (*group_matvec)(const void* F, int device, const uint64_t* m2, const uint64_t* bias2, int r, int g,
                         const void* in, void* out, size_t ngroups, hipStream_t st);
     int (*beaver)(const void* F, int device, const void* z, const void* x, const void* y, const void* d, const void* e,
@@ -1419,6 +1499,31 @@ struct Launchers {
         (void)lc;
         return 0;
     }
+    static int gauss(const void* Fp, int device, void* A, int n, int ncols, size_t batch, int det_mode,
+                     const ExpArgs* ex, void* det, int* sing, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        (void)device;
+        constexpr int TI = 4;
+        constexpr size_t ZMAX = 32768;                    // grid.z limit: larger batches go in chunks
+        for (size_t b0 = 0; b0 < batch; b0 += ZMAX) {
+            unsigned nb = (unsigned)(batch - b0 < ZMAX ? batch - b0 : ZMAX);
+            E* Ab = (E*)A + b0 * (size_t)n * ncols;
+            E* db = det ? (E*)det + b0 : nullptr;
+            for (int k = 0; k < n; ++k) {
+                hipLaunchKernelGGL((k_gauss_pivot<F>), dim3(nb), dim3(BLOCK), 0, st, f, Ab, n, ncols, k, *ex, db,
+                                   sing + b0);
+                int cols = ncols - k - 1;
+                int rows = det_mode ? n - k - 1 : n;
+                if (cols > 0 && rows > 0) {
+                    dim3 grid((cols + BLOCK - 1) / BLOCK, (rows + TI - 1) / TI, nb);
+                    hipLaunchKernelGGL((k_gauss_elim<F, TI>), grid, dim3(BLOCK), 0, st, f, Ab, n, ncols, k, det_mode,
+                                       sing + b0);
+                }
+            }
+        }
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
     static int group_matvec(const void* Fp, int device, const uint64_t* m2, const uint64_t* bias2, int r, int g,
                             const void* in, void* out, size_t ngroups, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
@@ -1472,7 +1577,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &group_matvec, &beaver, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &gauss, &group_matvec, &beaver, &prss};
         return &ops;
     }
 };

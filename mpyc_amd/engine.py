@@ -399,6 +399,18 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
         return out
 
+    def gauss(self, a: DevArray, n: int, ncols: int, batch: int = 1, det: bool = False):
+        """Gaussian elimination in place on `batch` row-major (n, ncols) matrices (finfields.py:872-955).
+        det=False: (A | B) -> (. | A^-1 B).  det=True: returns the reference's determinant per matrix.
+        Returns (det DevArray or None, singular flags as an int32 tensor on the device)."""
+        if a.n != batch * n * ncols:
+            raise ValueError('array size does not match (batch, n, ncols)')
+        sing = torch.empty(max(batch, 1), dtype=torch.int32, device=self.torch_device)
+        d = self.empty(batch) if det else None
+        _ffi.check(self._L.ffgpu_gauss(self._h, a.ptr, n, ncols, batch, 1 if det else 0, d.ptr if det else None,
+                                       sing.data_ptr(), self._stream()), 'gauss')
+        return d, sing
+
     def group_matvec(self, x: DevArray, matrix: Sequence[Sequence[int]], bias: Optional[Sequence[int]] = None,
                      out: Optional[DevArray] = None) -> DevArray:
         """out[i*r+a] = bias[a] + sum_c matrix[a][c] * x[i*g+c] over groups of g = len(matrix[0]) consecutive

@@ -947,6 +947,73 @@ class FieldArray:
             raise NotImplementedError('sum along an axis is not accelerated')
         return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
 
+    # ---- linear algebra (finfields.py:872-978) --------------------------------------------------
+    @classmethod
+    def _eye(cls, n):
+        ctx = _context(cls.field)
+        e = ctx.empty(n * n)
+        e.t.zero_()
+        v = e.t.view(n, n, 2)[..., 0] if ctx.elem_bytes == 16 else e.t.view(n, n)
+        v.fill_diagonal_(1)
+        return cls._wrap(e, (n, n))
+
+    @staticmethod
+    def gauss_solve(A, B):
+        """np.linalg.solve: Gauss-Jordan on (A | B) on the device (finfields.py:872-908)."""
+        cls = type(A)
+        n = A.shape[0] if A.ndim else 0
+        if A.shape != (n, n):
+            raise np.linalg.LinAlgError('array must be square')
+        if not isinstance(B, FieldArray):
+            B = cls(B)
+        if B.ndim != 2 or B.shape[0] != n:
+            raise ValueError('right-hand side must be a 2-D array with as many rows as A')
+        if n == 0:
+            return B.copy()
+        aug = A._from_limb_view(torch.cat([A._limb_view(), B._limb_view()], dim=1))
+        _, sing = A.ctx.gauss(aug._dev, n, n + B.shape[1], 1)
+        if int(sing[0]):
+            raise ZeroDivisionError('no inverse exists')
+        return A._from_limb_view(aug._limb_view()[:, n:])
+
+    @staticmethod
+    def gauss_inv(A):
+        """np.linalg.inv (finfields.py:910-916)."""
+        return FieldArray.gauss_solve(A, type(A)._eye(len(A)))
+
+    @staticmethod
+    def gauss_det(a):
+        """np.linalg.det over the last two dimensions (finfields.py:918-955): product of the pivots under
+        the reference's pivot rule (it does not flip the sign on row swaps; neither does this)."""
+        cls = type(a)
+        if a.ndim < 2 or a.shape[-2] != a.shape[-1]:
+            return np.linalg.det(np.empty(a.shape))          # NumPy's own error message
+        n = a.shape[-1]
+        batch = a.size // (n * n) if n else int(np.prod(a.shape[:-2], dtype=np.int64))
+        if n == 0:
+            d = cls(np.ones(a.shape[:-2], dtype=object))
+            return cls.field(1) if a.ndim == 2 else d
+        if batch == 0:
+            return cls(np.empty(a.shape[:-2], dtype=object))
+        d, _ = a.ctx.gauss(a.copy()._dev, n, n, batch, det=True)
+        if a.ndim == 2:
+            return cls.field(d.to_ints()[0])
+        return cls._wrap(d, a.shape[:-2])
+
+    @staticmethod
+    def matrix_pow(A, n):
+        """np.linalg.matrix_power, negative n through the inverse (finfields.py:957-978)."""
+        cls = type(A)
+        if n < 0:
+            A, n = FieldArray.gauss_inv(A), -n
+        C, D = cls._eye(len(A)), A
+        for i in range(n.bit_length()):
+            if (n >> i) & 1:
+                C = C @ D
+            if i + 1 < n.bit_length():
+                D = D @ D
+        return C
+
     # ---- NumPy protocol (finfields.py:728-819): data movement on the device limb tensors, arithmetic
     #      through the kernels; anything not listed raises instead of silently computing on the host ----
     def __array__(self, dtype=None, copy=None):
@@ -1092,5 +1159,7 @@ _ARRAY_FUNCTIONS = {
     'roll': _np_roll, 'flip': _np_flip,
     'sum': lambda a, axis=None, **kw: a.sum(axis),
     'dot': lambda a, b: a @ b, 'matmul': lambda a, b: a @ b,
+    'solve': FieldArray.gauss_solve, 'inv': FieldArray.gauss_inv, 'det': FieldArray.gauss_det,
+    'matrix_power': FieldArray.matrix_pow,
     'negative': lambda a: -a, 'add': lambda a, b: a + b, 'subtract': lambda a, b: a - b, 'multiply': lambda a, b: a * b,
 }

@@ -126,6 +126,71 @@ def vec(op, F: Field, a: Sequence[int], b: Sequence[int]) -> List[int]:
 
 
 # --------------------------------------------------------------------------
+# Gaussian elimination (finfields.py:872-955)
+# --------------------------------------------------------------------------
+def gauss_solve(F: Field, A: Sequence[Sequence[int]], B: Sequence[Sequence[int]]) -> List[List[int]]:
+    """finfields.py:872-908: LU in place with the reciprocal of the pivot stored on the diagonal, first
+    nonzero entry at or below the diagonal as pivot, back substitution.  Raises ZeroDivisionError."""
+    n = len(A)
+    M = [list(ra) + list(rb) for ra, rb in zip(A, B)]
+    for k in range(n):
+        if M[k][k] == 0:                                           # :885-893
+            for x in range(k + 1, n):
+                if M[x][k] != 0:
+                    break
+            else:
+                raise ZeroDivisionError('no inverse exists')
+            M[k], M[x] = M[x], M[k]
+        M[k][k] = inv(F, M[k][k])                                  # :894
+        for i in range(k + 1, n):                                  # :895-896
+            M[i][k] = mul(F, M[i][k], M[k][k])
+            for j in range(k + 1, len(M[i])):
+                M[i][j] = sub(F, M[i][j], mul(F, M[i][k], M[k][j]))
+    for i in range(n - 1, -1, -1):                                 # :899-901
+        for j in range(n, len(M[i])):
+            acc = M[i][j]
+            for c in range(i + 1, n):
+                acc = sub(F, acc, mul(F, M[i][c], M[c][j]))
+            M[i][j] = mul(F, acc, M[i][i])
+    return [row[n:] for row in M]
+
+
+def gauss_det(F: Field, A: Sequence[Sequence[int]]) -> int:
+    """finfields.py:931-949: product of the pivots; row swaps do NOT change the sign (reference behaviour)."""
+    n = len(A)
+    M = [list(r) for r in A]
+    for k in range(n):
+        if M[k][k] == 0:
+            for x in range(k + 1, n):
+                if M[x][k] != 0:
+                    break
+            else:
+                return 0
+            M[k], M[x] = M[x], M[k]
+        inv_k = inv(F, M[k][k])
+        for i in range(k + 1, n):
+            M[i][k] = mul(F, M[i][k], inv_k)
+            for j in range(k + 1, n):
+                M[i][j] = sub(F, M[i][j], mul(F, M[i][k], M[k][j]))
+    d = 1
+    for k in range(n):
+        d = mul(F, d, M[k][k])
+    return d
+
+
+def matmul(F: Field, A, B):
+    """finfields.py:1126-1135."""
+    return [[_dot(F, ra, [rb[j] for rb in B]) for j in range(len(B[0]))] for ra in A]
+
+
+def _dot(F: Field, a, b):
+    acc = 0
+    for x, y in zip(a, b):
+        acc = add(F, acc, mul(F, x, y))
+    return acc
+
+
+# --------------------------------------------------------------------------
 # Shamir share generation
 # --------------------------------------------------------------------------
 def np_random_split(F: Field, s: Sequence[int], t: int, m: int, draws: Sequence[int]) -> List[List[int]]:

@@ -322,7 +322,61 @@ def matmul_cases():
     print('wrote matmul.json', os.path.getsize(os.path.join(OUT, 'matmul.json')))
 
 
+def linalg_cases():
+    """np.linalg.det / inv / solve / matrix_power from the reference (finfields.py:872-978;
+    tests/test_finfields.py:405-431), incl. matrices that need row swaps (zero pivots) and singular ones."""
+    import numpy as np
+    r = random.Random(77)
+    out = {}
+    for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P128', finfields.GF(P128)),
+                    ('P128G', finfields.GF(P128G)), ('P63G', finfields.GF(P63G)), ('GF19', finfields.GF(19)),
+                    ('GF2', finfields.GF(2)), ('P31', finfields.GF(P31)),
+                    ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))), ('GF2_64', finfields.GF(GF2X(BINARIES['GF2_64']))),
+                    ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
+        q = F.order
+        cases = []
+        for n, kind in ((1, 'rand'), (2, 'swap'), (3, 'rand'), (3, 'swap'), (4, 'singular'), (5, 'swap2'), (6, 'rand'),
+                        (9, 'rand'), (3, 'zero')):
+            A = [[r.randrange(q) for _ in range(n)] for _ in range(n)]
+            if kind.startswith('swap'):
+                A[0][0] = 0
+                if n > 2:
+                    A[1][0] = 0                    # first usable pivot is two rows down
+                if kind == 'swap2' and n > 3:
+                    A[3][3] = 0
+            elif kind == 'singular':
+                A[n - 1] = [int(v) for v in (F.array(A[0]) + F.array(A[1])).value]    # dependent row
+            elif kind == 'zero':
+                A = [[0] * n for _ in range(n)]
+            a = F.array(A)
+            B = [[r.randrange(q) for _ in range(2)] for _ in range(n)]
+            case = {'n': n, 'kind': kind, 'A': [hxl(row) for row in A], 'B': [hxl(row) for row in B],
+                    'det': hx(np.linalg.det(a))}
+            try:
+                case['inv'] = [hxl(int(x) for x in row) for row in np.linalg.inv(a).value]
+                case['solve'] = [hxl(int(x) for x in row) for row in np.linalg.solve(a, F.array(B)).value]
+                case['pow_m3'] = [hxl(int(x) for x in row) for row in np.linalg.matrix_power(a, -3).value]
+            except ZeroDivisionError as exc:
+                case['error'] = str(exc)
+            case['pow5'] = [hxl(int(x) for x in row) for row in np.linalg.matrix_power(a, 5).value]
+            cases.append(case)
+        stack = [[[r.randrange(q) for _ in range(3)] for _ in range(3)] for _ in range(4)]
+        stack[2][0][0] = 0
+        stack[3][2] = stack[3][1]
+        dets = np.linalg.det(F.array(stack).reshape(2, 2, 3, 3))
+        out[name] = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int), 'cases': cases,
+                     'stack': [[hxl(row) for row in m] for m in stack],
+                     'stack_det': [hxl(int(x) for x in row) for row in dets.value]}
+    with open(os.path.join(OUT, 'linalg.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote linalg.json', os.path.getsize(os.path.join(OUT, 'linalg.json')))
+
+
 if __name__ == '__main__':
+    if 'linalg' in sys.argv[1:]:
+        linalg_cases()
+        sys.exit(0)
     main()
     prss_cases()
     matmul_cases()
+    linalg_cases()

@@ -407,3 +407,38 @@ def test_small_matrix_over_last_axis(api):
     Fo = Field(0x11b, True)
     want = [functools.reduce(lambda s, c: s ^ mul(Fo, A[r][c], row[c]), range(8), 0) for row in x for r in range(8)]
     assert ints(y) == want
+
+
+def test_linalg_golden(api):
+    """np.linalg.det / inv / solve / matrix_power on GPU field arrays vs the reference's outputs
+    (tests/test_finfields.py:405-431 use the same entry points)."""
+    import json
+    import os
+    finfields, gfpx, _ = api
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'linalg.json')))
+    for name, fc in g.items():
+        modulus = int(fc['modulus'], 16)
+        F = finfields.GF(gfpx.BinaryPolynomial(modulus)) if fc['binary'] else finfields.GF(modulus)
+        red = lambda v: int(v, 16) if fc['binary'] else int(v, 16) % modulus
+        mat = lambda m: [[red(v) for v in row] for row in m]
+        for c in fc['cases']:
+            a = F.array(mat(c['A']))
+            d = np.linalg.det(a)
+            assert isinstance(d, F) and int(d) % F.order == red(c['det']) % F.order if not fc['binary'] else int(d) == red(c['det'])
+            assert ints(np.linalg.matrix_power(a, 5)) == [v for row in mat(c['pow5']) for v in row], (name, c['kind'])
+            if 'error' in c:
+                with pytest.raises(ZeroDivisionError, match='no inverse exists'):
+                    np.linalg.inv(a)
+                continue
+            assert ints(np.linalg.inv(a)) == [v for row in mat(c['inv']) for v in row]
+            x = np.linalg.solve(a, F.array(mat(c['B'])))
+            assert x.shape == (c['n'], 2) and ints(x) == [v for row in mat(c['solve']) for v in row]
+            assert ints(np.linalg.matrix_power(a, -3)) == [v for row in mat(c['pow_m3']) for v in row]
+            assert ints(a @ np.linalg.inv(a)) == [int(i == j) for i in range(c['n']) for j in range(c['n'])]
+        st = F.array([mat(m) for m in fc['stack']]).reshape(2, 2, 3, 3)
+        dets = np.linalg.det(st)
+        assert dets.shape == (2, 2) and ints(dets) == [red(v) for row in fc['stack_det'] for v in row]
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.det(F.array([[1, 2, 3], [4, 5, 6]]))
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.inv(F.array([[1, 2, 3], [4, 5, 6]]))

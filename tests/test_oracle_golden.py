@@ -1,5 +1,6 @@
 """Pin the oracle (oracle/pyoracle.py, oracle/fforacle.c) to the REAL reference:
 tests/golden/*.json were produced by tests/golden/make_golden.py running lschoe/mpyc."""
+import pytest
 import json
 import os
 
@@ -137,3 +138,26 @@ def test_c_oracle_threads(coracle):
     coracle.set_threads(1)
     assert (one == many).all()
     assert [int(v) for v in one[:50]] == [int(x) * int(y) % p for x, y in zip(a[:50], b[:50])]
+
+
+def test_py_linalg():
+    """np.linalg.det / inv / solve of the reference (tests/golden/linalg.json) vs the restatement."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'linalg.json')))
+    for name, fc in g.items():
+        F = po.Field(int(fc['modulus'], 16), fc['binary'])
+        ux = lambda m: [[int(v, 16) for v in row] for row in m]
+        red = lambda v: int(v, 16) if fc['binary'] else int(v, 16) % F.modulus
+        for c in fc['cases']:
+            A, B = ux(c['A']), ux(c['B'])
+            assert po.gauss_det(F, A) == red(c['det']), (name, c['kind'])
+            if 'error' in c:
+                with pytest.raises(ZeroDivisionError, match='no inverse exists'):
+                    po.gauss_solve(F, A, B)
+                continue
+            eye = [[int(i == j) for j in range(c['n'])] for i in range(c['n'])]
+            assert po.gauss_solve(F, A, eye) == [[red(v) for v in row] for row in c['inv']], (name, c['kind'])
+            assert po.gauss_solve(F, A, B) == [[red(v) for v in row] for row in c['solve']], (name, c['kind'])
+        dets = [red(v) for row in fc['stack_det'] for v in row]
+        assert [po.gauss_det(F, ux(m)) for m in fc['stack']] == dets
