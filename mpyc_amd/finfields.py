@@ -943,9 +943,37 @@ class FieldArray:
 
     def sum(self, axis=None):
         """Sum of all elements as a field element (np.sum on a field array, finfields.py:766-819)."""
-        if axis is not None:
-            raise NotImplementedError('sum along an axis is not accelerated')
-        return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
+        if axis is None or self.ndim == 1:
+            return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
+        # reduce one axis: move it last, then (rows, k) @ ones(k) through the product kernel
+        axis = axis if axis >= 0 else axis + self.ndim
+        moved = _np_movement(np.moveaxis, (self, axis, -1), {})
+        k = moved.shape[-1]
+        rows = moved.size // k if k else 0
+        if k == 0:
+            return type(self)(np.zeros(moved.shape[:-1], dtype=object))
+        ones = type(self)._wrap(self.ctx.from_ints([1] * k), (k,))
+        return (moved.reshape(rows, k) @ ones).reshape(moved.shape[:-1])
+
+    def prod(self):
+        """Product of all elements (finfields.py:1339-1349): log2(n) halving passes of the mul kernel."""
+        cls, ctx = type(self), self.ctx
+        if self.size == 0:
+            return cls.field(1)
+        cur, n = self._dev, self.size
+        while n > 1:
+            h = n // 2
+            lo = DevArray(ctx, cur.t[:h], h)
+            hi = DevArray(ctx, cur.t[h:2 * h], h)
+            nxt = ctx.empty(h + (n & 1))
+            ctx.mul(lo, hi, out=DevArray(ctx, nxt.t[:h], h))
+            if n & 1:
+                nxt.t[h:].copy_(cur.t[2 * h:])
+            cur, n = nxt, h + (n & 1)
+        return cls.field(cur.to_ints()[0])
+
+    def trace(self, offset=0):
+        return _np_movement(np.diagonal, (self, offset), {}).sum()
 
     # ---- linear algebra (finfields.py:872-978) --------------------------------------------------
     @classmethod
@@ -1046,6 +1074,8 @@ class FieldArray:
 
     def __array_function__(self, func, types, args, kwargs):
         impl = _ARRAY_FUNCTIONS.get(func.__name__)
+        if impl is None and func.__name__ in _MOVEMENT_FUNCTIONS:
+            return _np_movement(func, args, kwargs)
         if impl is None:
             raise NotImplementedError(f'numpy.{func.__name__} is not supported on GPU field arrays')
         return impl(*args, **kwargs)
@@ -1148,6 +1178,123 @@ def _np_flip(a, axis=None):
     return a._from_limb_view(torch.flip(a._limb_view(), dims=dims))
 
 
+
+# ---- generic data-movement functions ------------------------------------------------------------------
+# The reference lets NumPy run any function on the object array and re-wraps the result
+# (finfields.py:766-819).  For functions that only MOVE elements (no arithmetic) the same generality comes
+# from running the NumPy function on int64 INDEX arrays on the host (index 0 = the zero element, so tril /
+# diag / pad work) and gathering on the device with the resulting index array.
+_MOVEMENT_FUNCTIONS = frozenset((
+    'reshape', 'ravel', 'transpose', 'swapaxes', 'moveaxis', 'rollaxis', 'squeeze', 'expand_dims',
+    'atleast_1d', 'atleast_2d', 'atleast_3d', 'concatenate', 'stack', 'vstack', 'hstack', 'dstack',
+    'column_stack', 'block', 'split', 'array_split', 'vsplit', 'hsplit', 'dsplit', 'tile', 'repeat', 'flip',
+    'fliplr', 'flipud', 'roll', 'rot90', 'take', 'take_along_axis', 'diag', 'diagonal', 'diagflat', 'tril',
+    'triu', 'delete', 'append', 'broadcast_to', 'compress', 'pad', 'where', 'copy', 'resize', 'select', 'choose'))
+
+
+def _np_movement(func, args, kwargs):
+    name = func.__name__
+    if name == 'pad' and ('constant_values' in kwargs or 'end_values' in kwargs or len(args) > 3):
+        raise NotImplementedError('np.pad on GPU field arrays: only zero / element-copy padding')
+    pool, state = [], {'offset': 1, 'cls': None}
+
+    def find_cls(x):
+        if isinstance(x, FieldArray):
+            return type(x)
+        if isinstance(x, (list, tuple)):
+            for y in x:
+                c = find_cls(y)
+                if c is not None:
+                    return c
+        return None
+
+    cls = find_cls(args) or find_cls(tuple(kwargs.values()))
+
+    def index_of(x):
+        idx = np.arange(state['offset'], state['offset'] + x.size, dtype=np.int64).reshape(x.shape)
+        pool.append(x)
+        state['offset'] += x.size
+        return idx
+
+    def sub(x, inside=False):
+        if isinstance(x, FieldArray):
+            if x.field is not cls.field:
+                raise TypeError('arrays over different fields')
+            return index_of(x)
+        if isinstance(x, (list, tuple)) and find_cls(x) is not None:
+            return type(x)(sub(y, True) for y in x)
+        if inside and not isinstance(x, FieldArray):
+            return index_of(cls(x))                       # plain ints / lists next to field arrays
+        return x
+
+    args = list(args)
+    if name == 'append' and len(args) > 1 and not isinstance(args[1], FieldArray):
+        args[1] = cls(args[1])
+    if name == 'where' and len(args) == 3:
+        args[1:] = [a if isinstance(a, FieldArray) else cls(a) for a in args[1:]]
+    iargs = [sub(a) for a in args]
+    ikw = {k: sub(v) for k, v in kwargs.items()}
+    res = func(*iargs, **ikw)
+    ctx = pool[0].ctx
+    eb = ctx.elem_bytes
+    flats = [p._dev.t.reshape(-1, 2) if eb == 16 else p._dev.t.reshape(-1) for p in pool]
+    zero = torch.zeros((1, 2) if eb == 16 else (1,), dtype=flats[0].dtype, device=flats[0].device)
+    table = torch.cat([zero] + flats)
+
+    def back(r):
+        if isinstance(r, np.ndarray):
+            idx = torch.from_numpy(np.ascontiguousarray(r, dtype=np.int64).reshape(-1)).to(table.device)
+            t = table.index_select(0, idx)
+            return cls._wrap(DevArray(ctx, t, idx.shape[0]), tuple(r.shape))
+        if isinstance(r, (list, tuple)):
+            return type(r)(back(y) for y in r)
+        if isinstance(r, (int, np.integer)):
+            return cls.field(DevArray(ctx, table[int(r):int(r) + 1], 1).to_ints()[0])
+        return r
+
+    return back(res)
+
+
+def _np_outer(a, b):
+    cls = type(a) if isinstance(a, FieldArray) else type(b)
+    a = a if isinstance(a, FieldArray) else cls(a)
+    b = b if isinstance(b, FieldArray) else cls(b)
+    return a.reshape(-1, 1) * b.reshape(1, -1)
+
+
+def _np_convolve(a, v, mode='full'):
+    """np.convolve over the field (runtime.np_convolve's local part, runtime.py:2580): Toeplitz gather of
+    the longer operand (index 0 = zero element) times the shorter one through the product kernel."""
+    cls = type(a) if isinstance(a, FieldArray) else type(v)
+    a = a if isinstance(a, FieldArray) else cls(a)
+    v = v if isinstance(v, FieldArray) else cls(v)
+    if a.ndim != 1 or v.ndim != 1 or a.size == 0 or v.size == 0:
+        raise ValueError('convolve: 1-D non-empty arrays required')
+    if a.size < v.size:
+        a, v = v, a
+    na, nv = a.size, v.size
+    k = np.arange(na + nv - 1, dtype=np.int64)[:, None] - np.arange(nv, dtype=np.int64)[None, :]
+    idx = np.where((k >= 0) & (k < na), k + 1, 0)                    # T[k][j] = a[k - j]
+    ctx, eb = a.ctx, a.ctx.elem_bytes
+    flat = a._dev.t.reshape(-1, 2) if eb == 16 else a._dev.t.reshape(-1)
+    zero = torch.zeros((1, 2) if eb == 16 else (1,), dtype=flat.dtype, device=flat.device)
+    t = torch.cat([zero, flat]).index_select(0, torch.from_numpy(idx.reshape(-1)).to(flat.device))
+    T = cls._wrap(DevArray(ctx, t, idx.size), idx.shape)
+    full = T @ v
+    if mode == 'full':
+        return full
+    if mode == 'same':
+        lo = (nv - 1) // 2
+        return full[lo:lo + na]
+    if mode == 'valid':
+        return full[nv - 1:na]
+    raise ValueError("mode must be 'full', 'same' or 'valid'")
+
+
+def _np_nonzero_mask(a):
+    return (~a._zero_mask()).cpu().numpy().reshape(a.shape)
+
+
 _ARRAY_FUNCTIONS = {
     'shape': lambda a: a.shape, 'ndim': lambda a: a.ndim, 'size': lambda a: a.size,
     'reshape': lambda a, *shape, **kw: a.reshape(*shape if shape else (kw.get('newshape', kw.get('shape')),)),
@@ -1159,6 +1306,12 @@ _ARRAY_FUNCTIONS = {
     'roll': _np_roll, 'flip': _np_flip,
     'sum': lambda a, axis=None, **kw: a.sum(axis),
     'dot': lambda a, b: a @ b, 'matmul': lambda a, b: a @ b,
+    'outer': _np_outer, 'convolve': _np_convolve, 'prod': lambda a, axis=None, **kw: a.prod(),
+    'trace': lambda a, offset=0, **kw: a.trace(offset),
+    'nonzero': lambda a: np.nonzero(_np_nonzero_mask(a)), 'flatnonzero': lambda a: np.flatnonzero(_np_nonzero_mask(a)),
+    'count_nonzero': lambda a, **kw: int(np.count_nonzero(_np_nonzero_mask(a))),
+    'any': lambda a, **kw: bool(_np_nonzero_mask(a).any()), 'all': lambda a, **kw: bool(_np_nonzero_mask(a).all()),
+    'array_equal': lambda a, b: a.shape == np.shape(b) and bool((a == b).all()),
     'solve': FieldArray.gauss_solve, 'inv': FieldArray.gauss_inv, 'det': FieldArray.gauss_det,
     'matrix_power': FieldArray.matrix_pow,
     'negative': lambda a: -a, 'add': lambda a, b: a + b, 'subtract': lambda a, b: a - b, 'multiply': lambda a, b: a * b,

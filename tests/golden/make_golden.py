@@ -372,7 +372,37 @@ def linalg_cases():
     print('wrote linalg.json', os.path.getsize(os.path.join(OUT, 'linalg.json')))
 
 
+def npfunc_cases():
+    """NumPy functions with arithmetic routed through __array_function__ (finfields.py:766-819, 1332-1356):
+    convolve (runtime.np_convolve's local part), outer, prod, trace, sum along an axis."""
+    import numpy as np
+    r = random.Random(78)
+    out = {}
+    for name, F in (('P61', finfields.GF(P61)), ('P128', finfields.GF(P128)), ('GF19', finfields.GF(19)),
+                    ('P31', finfields.GF(P31)), ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))),
+                    ('GF2_64', finfields.GF(GF2X(BINARIES['GF2_64'])))):
+        q = F.order
+        a = [r.randrange(q) for _ in range(9)]
+        v = [r.randrange(q) for _ in range(4)]
+        m = [[r.randrange(q) for _ in range(5)] for _ in range(3)]
+        fa, fv, fm = F.array(a), F.array(v), F.array(m)
+        L = lambda x: hxl(int(e) for e in np.asarray(x.value).reshape(-1))
+        out[name] = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int),
+                     'a': hxl(a), 'v': hxl(v), 'm': [hxl(row) for row in m],
+                     'conv_full': L(np.convolve(fa, fv)), 'conv_same': L(np.convolve(fa, fv, 'same')),
+                     'conv_valid': L(np.convolve(fa, fv, 'valid')), 'conv_swapped': L(np.convolve(fv, fa)),
+                     'outer': L(np.outer(fa, fv)), 'prod': hx(np.prod(fa)), 'prod_m': hx(fm.prod()),
+                     'trace': hx(np.trace(fm)), 'sum0': L(np.sum(fm, axis=0)), 'sum1': L(fm.sum(axis=1)),
+                     'sum': hx(np.sum(fm))}
+    with open(os.path.join(OUT, 'npfuncs.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote npfuncs.json', os.path.getsize(os.path.join(OUT, 'npfuncs.json')))
+
+
 if __name__ == '__main__':
+    if 'npfuncs' in sys.argv[1:]:
+        npfunc_cases()
+        sys.exit(0)
     if 'linalg' in sys.argv[1:]:
         linalg_cases()
         sys.exit(0)
@@ -380,3 +410,4 @@ if __name__ == '__main__':
     prss_cases()
     matmul_cases()
     linalg_cases()
+    npfunc_cases()

@@ -442,3 +442,74 @@ def test_linalg_golden(api):
         np.linalg.det(F.array([[1, 2, 3], [4, 5, 6]]))
     with pytest.raises(np.linalg.LinAlgError):
         np.linalg.inv(F.array([[1, 2, 3], [4, 5, 6]]))
+
+
+def test_numpy_functions_golden(api):
+    """convolve / outer / prod / trace / sum(axis) on GPU field arrays vs the reference's outputs."""
+    import json
+    import os
+    finfields, gfpx, _ = api
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'npfuncs.json')))
+    for name, c in g.items():
+        modulus = int(c['modulus'], 16)
+        F = finfields.GF(gfpx.BinaryPolynomial(modulus)) if c['binary'] else finfields.GF(modulus)
+        red = lambda v: int(v, 16) if c['binary'] else int(v, 16) % modulus
+        L = lambda key: [red(v) for v in c[key]]
+        a, v, m = F.array(L('a')), F.array(L('v')), F.array([[red(x) for x in row] for row in c['m']])
+        assert ints(np.convolve(a, v)) == L('conv_full'), name
+        assert ints(np.convolve(a, v, 'same')) == L('conv_same')
+        assert ints(np.convolve(a, v, 'valid')) == L('conv_valid')
+        assert ints(np.convolve(v, a)) == L('conv_swapped')
+        o = np.outer(a, v)
+        assert o.shape == (9, 4) and ints(o) == L('outer')
+        val = lambda e: int(e) % modulus if not c['binary'] else int(e)
+        assert val(np.prod(a)) == red(c['prod']) and val(m.prod()) == red(c['prod_m'])
+        assert val(np.trace(m)) == red(c['trace']) and val(np.sum(m)) == red(c['sum'])
+        assert ints(np.sum(m, axis=0)) == L('sum0') and ints(m.sum(axis=1)) == L('sum1')
+
+
+def test_numpy_movement_functions(api):
+    """Pure data-movement NumPy functions: the reference applies NumPy to the object array
+    (finfields.py:766-819), so NumPy on the plain values is the expected result."""
+    finfields, gfpx, _ = api
+    rng = random.Random(9)
+    for F in (finfields.GF(2**61 - 1), finfields.GF(gfpx.GFpX(2)(0x11b)), finfields.GF(2**127 - 1)):
+        q = F.order
+        A = np.array([[rng.randrange(q) for _ in range(4)] for _ in range(3)], dtype=object)
+        B = np.array([[rng.randrange(q) for _ in range(4)] for _ in range(3)], dtype=object)
+        v = np.array([rng.randrange(q) for _ in range(5)], dtype=object)
+        a, b, w = F.array(A), F.array(B), F.array(v)
+
+        def same(got, want):
+            want = np.asarray(want, dtype=object)
+            assert got.shape == want.shape, (got.shape, want.shape)
+            assert ints(got) == [int(x) for x in want.reshape(-1)]
+
+        same(np.tile(a, (2, 3)), np.tile(A, (2, 3)))
+        same(np.repeat(a, 2, axis=1), np.repeat(A, 2, axis=1))
+        same(np.tril(a), np.tril(A))
+        same(np.triu(a, 1), np.triu(A, 1))
+        same(np.diag(w), np.diag(v))
+        same(np.diag(a), np.diag(A))
+        same(np.diagonal(a, 1), np.diagonal(A, 1))
+        same(np.block([[a, b], [b, a]]), np.block([[A, B], [B, A]]))
+        same(np.dstack((a, b)), np.dstack((A, B)))
+        same(np.column_stack((w, w)), np.column_stack((v, v)))
+        same(np.take(a, [0, 3, 5, 11]), np.take(A, [0, 3, 5, 11]))
+        same(np.delete(w, 2), np.delete(v, 2))
+        same(np.append(w, [1, 2]), np.append(v, [1, 2]))
+        same(np.rot90(a), np.rot90(A))
+        same(np.swapaxes(a, 0, 1), np.swapaxes(A, 0, 1))
+        same(np.expand_dims(w, 0), np.expand_dims(v, 0))
+        same(np.pad(w, (1, 2)), np.pad(v, (1, 2)))
+        same(np.where(np.arange(12).reshape(3, 4) % 2 == 0, a, b), np.where(np.arange(12).reshape(3, 4) % 2 == 0, A, B))
+        same(np.broadcast_to(w, (2, 5)), np.broadcast_to(v, (2, 5)))
+        parts = np.hsplit(a, 2)
+        assert isinstance(parts, (list, tuple)) and len(parts) == 2
+        same(parts[1], np.hsplit(A, 2)[1])
+        same(np.concatenate((a, [[1, 2, 3, 4]]), axis=0), np.concatenate((A, [[1, 2, 3, 4]]), axis=0))
+        z = F.array([0, 3, 0, 7])
+        assert list(np.flatnonzero(z)) == [1, 3] and np.count_nonzero(z) == 2 and np.any(z) and not np.all(z)
+        assert np.array_equal(a, F.array(A)) and not np.array_equal(a, b)
+        with pytest.raises(NotImplementedError):
+            np.cumsum(a)
