@@ -197,6 +197,13 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
                  size_t M, size_t K, size_t N, void* stream);
 
+/* ---- square roots, p = 1 (mod 4) --------------------------------------------- */
+/* out[i] = the square root the reference returns for a[i] (Cipolla-Lehmer with the smallest b such that
+ * b^2 - 4a is a non-residue; 0 for a = 0).  Primes p = 3 (mod 4) and GF(2^n) take ffgpu_pow with the
+ * exponents (p+1)/4 resp. q/2; FFGPU_ENOTSUP for those here.
+ * replaces: finfields.py:447-470 (PrimeFieldElement._sqrt) mapped over arrays by :1459-1460.          */
+int ffgpu_sqrt_cl(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream);
+
 /* ---- Gaussian elimination ---------------------------------------------------- */
 /* In place on `batch` row-major (n x ncols) matrices stored back to back (ncols >= n).
  * mode 0 (solve): (A | B) -> (. | A^-1 B), Gauss-Jordan; the solution occupies columns n..ncols-1.

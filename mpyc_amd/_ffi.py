@@ -62,6 +62,7 @@ _SIGS = {
     'ffgpu_mul_split_rng': [_vp, _vp, _vp, ctypes.c_char_p, ctypes.c_uint64, _int, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_recombine': [_vp, ctypes.POINTER(_vp), _u64p, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_matmul': [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _sz, _sz, _sz, _vp],
+    'ffgpu_sqrt_cl': [_vp, _vp, _vp, _sz, _vp],
     'ffgpu_gauss': [_vp, _vp, _int, _int, _sz, _int, _vp, _vp, _vp],
     'ffgpu_group_matvec': [_vp, _u64p, _u64p, _int, _int, _vp, _vp, _sz, _vp],
     'ffgpu_dot': [_vp, _vp, _vp, _vp, _vp, _sz, _vp],

@@ -384,6 +384,21 @@ static bool inverse_exponent(const ffgpu_ctx* ctx, ExpArgs* ex) {
     return true;
 }
 
+int ffgpu_sqrt_cl(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (ctx->kind != FFGPU_PRIME || (ctx->modulus[0] & 3) != 1) return FFGPU_ENOTSUP;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(a && out);
+    ff_u128 p = ff_make128(ctx->modulus[1], ctx->modulus[0]);
+    ff_u128 e1 = (p - 1) >> 1, e2 = (p >> 1) + 1;          // (p-1)/2 and (p+1)/2 (p odd; no overflow at 128 bits)
+    uint64_t l1[2] = {ff_lo(e1), ff_hi(e1)}, l2[2] = {ff_lo(e2), ff_hi(e2)};
+    ExpArgs eleg, elad;
+    make_exp(l1, 2, &eleg);
+    make_exp(l2, 2, &elad);
+    DeviceGuard g(ctx->device);
+    return launch_status(ctx->ops->sqrt_cl(ctx->policy, ctx->device, a, &eleg, &elad, out, n, (hipStream_t)stream));
+}
+
 int ffgpu_gauss(ffgpu_ctx* ctx, void* a, int n, int ncols, size_t batch, int mode, void* det_out,
                 void* dev_singular, void* stream) {
     ARGCHK(ctx && n >= 0 && ncols >= n && (mode == 0 || mode == 1));

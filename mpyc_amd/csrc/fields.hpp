@@ -52,6 +52,7 @@ struct PM64 {
     typedef uint64_t elem;
     typedef uint64_t word;
     enum { EPW = 1 };
+    enum { BINARY = 0 };
     uint64_t p;     // modulus
     uint64_t mask;  // 2^k - 1
     uint32_t c;     // 2^k - p
@@ -225,6 +226,7 @@ struct RC64 {
     typedef uint64_t elem;
     typedef uint64_t word;
     enum { EPW = 1 };
+    enum { BINARY = 0 };
     uint64_t p;  // modulus
     uint64_t d;  // p << s, top bit set
     uint64_t v;  // floor((2^128-1)/d) - 2^64
@@ -329,6 +331,7 @@ struct RC32 {
     typedef uint32_t elem;
     typedef uint32_t word;
     enum { EPW = 1 };
+    enum { BINARY = 0 };
     uint32_t p, d, v, s;
 
     struct acc {
@@ -431,6 +434,7 @@ struct PM128 {
     typedef u128e elem;
     typedef u128e word;
     enum { EPW = 1 };
+    enum { BINARY = 0 };
     uint64_t p_lo, p_hi;        // modulus
     uint64_t mask_lo, mask_hi;  // 2^k - 1
     uint32_t c;                 // 2^k - p
@@ -645,6 +649,7 @@ struct MONT128 {
     typedef u128e elem;
     typedef u128e word;
     enum { EPW = 1 };
+    enum { BINARY = 0 };
     uint64_t p_lo, p_hi;
     uint64_t r2_lo, r2_hi;  // R^2 mod p
     uint64_t pinv;          // -p^{-1} mod 2^64
@@ -785,6 +790,7 @@ struct GF2P8 {
     typedef uint8_t elem;
     typedef uint32_t word;
     enum { EPW = 4 };
+    enum { BINARY = 1 };
     uint32_t n;     // extension degree
     uint32_t red;   // modulus without leading term, broadcast to 4 bytes
     uint32_t top;   // bit n-1 of every byte
@@ -918,6 +924,7 @@ struct GF2W64 {
     typedef uint64_t elem;
     typedef uint64_t word;
     enum { EPW = 1 };
+    enum { BINARY = 1 };
     uint64_t red;   // modulus without leading term
     uint64_t emask; // 2^n - 1
     uint32_t n;
@@ -996,6 +1003,7 @@ struct GF2W128 {
     typedef u128e elem;
     typedef u128e word;
     enum { EPW = 1 };
+    enum { BINARY = 1 };
     uint64_t red_lo, red_hi;      // modulus without leading term
     uint64_t emask_lo, emask_hi;  // 2^n - 1
     uint32_t n;                   // 65..128

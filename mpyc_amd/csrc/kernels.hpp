@@ -982,6 +982,70 @@ __global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word
 
 
 
+
+// ---- square roots for p = 1 mod 4: Cipolla-Lehmer, exactly as finfields.py:447-470 -----------------
+// Per element: smallest b >= 1 with b^2 - 4a a non-residue (Legendre symbol by exponentiation; lanes
+// that found theirs idle until the wave is done: 2 candidates expected), then X^((p+1)/2) mod
+// X^2 - bX + a by the reference's ladder (public exponent: uniform control flow).  a = 0 -> 0.
+// Non-residues give the same (meaningless) value as the reference, which does not test either.
+template <class F>
+FF_HD typename F::word ff_small(const F&, uint32_t b) {
+    if constexpr (sizeof(typename F::word) == 16) {
+        typename F::word w;
+        w.lo = b;
+        w.hi = 0;
+        return w;
+    } else {
+        return (typename F::word)b;
+    }
+}
+template <class F>
+FF_HD bool ff_is_zero(const F& f, typename F::word v) {
+    uint32_t zm;
+    ff_zero_fix(f, v, zm);
+    return zm & 1;
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_sqrt_cl(F f, const typename F::elem* __restrict__ a, ExpArgs eleg, ExpArgs elad,
+                                                    typename F::elem* __restrict__ o, size_t n) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const W one = ff_one_elem(f);
+    const W m1 = f.neg(one);
+    for (size_t e = gid; e < n; e += gsz) {
+        const W x = ld_elem<F>(a, e);
+        if (ff_is_zero(f, x)) {
+            st_elem<F>(o, e, x);
+            continue;
+        }
+        const W x2 = f.add(x, x);
+        const W x4 = f.add(x2, x2);
+        uint32_t b = 1;
+        W bw;
+        for (;;) {
+            bw = ff_small(f, b);
+            W d = f.sub(f.mul(bw, bw), x4);
+            if (!ff_is_zero(f, d) && ff_is_zero(f, f.sub(ff_pow(f, d, eleg), m1))) break;
+            ++b;
+        }
+        W u = f.sub(one, one), v = one;
+        for (int i = elad.nbits - 1; i >= 0; --i) {
+            W u2 = f.mul(u, u);
+            W nu = f.add(f.mul(f.add(u, u), v), f.mul(bw, u2));
+            v = f.sub(f.mul(v, v), f.mul(x, u2));
+            u = nu;
+            if ((elad.e[i >> 6] >> (i & 63)) & 1) {
+                W t = f.add(v, f.mul(bw, u));
+                v = f.neg(f.mul(x, u));
+                u = t;
+            }
+        }
+        st_elem<F>(o, e, v);
+    }
+}
+
 // ---- Gaussian elimination on a batch of (n x ncols) matrices, in place -----------------------------
 // finfields.py:872-955 (gauss_solve / gauss_inv / gauss_det behind np.linalg.solve / inv / det).
 // Two launches per pivot column k, for every matrix of the batch at once:
@@ -1130,6 +1194,8 @@ struct FieldOps {
                   size_t ldc, int M, int K, int N, hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
+    int (*sqrt_cl)(const void* F, int device, const void* a, const ExpArgs* eleg, const ExpArgs* elad, void* out, size_t n,
+                   hipStream_t st);
     int (*gauss)(const void* F, int device, void* A, int n, int ncols, size_t batch, int det_mode, const ExpArgs* ex,
                  void* det, int* sing, hipStream_t st);
     int (*group_matvec)(const void* F, int device, const uint64_t* m2, const uint64_t* bias2, int r, int g,
@@ -1499,6 +1565,19 @@ struct Launchers {
         (void)lc;
         return 0;
     }
+    static int sqrt_cl(const void* Fp, int device, const void* a, const ExpArgs* eleg, const ExpArgs* elad, void* out,
+                       size_t n, hipStream_t st) {
+        if constexpr (F::BINARY) {
+            return 2;
+        } else {
+            const F& f = *reinterpret_cast<const F*>(Fp);
+            LaunchCfg lc = launch_cfg(device);
+            unsigned grid = grid_for(n, lc);
+            hipLaunchKernelGGL((k_sqrt_cl<F>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *eleg, *elad, (E*)out, n);
+            FFGPU_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     static int gauss(const void* Fp, int device, void* A, int n, int ncols, size_t batch, int det_mode,
                      const ExpArgs* ex, void* det, int* sing, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
@@ -1577,7 +1656,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &gauss, &group_matvec, &beaver, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &sqrt_cl, &gauss, &group_matvec, &beaver, &prss};
         return &ops;
     }
 };

@@ -399,6 +399,12 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
         return out
 
+    def sqrt_cl(self, a: DevArray, out: Optional[DevArray] = None) -> DevArray:
+        """Square roots for p = 1 mod 4 (Cipolla-Lehmer, finfields.py:447-470)."""
+        out = out or self.empty(a.n)
+        _ffi.check(self._L.ffgpu_sqrt_cl(self._h, a.ptr, out.ptr, a.n, self._stream()), 'sqrt_cl')
+        return out
+
     def gauss(self, a: DevArray, n: int, ncols: int, batch: int = 1, det: bool = False):
         """Gaussian elimination in place on `batch` row-major (n, ncols) matrices (finfields.py:872-955).
         det=False: (A | B) -> (. | A^-1 B).  det=True: returns the reference's determinant per matrix.

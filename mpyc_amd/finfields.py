@@ -808,7 +808,9 @@ class FieldArray:
         elif ops.modulus & 3 == 3:
             e = (ops.modulus * 3 - 5) >> 2 if INV else (ops.modulus + 1) >> 2
         else:
-            raise NotImplementedError('sqrt for p = 1 mod 4 (Tonelli-Shanks, finfields.py:447-478) is not accelerated')
+            # p = 1 mod 4: Cipolla-Lehmer on the device, then the reciprocal for INV (finfields.py:447-470)
+            r = self._wrap(self.ctx.sqrt_cl(self._dev), self._shape)
+            return r.reciprocal() if INV else r
         if e == 0:
             return self ** 0
         return self._wrap(self.ctx.pow(self._dev, e), self._shape)

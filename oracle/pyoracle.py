@@ -121,6 +121,27 @@ def inv(F: Field, a: int) -> int:
     return pow(a, -1, F.modulus)
 
 
+def sqrt_prime(F: Field, a: int) -> int:
+    """finfields.py:440-470: 0 -> 0; p = 3 mod 4: a^((p+1)/4); p = 1 mod 4: Cipolla-Lehmer with the
+    smallest b such that b^2 - 4a is a non-residue, X^((p+1)/2) mod X^2 - bX + a by the same ladder."""
+    p = F.modulus
+    if a == 0 or p == 2:
+        return a
+    if p & 3 == 3:
+        return pow(a, (p + 1) >> 2, p)
+    b = 1
+    while pow((b * b - 4 * a) % p, (p - 1) >> 1, p) != p - 1:
+        b += 1
+    u, v = 0, 1
+    e = (p + 1) >> 1
+    for i in range(e.bit_length() - 1, -1, -1):
+        u2 = u * u % p
+        u, v = ((u << 1) * v + b * u2) % p, (v * v - a * u2) % p
+        if (e >> i) & 1:
+            u, v = (v + b * u) % p, (-a * u) % p
+    return v
+
+
 def vec(op, F: Field, a: Sequence[int], b: Sequence[int]) -> List[int]:
     return [op(F, x, y) for x, y in zip(a, b)]
 

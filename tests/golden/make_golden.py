@@ -372,6 +372,38 @@ def linalg_cases():
     print('wrote linalg.json', os.path.getsize(os.path.join(OUT, 'linalg.json')))
 
 
+def sqrt_cases():
+    """F.array.sqrt() for p = 1 mod 4 (Cipolla-Lehmer, finfields.py:447-470 via :1459-1460), incl. zero,
+    non-residues (the reference returns a deterministic non-root for those) and INV=True."""
+    import numpy as np
+    from mpyc import gmpy as g
+    r = random.Random(79)
+    out = {}
+
+    def prime_1mod4_below(x):
+        x -= 1
+        while not (x % 4 == 1 and g.is_prime(x)):
+            x -= 1
+        return x
+
+    for name, start in (('p5', 6), ('p13', 14), ('p17', 18), ('P31', 2**31), ('P40', 2**40), ('P61', 2**61),
+                        ('P64', 2**64), ('P63G', 6616326157076047771), ('P96', 2**96), ('P128', 2**128),
+                        ('P128G', 258797994007609146293811961253269568351)):
+        p = prime_1mod4_below(start)
+        F = finfields.GF(p)
+        vals = [0, 1, 4 % p, p - 1, 2 % p, 3 % p] + [r.randrange(p) for _ in range(10)]
+        sq = [pow(r.randrange(1, p), 2, p) for _ in range(8)]
+        a = F.array(vals + sq)
+        roots = a.sqrt()
+        inv_roots = F.array(sq + [1]).sqrt(INV=True)
+        out[name] = {'modulus': hx(p), 'a': hxl(vals + sq), 'sqrt': hxl(int(v) % p for v in roots.value),
+                     'sq': hxl(sq + [1]), 'inv_sqrt': hxl(int(v) % p for v in inv_roots.value),
+                     'is_sqr': [bool(b) for b in a.is_sqr()]}
+    with open(os.path.join(OUT, 'sqrt.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote sqrt.json', os.path.getsize(os.path.join(OUT, 'sqrt.json')))
+
+
 def npfunc_cases():
     """NumPy functions with arithmetic routed through __array_function__ (finfields.py:766-819, 1332-1356):
     convolve (runtime.np_convolve's local part), outer, prod, trace, sum along an axis."""
@@ -400,6 +432,9 @@ def npfunc_cases():
 
 
 if __name__ == '__main__':
+    if 'sqrt' in sys.argv[1:]:
+        sqrt_cases()
+        sys.exit(0)
     if 'npfuncs' in sys.argv[1:]:
         npfunc_cases()
         sys.exit(0)
@@ -411,3 +446,4 @@ if __name__ == '__main__':
     matmul_cases()
     linalg_cases()
     npfunc_cases()
+    sqrt_cases()

@@ -513,3 +513,26 @@ def test_numpy_movement_functions(api):
         assert np.array_equal(a, F.array(A)) and not np.array_equal(a, b)
         with pytest.raises(NotImplementedError):
             np.cumsum(a)
+
+
+def test_sqrt_p_1_mod_4_golden(api):
+    """sqrt / inverse sqrt / is_sqr for primes p = 1 mod 4 (Cipolla-Lehmer) vs the reference's outputs,
+    including its values for zero and for non-residues."""
+    import json
+    import os
+    finfields, _, _ = api
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sqrt.json')))
+    for name, c in g.items():
+        p = int(c['modulus'], 16)
+        assert p % 4 == 1
+        F = finfields.GF(p)
+        a = F.array([int(v, 16) for v in c['a']])
+        assert ints(a.sqrt()) == [int(v, 16) for v in c['sqrt']], name
+        assert ints(np.sqrt(a)) == [int(v, 16) for v in c['sqrt']]
+        assert [bool(b) for b in a.is_sqr()] == c['is_sqr']
+        sq = F.array([int(v, 16) for v in c['sq']])
+        assert ints(sq.sqrt(INV=True)) == [int(v, 16) for v in c['inv_sqrt']], name
+        r = sq.sqrt()
+        assert ints(r * r) == ints(sq)
+        with pytest.raises(ZeroDivisionError):
+            F.array([1, 0]).sqrt(INV=True)

@@ -161,3 +161,11 @@ def test_py_linalg():
             assert po.gauss_solve(F, A, B) == [[red(v) for v in row] for row in c['solve']], (name, c['kind'])
         dets = [red(v) for row in fc['stack_det'] for v in row]
         assert [po.gauss_det(F, ux(m)) for m in fc['stack']] == dets
+
+
+def test_py_sqrt():
+    g = json.load(open(os.path.join(GOLDEN, 'sqrt.json')))
+    for name, c in g.items():
+        F = po.Field(int(c['modulus'], 16), False)
+        assert [po.sqrt_prime(F, int(v, 16)) for v in c['a']] == [int(v, 16) for v in c['sqrt']], name
+        assert [po.inv(F, po.sqrt_prime(F, int(v, 16))) for v in c['sq']] == [int(v, 16) for v in c['inv_sqrt']]
