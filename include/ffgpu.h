@@ -18,7 +18,8 @@
  *         elem_bytes == 1   GF(2^n), n <= 8           uint8  [n]
  *         elem_bytes == 4   prime p < 2^32            uint32 [n]
  *         elem_bytes == 8   prime p < 2^64, GF(2^n) n<=64   uint64 [n]
- *         elem_bytes == 16  prime p < 2^128, GF(2^n) n<=128 {lo,hi} uint64 pairs
+ *         elem_bytes == 12  prime p = 2^k - c, 65 <= k <= 96, c < 2^31   3 x uint32 (12-byte LE integer)
+ *         elem_bytes == 16  other primes p < 2^128, GF(2^n) n<=128 {lo,hi} uint64 pairs
  *     This is exactly the byte layout of field.to_bytes() (finfields.py:91-102)
  *     for byte_length in {1,4,8,16}.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
@@ -79,7 +80,7 @@ int         ffgpu_device_count(int* count);
 int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device,
                      ffgpu_ctx** out);
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx);
-int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8 or 16               */
+int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8, 12 or 16           */
 int ffgpu_ctx_reduction(const ffgpu_ctx* ctx);    /* one of FFGPU_RED_*          */
 int ffgpu_ctx_device(const ffgpu_ctx* ctx);
 

@@ -23,6 +23,7 @@ const FieldOps* ffgpu_ops_rc64();
 const FieldOps* ffgpu_ops_rc32();
 const FieldOps* ffgpu_ops_pm128_k128();      // PM128<true>
 const FieldOps* ffgpu_ops_pm128_gen();       // PM128<false>
+const FieldOps* ffgpu_ops_pm96();            // PM96
 const FieldOps* ffgpu_ops_mont128();
 const FieldOps* ffgpu_ops_gf2p8();
 const FieldOps* ffgpu_ops_gf2w64();
@@ -124,6 +125,7 @@ static const FieldOps* ops_for(int kind) {
         case POL_RC32: return ffgpu_ops_rc32();
         case POL_PM128_K128: return ffgpu_ops_pm128_k128();
         case POL_PM128_GEN: return ffgpu_ops_pm128_gen();
+        case POL_PM96: return ffgpu_ops_pm96();
         case POL_MONT128: return ffgpu_ops_mont128();
         case POL_GF2P8: return ffgpu_ops_gf2p8();
         case POL_GF2W64: return ffgpu_ops_gf2w64();

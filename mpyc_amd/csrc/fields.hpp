@@ -640,6 +640,20 @@ struct PM128 {
 };
 
 // ---------------------------------------------------------------------------
+// PM96: the PM128 arithmetic for 65 <= k <= 96 with elements STORED in 12 bytes
+// (three little-endian 32-bit limbs = the reference's field.to_bytes layout for these
+// fields, finfields.py:91-102).  A lane moves one element per global_load/store_dwordx3,
+// which streams as fast as dwordx4 (tools/tune_x3.hip: 6.5 TB/s), so every HBM-bound
+// kernel gains the 25 % the narrower storage saves.  Default SecInt(33..64) fields land here.
+// ---------------------------------------------------------------------------
+struct e96 {
+    uint32_t x[3];
+};
+struct PM96 : PM128<false> {
+    typedef e96 elem;
+};
+
+// ---------------------------------------------------------------------------
 // MONT128: arbitrary odd modulus 2^64 < p < 2^128 (two limbs).  Canonical
 // in/out: mul(a,b) = REDC(REDC(a*b) * R^2) with R = 2^128, i.e. two word-serial
 // Montgomery reductions; chains (Horner, dot products) stay cheap because the

@@ -68,10 +68,46 @@ __device__ __forceinline__ void stg(P* p, const P& x) {
     }
 }
 
+// Memory-side pack of a field: what one lane moves per access.  16 bytes (= the register pack) for all
+// fields but PM96, whose 12-byte elements go one per lane through dwordx3 accesses.
+template <class F>
+struct MemPack {
+    typedef Pack<typename F::word> type;
+};
+template <>
+struct MemPack<PM96> {
+    typedef e96 type;
+};
+typedef uint32_t ff_u32x3 __attribute__((ext_vector_type(3)));
+template <bool NT>
+__device__ __forceinline__ Pack<u128e> ldg(const e96* p) {
+    ff_u32x3 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const ff_u32x3*>(p));
+    else v = *reinterpret_cast<const ff_u32x3*>(p);
+    Pack<u128e> r;
+    r.w[0].lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    r.w[0].hi = v.z;
+    return r;
+}
+template <bool NT>
+__device__ __forceinline__ void stg(e96* p, const Pack<u128e>& x) {
+    ff_u32x3 v;
+    v.x = (uint32_t)x.w[0].lo;
+    v.y = (uint32_t)(x.w[0].lo >> 32);
+    v.z = (uint32_t)x.w[0].hi;
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<ff_u32x3*>(p));
+    else *reinterpret_cast<ff_u32x3*>(p) = v;
+}
+
 // element <-> word for the scalar tail (identity unless words pack elements)
 template <class F>
 __device__ __forceinline__ typename F::word ld_elem(const typename F::elem* p, size_t i) {
-    if constexpr (F::EPW == 1) {
+    if constexpr (sizeof(typename F::elem) == 12) {
+        typename F::word w;
+        w.lo = (uint64_t)p[i].x[0] | ((uint64_t)p[i].x[1] << 32);
+        w.hi = p[i].x[2];
+        return w;
+    } else if constexpr (F::EPW == 1) {
         return p[i];
     } else {
         return (typename F::word)p[i];
@@ -79,7 +115,11 @@ __device__ __forceinline__ typename F::word ld_elem(const typename F::elem* p, s
 }
 template <class F>
 __device__ __forceinline__ void st_elem(typename F::elem* p, size_t i, typename F::word w) {
-    if constexpr (F::EPW == 1) {
+    if constexpr (sizeof(typename F::elem) == 12) {
+        p[i].x[0] = (uint32_t)w.lo;
+        p[i].x[1] = (uint32_t)(w.lo >> 32);
+        p[i].x[2] = (uint32_t)w.hi;
+    } else if constexpr (F::EPW == 1) {
         p[i] = w;
     } else {
         p[i] = (typename F::elem)w;
@@ -103,9 +143,10 @@ __global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __re
                                                 const typename F::elem* __restrict__ b,
                                                 typename F::elem* __restrict__ o, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
-    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    typedef typename MemPack<F>::type MP;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    const MP* __restrict__ bv = reinterpret_cast<const MP*>(b);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
@@ -129,8 +170,9 @@ __global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __re
                                                 typename F::word s, typename F::elem* __restrict__ o,
                                                 size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    typedef typename MemPack<F>::type MP;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
@@ -153,10 +195,11 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
                                                    const typename F::elem* __restrict__ c,
                                                    typename F::elem* __restrict__ o, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
-    const P* __restrict__ cv = reinterpret_cast<const P*>(c);
-    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    typedef typename MemPack<F>::type MP;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    const MP* __restrict__ bv = reinterpret_cast<const MP*>(b);
+    const MP* __restrict__ cv = reinterpret_cast<const MP*>(c);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
@@ -187,6 +230,7 @@ __global__ __launch_bounds__(BLOCK) void k_beaver(F f, const typename F::elem* _
                                                    const typename F::elem* __restrict__ e,
                                                    typename F::elem* __restrict__ o, int add_de, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
@@ -196,12 +240,12 @@ __global__ __launch_bounds__(BLOCK) void k_beaver(F f, const typename F::elem* _
         return add_de ? f.muladd(dd, ee, c) : c;       // public term: all parties (Shamir) / one party (additive)
     };
     for (size_t i = gid; i < nvec; i += gsz) {
-        P pz = ldg<NT>(reinterpret_cast<const P*>(z) + i), px = ldg<NT>(reinterpret_cast<const P*>(x) + i);
-        P py = ldg<NT>(reinterpret_cast<const P*>(y) + i), pd = ldg<NT>(reinterpret_cast<const P*>(d) + i);
-        P pe = ldg<NT>(reinterpret_cast<const P*>(e) + i), r;
+        P pz = ldg<NT>(reinterpret_cast<const MP*>(z) + i), px = ldg<NT>(reinterpret_cast<const MP*>(x) + i);
+        P py = ldg<NT>(reinterpret_cast<const MP*>(y) + i), pd = ldg<NT>(reinterpret_cast<const MP*>(d) + i);
+        P pe = ldg<NT>(reinterpret_cast<const MP*>(e) + i), r;
 #pragma unroll
         for (int q = 0; q < P::N; ++q) r.w[q] = comb(pz.w[q], px.w[q], py.w[q], pd.w[q], pe.w[q]);
-        stg<NT>(reinterpret_cast<P*>(o) + i, r);
+        stg<NT>(reinterpret_cast<MP*>(o) + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t k_ = done + gid; k_ < n; k_ += gsz)
@@ -224,12 +268,13 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
                                                   size_t nvec, size_t n, RngArgs ra) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     constexpr int TT = T > 0 ? T : 1;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    const MP* __restrict__ bv = reinterpret_cast<const MP*>(b);
     // With the in-kernel CSPRNG a thread serves a GROUP of G adjacent packs from shared keystream
     // blocks (rng.hpp RngLayout); without it G = 1 and this is the plain one-pack-per-thread loop.
     constexpr int G = (RNG && T > 0) ? RngLayout<F, TT, P::N>::G : 1;
@@ -255,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             } else {
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
-                    P t_ = ldg<NT>(reinterpret_cast<const P*>(coef + (size_t)j * cstride) + i);
+                    P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
 #pragma unroll
                     for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
                 }
@@ -291,7 +336,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                         y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
                     }
                 }
-                stg<NT>(reinterpret_cast<P*>(out + (size_t)(party - 1) * ostride) + i, y);
+                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
         }
     }
@@ -337,6 +382,7 @@ template <class F, int T>
 __global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __restrict__ coef, size_t cstride,
                                                        size_t nvec, size_t n, RngArgs ra) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     constexpr int EPV = P::N * F::EPW;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -361,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __r
                         for (int uu = 1; uu < G; ++uu) v = (uu == u) ? cg[uu][j][q] : v;
                         t_.w[q] = v;
                     }
-                    stg<true>(reinterpret_cast<P*>(coef + (size_t)j * cstride) + i, t_);
+                    stg<true>(reinterpret_cast<MP*>(coef + (size_t)j * cstride) + i, t_);
                 }
             } else {
                 for (int j = 0; j < T; ++j)
@@ -460,12 +506,13 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
                                                       typename F::elem* __restrict__ out, size_t ostride,
                                                       size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
         P x[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = ldg<NT>(reinterpret_cast<const P*>(ra.rows[j]) + i);
+        for (int j = 0; j < K; ++j) x[j] = ldg<NT>(reinterpret_cast<const MP*>(ra.rows[j]) + i);
         for (int r = 0; r < w; ++r) {
             P y;
 #pragma unroll
@@ -476,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
                 for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], x[j].w[q]);
                 y.w[q] = f.acc_reduce(s);
             }
-            stg<NT>(reinterpret_cast<P*>(out + (size_t)r * ostride) + i, y);
+            stg<NT>(reinterpret_cast<MP*>(out + (size_t)r * ostride) + i, y);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -580,8 +627,9 @@ template <class F, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
                                                 typename F::elem* __restrict__ o, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    typedef typename MemPack<F>::type MP;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
@@ -604,9 +652,10 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
                                                       int* __restrict__ flag) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    P* __restrict__ ov = reinterpret_cast<P*>(o);
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     uint32_t anyzero = 0;
@@ -791,13 +840,13 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* _
             int mm = idx / BK, kk = idx % BK;
             int gm = m0 + mm, gk = k0 + kk;
             const bool ok = gm < M && gk < K;      // out-of-range: read element 0, then zero it
-            As[kk][mm] = ff_keep_if<W>(f.prep(A[ok ? (size_t)gm * lda + gk : 0]), ok);
+            As[kk][mm] = ff_keep_if<W>(f.prep(ld_elem<F>(A, ok ? (size_t)gm * lda + gk : 0)), ok);
         }
         for (int idx = threadIdx.x; idx < BK * BN; idx += BLOCK) {
             int kk = idx / BN, nn = idx % BN;
             int gk = k0 + kk, gn = n0 + nn;
             const bool ok = gk < K && gn < N;
-            Bs[kk][nn] = ff_keep_if<W>(B[ok ? (size_t)gk * ldb + gn : 0], ok);
+            Bs[kk][nn] = ff_keep_if<W>(ld_elem<F>(B, ok ? (size_t)gk * ldb + gn : 0), ok);
         }
         __syncthreads();
 #pragma unroll 4
@@ -835,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* _
             if (gm < M && gn < N) {
                 W r = f.acc_reduce(acc[i][j]);
                 if (have) r = f.add(tot[i][j], r);
-                C[(size_t)gm * ldc + gn] = r;
+                st_elem<F>(C, (size_t)gm * ldc + gn, r);
             }
         }
 }
@@ -904,10 +953,11 @@ __global__ __launch_bounds__(BLOCK) void k_dot_partial(F f, const typename F::el
                                                         const typename F::elem* __restrict__ b,
                                                         typename F::word* __restrict__ partial, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     __shared__ W sm[BLOCK];
-    const P* __restrict__ av = reinterpret_cast<const P*>(a);
-    const P* __restrict__ bv = reinterpret_cast<const P*>(b);
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    const MP* __restrict__ bv = reinterpret_cast<const MP*>(b);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     const W one = f.prep(ff_one(f));
@@ -975,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word
             w = (w ^ (w >> 8) ^ (w >> 16) ^ (w >> 24)) & 0xffu;
             out[0] = (typename F::elem)w;
         } else {
-            out[0] = r;
+            st_elem<F>(out, 0, r);
         }
     }
 }
@@ -1209,7 +1259,7 @@ struct FieldOps {
 // canonical 2-limb host scalar -> policy word (broadcast for packed fields)
 template <class F>
 inline typename F::word word_from_limbs(const F& f, uint64_t lo, uint64_t hi) {
-    if constexpr (sizeof(typename F::elem) == 16) {
+    if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = lo;
         w.hi = hi;
@@ -1237,11 +1287,14 @@ template <class F>
 struct Launchers {
     typedef typename F::elem E;
     typedef typename F::word W;
-    enum { EPV = (16 / sizeof(W)) * F::EPW };  // elements per 16-byte pack
+    enum { EPV = (16 / sizeof(W)) * F::EPW };  // elements per pack (one lane's access)
+    enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : 16 };   // dwordx3 needs dword alignment only
+    static bool al(const void* p) { return ((uintptr_t)p & (PACK_ALIGN - 1)) == 0; }
+    static bool stride_ok(size_t stride) { return (stride * sizeof(E)) % PACK_ALIGN == 0; }
 
     template <int OP>
     static void go_ew2(const F& f, const LaunchCfg& lc, const E* a, const E* b, E* o, size_t n, hipStream_t st) {
-        bool vec = aligned16(a) && aligned16(b) && aligned16(o);
+        bool vec = al(a) && al(b) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         if (lc.nt)
@@ -1268,7 +1321,7 @@ struct Launchers {
 
     template <int OP>
     static void go_ew1(const F& f, const LaunchCfg& lc, const E* a, W s, E* o, size_t n, hipStream_t st) {
-        bool vec = aligned16(a) && aligned16(o);
+        bool vec = al(a) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         if (lc.nt)
@@ -1300,7 +1353,7 @@ struct Launchers {
                       size_t n, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        bool vec = aligned16(a) && aligned16(b) && aligned16(c) && aligned16(o);
+        bool vec = al(a) && al(b) && al(c) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         if (lc.nt)
@@ -1346,9 +1399,9 @@ struct Launchers {
                                t, m, out, ostride, n, ra);
             return 0;
         }
-        bool vec = aligned16(a) && (!FUSE || aligned16(b)) && aligned16(out) &&
-                   ((ostride * sizeof(E)) % 16 == 0 || m <= 1) &&
-                   (RNG || t == 0 || (aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1)));
+        bool vec = al(a) && (!FUSE || al(b)) && al(out) &&
+                   (stride_ok(ostride) || m <= 1) &&
+                   (RNG || t == 0 || (al(coef) && (stride_ok(cstride) || t <= 1)));
         size_t nvec = vec ? n / EPV : 0;
         // RNG kernels serve up to 4 packs per thread (RngLayout::G); a slightly larger grid is harmless
         unsigned grid = grid_for(nvec ? (RNG ? (n / EPV + 2) / 2 : nvec) : n, lc);
@@ -1397,7 +1450,7 @@ struct Launchers {
             FFGPU_CHECK_LAUNCH();
             return 0;
         }
-        bool vec = aligned16(coef) && ((cstride * sizeof(E)) % 16 == 0 || t <= 1);
+        bool vec = al(coef) && (stride_ok(cstride) || t <= 1);
         size_t nvec = vec ? n / EPV : 0;
         switch (t) {
             case 1: hipLaunchKernelGGL((k_rng_coeffs<F, 1>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
@@ -1414,10 +1467,10 @@ struct Launchers {
     static void go_rec(const F& f, const LaunchCfg& lc, const void* const* rows, const uint64_t* lam2, int w,
                        E* out, size_t ostride, size_t n, hipStream_t st) {
         RecArgs<F, K> ra;
-        bool vec = aligned16(out) && ((ostride * sizeof(E)) % 16 == 0 || w <= 1);
+        bool vec = al(out) && (stride_ok(ostride) || w <= 1);
         for (int j = 0; j < K; ++j) {
             ra.rows[j] = (const E*)rows[j];
-            vec = vec && aligned16(rows[j]);
+            vec = vec && al(rows[j]);
         }
         for (int r = 0; r < w; ++r)
             for (int j = 0; j < K; ++j) {
@@ -1484,7 +1537,7 @@ struct Launchers {
                    hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        bool vec = aligned16(a) && aligned16(out);
+        bool vec = al(a) && al(out);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_pow<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out, nvec, n);
@@ -1495,7 +1548,7 @@ struct Launchers {
                    hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        bool vec = aligned16(a) && aligned16(out);
+        bool vec = al(a) && al(out);
         size_t nvec = vec ? n / EPV : 0;
         constexpr int CH = sizeof(W) == 16 ? 8 : 8;   // packs per thread
         size_t iters = nvec ? (nvec + CH - 1) / CH : n;
@@ -1548,7 +1601,7 @@ struct Launchers {
                    hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        bool vec = aligned16(a) && (!b || aligned16(b));
+        bool vec = al(a) && (!b || al(b));
         size_t nvec = vec ? n / EPV : 0;
         size_t iters = nvec ? nvec : n;
         size_t want = (iters + (size_t)BLOCK * 8 - 1) / ((size_t)BLOCK * 8);     // >= 8 packs per thread
@@ -1627,7 +1680,7 @@ struct Launchers {
                       const void* e, void* out, int add_de, size_t n, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        bool vec = aligned16(z) && aligned16(x) && aligned16(y) && aligned16(d) && aligned16(e) && aligned16(out);
+        bool vec = al(z) && al(x) && al(y) && al(d) && al(e) && al(out);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_beaver<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)z, (const E*)x, (const E*)y,

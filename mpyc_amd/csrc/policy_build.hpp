@@ -18,6 +18,7 @@ enum PolicyKind {
     POL_RC32,
     POL_PM128_K128,     // PM128<true>
     POL_PM128_GEN,      // PM128<false>
+    POL_PM96,           // PM96 (12-byte storage)
     POL_MONT128,
     POL_GF2P8,
     POL_GF2W64,
@@ -107,6 +108,11 @@ inline int build_prime_policy(PolicyBlob* c, ff_u128 p) {
             f.p_lo = ff_lo(p); f.p_hi = ff_hi(p); f.mask_lo = ff_lo(mask); f.mask_hi = ff_hi(mask);
             f.c = (uint32_t)cc; f.k = 128;
             store_policy(c, f, POL_PM128_K128, PB_RED_PM);
+        } else if (k <= 96) {
+            PM96 f;
+            f.p_lo = ff_lo(p); f.p_hi = ff_hi(p); f.mask_lo = ff_lo(mask); f.mask_hi = ff_hi(mask);
+            f.c = (uint32_t)cc; f.k = (uint32_t)k;
+            store_policy(c, f, POL_PM96, PB_RED_PM);
         } else {
             PM128<false> f;
             f.p_lo = ff_lo(p); f.p_hi = ff_hi(p); f.mask_lo = ff_lo(mask); f.mask_hi = ff_hi(mask);
@@ -213,6 +219,7 @@ inline void rng_const(const PolicyBlob& pb, uint64_t out[2]) {
         case POL_RC32: rng_const_prime<RC32>(pb, 32, out); break;
         case POL_PM128_K128: rng_const_prime<PM128<true> >(pb, 128, out); break;
         case POL_PM128_GEN: rng_const_prime<PM128<false> >(pb, 128, out); break;
+        case POL_PM96: rng_const_prime<PM96>(pb, 128, out); break;
         case POL_MONT128: rng_const_prime<MONT128>(pb, 128, out); break;
         default: break;  // binary fields: masks only
     }

@@ -126,6 +126,24 @@ struct Sampler<PM128<K128> > {
 };
 
 template <>
+struct Sampler<PM96> {
+    enum { S = 12, SPARE = 2 };   // three keystream words per sample
+    typedef PM96 F;
+    static FF_HD ff_u128 get(const F& f, const uint32_t* w) {
+        uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        return ff_make128((uint64_t)w[2], lo) & f.M();
+    }
+    static FF_HD u128e sample(const F& f, uint64_t, uint64_t, const uint32_t* w, const uint32_t* spare) {
+        ff_u128 v = get(f, w);
+        if (v >= f.P()) {
+            v = get(f, spare);
+            if (v >= f.P()) v = f.csub(get(f, spare + 3));
+        }
+        return F::E(v);
+    }
+};
+
+template <>
 struct Sampler<MONT128> {
     enum { S = 32, SPARE = 0 };
     static FF_HD u128e sample(const MONT128& f, uint64_t Rlo, uint64_t Rhi, const uint32_t* w, const uint32_t*) {

@@ -20,20 +20,31 @@ _MASK64 = (1 << 64) - 1
 
 
 def _np_dtype(eb: int):
-    return {1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb]
+    return {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb]
 
 
 def _torch_dtype(eb: int):
-    return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 16: torch.int64}[eb]
+    return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 12: torch.int32, 16: torch.int64}[eb]
+
+
+def limbs_of(eb: int) -> int:
+    """Trailing limb dimension of a device tensor: 0 (scalar dtype), 2 (16 bytes = 2 x int64), 3 (12 bytes = 3 x int32)."""
+    return {16: 2, 12: 3}.get(eb, 0)
 
 
 def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
-    """Canonical Python ints -> limb array ((n,) for eb<=8, (n,2) uint64 for eb=16)."""
+    """Canonical Python ints -> limb array ((n,) for eb<=8, (n,2) uint64 for eb=16, (n,3) uint32 for eb=12)."""
     if isinstance(vals, np.ndarray) and vals.dtype != object:
         vals = vals.reshape(-1)
         if eb == 16:
             out = np.zeros((vals.size, 2), dtype=np.uint64)
             out[:, 0] = vals.astype(np.uint64)
+            return out
+        if eb == 12:
+            v64 = vals.astype(np.uint64)
+            out = np.zeros((vals.size, 3), dtype=np.uint32)
+            out[:, 0] = (v64 & np.uint64(0xffffffff)).astype(np.uint32)
+            out[:, 1] = (v64 >> np.uint64(32)).astype(np.uint32)
             return out
         return vals.astype(_np_dtype(eb))
     vals = list(vals) if not isinstance(vals, (list, np.ndarray)) else vals
@@ -41,6 +52,9 @@ def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
     if eb == 16:
         buf = b''.join(int(v).to_bytes(16, 'little') for v in vals)
         return np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).copy()
+    if eb == 12:
+        buf = b''.join(int(v).to_bytes(12, 'little') for v in vals)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(n, 3).copy()
     if n == 0:
         return np.zeros(0, dtype=_np_dtype(eb))
     return np.array(vals, dtype=object).astype(np.uint64).astype(_np_dtype(eb))
@@ -52,6 +66,9 @@ def np_to_ints(arr: np.ndarray, eb: int) -> List[int]:
         lo = a[:, 0].astype(object)
         hi = a[:, 1].astype(object)
         return list((hi << 64) | lo) if len(a) else []
+    if eb == 12:
+        a = arr.view(np.uint32).reshape(-1, 3).astype(object)
+        return list((a[:, 2] << 64) | (a[:, 1] << 32) | a[:, 0]) if len(a) else []
     return [int(v) for v in arr.reshape(-1).astype(object)] if arr.size else []
 
 
@@ -70,7 +87,7 @@ class DevArray:
     def to_numpy(self) -> np.ndarray:
         a = self.t.cpu().numpy()
         eb = self.ctx.elem_bytes
-        if eb == 4:
+        if eb in (4, 12):
             a = a.view(np.uint32)
         elif eb >= 8:
             a = a.view(np.uint64)
@@ -100,14 +117,14 @@ class DevMatrix:
 
     def row(self, i: int) -> DevArray:
         eb = self.ctx.elem_bytes
-        if eb == 16:
+        if limbs_of(eb):
             return DevArray(self.ctx, self.t[i, :self.n, :], self.n)
         return DevArray(self.ctx, self.t[i, :self.n], self.n)
 
     def to_numpy(self) -> np.ndarray:
         a = self.t.cpu().numpy()
         eb = self.ctx.elem_bytes
-        if eb == 4:
+        if eb in (4, 12):
             a = a.view(np.uint32)
         elif eb >= 8:
             a = a.view(np.uint64)
@@ -160,6 +177,7 @@ class FieldContext:
         _ffi.check(rc, 'ctx_create')
         self._h = h
         self.elem_bytes = L.ffgpu_ctx_elem_bytes(h)
+        self.limbs = limbs_of(self.elem_bytes)        # trailing limb dimension of device tensors (0, 2 or 3)
         self.reduction = _ffi.RED_NAMES.get(L.ffgpu_ctx_reduction(h), '?')
         if binary:
             self.order = 1 << (self.modulus.bit_length() - 1)
@@ -185,18 +203,18 @@ class FieldContext:
 
     def empty(self, n: int) -> DevArray:
         eb = self.elem_bytes
-        shape = (n, 2) if eb == 16 else (n,)
+        shape = (n, limbs_of(eb)) if limbs_of(eb) else (n,)
         return DevArray(self, torch.empty(shape, dtype=_torch_dtype(eb), device=self.torch_device), n)
 
     def empty_matrix(self, rows: int, n: int) -> DevMatrix:
         eb = self.elem_bytes
-        per = 256 // eb
+        per = 64 if eb == 12 else 256 // eb          # elements per 256-byte-aligned pitch unit (768 B for 12-byte elements)
         stride = max(per, (n + per - 1) // per * per)
         if (stride * eb) % 16384 == 0:
             # rows a multiple of 16 KiB apart alias onto the same HBM channels when m rows are
             # written at once (measured -12 % at a 64 MiB pitch): skew the pitch by 17 x 256 B
             stride += 17 * per
-        shape = (rows, stride, 2) if eb == 16 else (rows, stride)
+        shape = (rows, stride, limbs_of(eb)) if limbs_of(eb) else (rows, stride)
         return DevMatrix(self, torch.empty(shape, dtype=_torch_dtype(eb), device=self.torch_device), rows, n,
                          stride)
 
@@ -207,7 +225,7 @@ class FieldContext:
         if not a.flags.writeable:
             a = a.copy()
         n = a.shape[0]
-        if eb == 4:
+        if eb in (4, 12):
             t = torch.from_numpy(a.view(np.int32))
         elif eb >= 8:
             t = torch.from_numpy(a.view(np.int64))

@@ -629,11 +629,11 @@ class FieldArray:
     def _limb_view(self):
         """limb tensor shaped like the array (+ trailing 2 for two-limb fields)."""
         t = self._dev.t
-        return t.reshape(tuple(self._shape) + ((2,) if self.ctx.elem_bytes == 16 else ()))
+        return t.reshape(tuple(self._shape) + ((self.ctx.limbs,) if self.ctx.limbs else ()))
 
     def __getitem__(self, key):
         t = self._limb_view()
-        if self.ctx.elem_bytes == 16:
+        if self.ctx.limbs:
             key = key if isinstance(key, tuple) else (key,)
             sub = t[key + (Ellipsis, slice(None))] if Ellipsis not in key else t[key]
             shape = sub.shape[:-1]
@@ -641,10 +641,10 @@ class FieldArray:
             sub = t[key]
             shape = sub.shape
         if len(shape) == 0:
-            flat = sub.reshape(1, 2) if self.ctx.elem_bytes == 16 else sub.reshape(1)
+            flat = sub.reshape(1, self.ctx.limbs) if self.ctx.limbs else sub.reshape(1)
             return type(self).field(DevArray(self.ctx, flat, 1).to_ints()[0])
         n = int(np.prod(shape, dtype=np.int64))
-        flat = sub.reshape(n, 2) if self.ctx.elem_bytes == 16 else sub.reshape(n)
+        flat = sub.reshape(n, self.ctx.limbs) if self.ctx.limbs else sub.reshape(n)
         if not flat.is_contiguous():
             flat = flat.contiguous()
         return self._wrap(DevArray(self.ctx, flat, n), shape)
@@ -658,7 +658,7 @@ class FieldArray:
         src = value._limb_view()
         self._flush_products_reading(self._dev)
         t = self._limb_view()
-        if self.ctx.elem_bytes == 16:
+        if self.ctx.limbs:
             key = key if isinstance(key, tuple) else (key,)
             t[key + (Ellipsis, slice(None))] = src
         else:
@@ -705,8 +705,8 @@ class FieldArray:
                 out.append(x._dev)
                 continue
             t = x._limb_view()
-            if x.ctx.elem_bytes == 16:
-                t = t.expand(*shape, 2).contiguous().view(-1, 2)
+            if x.ctx.limbs:
+                t = t.expand(*shape, x.ctx.limbs).contiguous().view(-1, x.ctx.limbs)
             else:
                 t = t.expand(*shape).contiguous().view(-1)
             out.append(DevArray(x.ctx, t, t.shape[0]))
@@ -908,7 +908,7 @@ class FieldArray:
     def _zero_mask(self):
         t = self._dev.t
         z = (t == 0)
-        return z.all(dim=-1) if self.ctx.elem_bytes == 16 else z
+        return z.all(dim=-1) if self.ctx.limbs else z
 
     def __eq__(self, other):
         opd = self._operand(other)
@@ -919,7 +919,7 @@ class FieldArray:
             o = type(self)([o])
         a, b, shape = self._broadcast(o)
         eq = (a.t == b.t)
-        if self.ctx.elem_bytes == 16:
+        if self.ctx.limbs:
             eq = eq.all(dim=-1)
         return eq.cpu().numpy().reshape(shape)
 
@@ -983,7 +983,7 @@ class FieldArray:
         ctx = _context(cls.field)
         e = ctx.empty(n * n)
         e.t.zero_()
-        v = e.t.view(n, n, 2)[..., 0] if ctx.elem_bytes == 16 else e.t.view(n, n)
+        v = e.t.view(n, n, ctx.limbs)[..., 0] if ctx.limbs else e.t.view(n, n)
         v.fill_diagonal_(1)
         return cls._wrap(e, (n, n))
 
@@ -1092,15 +1092,15 @@ class FieldArray:
         if not axes:
             axes = tuple(reversed(range(self.ndim)))
         t = self._limb_view()
-        perm = tuple(axes) + ((self.ndim,) if self.ctx.elem_bytes == 16 else ())
+        perm = tuple(axes) + ((self.ndim,) if self.ctx.limbs else ())
         return self._from_limb_view(t.permute(*perm))
 
     def _from_limb_view(self, t):
         """limb tensor (array shape [+ trailing 2]) -> FieldArray with contiguous device data"""
-        eb = self.ctx.elem_bytes
-        shape = tuple(t.shape[:-1]) if eb == 16 else tuple(t.shape)
+        lb = self.ctx.limbs
+        shape = tuple(t.shape[:-1]) if lb else tuple(t.shape)
         n = int(np.prod(shape, dtype=np.int64)) if shape else 1
-        flat = t.contiguous().view(n, 2) if eb == 16 else t.contiguous().view(n)
+        flat = t.contiguous().view(n, lb) if lb else t.contiguous().view(n)
         return self._wrap(DevArray(self.ctx, flat, n), shape)
 
     def tolist(self):
@@ -1131,8 +1131,8 @@ class FieldArray:
             b = np.concatenate([b, np.zeros((n, eb - r), dtype=np.uint8)], axis=1)
         elif r > eb:
             b = b[:, :eb]
-        raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb])
-        raw = raw.reshape(n, 2) if eb == 16 else raw.reshape(n)
+        raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb])
+        raw = raw.reshape(n, ctx.limbs) if ctx.limbs else raw.reshape(n)
         return cls._wrap(ctx.from_numpy(raw), shape if shape is not None else (n,))
 
     def __repr__(self):
@@ -1142,8 +1142,8 @@ class FieldArray:
 def _matrix_to_array(cls, mtx: DevMatrix) -> FieldArray:
     """(rows, n) DevMatrix with padded pitch -> contiguous (rows, n) FieldArray."""
     ctx = mtx.ctx
-    if ctx.elem_bytes == 16:
-        t = mtx.t[:, :mtx.n, :].contiguous().view(-1, 2)
+    if ctx.limbs:
+        t = mtx.t[:, :mtx.n, :].contiguous().view(-1, ctx.limbs)
     else:
         t = mtx.t[:, :mtx.n].contiguous().view(-1)
     return cls._wrap(DevArray(ctx, t, mtx.rows * mtx.n), (mtx.rows, mtx.n))
@@ -1239,8 +1239,9 @@ def _np_movement(func, args, kwargs):
     res = func(*iargs, **ikw)
     ctx = pool[0].ctx
     eb = ctx.elem_bytes
-    flats = [p._dev.t.reshape(-1, 2) if eb == 16 else p._dev.t.reshape(-1) for p in pool]
-    zero = torch.zeros((1, 2) if eb == 16 else (1,), dtype=flats[0].dtype, device=flats[0].device)
+    lb = ctx.limbs
+    flats = [p._dev.t.reshape(-1, lb) if lb else p._dev.t.reshape(-1) for p in pool]
+    zero = torch.zeros((1, lb) if lb else (1,), dtype=flats[0].dtype, device=flats[0].device)
     table = torch.cat([zero] + flats)
 
     def back(r):
@@ -1278,8 +1279,9 @@ def _np_convolve(a, v, mode='full'):
     k = np.arange(na + nv - 1, dtype=np.int64)[:, None] - np.arange(nv, dtype=np.int64)[None, :]
     idx = np.where((k >= 0) & (k < na), k + 1, 0)                    # T[k][j] = a[k - j]
     ctx, eb = a.ctx, a.ctx.elem_bytes
-    flat = a._dev.t.reshape(-1, 2) if eb == 16 else a._dev.t.reshape(-1)
-    zero = torch.zeros((1, 2) if eb == 16 else (1,), dtype=flat.dtype, device=flat.device)
+    lb = ctx.limbs
+    flat = a._dev.t.reshape(-1, lb) if lb else a._dev.t.reshape(-1)
+    zero = torch.zeros((1, lb) if lb else (1,), dtype=flat.dtype, device=flat.device)
     t = torch.cat([zero, flat]).index_select(0, torch.from_numpy(idx.reshape(-1)).to(flat.device))
     T = cls._wrap(DevArray(ctx, t, idx.size), idx.shape)
     full = T @ v

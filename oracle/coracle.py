@@ -40,6 +40,8 @@ def elem_bytes(modulus: int, binary: bool) -> int:
         n = modulus.bit_length() - 1
         return 1 if n <= 8 else 8 if n <= 64 else 16
     b = modulus.bit_length()
+    if 64 < b <= 96 and (1 << b) - modulus < (1 << 31):
+        return 12                      # p = 2^k - c, k <= 96: three 32-bit limbs (include/ffgpu.h)
     return 4 if b <= 32 else 8 if b <= 64 else 16
 
 
@@ -67,7 +69,7 @@ class CField:
 
     def split(self, s: np.ndarray, coef: np.ndarray, t: int, m: int) -> np.ndarray:
         """s: (n,) elements, coef: (t, n) elements -> (m, n).  Arrays are raw byte-compatible
-        numpy arrays (uint8/uint32/uint64, or (..., 2) uint64 for 16-byte elements)."""
+        numpy arrays (uint8/uint32/uint64, (..., 2) uint64 for 16-byte and (..., 3) uint32 for 12-byte elements)."""
         s = np.ascontiguousarray(s)
         n = s.nbytes // self.eb
         coef = np.ascontiguousarray(coef)
@@ -103,8 +105,8 @@ def chacha_block(key32: bytes, w12_15, rounds: int = 20):
 def rng_coeffs(cf: 'CField', key32: bytes, nonce: int, rounds: int, t: int, n: int) -> np.ndarray:
     """(t, n) coefficient matrix exactly as the device CSPRNG draws it (mpyc_amd/csrc/rng.hpp)."""
     eb = cf.eb
-    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb]
-    shape = (t, n, 2) if eb == 16 else (t, n)
+    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb]
+    shape = (t, n, 2) if eb == 16 else (t, n, 3) if eb == 12 else (t, n)
     out = np.zeros(shape, dtype=dt)
     lib().orc_rng_coeffs(cf._buf, key32, ctypes.c_uint64(nonce), rounds, t, out.ctypes.data_as(ctypes.c_void_p),
                          ctypes.c_size_t(n), ctypes.c_size_t(n))
@@ -113,7 +115,7 @@ def rng_coeffs(cf: 'CField', key32: bytes, nonce: int, rounds: int, t: int, n: i
 
 def matmul(cf: 'CField', A: np.ndarray, B: np.ndarray, M: int, K: int, N: int) -> np.ndarray:
     A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
-    shape = (M * N, 2) if cf.eb == 16 else (M * N,)
+    shape = (M * N, 2) if cf.eb == 16 else (M * N, 3) if cf.eb == 12 else (M * N,)
     C = np.zeros(shape, dtype=A.dtype)
     lib().orc_matmul(cf._buf, A.ctypes.data_as(ctypes.c_void_p), B.ctypes.data_as(ctypes.c_void_p),
                      C.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(M), ctypes.c_size_t(K), ctypes.c_size_t(N))

@@ -13,7 +13,7 @@
  * for two-limb moduli, shift-and-xor for GF(2^n)); it shares no code and no
  * reduction trick with the HIP kernels.
  *
- * Element layout: little-endian, width eb in {1,4,8,16} bytes, as include/ffgpu.h.
+ * Element layout: little-endian, width eb in {1,4,8,12,16} bytes, as include/ffgpu.h.
  * Reference lines restated (paths relative to the mpyc checkout):
  *   orc_ew        finfields.py:1056-1124,1189-1192 (+,-,*,neg), :717-725 (reduce),
  *                 gfpx.py:982-1045 (GF(2^n) add/mul/mod)

@@ -16,18 +16,29 @@ def field_of(case):
 
 
 def pack(vals, eb):
-    """ints -> raw little-endian numpy array ((n,) or (n,2) uint64)."""
+    """ints -> raw little-endian numpy array ((n,), (n,2) uint64 for 16 bytes, (n,3) uint32 for 12 bytes)."""
     if eb == 16:
         buf = b''.join(int(v).to_bytes(16, 'little') for v in vals)
         return np.frombuffer(buf, dtype=np.uint64).reshape(len(vals), 2).copy()
+    if eb == 12:
+        buf = b''.join(int(v).to_bytes(12, 'little') for v in vals)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(len(vals), 3).copy()
     dt = {1: np.uint8, 4: np.uint32, 8: np.uint64}[eb]
     return np.array([int(v) for v in vals], dtype=object).astype(np.uint64).astype(dt) if len(vals) else np.zeros(0, dt)
+
+
+def lshape(eb, *dims):
+    """numpy shape of a raw limb array with the given leading dims"""
+    return tuple(dims) + ({16: (2,), 12: (3,)}.get(eb, ()))
 
 
 def unpack(arr, eb):
     if eb == 16:
         a = np.ascontiguousarray(arr).reshape(-1, 2)
         return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in range(a.shape[0])]
+    if eb == 12:
+        a = np.ascontiguousarray(arr).view(np.uint32).reshape(-1, 3)
+        return [int(a[i, 0]) | (int(a[i, 1]) << 32) | (int(a[i, 2]) << 64) for i in range(a.shape[0])]
     return [int(v) for v in np.asarray(arr).reshape(-1)]
 
 

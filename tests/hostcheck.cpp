@@ -16,7 +16,12 @@ template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
     typename F::elem e;
     memcpy(&e, p + i * sizeof(e), sizeof(e));
-    if constexpr (F::EPW == 1) {
+    if constexpr (sizeof(typename F::elem) == 12) {
+        typename F::word w;
+        w.lo = (uint64_t)e.x[0] | ((uint64_t)e.x[1] << 32);
+        w.hi = e.x[2];
+        return w;
+    } else if constexpr (F::EPW == 1) {
         return e;
     } else {
         return (typename F::word)e;
@@ -25,7 +30,11 @@ static typename F::word ldw(const unsigned char* p, size_t i) {
 template <class F>
 static void stw(unsigned char* p, size_t i, typename F::word w) {
     typename F::elem e;
-    if constexpr (F::EPW == 1) {
+    if constexpr (sizeof(typename F::elem) == 12) {
+        e.x[0] = (uint32_t)w.lo;
+        e.x[1] = (uint32_t)(w.lo >> 32);
+        e.x[2] = (uint32_t)w.hi;
+    } else if constexpr (F::EPW == 1) {
         e = w;
     } else {
         e = (typename F::elem)w;
@@ -35,7 +44,7 @@ static void stw(unsigned char* p, size_t i, typename F::word w) {
 
 template <class F>
 static typename F::word cst(const F& f, const uint64_t* l) {
-    if constexpr (sizeof(typename F::elem) == 16) {
+    if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = l[0];
         w.hi = l[1];
@@ -118,6 +127,7 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
         case POL_RC32: return run<RC32>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_PM128_K128: return run<PM128<true> >(pb, op, a, b, c, out, n, x, lam, k);
         case POL_PM128_GEN: return run<PM128<false> >(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM96: return run<PM96>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_MONT128: return run<MONT128>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2P8: return run<GF2P8>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
@@ -193,6 +203,7 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
         case POL_RC32: return rng_rows<RC32>(pb, rk, t, out, cstride, n);
         case POL_PM128_K128: return rng_rows<PM128<true> >(pb, rk, t, out, cstride, n);
         case POL_PM128_GEN: return rng_rows<PM128<false> >(pb, rk, t, out, cstride, n);
+        case POL_PM96: return rng_rows<PM96>(pb, rk, t, out, cstride, n);
         case POL_MONT128: return rng_rows<MONT128>(pb, rk, t, out, cstride, n);
         case POL_GF2P8: return rng_rows<GF2P8>(pb, rk, t, out, cstride, n);
         case POL_GF2W64: return rng_rows<GF2W64>(pb, rk, t, out, cstride, n);

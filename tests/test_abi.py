@@ -56,7 +56,8 @@ def test_ctx_classification(L):
     from mpyc_amd import _ffi
     cases = [
         (_ffi.PRIME, 2**61 - 1, 8, 1), (_ffi.PRIME, 2**64 - 189, 8, 1), (_ffi.PRIME, 2**128 - 173, 16, 1),
-        (_ffi.PRIME, 2**127 - 1, 16, 1), (_ffi.PRIME, 2**96 - 17, 16, 1), (_ffi.PRIME, 19, 4, 2),
+        (_ffi.PRIME, 2**127 - 1, 16, 1), (_ffi.PRIME, 2**96 - 17, 12, 1), (_ffi.PRIME, 2**80 - 65, 12, 1),
+        (_ffi.PRIME, 2**97 - 141, 16, 1), (_ffi.PRIME, 19, 4, 2),
         (_ffi.PRIME, 2**31 - 1, 4, 2), (_ffi.PRIME, 6616326157076047771, 8, 2),
         (_ffi.PRIME, 258797994007609146293811961253269568351, 16, 5),
         (_ffi.BINARY, 0x11b, 1, 3), (_ffi.BINARY, 0b111, 1, 3), (_ffi.BINARY, (1 << 64) | 0x1b, 8, 4),

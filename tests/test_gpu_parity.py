@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
-from fieldutil import P61, P64, P128, edge_values, field_of, pack, rand_values, unhex, unpack
+from fieldutil import P61, P64, P128, edge_values, field_of, pack, rand_values, unhex, unpack, lshape
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,7 @@ def devmat(ctx, rows_of_ints):
     eb = ctx.elem_bytes
     r, n = len(rows_of_ints), len(rows_of_ints[0])
     flat = pack([v for row in rows_of_ints for v in row], eb)
-    return ctx.matrix_from_numpy(flat.reshape((r, n, 2) if eb == 16 else (r, n)))
+    return ctx.matrix_from_numpy(flat.reshape(lshape(eb, r, n)))
 
 
 def hostmat(mtx):
@@ -164,6 +164,9 @@ def rand_np(F, eb, n, seed):
             for i in np.nonzero(big)[0]:
                 v = ((int(out[i, 1]) << 64) | int(out[i, 0])) - p
                 out[i, 0], out[i, 1] = v & (2**64 - 1), v >> 64
+        if eb == 12:                                   # three 32-bit limbs: lo32, mid32, hi32 (hi < 2^32)
+            out = np.stack([out[:, 0] & np.uint64(0xffffffff), out[:, 0] >> np.uint64(32), out[:, 1]],
+                           axis=1).astype(np.uint32)
     ev = pack(edge_values(F), eb)
     k = min(len(ev), n)
     out[:k] = ev[:k]
@@ -176,7 +179,7 @@ def test_vs_oracle_elementwise(eng, coracle, modulus, binary):
     ctx = ctx_for(eng, modulus, binary)
     eb = ctx.elem_bytes
     cf = coracle.CField(modulus, binary)
-    n = 20011 if eb == 16 and (binary or ctx.reduction == 'montgomery') else 100003   # odd: exercises tails
+    n = 20011 if eb >= 12 and (binary or ctx.reduction == 'montgomery') else 100003   # odd: exercises tails
     A, B, Cc = rand_np(F, eb, n, 11), rand_np(F, eb, n, 12), rand_np(F, eb, n, 13)
     dA, dB, dC = ctx.from_numpy(A), ctx.from_numpy(B), ctx.from_numpy(Cc)
     assert (ctx.add(dA, dB).to_numpy() == cf.ew(coracle.ADD, A, B)).all()
@@ -202,13 +205,13 @@ def test_vs_oracle_sharing(eng, coracle, modulus, binary):
     ctx = ctx_for(eng, modulus, binary)
     eb = ctx.elem_bytes
     cf = coracle.CField(modulus, binary)
-    n = 3001 if eb == 16 else 30011          # the C oracle's two-limb mulmod is shift-and-add
+    n = 3001 if eb >= 12 else 30011          # the C oracle's two-limb mulmod is shift-and-add
     S, B = rand_np(F, eb, n, 21), rand_np(F, eb, n, 22)
     dS, dB = ctx.from_numpy(S), ctx.from_numpy(B)
     for (t, m) in [(0, 1), (1, 3), (2, 5), (3, 7), (4, 9), (6, 13)]:
         if m >= F.order:
             continue
-        Cn = rand_np(F, eb, max(t, 1) * n, 30 + t).reshape((max(t, 1), n, 2) if eb == 16 else (max(t, 1), n))
+        Cn = rand_np(F, eb, max(t, 1) * n, 30 + t).reshape(lshape(eb, max(t, 1), n))
         dC = ctx.matrix_from_numpy(Cn)
         want = cf.split(S, Cn, t, m)
         sh = ctx.split(dS, dC, t, m)
@@ -254,7 +257,7 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
         if e < 0:
             continue
         got = unpack(ctx.pow(dA, e).to_numpy(), eb)
-        sample = range(0, n, 97) if eb == 16 and e > 1000 else range(n)
+        sample = range(0, n, 97) if eb >= 12 and e > 1000 else range(n)
         assert all(got[i] == fpow(vals[i], e) for i in sample), (hex(modulus), e)
     # inverse: zeros are flagged (ZeroDivisionError) and map to 0 when unchecked
     with pytest.raises(ZeroDivisionError):
@@ -293,7 +296,7 @@ def test_binary_fields_dense_and_small(eng, coracle):
         want = cf.ew(coracle.MUL, A, B)
         assert (ctx.mul(dA, dB).to_numpy() == want).all(), hex(mod)
         t, m = 2, 5
-        Cn = rand_np(F, eb, t * n, 93).reshape((t, n, 2) if eb == 16 else (t, n))
+        Cn = rand_np(F, eb, t * n, 93).reshape(lshape(eb, t, n))
         sh = ctx.split(dA, ctx.matrix_from_numpy(Cn), t, m, mul_by=dB)
         xs = [2, 4, 5, 1, 3]
         rec = ctx.recombine([sh.row(x - 1) for x in xs], po.recombination_vector(F, xs, 0))
@@ -476,7 +479,7 @@ def test_beaver_combine(eng, coracle):
         A, B, X, Y = (rand_np(F, eb, n, s) for s in (601, 602, 603, 604))
         Z = cf.ew(coracle.MUL, X, Y)
         def share(V, seed):
-            C = rand_np(F, eb, n, seed).reshape((1, n, 2) if eb == 16 else (1, n))
+            C = rand_np(F, eb, n, seed).reshape(lshape(eb, 1, n))
             return ctx.split(ctx.from_numpy(V), ctx.matrix_from_numpy(C), t, m)
         sa, sb, sx, sy, sz = (share(V, 700 + i) for i, V in enumerate((A, B, X, Y, Z)))
         lam2 = po.recombination_vector(F, [1, 2], 0)
@@ -554,7 +557,7 @@ def test_matmul(eng, coracle):
         ctx = ctx_for(eng, modulus, binary)
         eb = ctx.elem_bytes
         cf = coracle.CField(modulus, binary)
-        slow = eb == 16
+        slow = eb >= 12
         for (M, K, N) in [(1, 1, 1), (64, 64, 64), (70, 130, 65), (3, 500, 5), (33, 17, 129)] if not slow else \
                 [(1, 1, 1), (33, 40, 35), (3, 300, 5)]:
             A, B = rand_np(F, eb, M * K, 81), rand_np(F, eb, K * N, 82)
@@ -665,7 +668,7 @@ def test_many_rows_and_outputs(eng, coracle):
         cf = coracle.CField(modulus, binary)
         n, t, m = 5003, 12, 25
         S = rand_np(F, eb, n, 41)
-        Cn = rand_np(F, eb, t * n, 42).reshape((t, n, 2) if eb == 16 else (t, n))
+        Cn = rand_np(F, eb, t * n, 42).reshape(lshape(eb, t, n))
         sh = ctx.split(ctx.from_numpy(S), ctx.matrix_from_numpy(Cn), t, m)
         want = cf.split(S, Cn, t, m)
         assert (sh.to_numpy() == want).all()
@@ -674,7 +677,7 @@ def test_many_rows_and_outputs(eng, coracle):
         rec = ctx.recombine([sh.row(x - 1) for x in xs], lam)
         assert (rec.to_numpy() == S).all()
         # 11 recombination points at once from 3 rows of a degree-2 sharing
-        Cn2 = rand_np(F, eb, 2 * n, 43).reshape((2, n, 2) if eb == 16 else (2, n))
+        Cn2 = rand_np(F, eb, 2 * n, 43).reshape(lshape(eb, 2, n))
         sh2 = ctx.split(ctx.from_numpy(S), ctx.matrix_from_numpy(Cn2), 2, 5)
         x_rs = list(range(0, 11)) if F.order > 11 else [0, 1, 2]
         xs = [1, 2, 3]

@@ -51,11 +51,11 @@ def test_policy_selection(hostcheck, golden_fields):
         _, pk = run(hostcheck, F, HC_ADD, [0], [0])
         kinds[name] = pk
     # PolicyKind enum order in policy_build.hpp
-    PM64_MERS, PM64_K64, PM64_GEN, RC64, RC32, PM128_K128, PM128_GEN, MONT128, GF2P8, GF2W64, GF2W128 = range(1, 12)
+    PM64_MERS, PM64_K64, PM64_GEN, RC64, RC32, PM128_K128, PM128_GEN, PM96, MONT128, GF2P8, GF2W64, GF2W128 = range(1, 13)
     assert kinds['P61'] == PM64_MERS and kinds['P64'] == PM64_K64 and kinds['P40'] == PM64_GEN
     assert kinds['P63G'] == RC64 and kinds['P31'] == RC32 and kinds['GF19'] == RC32 and kinds['GF2'] == RC32
-    assert kinds['P128'] == PM128_K128 and kinds['P127'] == PM128_GEN and kinds['P96'] == PM128_GEN
-    assert kinds['P80'] == PM128_GEN and kinds['P128G'] == MONT128 and kinds['P100G'] == MONT128
+    assert kinds['P128'] == PM128_K128 and kinds['P127'] == PM128_GEN and kinds['P96'] == PM96
+    assert kinds['P80'] == PM96 and kinds['P128G'] == MONT128 and kinds['P100G'] == MONT128
     assert kinds['GF2_8'] == GF2P8 and kinds['GF2_4'] == GF2P8 and kinds['GF2_1'] == GF2P8
     assert kinds['GF2_16'] == GF2W64 and kinds['GF2_64'] == GF2W64
     assert kinds['GF2_100'] == GF2W128 and kinds['GF2_128'] == GF2W128

@@ -8,7 +8,7 @@ import numpy as np
 
 from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
-from fieldutil import field_of, pack, unhex, unpack
+from fieldutil import field_of, pack, unhex, unpack, lshape
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
@@ -106,7 +106,7 @@ def test_c_oracle(coracle, golden_fields, golden_sbox):
         for sc in case['sharing']:
             t, m, draws = sc['t'], sc['m'], unhex(sc['draws'])
             S = pack(s, eb)
-            C = pack(draws, eb).reshape((t, n, 2) if eb == 16 else (t, n))
+            C = pack(draws, eb).reshape(lshape(eb, t, n))
             sh = cf.split(S, C, t, m)
             got = [unpack(sh[i], eb) for i in range(m)]
             assert got == [unhex(r) for r in sc['np_shares']], (name, t, m)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle.coracle import elem_bytes
-from fieldutil import field_of, unpack
+from fieldutil import field_of, unpack, lshape
 
 KEY = bytes(range(32))
 
@@ -35,8 +35,8 @@ def test_chacha_rfc8439_kat(hostcheck, coracle):
 
 def hc_coeffs(hostcheck, F, key, nonce, rounds, t, n):
     eb = elem_bytes(F.modulus, F.binary)
-    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 16: np.uint64}[eb]
-    out = np.zeros((t, n, 2) if eb == 16 else (t, n), dtype=dt)
+    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb]
+    out = np.zeros(lshape(eb, t, n), dtype=dt)
     lim = (ctypes.c_uint64 * 3)(*[(F.modulus >> (64 * i)) & (2**64 - 1) for i in range(3)])
     rc = hostcheck.hc_rng_coeffs(int(F.binary), lim, 3, key, ctypes.c_uint64(nonce), rounds, t,
                                  out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), ctypes.c_size_t(n))
@@ -53,7 +53,7 @@ def test_sampler_and_layout_match_oracle(hostcheck, coracle, golden_fields):
             got = hc_coeffs(hostcheck, F, KEY, nonce, rounds, t, n)
             want = coracle.rng_coeffs(cf, KEY, nonce, rounds, t, n)
             assert (got == want).all(), (name, t, n)
-            vals = unpack(got.reshape(-1, 2) if cf.eb == 16 else got.reshape(-1), cf.eb)
+            vals = unpack(got.reshape(lshape(cf.eb, -1)), cf.eb)
             assert all(0 <= v < F.order for v in vals), name
 
 
