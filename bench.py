@@ -323,6 +323,24 @@ def main():
             ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
             kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
                                     units_per_s=round(n / (ms * 1e-3), 1))
+            # boundary handed HOST buffers (pinned): h2d of both operands + mulmod + d2h of the product, end to end
+            # through ffgpu_h2d / ffgpu_mul / ffgpu_d2h.  Reported for DESIGN.md only -- never the headline value.
+            from mpyc_amd import _ffi
+            ha, hb, hc = (torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(3))
+            ha.copy_(sets[0].a.t.cpu())
+            hb.copy_(sets[0].b.t.cpu())
+            L, h, st = ctx._L, ctx._h, ctx._stream()
+
+            def host_mul():
+                _ffi.check(L.ffgpu_h2d(h, sets[0].a.ptr, ha.data_ptr(), n * eb, st), 'h2d')
+                _ffi.check(L.ffgpu_h2d(h, sets[0].b.ptr, hb.data_ptr(), n * eb, st), 'h2d')
+                ctx.mul(sets[0].a, sets[0].b, out=sets[0].c)
+                _ffi.check(L.ffgpu_d2h(h, hc.data_ptr(), sets[0].c.ptr, n * eb, st), 'd2h')
+            ms = time_launches(lambda s_: host_mul(), [0], 3)
+            kern['mul_p61_pcie_inclusive'] = {'ms_per_launch': round(ms, 4), 'unit': 'GB/s', 'bound': 'pcie',
+                                              'achieved': round(3 * eb * n / (ms * 1e-3) / 1e9, 1), 'frac': 0.0,
+                                              'units_per_s': round(n / (ms * 1e-3), 1)}
+            del ha, hb, hc
             # launch-bound regime: a gate on 4096 elements, eager vs captured in a HIP graph.  (Run over the
             # 40-bit prime 2^40-87 so that its kernel instantiations do not mix into the rocprof averages of
             # the headline GF(2^61-1) kernels.)
