@@ -495,6 +495,32 @@ def main():
                                                  units_per_s=round(n8 / (ms * 1e-3), 1))
                 del bufs
                 torch.cuda.empty_cache()
+            # configs[4] proper: the np_aes S-box layer over SECURE bytes (demos/np_aes.py:37-43) -- x^254 by 11 GRR
+            # multiplications, bit decomposition with shared random bits, GF(2) affine map on bit shares,
+            # recomposition -- the compute of all m = 3 parties (t = 1) on this GPU, no networking
+            # (mpyc_amd/protocols.py; opened result checked against the public S-box kernel).
+            from mpyc_amd import finfields as gff, gfpx as ggx, protocols
+            F8 = gff.GF(ggx.GFpX(2)(0x11b))
+            A8 = [[(rows8[r__] >> c__) & 1 for c__ in range(8)] for r__ in range(8)]
+            B8 = [(b8 >> r__) & 1 for r__ in range(8)]
+            for n8, tag in ((1_000_000, '1e6'), (100_000_000, '1e8')):
+                xpub = DevArray(ctx8, torch.randint(0, 256, (n8,), dtype=torch.uint8, device=ctx.torch_device, generator=gen), n8)
+                xs = protocols.share(ctx8, xpub, 1, 3)
+                rb = DevArray(ctx8, torch.randint(0, 2, (8 * n8,), dtype=torch.uint8, device=ctx.torch_device, generator=gen), 8 * n8)
+                rbits = protocols.share(ctx8, rb, 1, 3)
+                res = protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8)
+                if not torch.equal(protocols.open_(ctx8, F8, res, 1).t, ctx8.sbox(xpub, rows8, b8).t):
+                    raise SystemExit('bench parity check failed for the secure S-box layer')
+                del res
+                ms = time_launches(lambda s_: protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
+                # algorithmic bytes per secure byte over all 3 parties: 11 gates x 3 x (5 fused split + 4 recombine)
+                # = 297, bit decomposition 3 x (9 + 3 + 17) + 3 = 90, affine + recomposition 3 x 9 = 27
+                bpu = 414
+                kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
+                                                             units_per_s=round(n8 / (ms * 1e-3), 1),
+                                                             kernels_per_layer=88)
+                del xs, rbits, rb, xpub
+                torch.cuda.empty_cache()
             # dominant kernel of the timed step = the one with the largest share of step time
         try:
             optional_measurements()

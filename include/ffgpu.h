@@ -250,6 +250,20 @@ int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, 
                        const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream);
 
 /* ---- GF(2^8) S-box layer (local / public values) ----------------------- */
+/* GF(2^n<=8), the linear layer of the AES S-box on BIT SHARES: for every group of 8 elements (the shares of the
+ * 8 bits of one byte, 8-byte aligned): y = M x + bias with a public 8x8 matrix M (row-major canonical scalars);
+ * from_bits = 0: out = y (8 elements per group); from_bits = 1: out = sum_r 2^r y_r (one element per group).
+ * replaces: demos/np_aes.py:40-42 (`A @ x[..., np.newaxis]`, `x += B`, `mpc.np_from_bits(x)`) in one pass;
+ *           finfields.py:1126-1146 + runtime.py:4475-4484.  ffgpu_group_matvec is the general form.           */
+int ffgpu_gf256_bit_affine(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int from_bits,
+                           const void* in, void* out, size_t n, void* stream);
+
+/* GF(2^n<=8): out[8 i + j] = ((in[i] >> j) & 1) + addend[8 i + j] for PUBLIC bytes `in` (addend may be NULL):
+ * the local tail of the secure bit decomposition over a binary field, where every party adds the bits of the
+ * opened masked value c to its shares of the random bits.
+ * replaces: runtime.py:4418-4423 (`c_bits = np.int8(np.right_shift.outer(c, shifts) & 1); return c_bits + r_bits`). */
+int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void* out, size_t n, void* stream);
+
 /* out[h] = A * bits(in[h]^254) + B packed back to a byte, with the 8x8 GF(2)
  * matrix given as 8 row bytes (bit c of host_rows8[r] = A[r][c]) and B as a byte.
  * replaces: demos/np_aes.py:37-43 sbox() evaluated on public values.           */

@@ -68,6 +68,8 @@ _SIGS = {
     'ffgpu_dot': [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_sum': [_vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_prss_combine': [_vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _u64p, _int, _vp, _sz, _vp],
+    'ffgpu_gf256_bit_affine': [_vp, _u64p, _u64p, _int, _vp, _vp, _sz, _vp],
+    'ffgpu_gf256_to_bits': [_vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_gf256_sbox': [_vp, _vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint8, _vp, _sz, _vp],
     'ffgpu_time_mul': [_vp, _vp, _vp, _vp, _sz, _int, _vp, _fp],
     'ffgpu_time_split': [_vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],

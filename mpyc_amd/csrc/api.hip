@@ -30,6 +30,9 @@ const FieldOps* ffgpu_ops_gf2w64();
 const FieldOps* ffgpu_ops_gf2w128();
 int ffgpu_sbox_build_lut(const void* gf2p8_policy, const uint8_t* rows8, uint8_t b, uint8_t* lut256);
 int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_gf8_to_bits(int device, const void* in, const void* addend, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
+                            const void* in, void* out, size_t ngroups, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
@@ -573,8 +576,35 @@ int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64
     if (ngroups == 0) return FFGPU_OK;
     ARGCHK(in && out);
     DeviceGuard gd(ctx->device);
+    if (ctx->kind == FFGPU_BINARY && ctx->elem_bytes == 1 && g == 8 && (((uintptr_t)in) & 7u) == 0) {
+        // groups of 8 bytes: packed-byte kernel (misc.hip)
+        if (r == 8 && (((uintptr_t)out) & 7u) == 0)
+            return launch_status(ffgpu_launch_gf8_group8(ctx->policy, ctx->device, host_matrix, host_bias, 0, in, out,
+                                                         ngroups, (hipStream_t)stream));
+        bool pow2 = (r == 1);
+        for (int c = 0; pow2 && c < 8; ++c) pow2 = (host_matrix[2 * c] == (1ull << c));
+        if (pow2 && (!host_bias || (host_bias[0] & 0xffu) == 0)) {   // np_from_bits: identity, then fold by 2^r
+            uint64_t eye[128];
+            memset(eye, 0, sizeof(eye));
+            for (int c = 0; c < 8; ++c) eye[2 * (c * 8 + c)] = 1;
+            return launch_status(ffgpu_launch_gf8_group8(ctx->policy, ctx->device, eye, nullptr, 1, in, out, ngroups,
+                                                         (hipStream_t)stream));
+        }
+    }
     return launch_status(ctx->ops->group_matvec(ctx->policy, ctx->device, host_matrix, host_bias, r, g, in, out,
                                                 ngroups, (hipStream_t)stream));
+}
+
+int ffgpu_gf256_bit_affine(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int from_bits,
+                           const void* in, void* out, size_t n, void* stream) {
+    ARGCHK(ctx && host_matrix);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(in && out);
+    if ((((uintptr_t)in) & 7u) || (!from_bits && (((uintptr_t)out) & 7u))) return FFGPU_EINVAL;
+    DeviceGuard gd(ctx->device);
+    return launch_status(ffgpu_launch_gf8_group8(ctx->policy, ctx->device, host_matrix, host_bias, from_bits ? 1 : 0, in,
+                                                 out, n, (hipStream_t)stream));
 }
 
 static int do_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream) {
@@ -607,6 +637,15 @@ int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, 
     DeviceGuard g(ctx->device);
     return launch_status(ctx->ops->prss(ctx->policy, ctx->device, host_streams, ks, d, l, mask_bits, host_weights,
                                         r2, accumulate, out, n, (hipStream_t)stream));
+}
+
+int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(in && out);
+    DeviceGuard g(ctx->device);
+    return launch_status(ffgpu_launch_gf8_to_bits(ctx->device, in, addend, out, n, (hipStream_t)stream));
 }
 
 int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b, void* out,

@@ -1203,6 +1203,34 @@ __global__ __launch_bounds__(BLOCK) void k_group_matvec(F f, GroupMatArgs<F> ga,
     }
 }
 
+
+// GF(2^n <= 8), groups of 8 bytes (the bit shares of one byte, np_aes / np_from_bits): one 8-byte load per
+// lane, R = 8 -> one 8-byte store, R = 1 -> one byte.  Same arithmetic as k_group_matvec.
+template <class F, int R>
+__global__ __launch_bounds__(BLOCK) void k_group8_bytes(F f, GroupMatArgs<F> ga, const uint8_t* __restrict__ in,
+                                                         uint8_t* __restrict__ out, size_t ngroups) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < ngroups; i += gsz) {
+        const uint64_t v = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(in) + i);
+        W x[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = (W)((v >> (8 * c)) & 0xffu);
+        uint64_t o = 0;
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+            typename F::acc s;
+            f.acc_zero(s);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) f.acc_mac(s, ga.m[a * 8 + c], x[c]);
+            o |= (uint64_t)(f.add(f.acc_reduce(s), ga.bias[a]) & 0xffu) << (8 * a);
+        }
+        if constexpr (R == 8) __builtin_nontemporal_store(o, reinterpret_cast<uint64_t*>(out) + i);
+        else out[i] = (uint8_t)o;
+    }
+}
+
 // ---- launch plumbing -------------------------------------------------------
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
@@ -1672,6 +1700,21 @@ struct Launchers {
         ga.r = r;
         ga.g = g;
         unsigned grid = grid_for(ngroups, lc);
+        if constexpr (F::EPW == 4) {
+            const bool al8 = (((uintptr_t)in) & 7u) == 0;
+            if (g == 8 && r == 8 && al8 && (((uintptr_t)out) & 7u) == 0) {
+                hipLaunchKernelGGL((k_group8_bytes<F, 8>), dim3(grid), dim3(BLOCK), 0, st, f, ga, (const uint8_t*)in,
+                                   (uint8_t*)out, ngroups);
+                FFGPU_CHECK_LAUNCH();
+                return 0;
+            }
+            if (g == 8 && r == 1 && al8) {
+                hipLaunchKernelGGL((k_group8_bytes<F, 1>), dim3(grid), dim3(BLOCK), 0, st, f, ga, (const uint8_t*)in,
+                                   (uint8_t*)out, ngroups);
+                FFGPU_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         hipLaunchKernelGGL((k_group_matvec<F>), dim3(grid), dim3(BLOCK), 0, st, f, ga, (const E*)in, (E*)out, ngroups);
         FFGPU_CHECK_LAUNCH();
         return 0;

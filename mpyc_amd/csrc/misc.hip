@@ -90,6 +90,129 @@ int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* o
     return 0;
 }
 
+// ---- GF(2^8): public byte -> its 8 bits as field elements, optionally added to bit shares ----------
+// out[8 i + j] = ((in[i] >> j) & 1) ^ addend[8 i + j]    (runtime.py:4418-4423: c_bits + r_bits)
+// One input byte becomes one 8-byte store; a lane takes 2 input bytes -> 16 bytes out.
+__device__ __forceinline__ uint64_t spread_bits(uint32_t v) {
+    uint64_t t = ((uint64_t)v * 0x0101010101010101ull) & 0x8040201008040201ull;   // bit j alone in byte j
+    return ((t + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;             // -> 0/1 per byte
+}
+__global__ __launch_bounds__(BLOCK) void k_gf8_to_bits(const uint8_t* __restrict__ in, const uint8_t* __restrict__ addend,
+                                                        uint8_t* __restrict__ out, size_t npair, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const uint16_t* __restrict__ iv = reinterpret_cast<const uint16_t*>(in);
+    const uint4* __restrict__ av = reinterpret_cast<const uint4*>(addend);
+    uint4* __restrict__ ov = reinterpret_cast<uint4*>(out);
+    for (size_t i = gid; i < npair; i += gsz) {
+        const uint32_t v = iv[i];
+        uint64_t lo = spread_bits(v & 0xffu), hi = spread_bits(v >> 8);
+        if (addend) {
+            uint4 a = ldg<true>(av + i);
+            lo ^= (uint64_t)a.x | ((uint64_t)a.y << 32);
+            hi ^= (uint64_t)a.z | ((uint64_t)a.w << 32);
+        }
+        stg<true>(ov + i, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
+    }
+    for (size_t e = 2 * npair + gid; e < n; e += gsz) {
+        uint64_t b = spread_bits(in[e]);
+        for (int j = 0; j < 8; ++j) out[8 * e + j] = (uint8_t)((b >> (8 * j)) & 1u) ^ (addend ? addend[8 * e + j] : 0);
+    }
+}
+
+int ffgpu_launch_gf8_to_bits(int device, const void* in, const void* addend, void* out, size_t n, hipStream_t st) {
+    LaunchCfg lc = launch_cfg(device);
+    bool vec = (((uintptr_t)in) & 1u) == 0 && (((uintptr_t)out) & 15u) == 0 && (!addend || (((uintptr_t)addend) & 15u) == 0);
+    size_t npair = vec ? n / 2 : 0;
+    unsigned grid = grid_for(npair ? npair : n, lc);
+    hipLaunchKernelGGL(k_gf8_to_bits, dim3(grid), dim3(BLOCK), 0, st, (const uint8_t*)in, (const uint8_t*)addend,
+                       (uint8_t*)out, npair, n);
+    FFGPU_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- GF(2^n<=8): a public 8x8 matrix over every group of 8 bytes, on packed bytes ---------------------
+// out_r = bias_r + sum_c M[r][c] (x) x_c for the 8 field elements x_0..x_7 of a group (the bit shares of one
+// byte: demos/np_aes.py:40-41), optionally followed by np_from_bits (runtime.py:4475-4484: sum_r 2^r out_r)
+// in registers.  The group is one 64-bit value; M is applied diagonal by diagonal:
+//     out = XOR_d XOR_b  xtime^b(rot_d(v)) & mask[d][b],   mask[d][b] byte r = 0xff iff bit b of M[r][(r+d)%8]
+// (rot_d = rotate right by d bytes, two v_alignbyte; empty diagonals / bit planes are skipped by scalar
+// branches).  A 0/1 matrix costs ~6 VALU ops per non-empty diagonal (AES: 5), against ~100 for the
+// element-by-element loop -- the difference between 0.9 and 6 TB/s for this 16-bytes-per-group kernel.
+struct Gf8Group8Args {
+    uint64_t mask[8][8];
+    int nplanes[8];
+    uint64_t bias;
+    int fold;       // 1: store sum_r 2^r out_r (one byte) instead of the 8 bytes
+};
+
+__global__ __launch_bounds__(BLOCK) void k_gf8_group8(GF2P8 f, Gf8Group8Args ga, const uint64_t* __restrict__ in,
+                                                       uint8_t* __restrict__ out, size_t ngroups) {
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t i = gid; i < ngroups; i += gsz) {
+        const uint64_t v = __builtin_nontemporal_load(in + i);
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        uint32_t alo = (uint32_t)ga.bias, ahi = (uint32_t)(ga.bias >> 32);
+        for (int d = 0; d < 8; ++d) {
+            const int np = ga.nplanes[d];
+            if (np == 0) continue;
+            const uint32_t s0 = (d & 4) ? hi : lo, s1 = (d & 4) ? lo : hi;     // rotate right by d bytes
+            uint32_t plo = __builtin_amdgcn_alignbyte(s1, s0, (uint32_t)(d & 3));
+            uint32_t phi = __builtin_amdgcn_alignbyte(s0, s1, (uint32_t)(d & 3));
+            for (int b = 0; b < np; ++b) {
+                const uint64_t mk = ga.mask[d][b];
+                alo ^= plo & (uint32_t)mk;
+                ahi ^= phi & (uint32_t)(mk >> 32);
+                if (b + 1 < np) {
+                    plo = f.xtime(plo);
+                    phi = f.xtime(phi);
+                }
+            }
+        }
+        if (ga.fold) {
+            // Horner over the 8 bytes, most significant first: t = 2 t + out_r
+            uint32_t t = ahi >> 24;
+            t = f.xtime(t) ^ ((ahi >> 16) & 0xffu);
+            t = f.xtime(t) ^ ((ahi >> 8) & 0xffu);
+            t = f.xtime(t) ^ (ahi & 0xffu);
+            t = f.xtime(t) ^ (alo >> 24);
+            t = f.xtime(t) ^ ((alo >> 16) & 0xffu);
+            t = f.xtime(t) ^ ((alo >> 8) & 0xffu);
+            t = f.xtime(t) ^ (alo & 0xffu);
+            out[i] = (uint8_t)t;
+        } else {
+            __builtin_nontemporal_store((uint64_t)alo | ((uint64_t)ahi << 32), reinterpret_cast<uint64_t*>(out) + i);
+        }
+    }
+}
+
+// matrix: (8, 8) field constants (low byte of each 2-limb scalar), bias: 8 constants or NULL
+int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
+                            const void* in, void* out, size_t ngroups, hipStream_t st) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    Gf8Group8Args ga;
+    memset(&ga, 0, sizeof(ga));
+    for (int r = 0; r < 8; ++r) {
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t w = (uint32_t)(m2[2 * (r * 8 + c)] & 0xffu);
+            const int d = (c - r + 8) & 7;                   // out_r takes x_{(r+d)%8}
+            for (int b = 0; b < 8; ++b)
+                if ((w >> b) & 1) {
+                    ga.mask[d][b] |= 0xffull << (8 * r);
+                    if (ga.nplanes[d] < b + 1) ga.nplanes[d] = b + 1;
+                }
+        }
+        if (bias2) ga.bias |= (uint64_t)(bias2[2 * r] & 0xffu) << (8 * r);
+    }
+    ga.fold = fold;
+    LaunchCfg lc = launch_cfg(device);
+    unsigned grid = grid_for(ngroups, lc);
+    hipLaunchKernelGGL(k_gf8_group8, dim3(grid), dim3(BLOCK), 0, st, f, ga, (const uint64_t*)in, (uint8_t*)out, ngroups);
+    FFGPU_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- GF(2^n), n <= 8: multiplication through log / antilog tables in LDS ---------------------
 // c = exp[log a + log b].  log[0] = 2*(q-1) so that any sum involving a zero operand lands in the
 // zero-padded tail of exp[] (no zero test, no select).  Both tables come from the host (built at

@@ -497,6 +497,33 @@ class FieldContext:
                                               self._stream()), 'prss_combine')
         return out
 
+    def bit_affine(self, bits: DevArray, matrix: Sequence[Sequence[int]], bias: Optional[Sequence[int]] = None,
+                   from_bits: bool = False, out: Optional[DevArray] = None) -> DevArray:
+        """GF(2^n<=8): y = M bits + bias per group of 8 bit shares (np_aes.py:40-41); from_bits: also
+        recompose sum_r 2^r y_r in the same pass (np_aes.py:42)."""
+        if bits.n % 8:
+            raise ValueError('bit array length must be a multiple of 8')
+        ng = bits.n // 8
+        out = out or self.empty(ng if from_bits else bits.n)
+        m = (ctypes.c_uint64 * 128)()
+        for i, v in enumerate(v for row in matrix for v in row):
+            m[2 * i] = int(v)
+        b = None
+        if bias is not None:
+            b = (ctypes.c_uint64 * 16)()
+            for i, v in enumerate(bias):
+                b[2 * i] = int(v)
+        _ffi.check(self._L.ffgpu_gf256_bit_affine(self._h, m, b, 1 if from_bits else 0, bits.ptr, out.ptr, ng,
+                                                  self._stream()), 'bit_affine')
+        return out
+
+    def to_bits(self, x: DevArray, addend: Optional[DevArray] = None, out: Optional[DevArray] = None) -> DevArray:
+        """GF(2^n<=8): bits of PUBLIC bytes as field elements (8 per byte), plus `addend` (runtime.py:4418-4423)."""
+        out = out or self.empty(8 * x.n)
+        _ffi.check(self._L.ffgpu_gf256_to_bits(self._h, x.ptr, addend.ptr if addend is not None else None, out.ptr,
+                                               x.n, self._stream()), 'to_bits')
+        return out
+
     def sbox(self, x: DevArray, rows8: Sequence[int], b: int, out=None):
         out = out or self.empty(x.n)
         r = (ctypes.c_uint8 * 8)(*rows8)

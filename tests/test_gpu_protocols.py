@@ -1,0 +1,139 @@
+"""End-to-end gate compositions for all m parties on one GPU (mpyc_amd/protocols.py): the opened result of
+the secure protocol must equal the plaintext function -- GRR multiplication (runtime.py:1096-1141, 603-689),
+x^254 by the reference's addition chain (runtime.py:1356-1367), bit decomposition over GF(2^8)
+(runtime.py:4411-4423) and the whole AES S-box layer of demos/np_aes.py:37-43 against the FIPS-197 table."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from fieldutil import pack, unpack
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def mods():
+    assert torch.cuda.is_available()
+    from mpyc_amd import engine, finfields, gfpx, protocols
+    return engine, finfields, gfpx, protocols
+
+
+@pytest.mark.parametrize('modulus,t,m', [(2**61 - 1, 1, 3), (2**61 - 1, 3, 7), (2**96 - 17, 2, 5),
+                                         (2**128 - 173, 1, 4), (2**31 - 1, 1, 3)])
+def test_secure_multiplication_opens_to_product(mods, modulus, t, m):
+    engine, finfields, _, protocols = mods
+    F = finfields.GF(modulus)
+    ctx = engine.FieldContext(modulus, device=0)
+    rng = random.Random(modulus % 1000 + t)
+    n = 5003
+    a = [rng.randrange(modulus) for _ in range(n)]
+    b = [rng.randrange(modulus) for _ in range(n)]
+    a[:2], b[:2] = [0, modulus - 1], [5, modulus - 1]
+    eb = ctx.elem_bytes
+    xs = protocols.share(ctx, ctx.from_numpy(pack(a, eb)), t, m)
+    ys = protocols.share(ctx, ctx.from_numpy(pack(b, eb)), t, m)
+    assert unpack(protocols.open_(ctx, F, xs, t).to_numpy(), eb) == a          # sharing round trip
+    zs = protocols.multiply(ctx, F, xs, ys, t)
+    assert len(zs) == m
+    want = [x * y % modulus for x, y in zip(a, b)]
+    assert unpack(protocols.open_(ctx, F, zs, t).to_numpy(), eb) == want
+    # any t+1 of the new shares open to the product (the result is a proper degree-t sharing)
+    pick = sorted(rng.sample(range(m), t + 1))
+    lam = [int(v) for v in po.recombination_vector(po.Field(modulus, False), [i + 1 for i in pick], 0)]
+    assert unpack(ctx.recombine([zs[i] for i in pick], lam).to_numpy(), eb) == want
+    # ... and t of them reveal nothing recognisable: a fresh run gives different shares
+    zs2 = protocols.multiply(ctx, F, xs, ys, t)
+    assert not torch.equal(zs[0].t, zs2[0].t)
+
+
+def test_secure_aes_sbox_layer(mods):
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    Fo = po.Field(0x11b, True)
+    t, m = 1, 3
+    x = list(range(256)) * 5 + [0x53, 0x00, 0xff]                               # every byte value, ragged length
+    n = len(x)
+    xs = protocols.share(ctx, ctx.from_numpy(np.array(x, dtype=np.uint8)), t, m)
+    # x^254 over shares
+    y = protocols.pow254(ctx, F, xs, t)
+    assert unpack(protocols.open_(ctx, F, y, t).to_numpy(), 1) == [g['pow254'][v] for v in x]
+    # bit decomposition with shared random bits
+    rb = torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0')
+    rbits = protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m)
+    bits = protocols.to_bits_gf256(ctx, F, y, rbits, t)
+    opened = unpack(protocols.open_(ctx, F, bits, t).to_numpy(), 1)
+    assert opened == [(g['pow254'][v] >> j) & 1 for v in x for j in range(8)]
+    assert any(b > 1 for b in unpack(bits[0].to_numpy(), 1))                    # shares of bits are field elements
+    # the whole layer
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    out = protocols.sbox_layer(ctx, F, xs, rbits, t, A, B)
+    two_step = protocols.sbox_layer(ctx, F, xs, rbits, t, A, B, fused=False)
+    assert unpack(protocols.open_(ctx, F, two_step, t).to_numpy(), 1) == [g['table'][v] for v in x]
+    assert unpack(protocols.open_(ctx, F, out, t).to_numpy(), 1) == [g['table'][v] for v in x]
+    assert unpack(protocols.open_(ctx, F, out, t).to_numpy(), 1)[-3:] == [0xed, 0x63, 0x16]   # FIPS-197
+
+
+def test_to_bits_public(mods):
+    engine, _, _, _ = mods
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 7, 4097):
+        v = rng.integers(0, 256, size=n, dtype=np.uint8)
+        add = rng.integers(0, 256, size=8 * n, dtype=np.uint8)
+        want = ((v[:, None] >> np.arange(8, dtype=np.uint8)[None, :]) & 1).astype(np.uint8).reshape(-1)
+        assert (ctx.to_bits(ctx.from_numpy(v)).to_numpy() == want).all()
+        assert (ctx.to_bits(ctx.from_numpy(v), addend=ctx.from_numpy(add)).to_numpy() == (want ^ add)).all()
+        # unaligned views take the scalar path
+        if n > 2:
+            vv = ctx.from_numpy(v)
+            sub = engine.DevArray(ctx, vv.t[1:], n - 1)
+            assert (ctx.to_bits(sub).to_numpy() == want[8:]).all()
+
+
+def test_bit_affine_vs_python(mods):
+    """Packed-byte 8x8 kernel (diagonal decomposition) against Python for 0/1 and arbitrary byte matrices,
+    with and without the fused np_from_bits, and against the general group_matvec kernel."""
+    engine, _, _, _ = mods
+    for modulus in (0x11b, 0b1000011):                                        # GF(2^8) and GF(2^6)
+        ctx = engine.FieldContext(modulus, True, device=0)
+        Fo = po.Field(modulus, True)
+        q = Fo.order
+        rng = random.Random(12)
+        ng = 3001
+        x = [rng.randrange(q) for _ in range(8 * ng)]
+        dx = ctx.from_numpy(np.array(x, dtype=np.uint8))
+        for kind in ('bits', 'bytes', 'sparse'):
+            M = [[rng.randrange(2) if kind == 'bits' else rng.randrange(q) if kind == 'bytes' else
+                  (rng.randrange(q) if rng.random() < 0.2 else 0) for _ in range(8)] for _ in range(8)]
+            bias = [rng.randrange(q) for _ in range(8)]
+            want = []
+            for i in range(ng):
+                for r in range(8):
+                    acc = bias[r]
+                    for c in range(8):
+                        acc ^= po.mul(Fo, M[r][c], x[8 * i + c])
+                    want.append(acc)
+            assert unpack(ctx.bit_affine(dx, M, bias).to_numpy(), 1) == want, (hex(modulus), kind)
+            assert unpack(ctx.group_matvec(dx, M, bias).to_numpy(), 1) == want
+            folded = []
+            for i in range(ng):
+                acc = 0
+                for r in range(8):
+                    acc ^= po.mul(Fo, po.reduce(Fo, 1 << r), want[8 * i + r])
+                folded.append(acc)
+            assert unpack(ctx.bit_affine(dx, M, bias, from_bits=True).to_numpy(), 1) == folded, (hex(modulus), kind)
+        w = [[po.reduce(Fo, 1 << j) for j in range(8)]]
+        if modulus == 0x11b:                                                  # np_from_bits fast path == general kernel
+            sub = engine.DevArray(ctx, dx.t[8:], 8 * (ng - 1))
+            a = ctx.group_matvec(sub, w).to_numpy()
+            unaligned = engine.DevArray(ctx, ctx.from_numpy(np.array([0] + x[8:], dtype=np.uint8)).t[1:], 8 * (ng - 1))
+            assert (a == ctx.group_matvec(unaligned, w).to_numpy()).all()
