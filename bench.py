@@ -519,6 +519,18 @@ def main():
                 kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
                                                              units_per_s=round(n8 / (ms * 1e-3), 1),
                                                              kernels_per_layer=88)
+                if n8 <= 10**6:
+                    # the same layer captured once in a HIP graph (device-resident generator state: fresh
+                    # randomness on every replay) -- the launch-bound regime is where graphs pay
+                    st8 = ctx8.rng_state()
+                    cg8 = CapturedLaunches(lambda: protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8, rng=st8))
+                    cg8.replay()
+                    if not torch.equal(protocols.open_(ctx8, F8, cg8.result, 1).t, ctx8.sbox(xpub, rows8, b8).t):
+                        raise SystemExit('bench parity check failed for the graph-replayed secure S-box layer')
+                    msg = time_launches(lambda s_: cg8.replay(), [0], 20)
+                    kern[f'secure_sbox_layer_m3t1_{tag}_hipgraph'] = dict(roof(bpu * n8, msg), algorithmic_bytes_per_unit=bpu,
+                                                                           units_per_s=round(n8 / (msg * 1e-3), 1))
+                    del cg8
                 del xs, rbits, rb, xpub
                 torch.cuda.empty_cache()
             # dominant kernel of the timed step = the one with the largest share of step time

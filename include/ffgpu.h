@@ -178,6 +178,18 @@ int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint
                         uint64_t nonce, int rounds, int t, int m, void* shares, size_t share_stride,
                         size_t n, void* stream);
 
+/* Device-resident generator state, for launches captured in a HIP graph: the kernels read key / nonce /
+ * rounds from `dev_state` (ffgpu_rng_state_bytes() bytes of device memory) when they start, and the nonce is
+ * advanced on the device after every use, so each REPLAY of a captured ffgpu_split_rng_state draws fresh
+ * coefficients (a host key in the kernel arguments would be frozen into the graph).  One state per stream of
+ * launches; ffgpu_rng_state_init is not capturable (it synchronises).  mul_by: NULL or the second factor of
+ * the fused local product (as ffgpu_mul_split_rng).  No reference counterpart (secrets.randbelow, thresha.py:58). */
+size_t ffgpu_rng_state_bytes(void);
+int ffgpu_rng_state_init(ffgpu_ctx* ctx, void* dev_state, const uint8_t* host_key32, uint64_t nonce, int rounds,
+                         void* stream);
+int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_by, void* dev_state, int t, int m,
+                          void* shares, size_t share_stride, size_t n, void* stream);
+
 /* ---- Lagrange recombination ------------------------------------------- */
 /* out[r][h] = sum_{j<k} lambda[r][j] * rows[j][h]  (mod modulus), r < w.
  * host_rows: HOST array of k device pointers (rows arrive from k peers and need

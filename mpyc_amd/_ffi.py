@@ -60,6 +60,9 @@ _SIGS = {
     'ffgpu_rng_coeffs': [_vp, ctypes.c_char_p, ctypes.c_uint64, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_split_rng': [_vp, _vp, ctypes.c_char_p, ctypes.c_uint64, _int, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_mul_split_rng': [_vp, _vp, _vp, ctypes.c_char_p, ctypes.c_uint64, _int, _int, _int, _vp, _sz, _sz, _vp],
+    'ffgpu_rng_state_bytes': [],
+    'ffgpu_rng_state_init': [_vp, _vp, ctypes.c_char_p, ctypes.c_uint64, _int, _vp],
+    'ffgpu_split_rng_state': [_vp, _vp, _vp, _vp, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_recombine': [_vp, ctypes.POINTER(_vp), _u64p, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_matmul': [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _sz, _sz, _sz, _vp],
     'ffgpu_sqrt_cl': [_vp, _vp, _vp, _sz, _vp],
@@ -77,7 +80,8 @@ _SIGS = {
     'ffgpu_time_copy': [_vp, _vp, _vp, _sz, _int, _vp, _fp],
     'ffgpu_copy': [_vp, _vp, _vp, _sz, _vp],
 }
-_RESTYPES = {'ffgpu_strerror': ctypes.c_char_p, 'ffgpu_last_hip_error': ctypes.c_char_p}
+_RESTYPES = {'ffgpu_strerror': ctypes.c_char_p, 'ffgpu_last_hip_error': ctypes.c_char_p,
+             'ffgpu_rng_state_bytes': ctypes.c_size_t}
 
 EXPORTED = tuple(_SIGS)
 

@@ -33,6 +33,7 @@ int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* o
 int ffgpu_launch_gf8_to_bits(int device, const void* in, const void* addend, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
+int ffgpu_launch_rng_bump(void* dev_state, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
@@ -502,6 +503,40 @@ static int do_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, bool fused
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, nullptr, 0, t, m,
                                          shares, share_stride, n, (hipStream_t)stream, t > 0 ? &ra : nullptr));
 }
+size_t ffgpu_rng_state_bytes(void) { return sizeof(RngKey); }
+
+int ffgpu_rng_state_init(ffgpu_ctx* ctx, void* dev_state, const uint8_t* host_key32, uint64_t nonce, int rounds,
+                         void* stream) {
+    ARGCHK(ctx && dev_state);
+    RngArgs ra;
+    int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
+    if (rc != FFGPU_OK) return rc;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipMemcpyAsync(dev_state, &ra.rk, sizeof(RngKey), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));     // the source is on this stack frame
+    return FFGPU_OK;
+}
+
+int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_by, void* dev_state, int t, int m,
+                          void* shares, size_t share_stride, size_t n, void* stream) {
+    ARGCHK(ctx && dev_state);
+    ARGCHK(m >= 1 && t >= 0 && t < m);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(secrets && shares && (m == 1 || share_stride >= n));
+    RngArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.rk.rounds = 20;
+    ra.r0 = ctx->rng_r[0];
+    ra.r1 = ctx->rng_r[1];
+    ra.dev_key = (const RngKey*)dev_state;
+    DeviceGuard g(ctx->device);
+    int rc = ctx->ops->split(ctx->policy, ctx->device, secrets, mul_by, nullptr, 0, t, m, shares, share_stride, n,
+                             (hipStream_t)stream, t > 0 ? &ra : nullptr);
+    if (rc) return launch_status(rc);
+    if (t > 0) return launch_status(ffgpu_launch_rng_bump(dev_state, (hipStream_t)stream));
+    return FFGPU_OK;
+}
+
 int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,
                 void* shares, size_t share_stride, size_t n, void* stream) {
     return do_split(ctx, secrets, nullptr, false, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);

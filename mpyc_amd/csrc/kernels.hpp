@@ -259,7 +259,12 @@ __global__ __launch_bounds__(BLOCK) void k_beaver(F f, const typename F::elem* _
 struct RngArgs {
     RngKey rk;
     uint64_t r0, r1;  // 2^W mod p for the sampler
+    // device-resident generator state (ffgpu_rng_state_*): when set, key / nonce / rounds are read from it at
+    // kernel start instead of from the kernel arguments, so a captured HIP graph draws fresh coefficients on
+    // every replay (k_rng_bump advances the nonce after each use)
+    const RngKey* dev_key;
 };
+
 
 template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
                                                   size_t nvec, size_t n, RngArgs ra) {
+    if (ra.dev_key) ra.rk = *ra.dev_key;
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
 template <class F, int T>
 __global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __restrict__ coef, size_t cstride,
                                                        size_t nvec, size_t n, RngArgs ra) {
+    if (ra.dev_key) ra.rk = *ra.dev_key;
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
                                                       const typename F::elem* __restrict__ coef, size_t cstride,
                                                       int t, int m, typename F::elem* __restrict__ out,
                                                       size_t ostride, size_t n, RngArgs ra) {
+    if (ra.dev_key) ra.rk = *ra.dev_key;
     typedef typename F::word W;
     typedef Pack<W> P;
     constexpr int EPV = P::N * F::EPW;
@@ -469,6 +477,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
 template <class F>
 __global__ __launch_bounds__(BLOCK) void k_rng_coeffs_any(F f, typename F::elem* __restrict__ coef, size_t cstride,
                                                            int t, size_t n, RngArgs ra) {
+    if (ra.dev_key) ra.rk = *ra.dev_key;
     typedef typename F::word W;
     typedef Pack<W> P;
     constexpr int EPV = P::N * F::EPW;

@@ -135,6 +135,23 @@ class DevMatrix:
         return [np_to_ints(a[i], self.ctx.elem_bytes) for i in range(self.rows)]
 
 
+class RngState:
+    """Key / nonce / rounds of the device CSPRNG in device memory (FieldContext.rng_state)."""
+
+    __slots__ = ('ctx', 't')
+
+    def __init__(self, ctx, t):
+        self.ctx, self.t = ctx, t
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def nonce(self) -> int:
+        w = self.t.cpu().numpy().view(np.uint32)
+        return int(w[8]) | (int(w[9]) << 32)
+
+
 class CapturedLaunches:
     """A fixed sequence of engine calls captured into a HIP graph (through torch.cuda.CUDAGraph, which
     captures every launch issued on the capture stream -- including libffgpu's, since the engine always
@@ -152,7 +169,7 @@ class CapturedLaunches:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            fn()
+            self.result = fn()          # arrays allocated during capture live in the graph's pool
 
     def replay(self):
         self.graph.replay()
@@ -336,6 +353,20 @@ class FieldContext:
         _ffi.check(rc, 'split')
         return out
 
+    def rng_state(self, key: Optional[bytes] = None, nonce: int = 0, rounds: int = 20) -> 'RngState':
+        """Device-resident generator state (key from the host CSPRNG by default).  Pass it as `state=` to
+        split_rng: the kernels then read key/nonce from device memory and the nonce advances on the device
+        after every call, so the calls can be captured in a HIP graph and every replay draws fresh
+        coefficients."""
+        import secrets as _secrets
+        key = key if key is not None else _secrets.token_bytes(32)
+        if len(key) != 32:
+            raise ValueError('key must be 32 bytes')
+        t = torch.zeros(int(self._L.ffgpu_rng_state_bytes()), dtype=torch.uint8, device=self.torch_device)
+        _ffi.check(self._L.ffgpu_rng_state_init(self._h, t.data_ptr(), key, nonce, rounds, self._stream()),
+                   'rng_state_init')
+        return RngState(self, t)
+
     def rng_coeffs(self, key: bytes, nonce: int, t: int, n: int, rounds: int = 20,
                    out: Optional[DevMatrix] = None) -> DevMatrix:
         """Materialise the (t, n) coefficient matrix the fused split_rng kernel draws for
@@ -349,16 +380,22 @@ class FieldContext:
 
     def split_rng(self, secrets: DevArray, t: int, m: int, key: Optional[bytes] = None, nonce: int = 0,
                   rounds: int = 20, out: Optional[DevMatrix] = None,
-                  mul_by: Optional[DevArray] = None) -> DevMatrix:
+                  mul_by: Optional[DevArray] = None, state: Optional['RngState'] = None) -> DevMatrix:
         """np_random_split with coefficients drawn on the device (production mode): the t*n
         random coefficients never touch HBM.  key: 32 bytes; default = fresh from the host CSPRNG
         (the reference draws from `secrets` too, thresha.py:58)."""
         import secrets as _secrets
+        n = secrets.n
+        if state is not None:
+            out = out or self.empty_matrix(m, n)
+            _ffi.check(self._L.ffgpu_split_rng_state(self._h, secrets.ptr, mul_by.ptr if mul_by is not None else None,
+                                                     state.ptr, t, m, out.ptr, out.stride, n, self._stream()),
+                       'split_rng_state')
+            return out
         if key is None:
             key = _secrets.token_bytes(32)
         if len(key) != 32:
             raise ValueError('key must be 32 bytes')
-        n = secrets.n
         out = out or self.empty_matrix(m, n)
         if mul_by is None:
             rc = self._L.ffgpu_split_rng(self._h, secrets.ptr, key, nonce, rounds, t, m, out.ptr, out.stride, n,

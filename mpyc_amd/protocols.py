@@ -24,9 +24,11 @@ def _lagrange(field, xs: Sequence[int]) -> List[int]:
     return [int(v) for v in thresha._recombination_vector(field, tuple(xs), 0)]
 
 
-def share(ctx: FieldContext, x: DevArray, t: int, m: int) -> Shares:
-    """np_random_split (thresha.py:47-64) with coefficients from the device CSPRNG; row i -> party i+1."""
-    mtx = ctx.split_rng(x, t, m)
+def share(ctx: FieldContext, x: DevArray, t: int, m: int, rng=None) -> Shares:
+    """np_random_split (thresha.py:47-64) with coefficients from the device CSPRNG; row i -> party i+1.
+    rng: an engine.RngState (device-resident generator, required inside HIP-graph capture) or None (fresh
+    host key per call)."""
+    mtx = ctx.split_rng(x, t, m, state=rng)
     return [mtx.row(i) for i in range(m)]
 
 
@@ -41,7 +43,7 @@ def add_public(ctx: FieldContext, xs: Shares, c: DevArray) -> Shares:
     return [ctx.add(x, c) for x in xs]
 
 
-def multiply(ctx: FieldContext, field, xs: Shares, ys: Shares, t: int) -> Shares:
+def multiply(ctx: FieldContext, field, xs: Shares, ys: Shares, t: int, rng=None) -> Shares:
     """runtime.np_multiply (runtime.py:1096-1141) = local product of shares (degree 2t) + _reshare
     (runtime.py:603-689): each of the first 2t+1 parties re-shares its product with a fresh degree-t
     polynomial -- the product is formed inside the share-generation kernel (ffgpu_mul_split_rng) --, then
@@ -51,15 +53,15 @@ def multiply(ctx: FieldContext, field, xs: Shares, ys: Shares, t: int) -> Shares
     if m < k:
         raise ValueError('multiplication needs m >= 2t+1 parties')
     lam = _lagrange(field, range(1, k + 1))
-    sub = [ctx.split_rng(xs[i], t, m, mul_by=ys[i]) for i in range(k)]            # sender i -> row j for party j
+    sub = [ctx.split_rng(xs[i], t, m, mul_by=ys[i], state=rng) for i in range(k)]            # sender i -> row j for party j
     return [ctx.recombine([sub[i].row(j) for i in range(k)], lam) for j in range(m)]
 
 
-def pow254(ctx: FieldContext, field, xs: Shares, t: int) -> Shares:
+def pow254(ctx: FieldContext, field, xs: Shares, t: int, rng=None) -> Shares:
     """x^254 by the reference's addition chain (runtime.py:1356-1367): 11 secure multiplications.  The
     reference stacks (c, d) in two rounds to halve the number of MESSAGES; locally the stacked product is two
     products, issued here as such (no concatenation traffic)."""
-    mul = lambda a, b: multiply(ctx, field, a, b, t)
+    mul = lambda a, b: multiply(ctx, field, a, b, t, rng)
     d = xs
     c = mul(d, d)
     c = mul(c, c)
@@ -88,10 +90,10 @@ def from_bits(ctx: FieldContext, bits: Shares, l: int = 8) -> Shares:
 
 
 def sbox_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A: Sequence[Sequence[int]],
-               B: Sequence[int], fused: bool = True) -> Shares:
+               B: Sequence[int], fused: bool = True, rng=None) -> Shares:
     """The AES S-box on secret-shared bytes, as demos/np_aes.py:37-43:
     x = np_to_bits(x**254); x = A @ x + B over GF(2) (on bit shares, local); x = np_from_bits(x)."""
-    y = pow254(ctx, field, xs, t)
+    y = pow254(ctx, field, xs, t, rng)
     bits = to_bits_gf256(ctx, field, y, rbits, t)
     if fused:
         return [ctx.bit_affine(b, A, B, from_bits=True) for b in bits]           # both local steps in one pass

@@ -137,3 +137,65 @@ def test_bit_affine_vs_python(mods):
             a = ctx.group_matvec(sub, w).to_numpy()
             unaligned = engine.DevArray(ctx, ctx.from_numpy(np.array([0] + x[8:], dtype=np.uint8)).t[1:], 8 * (ng - 1))
             assert (a == ctx.group_matvec(unaligned, w).to_numpy()).all()
+
+
+def test_rng_state_matches_host_key_and_advances(mods):
+    engine, _, _, _ = mods
+    key = bytes(range(32))
+    for modulus, binary in ((2**61 - 1, False), (2**96 - 17, False), (0x11b, True)):
+        ctx = engine.FieldContext(modulus, binary, device=0)
+        F = po.Field(modulus, binary)
+        n = 3001
+        rng = random.Random(3)
+        s = ctx.from_numpy(pack([rng.randrange(F.order) for _ in range(n)], ctx.elem_bytes))
+        b = ctx.from_numpy(pack([rng.randrange(F.order) for _ in range(n)], ctx.elem_bytes))
+        st = ctx.rng_state(key=key, nonce=41, rounds=12)
+        for i, (t, m, mb) in enumerate(((1, 3, None), (3, 7, b), (6, 13, None))):     # t > 4: per-row streams
+            if m >= F.order:
+                continue
+            got = ctx.split_rng(s, t, m, mul_by=mb, state=st)
+            want = ctx.split_rng(s, t, m, key=key, nonce=41 + i, rounds=12, mul_by=mb)
+            assert torch.equal(got.t[:, :n], want.t[:, :n]), (hex(modulus), t, m)
+            assert st.nonce() == 42 + i
+        ctx.split_rng(s, 0, 1, state=st)                                            # t = 0 draws nothing
+        assert st.nonce() == 44
+
+
+def test_secure_sbox_layer_in_a_hip_graph(mods):
+    """The whole layer (88 kernels + nonce updates) captured once and replayed: every replay opens to the
+    S-box table, with fresh sharing randomness (device-resident generator state)."""
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    t, m = 1, 3
+    x = list(range(256)) * 4
+    n = len(x)
+    xs = protocols.share(ctx, ctx.from_numpy(np.array(x, dtype=np.uint8)), t, m)
+    rb = torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0')
+    rbits = protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m)
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    st = ctx.rng_state()
+    def layer():
+        y = protocols.pow254(ctx, F, xs, t, rng=st)
+        bits = protocols.to_bits_gf256(ctx, F, y, rbits, t)
+        return y, [ctx.bit_affine(b, A, B, from_bits=True) for b in bits]
+    cg = engine.CapturedLaunches(layer)
+    n0 = st.nonce()
+    seen = []
+    for _ in range(3):
+        cg.replay()
+        torch.cuda.synchronize()
+        y, out = cg.result
+        assert unpack(protocols.open_(ctx, F, out, t).to_numpy(), 1) == [g['table'][v] for v in x]
+        seen.append(y[0].t.clone())                  # shares of x^254: fresh re-sharing randomness per replay
+    assert st.nonce() == n0 + 3 * 33                                               # 11 gates x 3 senders per replay
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    # new inputs: refresh the captured input buffers in place
+    y = [(v * 7 + 3) % 256 for v in x]
+    ys = protocols.share(ctx, ctx.from_numpy(np.array(y, dtype=np.uint8)), t, m)
+    for dst, src in zip(xs, ys):
+        dst.t.copy_(src.t)
+    cg.replay()
+    assert unpack(protocols.open_(ctx, F, cg.result[1], t).to_numpy(), 1) == [g['table'][v] for v in y]
