@@ -536,3 +536,59 @@ def test_sqrt_p_1_mod_4_golden(api):
         assert ints(r * r) == ints(sq)
         with pytest.raises(ZeroDivisionError):
             F.array([1, 0]).sqrt(INV=True)
+
+
+def test_twelve_byte_field_through_the_mirror(api):
+    """SecInt(64)'s field size (96-bit Blum-like prime 2^96 - 17 and the 80-bit 2^80 - 65): elements live in
+    12 bytes on the device (3 x uint32); everything the mirror does with limb tensors must handle the
+    3-limb trailing axis: indexing, broadcasting, NumPy movement, linear algebra, wire format, sharing."""
+    finfields, _, thresha = api
+    rng = random.Random(96)
+    for p in (2**96 - 17, 2**80 - 65):
+        F = finfields.GF(p)
+        assert F.array([1]).ctx.elem_bytes == 12
+        a = [[rng.randrange(p) for _ in range(5)] for _ in range(4)]
+        b = [[rng.randrange(p) for _ in range(5)] for _ in range(4)]
+        A, B = F.array(a), F.array(b)
+        na, nb = np.array(a, dtype=object), np.array(b, dtype=object)
+
+        def same(got, want):
+            want = np.asarray(want, dtype=object) % p
+            assert got.shape == want.shape
+            assert ints(got) == [int(v) for v in want.reshape(-1)]
+
+        same(A * B + A - B, na * nb + na - nb)
+        same(-A, -na)
+        same(A * 3 + 7, na * 3 + 7)
+        same(A + F.array(b[0]), na + nb[0])                                   # broadcasting
+        same(A[1:3, ::2], na[1:3, ::2])
+        assert int(A[2, 3].value) == a[2][3]
+        C = A.copy()
+        C[0] = B[1]
+        C[3, 4] = -1
+        nc = na.copy()
+        nc[0] = nb[1]
+        nc[3, 4] = p - 1
+        same(C, nc)
+        same(A.T @ B, na.T @ nb)
+        same(np.concatenate((A, B), axis=1), np.concatenate((na, nb), axis=1))
+        same(np.tile(A, (2, 1)), np.tile(na, (2, 1)))
+        same(np.tril(A), np.tril(na))
+        same(np.sum(A, axis=0), na.sum(axis=0))
+        same((A ** 5).reshape(-1), (na ** 5).reshape(-1))
+        assert ints(A.reciprocal() * A) == [1] * 20
+        assert (A == F.array(a)).all() and not (A == B).all()
+        S = F.array([[rng.randrange(p) for _ in range(4)] for _ in range(4)])
+        assert ints(S @ np.linalg.inv(S)) == [int(i == j) for i in range(4) for j in range(4)]
+        # wire format (finfields.py:91-102): byte_length bytes per element; for the 96-bit prime = the device bytes
+        w = A.to_wire()
+        assert F.byte_length == (p.bit_length() + 7) // 8
+        assert w == b''.join(int(v).to_bytes(F.byte_length, 'little') for row in a for v in row)
+        same(F.array.from_wire(w, shape=(4, 5)), na)
+        # sharing round trip through the public API (device CSPRNG) and through the randbelow hook
+        s = F.array([rng.randrange(p) for _ in range(1000)])
+        sh = thresha.np_random_split(F, s, 2, 5)
+        back = thresha.np_recombine(F, [(x, sh[x - 1]) for x in (5, 1, 3)])
+        assert ints(back) == ints(s)
+        # negative / oversized host inputs reduce like the reference (finfields.py:724)
+        same(F.array([-1, p, p + 5, 2**200 + 3]), np.array([p - 1, 0, 5, (2**200 + 3) % p], dtype=object))
