@@ -18,16 +18,14 @@ that read it directly (runtime.py:561,643,...) or pickle it for the wire.
 from __future__ import annotations
 
 import functools
-import math
 import random as _random
 from typing import Optional
 
 import numpy as np
 import torch
 
-from . import _ffi
-from .engine import DevArray, DevMatrix, FieldContext, ints_to_np, np_to_ints
-from .gfpx import BinaryPolynomial, GFpX, _clinvert, _clmod, _clmul
+from .engine import DevArray, DevMatrix, FieldContext, ints_to_np
+from .gfpx import BinaryPolynomial, _clinvert, _clmod, _clmul
 
 __all__ = ['GF', 'find_prime_root', 'find_irreducible', 'FieldArray', 'PrimeFieldElement', 'BinaryFieldElement']
 

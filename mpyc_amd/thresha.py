@@ -26,7 +26,7 @@ from math import prod
 import numpy as np
 
 from .engine import DevArray, DevMatrix
-from .finfields import FieldArray, FiniteFieldElement, _context, _fops, _matrix_to_array, _scalar_value
+from .finfields import FieldArray, _context, _fops, _matrix_to_array
 
 __all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector',
            'pseudorandom_share', 'pseudorandom_share_zero', 'np_pseudorandom_share', 'np_pseudorandom_share_0', 'PRF']

@@ -2,8 +2,6 @@
 4 GiB, so every byte offset and, for GF(2^8), every element index crosses 2^32.  Whole-array checks use
 size-independent properties evaluated on the device (round trip, commutativity, linearity of the sum);
 windows at the start, across the 2^32 boundary and at the ragged tail are compared with the oracle."""
-import random
-
 import numpy as np
 import pytest
 

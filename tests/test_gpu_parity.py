@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
-from fieldutil import P61, P64, P128, edge_values, field_of, pack, rand_values, unhex, unpack, lshape
+from fieldutil import P61, P64, P128, edge_values, field_of, pack, unhex, unpack, lshape
 
 pytestmark = pytest.mark.gpu
 

@@ -3,11 +3,10 @@ kernel family against the pinned C oracle.  Fields are drawn from all reduction 
 bit lengths no other test uses (33..128-bit pseudo-Mersenne and generic primes, GF(2^n) for odd n)."""
 import random
 
-import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from fieldutil import pack, unpack, lshape
+from fieldutil import unpack, lshape
 from test_gpu_parity import rand_np
 
 pytestmark = pytest.mark.gpu

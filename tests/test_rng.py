@@ -2,7 +2,6 @@
 the field sampler and keystream layout against an independent restatement (oracle/fforacle.c) and
 against Python integers.  CPU-only (device code compiled with g++ by the hostcheck harness)."""
 import ctypes
-import struct
 
 import numpy as np
 import pytest
