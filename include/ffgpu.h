@@ -180,7 +180,7 @@ int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint
 
 /* Device-resident generator state, for launches captured in a HIP graph: the kernels read key / nonce /
  * rounds from `dev_state` (ffgpu_rng_state_bytes() bytes of device memory) when they start, and the nonce is
- * advanced on the device after every use, so each REPLAY of a captured ffgpu_split_rng_state draws fresh
+ * advanced on the device after every use (by the last workgroup of the share-generation kernel itself), so each REPLAY of a captured ffgpu_split_rng_state draws fresh
  * coefficients (a host key in the kernel arguments would be frozen into the graph).  One state per stream of
  * launches; ffgpu_rng_state_init is not capturable (it synchronises).  mul_by: NULL or the second factor of
  * the fused local product (as ffgpu_mul_split_rng).  No reference counterpart (secrets.randbelow, thresha.py:58). */

@@ -33,7 +33,6 @@ int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* o
 int ffgpu_launch_gf8_to_bits(int device, const void* in, const void* addend, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
-int ffgpu_launch_rng_bump(void* dev_state, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
@@ -533,8 +532,7 @@ int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_b
     int rc = ctx->ops->split(ctx->policy, ctx->device, secrets, mul_by, nullptr, 0, t, m, shares, share_stride, n,
                              (hipStream_t)stream, t > 0 ? &ra : nullptr);
     if (rc) return launch_status(rc);
-    if (t > 0) return launch_status(ffgpu_launch_rng_bump(dev_state, (hipStream_t)stream));
-    return FFGPU_OK;
+    return FFGPU_OK;       // the kernel's last workgroup advanced the nonce (rng_state_release)
 }
 
 int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,

@@ -263,8 +263,26 @@ struct RngArgs {
     // kernel start instead of from the kernel arguments, so a captured HIP graph draws fresh coefficients on
     // every replay (k_rng_bump advances the nonce after each use)
     const RngKey* dev_key;
+    int spread;   // 1: one pack per thread (small arrays), each thread recomputing its group's keystream
 };
 
+
+// Device-resident generator state: the LAST workgroup to finish advances the nonce (every workgroup has read
+// the state by then; the next launch on the stream starts after this one ends).  pad_ counts finished groups.
+__device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
+    if (!ra.dev_key) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RngKey* st = const_cast<RngKey*>(ra.dev_key);
+        __threadfence();
+        const uint32_t done = atomicAdd(&st->pad_, 1u);
+        if (done == gridDim.x - 1) {
+            st->pad_ = 0;
+            if (++st->nonce[0] == 0) st->nonce[1] += 65536u;   // rows of t > 4 calls use nonce[1] + j + 1, j < 64
+            __threadfence();
+        }
+    }
+}
 
 template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
@@ -287,62 +305,70 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     constexpr int EPV_ = P::N * F::EPW;
     const size_t npacks_all = (n + EPV_ - 1) / EPV_;               // the layout is defined over ALL packs of n
     const size_t ngroups = (RNG && T > 0) ? (npacks_all + G - 1) / G : nvec;
-    for (size_t ig = gid; ig < ngroups; ig += gsz) {
-        W cg[G][TT][P::N];
-        if constexpr (RNG && T > 0) rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
+    // one pack: loads, optional local product, m share evaluations, m stores
+    auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
+        P s = ldg<NT>(av + i);
+        P s2;
+        if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+        if constexpr (!(RNG && T > 0)) {
 #pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const size_t i = (size_t)u * ngroups + ig;             // stride NG: lanes stay on adjacent packs
-            if (i >= nvec) continue;
-            P s = ldg<NT>(av + i);
-            P s2;
-            if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
-            W c[TT][P::N];
-            if constexpr (RNG && T > 0) {
+            for (int j = 0; j < T; ++j) {
+                P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
 #pragma unroll
-                for (int j = 0; j < T; ++j)
+                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+            }
+        }
+        if constexpr (FUSE_MUL) {
 #pragma unroll
-                    for (int q = 0; q < P::N; ++q) c[j][q] = cg[u][j][q];
+            for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
+        }
+        for (int party = 1; party <= m; ++party) {
+            P y;
+            if constexpr (T == 0) {
+                y = s;
+            } else if constexpr (LAZY) {
+                // public powers x^(j+1): wave-uniform, scalar unit
+                uint32_t xp[TT];
+                xp[0] = (uint32_t)party;
+#pragma unroll
+                for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    typename F::sacc acc;
+                    f.sacc_init(acc, s.w[q]);
+#pragma unroll
+                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
+                    y.w[q] = f.sacc_reduce(acc);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
+                for (int q = 0; q < P::N; ++q) {
+                    W acc = c[T - 1][q];
 #pragma unroll
-                    for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
+                    y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
                 }
             }
-            if constexpr (FUSE_MUL) {
+            stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+        }
+    };
+    if (RNG && T > 0 && G > 1 && ra.spread) {
+        // small arrays: one pack per thread, every thread of a group recomputes the group's keystream
+        // (G x the ChaCha work, G x the parallelism -- the grouped loop leaves most CUs idle below ~10^5 packs)
+        for (size_t i = gid; i < nvec; i += gsz) {
+            W c[TT][P::N];
+            rng_draw_pack<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, (uint64_t)npacks_all, c);
+            do_pack(i, c);
+        }
+    } else {
+        for (size_t ig = gid; ig < ngroups; ig += gsz) {
+            W cg[G][TT][P::N];
+            if constexpr (RNG && T > 0) rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
-            }
-            for (int party = 1; party <= m; ++party) {
-                P y;
-                if constexpr (T == 0) {
-                    y = s;
-                } else if constexpr (LAZY) {
-                    // public powers x^(j+1): wave-uniform, scalar unit
-                    uint32_t xp[TT];
-                    xp[0] = (uint32_t)party;
-#pragma unroll
-                    for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
-#pragma unroll
-                    for (int q = 0; q < P::N; ++q) {
-                        typename F::sacc acc;
-                        f.sacc_init(acc, s.w[q]);
-#pragma unroll
-                        for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
-                        y.w[q] = f.sacc_reduce(acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < P::N; ++q) {
-                        W acc = c[T - 1][q];
-#pragma unroll
-                        for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
-                        y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
-                    }
-                }
-                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+            for (int u = 0; u < G; ++u) {
+                const size_t i = (size_t)u * ngroups + ig;             // stride NG: lanes stay on adjacent packs
+                if (i >= nvec) continue;
+                do_pack(i, cg[u]);
             }
         }
     }
@@ -380,6 +406,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             st_elem<F>(out + (size_t)(party - 1) * ostride, e, y);
         }
     }
+    if constexpr (RNG) rng_state_release(ra);
 }
 
 // materialise the coefficient matrix the fused kernel would draw (tests, debugging, and callers
@@ -472,6 +499,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
             st_elem<F>(out + (size_t)(party - 1) * ostride, e, f.muladd_small(acc, (uint32_t)party, s));
         }
     }
+    if constexpr (RNG) rng_state_release(ra);
 }
 
 template <class F>
@@ -1429,8 +1457,9 @@ struct Launchers {
     }
     template <bool FUSE, bool RNG>
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
-                       int t, int m, E* out, size_t ostride, size_t n, hipStream_t st, const RngArgs& ra) {
+                       int t, int m, E* out, size_t ostride, size_t n, hipStream_t st, const RngArgs& ra_in) {
         if (t > MAXT) {
+            const RngArgs& ra = ra_in;
             unsigned grid = grid_for(n, lc);
             hipLaunchKernelGGL((k_split_any<F, FUSE, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
                                t, m, out, ostride, n, ra);
@@ -1440,8 +1469,12 @@ struct Launchers {
                    (stride_ok(ostride) || m <= 1) &&
                    (RNG || t == 0 || (al(coef) && (stride_ok(cstride) || t <= 1)));
         size_t nvec = vec ? n / EPV : 0;
-        // RNG kernels serve up to 4 packs per thread (RngLayout::G); a slightly larger grid is harmless
-        unsigned grid = grid_for(nvec ? (RNG ? (n / EPV + 2) / 2 : nvec) : n, lc);
+        // RNG kernels serve up to 4 packs per thread (RngLayout::G); a slightly larger grid is harmless.
+        // Below ~2.6e5 packs the grouped loop cannot fill the chip: one pack per thread instead (ra.spread).
+        RngArgs ra = ra_in;
+        const bool spread = RNG && nvec > 0 && nvec < 262144;
+        ra.spread = spread ? 1 : 0;
+        unsigned grid = grid_for(nvec ? (RNG && !spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
         bool nt = lc.nt != 0;
         switch (t) {
             case 0: go_split<0, FUSE, false>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;

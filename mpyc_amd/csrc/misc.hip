@@ -718,15 +718,3 @@ int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipS
     FFGPU_CHECK_LAUNCH();
     return 0;
 }
-
-// ---- device-resident CSPRNG state: advance the nonce after a use (stream-ordered, graph-capturable) ----
-__global__ void k_rng_bump(RngKey* k) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (++k->nonce[0] == 0) k->nonce[1] += 65536u;    // rows of t > 4 calls use nonce[1] + j + 1, j < 64
-    }
-}
-int ffgpu_launch_rng_bump(void* dev_state, hipStream_t st) {
-    hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, (RngKey*)dev_state);
-    FFGPU_CHECK_LAUNCH();
-    return 0;
-}

@@ -31,4 +31,16 @@ for P, t, m in ((bench.P61, 1, 3), (bench.P64, 3, 7)):
     assert torch.equal(sets[0].y.t, sets[0].c.t)
     del sets
     torch.cuda.empty_cache()
+# 12-byte elements (PM96): does a dwordx3 stream move exactly its algorithmic bytes?
+from mpyc_amd.engine import DevArray
+ctx = FieldContext(2**96 - 17, device=0)
+bufs = []
+for _ in range(4):
+    x = torch.randint(0, 2**31 - 1, (3, n, 3), dtype=torch.int32, device='cuda:0', generator=gen)
+    bufs.append([DevArray(ctx, x[i], n) for i in range(3)])
+for rep in range(3):
+    for b in bufs:
+        ctx.mul(b[0], b[1], out=b[2])
+        ctx.add(b[0], b[1], out=b[2])
+torch.cuda.synchronize()
 print('pmc probe done')

@@ -24,6 +24,8 @@ alg = {  # algorithmic bytes per launch at n = 10^7 64-bit elements
     'k_recombine<PM64<false, true>, 3, true>': (240e6, 80e6),
     'k_split<PM64<true, false>, 3, false, true, true, false>': (320e6, 560e6),
     'k_recombine<PM64<true, false>, 7, true>': (560e6, 80e6),
+    'k_ew2<PM96, 2, true>': (240e6, 120e6),      # 12-byte elements, one per lane (dwordx3)
+    'k_ew2<PM96, 0, true>': (240e6, 120e6),
 }
 out, lines = {}, ['| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | read MB (2x FETCH) | write MB | traffic MB | algorithmic MB | traffic/alg |',
                   '|---|---|---|---|---|---|---|---|---|']
