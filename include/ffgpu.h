@@ -80,6 +80,11 @@ int         ffgpu_device_count(int* count);
 int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device,
                      ffgpu_ctx** out);
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx);
+/* Opt-in timing: with enable != 0 every compute call records a pair of events on its stream around the
+ * kernels it launches; ffgpu_last_kernel_ms waits for the most recent call and returns its GPU time
+ * (FFGPU_EINVAL if timing is off or nothing has been launched).  Off by default: no events, no cost.   */
+int ffgpu_ctx_set_timing(ffgpu_ctx* ctx, int enable);
+int ffgpu_last_kernel_ms(ffgpu_ctx* ctx, float* ms);
 int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8, 12 or 16           */
 int ffgpu_ctx_reduction(const ffgpu_ctx* ctx);    /* one of FFGPU_RED_*          */
 int ffgpu_ctx_device(const ffgpu_ctx* ctx);

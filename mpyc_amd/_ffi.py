@@ -35,6 +35,8 @@ _SIGS = {
     'ffgpu_device_count': [ctypes.POINTER(_int)],
     'ffgpu_ctx_create': [_int, _u64p, _int, _int, ctypes.POINTER(_vp)],
     'ffgpu_ctx_destroy': [_vp],
+    'ffgpu_ctx_set_timing': [_vp, _int],
+    'ffgpu_last_kernel_ms': [_vp, ctypes.POINTER(ctypes.c_float)],
     'ffgpu_ctx_elem_bytes': [_vp],
     'ffgpu_ctx_reduction': [_vp],
     'ffgpu_ctx_device': [_vp],

@@ -61,6 +61,9 @@ struct ffgpu_ctx {
     uint8_t sbox_lut[256];
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
+    // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
+    int timing, timed;
+    hipEvent_t ev0, ev1;
 };
 
 static thread_local char g_hip_err[256] = "";
@@ -116,6 +119,21 @@ struct DeviceGuard {
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// brackets the launches of one API call with two events when the context has timing switched on
+struct LaunchTimer {
+    ffgpu_ctx* c;
+    hipStream_t st;
+    LaunchTimer(ffgpu_ctx* ctx, hipStream_t s) : c(ctx && ctx->timing ? ctx : nullptr), st(s) {
+        if (c) (void)hipEventRecord(c->ev0, st);
+    }
+    ~LaunchTimer() {
+        if (c) {
+            (void)hipEventRecord(c->ev1, st);
+            c->timed = 1;
+        }
     }
 };
 
@@ -229,7 +247,30 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
 }
 
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
+    if (ctx && ctx->ev0) {
+        DeviceGuard g(ctx->device);
+        (void)hipEventDestroy(ctx->ev0);
+        (void)hipEventDestroy(ctx->ev1);
+    }
     free(ctx);
+    return FFGPU_OK;
+}
+int ffgpu_ctx_set_timing(ffgpu_ctx* ctx, int enable) {
+    if (!ctx) return FFGPU_EINVAL;
+    if (enable && !ctx->ev0) {
+        DeviceGuard g(ctx->device);
+        HIPCHK(hipEventCreate(&ctx->ev0));
+        HIPCHK(hipEventCreate(&ctx->ev1));
+    }
+    ctx->timing = enable ? 1 : 0;
+    ctx->timed = 0;
+    return FFGPU_OK;
+}
+int ffgpu_last_kernel_ms(ffgpu_ctx* ctx, float* ms) {
+    if (!ctx || !ms || !ctx->timed) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return FFGPU_OK;
 }
 int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx) { return ctx ? ctx->elem_bytes : -1; }
@@ -279,6 +320,7 @@ static int do_ew2(ffgpu_ctx* ctx, int op, const void* a, const void* b, void* ou
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && b && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->ew2(ctx->policy, ctx->device, op, a, b, out, n, (hipStream_t)stream));
 }
 static int do_ew1(ffgpu_ctx* ctx, int op, const void* a, const uint64_t* s, void* out, size_t n, void* stream) {
@@ -286,6 +328,7 @@ static int do_ew1(ffgpu_ctx* ctx, int op, const void* a, const uint64_t* s, void
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->ew1(ctx->policy, ctx->device, op, a, s, out, n, (hipStream_t)stream));
 }
 
@@ -301,11 +344,13 @@ int ffgpu_sub(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
 int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
     if (ctx && ctx->gf8_tab_min && n >= (size_t)ctx->gf8_tab_min && a && b && out) {
         DeviceGuard g(ctx->device);
+        LaunchTimer lt(ctx, (hipStream_t)stream);
         return launch_status(ffgpu_launch_gf8_mul_tab(ctx->gf8_tables, ctx->device, a, b, out, n,
                                                       (hipStream_t)stream));
     }
     if (ctx && ctx->gf2w_limbs && n && a && b && out) {
         DeviceGuard g(ctx->device);
+        LaunchTimer lt(ctx, (hipStream_t)stream);
         return launch_status(ffgpu_launch_gf2w_mul_win(ctx->policy, ctx->gf2w_limbs, ctx->gf2w_rtable, ctx->device,
                                                        a, b, out, n, (hipStream_t)stream));
     }
@@ -332,6 +377,7 @@ int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, vo
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && b && c && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->muladd(ctx->policy, ctx->device, a, b, c, out, n, (hipStream_t)stream));
 }
 
@@ -358,6 +404,7 @@ int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_l
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ex.nbits == 0) {
         // a^0 = 1 (also for a = 0, as pow(0, 0, p) = 1): 0*a + 1
         uint64_t zero[2] = {0, 0}, one[2] = {1, 0};
@@ -401,6 +448,7 @@ int ffgpu_sqrt_cl(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stre
     make_exp(l1, 2, &eleg);
     make_exp(l2, 2, &elad);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->sqrt_cl(ctx->policy, ctx->device, a, &eleg, &elad, out, n, (hipStream_t)stream));
 }
 
@@ -412,6 +460,7 @@ int ffgpu_gauss(ffgpu_ctx* ctx, void* a, int n, int ncols, size_t batch, int mod
     if (n == 0) return FFGPU_OK;
     ARGCHK(a);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     ExpArgs ex;
     inverse_exponent(ctx, &ex);
     if (hipMemsetAsync(dev_singular, 0, batch * sizeof(int), (hipStream_t)stream) != hipSuccess) return FFGPU_EHIP;
@@ -435,6 +484,7 @@ int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero
     ff_u128 e = q - 2;
     uint64_t el[2] = {ff_lo(e), ff_hi(e)};
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ctx->kind == FFGPU_PRIME && q == 2) {   // GF(2): 1^-1 = 1
         ExpArgs one;
         one.e[0] = 1; one.e[1] = 0; one.nbits = 1;
@@ -455,6 +505,7 @@ int ffgpu_beaver_combine(ffgpu_ctx* ctx, const void* z, const void* x, const voi
     if (n == 0) return FFGPU_OK;
     ARGCHK(z && x && y && d && e && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->beaver(ctx->policy, ctx->device, z, x, y, d, e, out, add_de ? 1 : 0, n,
                                           (hipStream_t)stream));
 }
@@ -468,6 +519,7 @@ static int do_split(ffgpu_ctx* ctx, const void* a, const void* b, bool fused, co
     ARGCHK(a && shares && (!fused || b) && (t == 0 || coeffs));
     ARGCHK((m == 1 || share_stride >= n) && (t <= 1 || coeff_stride >= n));
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, coeffs,
                                          coeff_stride, t, m, shares, share_stride, n, (hipStream_t)stream,
                                          nullptr));
@@ -499,6 +551,7 @@ static int do_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, bool fused
     ARGCHK(a && shares && (!fused || b));
     ARGCHK(m == 1 || share_stride >= n);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, nullptr, 0, t, m,
                                          shares, share_stride, n, (hipStream_t)stream, t > 0 ? &ra : nullptr));
 }
@@ -511,6 +564,7 @@ int ffgpu_rng_state_init(ffgpu_ctx* ctx, void* dev_state, const uint8_t* host_ke
     int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
     if (rc != FFGPU_OK) return rc;
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     HIPCHK(hipMemcpyAsync(dev_state, &ra.rk, sizeof(RngKey), hipMemcpyHostToDevice, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));     // the source is on this stack frame
     return FFGPU_OK;
@@ -529,6 +583,7 @@ int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_b
     ra.r1 = ctx->rng_r[1];
     ra.dev_key = (const RngKey*)dev_state;
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     int rc = ctx->ops->split(ctx->policy, ctx->device, secrets, mul_by, nullptr, 0, t, m, shares, share_stride, n,
                              (hipStream_t)stream, t > 0 ? &ra : nullptr);
     if (rc) return launch_status(rc);
@@ -554,6 +609,7 @@ int ffgpu_rng_coeffs(ffgpu_ctx* ctx, const uint8_t* host_key32, uint64_t nonce, 
     if (n == 0) return FFGPU_OK;
     ARGCHK(coeffs && (t == 1 || coeff_stride >= n));
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->rng_coeffs(ctx->policy, ctx->device, coeffs, coeff_stride, t, n,
                                               (hipStream_t)stream, &ra));
 }
@@ -575,6 +631,7 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
     ARGCHK(host_rows && host_lambda && out && (w == 1 || out_stride >= n));
     for (int j = 0; j < k; ++j) ARGCHK(host_rows[j]);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     // GF(2^n), 9 <= n <= 128 with a sparse modulus: shared nibble tables of the (uniform) Lagrange
     // coefficients in LDS instead of one full field multiplication per row and element
     if ((ctx->policy_kind == POL_GF2W64 || ctx->policy_kind == POL_GF2W128) && !ctx->gf2w_limbs && k <= 9 &&
@@ -598,6 +655,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
     ARGCHK(C && ldc >= N && M < (1u << 30) && N < (1u << 30) && K < (1u << 30));
     ARGCHK(K == 0 || (A && B && lda >= K && ldb >= N));
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N,
                                           (hipStream_t)stream));
 }
@@ -609,6 +667,7 @@ int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64
     if (ngroups == 0) return FFGPU_OK;
     ARGCHK(in && out);
     DeviceGuard gd(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ctx->kind == FFGPU_BINARY && ctx->elem_bytes == 1 && g == 8 && (((uintptr_t)in) & 7u) == 0) {
         // groups of 8 bytes: packed-byte kernel (misc.hip)
         if (r == 8 && (((uintptr_t)out) & 7u) == 0)
@@ -636,6 +695,7 @@ int ffgpu_gf256_bit_affine(ffgpu_ctx* ctx, const uint64_t* host_matrix, const ui
     ARGCHK(in && out);
     if ((((uintptr_t)in) & 7u) || (!from_bits && (((uintptr_t)out) & 7u))) return FFGPU_EINVAL;
     DeviceGuard gd(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_gf8_group8(ctx->policy, ctx->device, host_matrix, host_bias, from_bits ? 1 : 0, in,
                                                  out, n, (hipStream_t)stream));
 }
@@ -643,6 +703,7 @@ int ffgpu_gf256_bit_affine(ffgpu_ctx* ctx, const uint64_t* host_matrix, const ui
 static int do_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* workspace, size_t n, void* stream) {
     ARGCHK(ctx && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     if (n == 0) {   // empty sum = 0
         HIPCHK(hipMemsetAsync(out, 0, (size_t)ctx->elem_bytes, (hipStream_t)stream));
         return FFGPU_OK;
@@ -668,6 +729,7 @@ int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, 
     // limb radix constant for the wide reduction: 2^(8*elem_bytes) mod p (prime policies)
     uint64_t r2[2] = {ctx->rng_r[0], ctx->rng_r[1]};
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->prss(ctx->policy, ctx->device, host_streams, ks, d, l, mask_bits, host_weights,
                                         r2, accumulate, out, n, (hipStream_t)stream));
 }
@@ -678,6 +740,7 @@ int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void
     if (n == 0) return FFGPU_OK;
     ARGCHK(in && out);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_gf8_to_bits(ctx->device, in, addend, out, n, (hipStream_t)stream));
 }
 
@@ -705,6 +768,7 @@ int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, 
         memcpy(lut, ctx->sbox_lut, 256);
     }
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_sbox(lut, ctx->device, in, out, n, (hipStream_t)stream));
 }
 
@@ -757,6 +821,7 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
     if (bytes == 0) return FFGPU_OK;
     ARGCHK(src && dst);
     DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_copy(ctx->device, src, dst, bytes, (hipStream_t)stream));
 }
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, int reps, void* stream,

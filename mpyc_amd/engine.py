@@ -568,6 +568,16 @@ class FieldContext:
                    'sbox')
         return out
 
+    def set_timing(self, enable: bool = True):
+        """Record GPU events around every compute call (off by default)."""
+        _ffi.check(self._L.ffgpu_ctx_set_timing(self._h, 1 if enable else 0), 'set_timing')
+
+    def last_kernel_ms(self) -> float:
+        """GPU time of the most recent compute call (waits for it); needs set_timing(True)."""
+        ms = ctypes.c_float()
+        _ffi.check(self._L.ffgpu_last_kernel_ms(self._h, ctypes.byref(ms)), 'last_kernel_ms')
+        return float(ms.value)
+
     def sync(self):
         _ffi.check(self._L.ffgpu_stream_sync(self._h, self._stream()), 'sync')
 

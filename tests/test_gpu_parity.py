@@ -812,3 +812,25 @@ def test_full_size_gate_p128(eng):
         a = int(A[hh, 0]) | (int(A[hh, 1]) << 64)
         b = int(B[hh, 0]) | (int(B[hh, 1]) << 64)
         assert (int(pi[hh, 0]) | (int(pi[hh, 1]) << 64)) == a * b % P128
+
+
+def test_last_kernel_ms(eng):
+    """Opt-in event timing of the most recent call (`last_kernel_ms`)."""
+    from mpyc_amd import _ffi
+    ctx = eng.FieldContext(P61, device=0)
+    a = ctx.from_numpy(rand_np(po.Field(P61, False), 8, 1 << 22, 1))
+    with pytest.raises(ValueError):
+        ctx.last_kernel_ms()                                   # timing is off by default
+    ctx.set_timing(True)
+    out = ctx.mul(a, a)
+    ms = ctx.last_kernel_ms()
+    assert 0.0 < ms < 50.0
+    big = ctx.mul(a, a, out=out)
+    t1 = ctx.last_kernel_ms()
+    small = eng.DevArray(ctx, a.t[:1024], 1024)
+    ctx.mul(small, small)
+    t2 = ctx.last_kernel_ms()
+    assert t2 < t1                                             # 1024 elements take less than 4M
+    ctx.set_timing(False)
+    with pytest.raises(ValueError):
+        ctx.last_kernel_ms()
