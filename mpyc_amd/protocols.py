@@ -99,3 +99,77 @@ def sbox_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A: S
         return [ctx.bit_affine(b, A, B, from_bits=True) for b in bits]           # both local steps in one pass
     bits = [ctx.group_matvec(b, A, B) for b in bits]
     return from_bits(ctx, bits)
+
+
+# ---- AES-128 on secret-shared blocks (demos/np_aes.py:55-86) ------------------------------------------
+# Layout: position-major.  A batch of nblk blocks is ONE array of 16*nblk bytes per party; byte position
+# p = r + 4c of the AES state s[r][c] (= input byte p of the block, FIPS-197 sec. 3.4) occupies
+# buf[p*nblk : (p+1)*nblk].  SubBytes is then one S-box layer over the whole array, ShiftRows is a relabelling
+# of row views (no data movement) and MixColumns is the small-public-matrix-times-rows kernel
+# (ffgpu_recombine with w = k = 4, finfields.py:1126-1146 `C @ s`).
+_MIX = [[2, 3, 1, 1], [1, 2, 3, 1], [1, 1, 2, 3], [3, 1, 1, 2]]          # circulant([2, 3, 1, 1]), np_aes.py:33
+
+
+def _xpow(modulus: int, k: int) -> int:
+    """x^k in GF(2)[x] / modulus (bit patterns)."""
+    v, deg = 1, modulus.bit_length() - 1
+    for _ in range(k):
+        v <<= 1
+        if v >> deg:
+            v ^= modulus
+    return v
+
+
+def _row(ctx: FieldContext, buf: DevArray, p: int, nblk: int) -> DevArray:
+    return DevArray(ctx, buf.t[p * nblk:(p + 1) * nblk], nblk)
+
+
+def _cat(ctx: FieldContext, rows: Sequence[DevArray]) -> DevArray:
+    import torch
+    t = torch.cat([r.t for r in rows])
+    return DevArray(ctx, t, t.shape[0])
+
+
+def aes128_key_expansion(ctx: FieldContext, field, key: Shares, nblk: int, rbits_fn, t: int, A, B, rng=None):
+    """key_expansion for Nk = 4 (np_aes.py:55-72).  key: 16*nblk bytes per party (one key per block,
+    position-major).  Returns the 11 round keys, each a Shares of 16*nblk bytes.  rbits_fn(nbytes) supplies
+    shares of 8*nbytes random bits (np_random_bits) for each S-box call."""
+    m = len(key)
+    w = [[[_row(ctx, key[i], r + 4 * c, nblk) for r in range(4)] for i in range(m)] for c in range(4)]   # w[c][party][r]
+    for i in range(4, 44):
+        prev = w[i - 1]
+        if i % 4 == 0:
+            sub = sbox_layer(ctx, field, [_cat(ctx, prev[pi]) for pi in range(m)], rbits_fn(4 * nblk), t, A, B, rng=rng)
+            tcol = [[_row(ctx, sub[pi], (r + 1) % 4, nblk) for r in range(4)] for pi in range(m)]        # RotWord
+            rcon = _xpow(ctx.modulus, i // 4 - 1)                   # f256(1) << i//Nk - 1  (np_aes.py:67)
+            for pi in range(m):
+                tcol[pi][0] = ctx.add_scalar(tcol[pi][0], rcon)                                          # every party adds the public constant
+        else:
+            tcol = prev
+        w.append([[ctx.add(tcol[pi][r], w[i - 4][pi][r]) for r in range(4)] for pi in range(m)])
+    return [[_cat(ctx, [w[4 * j + c][pi][r] for c in range(4) for r in range(4)]) for pi in range(m)] for j in range(11)]
+
+
+def aes128_encrypt(ctx: FieldContext, field, K, state: Shares, nblk: int, rbits_fn, t: int, A, B, rng=None) -> Shares:
+    """encrypt (np_aes.py:75-86): AddRoundKey, 9 x (SubBytes, ShiftRows, MixColumns, AddRoundKey), final round
+    without MixColumns.  state: 16*nblk bytes per party, position-major."""
+    from .engine import DevMatrix
+    m = len(state)
+    lam = [v for row in _MIX for v in row]
+    s = [ctx.add(state[pi], K[0][pi]) for pi in range(m)]
+    for rnd in range(1, 11):
+        s = sbox_layer(ctx, field, s, rbits_fn(16 * nblk), t, A, B, rng=rng)
+        nxt = []
+        for pi in range(m):
+            # ShiftRows: s'[r][c] = s[r][(c + r) % 4]  (np.roll(s[r], -r))
+            shifted = lambda r, c: _row(ctx, s[pi], r + 4 * ((c + r) % 4), nblk)
+            if rnd < 10:
+                out = ctx.empty(16 * nblk)
+                for c in range(4):
+                    view = DevMatrix(ctx, out.t[4 * c * nblk:(4 * c + 4) * nblk].view(4, nblk), 4, nblk, nblk)
+                    ctx.recombine([shifted(k, c) for k in range(4)], lam, w=4, out=view)                 # C @ column c
+            else:
+                out = _cat(ctx, [shifted(r, c) for c in range(4) for r in range(4)])
+            nxt.append(ctx.add(out, K[rnd][pi]))
+        s = nxt
+    return s

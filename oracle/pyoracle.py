@@ -427,3 +427,41 @@ def np_pseudorandom_share_0(F: Field, m: int, i: int, keys: dict, bound: int, uc
                 acc = add(F, acc, mul(F, reduce(F, prl[h * d + j]), w))
             out[h] = add(F, out[h], mul(F, acc, f))
     return out
+
+
+# --------------------------------------------------------------------------
+# AES-128 (FIPS-197), as demos/np_aes.py:55-86 computes it on public values
+# --------------------------------------------------------------------------
+def aes128_encrypt(key: Sequence[int], block: Sequence[int]) -> List[int]:
+    """key, block: 16 bytes each (FIPS-197 byte order: byte p = s[p % 4][p // 4]).  S-box = sbox() above
+    (x^254 + affine map, np_aes.py:37-43); MixColumns = circulant([2,3,1,1]) (np_aes.py:33)."""
+    F = Field(0x11b, True)
+    sb = sbox(range(256))
+    w = [list(key[4 * c:4 * c + 4]) for c in range(4)]                  # columns
+    for i in range(4, 44):                                              # np_aes.py:55-72
+        tcol = list(w[i - 1])
+        if i % 4 == 0:
+            tcol = [sb[v] for v in tcol]
+            tcol = tcol[1:] + tcol[:1]
+            rc = 1
+            for _ in range(i // 4 - 1):
+                rc = mul(F, rc, 2)
+            tcol[0] ^= rc
+        w.append([a ^ b for a, b in zip(tcol, w[i - 4])])
+    K = [[w[4 * j + c][r] for c in range(4) for r in range(4)] for j in range(11)]
+    s = [a ^ b for a, b in zip(block, K[0])]
+    C = [[2, 3, 1, 1], [1, 2, 3, 1], [1, 1, 2, 3], [3, 1, 1, 2]]
+    for rnd in range(1, 11):                                            # np_aes.py:75-86
+        s = [sb[v] for v in s]
+        sh = [[s[r + 4 * ((c + r) % 4)] for c in range(4)] for r in range(4)]     # sh[r][c]
+        if rnd < 10:
+            sh = [[_xor_all(mul(F, C[r][k], sh[k][c]) for k in range(4)) for c in range(4)] for r in range(4)]
+        s = [sh[r][c] ^ K[rnd][r + 4 * c] for c in range(4) for r in range(4)]
+    return s
+
+
+def _xor_all(it):
+    acc = 0
+    for v in it:
+        acc ^= v
+    return acc

@@ -199,3 +199,41 @@ def test_secure_sbox_layer_in_a_hip_graph(mods):
         dst.t.copy_(src.t)
     cg.replay()
     assert unpack(protocols.open_(ctx, F, cg.result[1], t).to_numpy(), 1) == [g['table'][v] for v in y]
+
+
+@pytest.mark.parametrize('nblk', [32, 5])
+def test_secure_aes128_matches_fips197(mods, nblk):
+    """AES-128 on secret-shared keys and blocks for all m = 3 parties (demos/np_aes.py:55-86): the opened
+    ciphertexts equal FIPS-197 (appendix C.1 = the vector the reference demo prints, appendix B) and the
+    oracle for random keys/blocks.  nblk = 5 exercises the unaligned-row paths."""
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    t, m = 1, 3
+    rng = random.Random(197)
+    keys = [list(range(16)), list(bytes.fromhex('2b7e151628aed2a6abf7158809cf4f3c'))]
+    pts = [[17 * i for i in range(16)], list(bytes.fromhex('3243f6a8885a308d313198a2e0370734'))]
+    while len(keys) < nblk:
+        keys.append([rng.randrange(256) for _ in range(16)])
+        pts.append([rng.randrange(256) for _ in range(16)])
+    pm = lambda blocks: np.array([blocks[b][p] for p in range(16) for b in range(nblk)], dtype=np.uint8)   # position-major
+    ks = protocols.share(ctx, ctx.from_numpy(pm(keys)), t, m)
+    ps = protocols.share(ctx, ctx.from_numpy(pm(pts)), t, m)
+
+    def rbits_fn(nbytes):
+        rb = torch.randint(0, 2, (8 * nbytes,), dtype=torch.uint8, device='cuda:0')
+        return protocols.share(ctx, engine.DevArray(ctx, rb, 8 * nbytes), t, m)
+
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    K = protocols.aes128_key_expansion(ctx, F, ks, nblk, rbits_fn, t, A, B)
+    assert len(K) == 11
+    k10 = unpack(protocols.open_(ctx, F, K[10], t).to_numpy(), 1)
+    assert bytes(k10[p * nblk] for p in range(16)).hex() == '13111d7fe3944a17f307a78b4d2b30c5'   # FIPS-197 A.1/C.1 last round key
+    cs = protocols.aes128_encrypt(ctx, F, K, ps, nblk, rbits_fn, t, A, B)
+    c = unpack(protocols.open_(ctx, F, cs, t).to_numpy(), 1)
+    got = [[c[p * nblk + b] for p in range(16)] for b in range(nblk)]
+    assert bytes(got[0]).hex() == '69c4e0d86a7b0430d8cdb78070b4c55a'
+    assert bytes(got[1]).hex() == '3925841d02dc09fbdc118597196a0b32'
+    assert got == [po.aes128_encrypt(keys[b], pts[b]) for b in range(nblk)]

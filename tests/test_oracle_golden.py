@@ -169,3 +169,13 @@ def test_py_sqrt():
         F = po.Field(int(c['modulus'], 16), False)
         assert [po.sqrt_prime(F, int(v, 16)) for v in c['a']] == [int(v, 16) for v in c['sqrt']], name
         assert [po.inv(F, po.sqrt_prime(F, int(v, 16))) for v in c['sq']] == [int(v, 16) for v in c['inv_sqrt']]
+
+
+def test_py_aes128_fips197():
+    """FIPS-197 appendix C.1 (the vector the reference demo reproduces, docs/demos.rst:611) and appendix B."""
+    key = list(range(16))
+    pt = [17 * i for i in range(16)]
+    assert bytes(po.aes128_encrypt(key, pt)).hex() == '69c4e0d86a7b0430d8cdb78070b4c55a'
+    key = list(bytes.fromhex('2b7e151628aed2a6abf7158809cf4f3c'))
+    pt = list(bytes.fromhex('3243f6a8885a308d313198a2e0370734'))
+    assert bytes(po.aes128_encrypt(key, pt)).hex() == '3925841d02dc09fbdc118597196a0b32'
