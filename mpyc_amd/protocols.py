@@ -57,6 +57,19 @@ def multiply(ctx: FieldContext, field, xs: Shares, ys: Shares, t: int, rng=None)
     return [ctx.recombine([sub[i].row(j) for i in range(k)], lam) for j in range(m)]
 
 
+def matmul(ctx: FieldContext, field, xs: Shares, ys: Shares, M: int, K: int, N: int, t: int, rng=None) -> Shares:
+    """runtime.np_matmul (runtime.py:2481-2541): every party multiplies its share matrices locally
+    (`A @ B` then one reduction, :2531 -- the dense-product kernel) and the degree-2t result is re-shared as
+    in multiply().  xs: (M, K) and ys: (K, N) row-major share matrices; returns shares of the (M, N) product."""
+    m = len(xs)
+    k = 2 * t + 1
+    if m < k:
+        raise ValueError('multiplication needs m >= 2t+1 parties')
+    lam = _lagrange(field, range(1, k + 1))
+    sub = [ctx.split_rng(ctx.matmul(xs[i], ys[i], M, K, N), t, m, state=rng) for i in range(k)]
+    return [ctx.recombine([sub[i].row(j) for i in range(k)], lam) for j in range(m)]
+
+
 def pow254(ctx: FieldContext, field, xs: Shares, t: int, rng=None) -> Shares:
     """x^254 by the reference's addition chain (runtime.py:1356-1367): 11 secure multiplications.  The
     reference stacks (c, d) in two rounds to halve the number of MESSAGES; locally the stacked product is two

@@ -237,3 +237,22 @@ def test_secure_aes128_matches_fips197(mods, nblk):
     assert bytes(got[0]).hex() == '69c4e0d86a7b0430d8cdb78070b4c55a'
     assert bytes(got[1]).hex() == '3925841d02dc09fbdc118597196a0b32'
     assert got == [po.aes128_encrypt(keys[b], pts[b]) for b in range(nblk)]
+
+
+@pytest.mark.parametrize('modulus,t,m', [(2**61 - 1, 1, 3), (2**96 - 17, 2, 5), (2**31 - 1, 1, 4)])
+def test_secure_matmul_opens_to_product(mods, modulus, t, m):
+    """np_matmul gate (runtime.py:2481-2541): local dense products of share matrices + resharing."""
+    engine, finfields, _, protocols = mods
+    F = finfields.GF(modulus)
+    ctx = engine.FieldContext(modulus, device=0)
+    rng = random.Random(5)
+    M, K, N = 7, 33, 5
+    A = [[rng.randrange(modulus) for _ in range(K)] for _ in range(M)]
+    B = [[rng.randrange(modulus) for _ in range(N)] for _ in range(K)]
+    eb = ctx.elem_bytes
+    flat = lambda X: ctx.from_numpy(pack([v for row in X for v in row], eb))
+    xs = protocols.share(ctx, flat(A), t, m)
+    ys = protocols.share(ctx, flat(B), t, m)
+    zs = protocols.matmul(ctx, F, xs, ys, M, K, N, t)
+    want = [sum(A[i][k] * B[k][j] for k in range(K)) % modulus for i in range(M) for j in range(N)]
+    assert unpack(protocols.open_(ctx, F, zs, t).to_numpy(), eb) == want
