@@ -61,6 +61,7 @@ struct ffgpu_ctx {
     uint8_t sbox_lut[256];
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
+    void* gf8_tables_dev;   // device copy of gf8_tables (lazily, for the fused GF(2^n<=8) product)
     // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
     int timing, timed;
     hipEvent_t ev0, ev1;
@@ -246,7 +247,29 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     return FFGPU_OK;
 }
 
+// device copy of the GF(2^n<=8) log/antilog tables for the fused share-generation kernel (made on first use:
+// contexts can be created and classified on machines without a GPU)
+static const void* gf8_tables_on_device(ffgpu_ctx* ctx) {
+    static std::mutex mu;
+    if (!ctx->gf8_tab_min) return nullptr;                 // not a GF(2^n<=8) context with tables
+    std::lock_guard<std::mutex> g(mu);
+    if (!ctx->gf8_tables_dev) {
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof(ctx->gf8_tables)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, ctx->gf8_tables, sizeof(ctx->gf8_tables), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        ctx->gf8_tables_dev = d;
+    }
+    return ctx->gf8_tables_dev;
+}
+
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
+    if (ctx && ctx->gf8_tables_dev) {
+        DeviceGuard g(ctx->device);
+        (void)hipFree(ctx->gf8_tables_dev);
+    }
     if (ctx && ctx->ev0) {
         DeviceGuard g(ctx->device);
         (void)hipEventDestroy(ctx->ev0);
@@ -552,6 +575,7 @@ static int do_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, bool fused
     ARGCHK(m == 1 || share_stride >= n);
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
+    if (fused && t > 0) ra.aux = gf8_tables_on_device(ctx);
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, nullptr, 0, t, m,
                                          shares, share_stride, n, (hipStream_t)stream, t > 0 ? &ra : nullptr));
 }
@@ -584,6 +608,7 @@ int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_b
     ra.dev_key = (const RngKey*)dev_state;
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
+    if (mul_by && t > 0) ra.aux = gf8_tables_on_device(ctx);
     int rc = ctx->ops->split(ctx->policy, ctx->device, secrets, mul_by, nullptr, 0, t, m, shares, share_stride, n,
                              (hipStream_t)stream, t > 0 ? &ra : nullptr);
     if (rc) return launch_status(rc);

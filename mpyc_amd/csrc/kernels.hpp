@@ -264,6 +264,10 @@ struct RngArgs {
     // every replay (k_rng_bump advances the nonce after each use)
     const RngKey* dev_key;
     int spread;   // 1: one pack per thread (small arrays), each thread recomputing its group's keystream
+    // GF(2^n<=8) fused local product: log/antilog tables in device memory (512 B of u16 logs, then 1024 B of
+    // antilogs; misc.hip Gf8Tables).  When set, the product of the fused kernel goes through LDS lookups,
+    // which run beside the ChaCha VALU work instead of adding ~110 VALU ops per word to it.
+    const void* aux;
 };
 
 
@@ -305,6 +309,16 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     constexpr int EPV_ = P::N * F::EPW;
     const size_t npacks_all = (n + EPV_ - 1) / EPV_;               // the layout is defined over ALL packs of n
     const size_t ngroups = (RNG && T > 0) ? (npacks_all + G - 1) / G : nvec;
+    constexpr bool TABMUL = (F::EPW == 4) && FUSE_MUL && RNG;
+    __shared__ uint16_t s_lg[TABMUL ? 256 : 1];
+    __shared__ uint32_t s_ex[TABMUL ? 256 : 1];
+    if constexpr (TABMUL) {
+        if (ra.aux) {
+            s_lg[threadIdx.x] = reinterpret_cast<const uint16_t*>(ra.aux)[threadIdx.x];          // BLOCK == 256
+            s_ex[threadIdx.x] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ra.aux) + 512)[threadIdx.x];
+            __syncthreads();
+        }
+    }
     // one pack: loads, optional local product, m share evaluations, m stores
     auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
         P s = ldg<NT>(av + i);
@@ -318,7 +332,25 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                 for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
             }
         }
-        if constexpr (FUSE_MUL) {
+        if constexpr (TABMUL) {
+            if (ra.aux) {
+                const uint8_t* ex = reinterpret_cast<const uint8_t*>(s_ex);
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) {
+                        const uint32_t lsum = (uint32_t)s_lg[((uint32_t)s.w[q] >> (8 * k8)) & 0xffu] +
+                                              (uint32_t)s_lg[((uint32_t)s2.w[q] >> (8 * k8)) & 0xffu];
+                        acc |= (uint32_t)ex[lsum] << (8 * k8);
+                    }
+                    s.w[q] = (W)acc;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
+            }
+        } else if constexpr (FUSE_MUL) {
 #pragma unroll
             for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
         }
