@@ -20,6 +20,12 @@ def field_pool():
     primes = []
     for k in (33, 34, 40, 47, 56, 61, 63, 64, 65, 66, 80, 89, 96, 100, 113, 127, 128):   # pseudo-Mersenne: largest below 2^k
         primes.append(prev_prime(1 << k))
+    for k in (40, 63, 64, 80, 96, 128):                  # pseudo-Mersenne with the LARGEST admissible c (tightest carry chains)
+        cb = min((k - 1) // 2, 31) if k <= 64 else 31
+        c = (1 << cb) - 1
+        while not is_prime((1 << k) - c):
+            c -= 2
+        primes.append((1 << k) - c)
     for k in (17, 24, 31, 32, 35, 48, 62, 64, 70, 90, 110, 128):                       # generic: random k-bit primes
         x = rng.getrandbits(k) | (1 << (k - 1)) | 1
         while not is_prime(x):

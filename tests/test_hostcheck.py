@@ -184,3 +184,59 @@ def test_dense_binary_moduli_take_the_bitserial_path(hostcheck):
         a, b = rand_values(F, 1500, 2), rand_values(F, 1500, 3)
         got, _ = run(hostcheck, F, HC_MUL, a, b)
         assert got == po.vec(po.mul, F, a, b), hex(mod)
+
+
+def test_pseudo_mersenne_with_the_largest_admissible_c(hostcheck):
+    """The golden primes all have a tiny c = 2^k - p.  The fold-based policies are selected for c up to
+    2^min((k-1)/2, 31) (k <= 64) resp. 2^31 (k > 64), and that is where their carry chains are tightest:
+    for every width family take the prime with the LARGEST admissible c and the one just outside the range
+    (which must fall back to the reciprocal / Montgomery policies), and check every arithmetic entry at
+    extreme operands against Python integers."""
+    from mpyc_amd.finfields import is_prime
+    PM = {33: 3, 40: 3, 48: 3, 63: 3, 64: 2, 65: 8, 80: 8, 96: 8, 97: 7, 127: 7, 128: 6}      # expected policy kind
+    for k, kind in PM.items():
+        cb = min((k - 1) // 2, 31) if k <= 64 else 31
+        c = (1 << cb) - 1
+        while not is_prime((1 << k) - c):
+            c -= 2
+        p_in = (1 << k) - c
+        c = (1 << cb) + 1
+        while not is_prime((1 << k) - c):
+            c += 2
+        p_out = (1 << k) - c
+        for p, inside in ((p_in, True), (p_out, False)):
+            F = po.Field(p, False)
+            _, pk = run(hostcheck, F, HC_ADD, [0], [0])
+            assert (pk == kind) == inside, (k, hex(p), pk)
+            ev = edge_values(F) + [p - 1, p - 2, p - c, (1 << (k - 1)) % p, ((1 << k) - 1) % p] + rand_values(F, 6, k)
+            a, b = cross(sorted(set(ev)))
+            for op, fn in ((HC_ADD, po.add), (HC_SUB, po.sub), (HC_MUL, po.mul)):
+                got, _ = run(hostcheck, F, op, a, b)
+                assert got == po.vec(fn, F, a, b), (k, hex(p), op)
+            got, _ = run(hostcheck, F, HC_MULADD, a, b, a[::-1])
+            assert got == [(x * y + z) % p for x, y, z in zip(a, b, a[::-1])], (k, hex(p))
+            for x in (1, 3, 2**31 - 1, 2**32 - 1):
+                got, _ = run(hostcheck, F, HC_MULADD_SMALL, a, None, b, x=x)
+                assert got == [(y * x + cc) % p for y, cc in zip(a, b)], (k, hex(p), x)
+            raw = [0, 1, p, p + 1, (1 << k) - 1, (1 << (8 * ((k + 7) // 8 if k > 64 else (4 if k <= 32 else 8)))) - 1]
+            eb = elem_bytes(p, False)
+            raw = [v for v in raw if v < (1 << (8 * eb))] + [(1 << (8 * eb)) - 1]
+            got, _ = run(hostcheck, F, HC_REDUCE, raw)
+            assert got == [v % p for v in raw], (k, hex(p))
+            # recombination-style dot products of extreme values
+            for kk in (3, 9, 255):
+                n = 8
+                rows = [[p - 1] * n if j % 2 == 0 else rand_values(F, n, j) for j in range(kk)]
+                lam = [p - 1 if j % 2 == 0 else (p - c) % p for j in range(kk)]
+                got, _ = run(hostcheck, F, HC_DOT, [v for row in rows for v in row], lam=lam, k=kk, n=n)
+                assert got == [sum(lam[j] * rows[j][h] for j in range(kk)) % p for h in range(n)], (k, hex(p), kk)
+            # lazily reduced share generation wherever the policy declares it safe
+            for (t, m) in [(1, 3), (3, 7), (4, 255), (2, 65535)]:
+                ok, _ = run(hostcheck, F, HC_SACC_OK, [0], x=m, k=t)
+                if not ok[0] & 1:
+                    continue
+                n = 12
+                s = [p - 1] * n
+                rows = [[p - 1] * n for _ in range(t)]
+                got, _ = run(hostcheck, F, HC_SACC, s, None, [v for row in rows for v in row], x=m, k=t, n=n)
+                assert got == [(s[h] + sum(rows[j][h] * m**(j + 1) for j in range(t))) % p for h in range(n)], (k, hex(p), t, m)
