@@ -254,6 +254,14 @@ int ffgpu_dot(ffgpu_ctx* ctx, const void* a, const void* b, void* out, void* wor
 int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t n, void* stream);
 
 /* ---- pseudorandom secret sharing: combination step ----------------------- */
+/* HOST function: out_i = SHAKE128(msg_i) squeezed to out_len bytes, for nstreams independent messages on up
+ * to `threads` host threads (<= 0: all cores).  One sponge is sequential, so a stream cannot be spread over
+ * GPU lanes; the C(m, t) subset keys of a PRSS call can be spread over host cores.  Outputs go to caller
+ * buffers (pin them and upload them as the `host_streams` of ffgpu_prss_combine).
+ * replaces: thresha.py:255 `shake_128(self.key + s).digest(n * self.byte_length)`, once per key.         */
+int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* msg_lens, int nstreams, size_t out_len,
+                          uint8_t* const* outs, int threads);
+
 /* out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * weights[s][j]   (mod modulus)
  * host_streams: HOST array of ks DEVICE pointers to the raw SHAKE128 output of subset s
  * (n*d*l bytes each; the XOF is sequential per key and is computed on the host with hashlib, as in

@@ -512,16 +512,47 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_sum(self._h, a.ptr, out.ptr, self._workspace().data_ptr(), a.n, self._stream()), 'sum')
         return out
 
-    def prss_combine(self, streams: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int,
+    def shake128_streams(self, msgs: Sequence[bytes], out_len: int, threads: int = 0) -> List[torch.Tensor]:
+        """SHAKE128(msg).digest(out_len) for every msg, expanded in parallel on host threads into pinned
+        buffers (libffgpu's ffgpu_shake128_expand) and uploaded: the XOF streams of a PRSS call
+        (thresha.py:255, one per subset key).  Returns uint8 device tensors."""
+        k = len(msgs)
+        if k == 0 or out_len == 0:
+            return [torch.empty(0, dtype=torch.uint8, device=self.torch_device) for _ in msgs]
+        # one grow-only pinned staging buffer per context (allocating pinned memory per call costs more than
+        # the expansion itself), rows padded to 256 bytes
+        pitch = (out_len + 255) // 256 * 256
+        need = k * pitch
+        stage = getattr(self, '_pinned_stage', None)
+        if stage is None or stage.numel() < need:
+            stage = torch.empty(need, dtype=torch.uint8).pin_memory()
+            self._pinned_stage = stage
+        keep = [ctypes.create_string_buffer(mg, max(len(mg), 1)) for mg in msgs]
+        mp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in keep])
+        ml = (ctypes.c_size_t * k)(*[len(mg) for mg in msgs])
+        op = (ctypes.c_void_p * k)(*[stage.data_ptr() + j * pitch for j in range(k)])
+        _ffi.check(self._L.ffgpu_shake128_expand(mp, ml, k, out_len, op, threads), 'shake128_expand')
+        dev = stage[:need].to(self.torch_device, non_blocking=True)
+        torch.cuda.current_stream().synchronize()          # the staging buffer is reused by the next call
+        devs = [dev[j * pitch:j * pitch + out_len] for j in range(k)]
+        return devs
+
+    def prss_combine(self, streams: Sequence, d: int, l: int, weights: Sequence[int], n: int,
                      mask_bits: int = 0, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
-        """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs
-        (host bytes, n*d*l each), uploaded as-is (thresha.py:163-173, 201-217)."""
+        """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs, n*d*l
+        bytes each: host bytes (uploaded as they are) or uint8 device tensors from shake128_streams
+        (thresha.py:163-173, 201-217)."""
         ks = len(streams)
         if len(weights) != ks * d:
             raise ValueError('need ks*d weights')
         out = out or self.empty(n)
         devs = []
         for sbytes in streams:
+            if isinstance(sbytes, torch.Tensor):
+                if sbytes.numel() < n * d * l:
+                    raise ValueError('XOF stream too short')
+                devs.append(sbytes)
+                continue
             if len(sbytes) < n * d * l:
                 raise ValueError('XOF stream too short')
             a = np.frombuffer(sbytes, dtype=np.uint8, count=n * d * l)

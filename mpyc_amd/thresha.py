@@ -278,10 +278,9 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
         return ctx.mul_scalar(ctx.from_ints([0] * n), 0)
     d = (m - len(items[0][0])) if zero else 1
     i1 = ops.reduce_int(i + 1)
-    streams, weights = [], []
+    weights = []
     for S, prf in items:
         f = _f_S_i(field, m, i, S)
-        streams.append(prf.raw(uci, n * d))
         for j in range(d):
             if not zero:
                 weights.append(f)
@@ -293,11 +292,18 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
                 for _ in range(power):
                     w = ops.mul(w, i1)
                 weights.append(w)
-    # kernel argument limits: 48 streams / 96 weights per launch
+    # kernel argument limits: 48 streams / 96 weights per launch.  The XOF streams of a chunk (one per subset
+    # key; each is inherently sequential) are expanded in parallel on host threads into pinned buffers.
     per = max(1, min(48, 96 // d))
     first_launch = True
-    for k0 in range(0, len(streams), per):
-        ctx.prss_combine(streams[k0:k0 + per], d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits=mask_bits,
+    for k0 in range(0, len(items), per):
+        chunk = items[k0:k0 + per]
+        if all(type(prf) is PRF for _, prf in chunk):
+            streams = ctx.shake128_streams([prf.key + uci for _, prf in chunk], n * d * l)
+        else:                                   # foreign PRF objects (e.g. the reference's own class)
+            streams = [prf.raw(uci, n * d) if hasattr(prf, 'raw') else shake_128(prf.key + uci).digest(n * d * l)
+                       for _, prf in chunk]
+        ctx.prss_combine(streams, d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits=mask_bits,
                          out=out, accumulate=not first_launch)
         first_launch = False
     return out
