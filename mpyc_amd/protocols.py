@@ -186,3 +186,56 @@ def aes128_encrypt(ctx: FieldContext, field, K, state: Shares, nblk: int, rbits_
             nxt.append(ctx.add(out, K[rnd][pi]))
         s = nxt
     return s
+
+
+# ---- inverse cipher (demos/np_aes.py:46-52, 89-99) ------------------------------------------------------
+_MIX_INV = [[14, 11, 13, 9], [9, 14, 11, 13], [13, 9, 14, 11], [11, 13, 9, 14]]     # np.linalg.inv(C), np_aes.py:34
+
+
+def _gf2_inverse(A: Sequence[Sequence[int]]) -> List[List[int]]:
+    """Inverse of an 8x8 0/1 matrix over GF(2) (np.linalg.inv(A), np_aes.py:31): host scalars."""
+    n = len(A)
+    M = [list(r) + [int(i == j) for j in range(n)] for i, r in enumerate(A)]
+    for c in range(n):
+        p = next(r for r in range(c, n) if M[r][c])
+        M[c], M[p] = M[p], M[c]
+        for r in range(n):
+            if r != c and M[r][c]:
+                M[r] = [x ^ y for x, y in zip(M[r], M[c])]
+    return [row[n:] for row in M]
+
+
+def sbox1_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A, B, rng=None) -> Shares:
+    """AES inverse S-box on secret-shared bytes (np_aes.py:46-52): x = np_to_bits(x); x += B; x = A1 @ x;
+    x = np_from_bits(x) ** 254.  The two local steps are one pass: A1 (x + B) = A1 x + A1 B."""
+    A1 = _gf2_inverse(A)
+    bias = [0] * 8
+    for r in range(8):
+        for c in range(8):
+            bias[r] ^= A1[r][c] & B[c]
+    bits = to_bits_gf256(ctx, field, xs, rbits, t)
+    y = [ctx.bit_affine(b, A1, bias, from_bits=True) for b in bits]
+    return pow254(ctx, field, y, t, rng)
+
+
+def aes128_decrypt(ctx: FieldContext, field, K, state: Shares, nblk: int, rbits_fn, t: int, A, B, rng=None) -> Shares:
+    """decrypt (np_aes.py:89-99): for i = 10..1: AddRoundKey(K[i]); InvMixColumns unless i = 10; InvShiftRows;
+    InvSubBytes; finally AddRoundKey(K[0]).  Same position-major layout as aes128_encrypt."""
+    from .engine import DevMatrix
+    m = len(state)
+    lam = [v for row in _MIX_INV for v in row]
+    s = list(state)
+    for rnd in range(10, 0, -1):
+        nxt = []
+        for pi in range(m):
+            x = ctx.add(s[pi], K[rnd][pi])
+            if rnd < 10:
+                mixed = ctx.empty(16 * nblk)
+                for c in range(4):
+                    view = DevMatrix(ctx, mixed.t[4 * c * nblk:(4 * c + 4) * nblk].view(4, nblk), 4, nblk, nblk)
+                    ctx.recombine([_row(ctx, x, k + 4 * c, nblk) for k in range(4)], lam, w=4, out=view)     # C1 @ column c
+                x = mixed
+            # InvShiftRows: s'[r][c] = s[r][(c - r) % 4]  (np.roll(s[r], r))
+            nxt.append(_cat(ctx, [_row(ctx, x, r + 4 * ((c - r) % 4), nblk) for c in range(4) for r in range(4)]))
+        s = sbox1_layer(ctx, field, nxt, rbits_fn(16 * nblk), t, A, B, rng=rng)
+    return [ctx.add(s[pi], K[0][pi]) for pi in range(m)]

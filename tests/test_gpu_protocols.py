@@ -237,6 +237,10 @@ def test_secure_aes128_matches_fips197(mods, nblk):
     assert bytes(got[0]).hex() == '69c4e0d86a7b0430d8cdb78070b4c55a'
     assert bytes(got[1]).hex() == '3925841d02dc09fbdc118597196a0b32'
     assert got == [po.aes128_encrypt(keys[b], pts[b]) for b in range(nblk)]
+    # inverse cipher (np_aes.py:89-99) on the shared ciphertexts gives the plaintexts back
+    back = protocols.aes128_decrypt(ctx, F, K, cs, nblk, rbits_fn, t, A, B)
+    d = unpack(protocols.open_(ctx, F, back, t).to_numpy(), 1)
+    assert [[d[p * nblk + b] for p in range(16)] for b in range(nblk)] == pts
 
 
 @pytest.mark.parametrize('modulus,t,m', [(2**61 - 1, 1, 3), (2**96 - 17, 2, 5), (2**31 - 1, 1, 4)])
