@@ -513,12 +513,13 @@ def main():
                     raise SystemExit('bench parity check failed for the secure S-box layer')
                 del res
                 ms = time_launches(lambda s_: protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
-                # algorithmic bytes per secure byte over all 3 parties: 11 gates x 3 x (5 fused split + 4 recombine)
-                # = 297, bit decomposition 3 x (9 + 3 + 17) + 3 = 90, affine + recomposition 3 x 9 = 27
-                bpu = 414
+                # algorithmic bytes per secure byte over all 3 parties: x^254 as 11 fused chain gates (operands read
+                # as 1 or 3 sub-share rows each, 3 rows written) + one final recombination = 76 per party = 228;
+                # bit decomposition 3 x (9 + 3 + 17) + 3 = 90; affine + recomposition 3 x 9 = 27
+                bpu = 345
                 kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
                                                              units_per_s=round(n8 / (ms * 1e-3), 1),
-                                                             kernels_per_layer=88)
+                                                             kernels_per_layer=58)
                 if n8 <= 10**6:
                     # the same layer captured once in a HIP graph (device-resident generator state: fresh
                     # randomness on every replay) -- the launch-bound regime is where graphs pay

@@ -183,6 +183,20 @@ int ffgpu_mul_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, const uint
                         uint64_t nonce, int rounds, int t, int m, void* shares, size_t share_stride,
                         size_t n, void* stream);
 
+/* Fused chain gate: shares[i][h] = share of (A[h] * B[h]) for party i+1 where BOTH factors are given as
+ * recombinations, A[h] = sum_j lambda_a[j] * rows_a[j][h] (ka <= 7 rows) and B likewise (kb = 0: B = A, a
+ * squaring; a factor that already exists as an array is the 1-row case with lambda = 1).  One pass: recombine
+ * in registers, multiply, draw the degree-t coefficients from the device CSPRNG (dev_state != NULL: the
+ * device-resident state, else host key / nonce / rounds), write the m share rows.  In a chain of secure
+ * multiplications this is `np_recombine` of the previous gate (thresha.py:119-132) + the local product and
+ * `np_random_split` of the next one (runtime.py:1134-1138, thresha.py:47-64) without the recombined share
+ * ever going to HBM: 6 instead of 9 memory accesses per element for a squaring.  t <= 3, else FFGPU_ENOTSUP
+ * (callers then use ffgpu_recombine + ffgpu_mul_split_rng).  lambda: canonical 2-limb host scalars.          */
+int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
+                   const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb, const uint8_t* host_key32,
+                   uint64_t nonce, int rounds, void* dev_state, int t, int m, void* shares, size_t share_stride,
+                   size_t n, void* stream);
+
 /* Device-resident generator state, for launches captured in a HIP graph: the kernels read key / nonce /
  * rounds from `dev_state` (ffgpu_rng_state_bytes() bytes of device memory) when they start, and the nonce is
  * advanced on the device after every use (by the last workgroup of the share-generation kernel itself), so each REPLAY of a captured ffgpu_split_rng_state draws fresh

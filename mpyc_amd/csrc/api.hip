@@ -615,6 +615,36 @@ int ffgpu_split_rng_state(ffgpu_ctx* ctx, const void* secrets, const void* mul_b
     return FFGPU_OK;       // the kernel's last workgroup advanced the nonce (rng_state_release)
 }
 
+int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
+                   const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb, const uint8_t* host_key32,
+                   uint64_t nonce, int rounds, void* dev_state, int t, int m, void* shares, size_t share_stride,
+                   size_t n, void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(m >= 1 && t >= 1 && t < m && ka >= 1 && kb >= 0);
+    if (t > 3 || ka > 7 || kb > 7) return FFGPU_ENOTSUP;
+    ARGCHK(host_rows_a && host_lambda_a && (kb == 0 || (host_rows_b && host_lambda_b)));
+    RngArgs ra;
+    if (dev_state) {
+        memset(&ra, 0, sizeof(ra));
+        ra.rk.rounds = 20;
+        ra.r0 = ctx->rng_r[0];
+        ra.r1 = ctx->rng_r[1];
+        ra.dev_key = (const RngKey*)dev_state;
+    } else {
+        int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
+        if (rc != FFGPU_OK) return rc;
+    }
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(shares && (m == 1 || share_stride >= n));
+    for (int j = 0; j < ka; ++j) ARGCHK(host_rows_a[j]);
+    for (int j = 0; j < kb; ++j) ARGCHK(host_rows_b[j]);
+    DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
+    ra.aux = gf8_tables_on_device(ctx);
+    return launch_status(ctx->ops->gate(ctx->policy, ctx->device, host_rows_a, host_lambda_a, ka, host_rows_b,
+                                        host_lambda_b, kb, t, m, shares, share_stride, n, (hipStream_t)stream, &ra));
+}
+
 int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,
                 void* shares, size_t share_stride, size_t n, void* stream) {
     return do_split(ctx, secrets, nullptr, false, coeffs, coeff_stride, t, m, shares, share_stride, n, stream);

@@ -271,6 +271,55 @@ struct RngArgs {
 };
 
 
+// ---- operands of a gate given as RECOMBINATIONS (the fused chain kernel) ---------------------------------
+// In a chain of secure multiplications a party's new share y = sum_j lambda_j r_j (r_j = the sub-shares it
+// received, thresha.py:119-132) is consumed by the local product of the next gate (runtime.py:1134).  With
+// REC the share-generation kernel takes both factors in that form -- k rows and their Lagrange vector each; a
+// factor that already exists as an array is the 1-row case with lambda = 1 -- recombines them in registers,
+// multiplies and re-shares: y never goes to HBM and back (6 instead of 9 accesses per element for a squaring).
+enum { GATE_MAXK = 7 };
+template <class F>
+struct GateSrc {
+    const typename F::elem* rowsA[GATE_MAXK];
+    const typename F::elem* rowsB[GATE_MAXK];
+    typename F::word lamA[GATE_MAXK], lamB[GATE_MAXK];   // prepared (f.prep)
+    int kA, kB;
+    int square;                                          // 1: second factor = first factor
+};
+
+template <class F, bool NT>
+__device__ __forceinline__ Pack<typename F::word> gate_load(const F& f, const typename F::elem* const* rows,
+                                                            const typename F::word* lam, int k, size_t i) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typename F::acc acc[P::N];
+#pragma unroll
+    for (int q = 0; q < P::N; ++q) f.acc_zero(acc[q]);
+    for (int j = 0; j < k; ++j) {
+        const P x = ldg<NT>(reinterpret_cast<const MP*>(rows[j]) + i);
+#pragma unroll
+        for (int q = 0; q < P::N; ++q) f.acc_mac(acc[q], lam[j], x.w[q]);
+    }
+    P r;
+#pragma unroll
+    for (int q = 0; q < P::N; ++q) r.w[q] = f.acc_reduce(acc[q]);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ typename F::word gate_load_elem(const F& f, const typename F::elem* const* rows,
+                                                           const typename F::word* lam, int k, size_t e) {
+    typename F::acc acc;
+    f.acc_zero(acc);
+    for (int j = 0; j < k; ++j) {
+        typename F::word x = ld_elem<F>(rows[j], e);
+        if constexpr (F::EPW > 1) {
+            // packed fields: acc_mac works on words; a single element sits in the low byte
+        }
+        f.acc_mac(acc, lam[j], x);
+    }
+    return f.acc_reduce(acc);
+}
+
 // Device-resident generator state: the LAST workgroup to finish advances the nonce (every workgroup has read
 // the state by then; the next launch on the stream starts after this one ends).  pad_ counts finished groups.
 __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
@@ -288,12 +337,12 @@ __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
     }
 }
 
-template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG>
+template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG, bool REC = false>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
                                                   const typename F::elem* __restrict__ b,
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
-                                                  size_t nvec, size_t n, RngArgs ra) {
+                                                  size_t nvec, size_t n, RngArgs ra, GateSrc<F> gs) {
     if (ra.dev_key) ra.rk = *ra.dev_key;
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
@@ -321,9 +370,14 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     }
     // one pack: loads, optional local product, m share evaluations, m stores
     auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
-        P s = ldg<NT>(av + i);
-        P s2;
-        if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+        P s, s2;
+        if constexpr (REC) {
+            s = gate_load<F, NT>(f, gs.rowsA, gs.lamA, gs.kA, i);
+            s2 = gs.square ? s : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, i);
+        } else {
+            s = ldg<NT>(av + i);
+            if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+        }
         if constexpr (!(RNG && T > 0)) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
@@ -408,8 +462,14 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     constexpr int EPV = P::N * F::EPW;
     const size_t done = nvec * (size_t)EPV;
     for (size_t e = done + gid; e < n; e += gsz) {
-        W s = ld_elem<F>(a, e);
-        if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
+        W s;
+        if constexpr (REC) {
+            s = gate_load_elem<F>(f, gs.rowsA, gs.lamA, gs.kA, e);
+            s = f.mul(s, gs.square ? s : gate_load_elem<F>(f, gs.rowsB, gs.lamB, gs.kB, e));
+        } else {
+            s = ld_elem<F>(a, e);
+            if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
+        }
         W c[TT];
         if constexpr (RNG && T > 0) {
             W cc[TT][P::N];
@@ -1341,6 +1401,9 @@ struct FieldOps {
                   size_t ldc, int M, int K, int N, hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
+    int (*gate)(const void* F, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
+                const void* const* rowsB, const uint64_t* lamB2, int kB, int t, int m, void* out, size_t ostride,
+                size_t n, hipStream_t st, const RngArgs* rng);
     int (*sqrt_cl)(const void* F, int device, const void* a, const ExpArgs* eleg, const ExpArgs* elad, void* out, size_t n,
                    hipStream_t st);
     int (*gauss)(const void* F, int device, void* A, int n, int ncols, size_t batch, int det_mode, const ExpArgs* ex,
@@ -1463,29 +1526,29 @@ struct Launchers {
         return 0;
     }
 
-    template <int T, bool FUSE, bool RNG>
+    template <int T, bool FUSE, bool RNG, bool REC = false>
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
                          size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st,
-                         const RngArgs& ra) {
+                         const RngArgs& ra, const GateSrc<F>& gs) {
         bool lazy = false;
         if constexpr (F::HAS_SACC != 0 && T > 0) lazy = f.sacc_ok(T, m);
         if constexpr (F::HAS_SACC != 0 && T > 0) {
             if (lazy) {
                 if (nt || RNG)
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a,
-                                       b, coef, cstride, m, out, ostride, nvec, n, ra);
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG, REC>), dim3(grid), dim3(BLOCK), 0, st, f, a,
+                                       b, coef, cstride, m, out, ostride, nvec, n, ra, gs);
                 else
                     hipLaunchKernelGGL((k_split<F, T, FUSE, false, true, false>), dim3(grid), dim3(BLOCK), 0, st, f,
-                                       a, b, coef, cstride, m, out, ostride, nvec, n, ra);
+                                       a, b, coef, cstride, m, out, ostride, nvec, n, ra, gs);
                 return;
             }
         }
         if (nt || RNG)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
-                               coef, cstride, m, out, ostride, nvec, n, ra);
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG, REC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+                               coef, cstride, m, out, ostride, nvec, n, ra, gs);
         else
             hipLaunchKernelGGL((k_split<F, T, FUSE, false, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
-                               coef, cstride, m, out, ostride, nvec, n, ra);
+                               coef, cstride, m, out, ostride, nvec, n, ra, gs);
     }
     template <bool FUSE, bool RNG>
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
@@ -1508,14 +1571,53 @@ struct Launchers {
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (RNG && !spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
         bool nt = lc.nt != 0;
+        GateSrc<F> gs;
+        memset(&gs, 0, sizeof(gs));
         switch (t) {
-            case 0: go_split<0, FUSE, false>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
-            case 1: go_split<1, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
-            case 2: go_split<2, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
-            case 3: go_split<3, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
-            case 4: go_split<4, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra); break;
+            case 0: go_split<0, FUSE, false>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
+            case 1: go_split<1, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
+            case 2: go_split<2, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
+            case 3: go_split<3, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
+            case 4: go_split<4, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
             default: return 1;
         }
+        return 0;
+    }
+    // fused chain gate: both factors given as recombinations (GateSrc), product re-shared with the device CSPRNG
+    static int gate(const void* Fp, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
+                    const void* const* rowsB, const uint64_t* lamB2, int kB, int t, int m, void* out, size_t ostride,
+                    size_t n, hipStream_t st, const RngArgs* rng) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        if (t < 1 || t > 3 || kA < 1 || kA > GATE_MAXK || kB < 0 || kB > GATE_MAXK || !rng) return 2;
+        LaunchCfg lc = launch_cfg(device);
+        GateSrc<F> gs;
+        memset(&gs, 0, sizeof(gs));
+        bool vec = al(out) && (stride_ok(ostride) || m <= 1);
+        for (int j = 0; j < kA; ++j) {
+            gs.rowsA[j] = (const E*)rowsA[j];
+            gs.lamA[j] = f.prep(word_from_limbs<F>(f, lamA2[2 * j], lamA2[2 * j + 1]));
+            vec = vec && al(rowsA[j]);
+        }
+        for (int j = 0; j < kB; ++j) {
+            gs.rowsB[j] = (const E*)rowsB[j];
+            gs.lamB[j] = f.prep(word_from_limbs<F>(f, lamB2[2 * j], lamB2[2 * j + 1]));
+            vec = vec && al(rowsB[j]);
+        }
+        gs.kA = kA;
+        gs.kB = kB;
+        gs.square = kB == 0;
+        size_t nvec = vec ? n / EPV : 0;
+        RngArgs ra = *rng;
+        const bool spread = nvec > 0 && nvec < 262144;
+        ra.spread = spread ? 1 : 0;
+        unsigned grid = grid_for(nvec ? (!spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
+        E* o = (E*)out;
+        switch (t) {
+            case 1: go_split<1, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
+            case 2: go_split<2, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
+            default: go_split<3, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
+        }
+        FFGPU_CHECK_LAUNCH();
         return 0;
     }
     static int split(const void* Fp, int device, const void* a, const void* b, const void* coef,
@@ -1826,7 +1928,7 @@ struct Launchers {
     }
 
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &sqrt_cl, &gauss, &group_matvec, &beaver, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &gate, &sqrt_cl, &gauss, &group_matvec, &beaver, &prss};
         return &ops;
     }
 };

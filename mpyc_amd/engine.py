@@ -406,6 +406,26 @@ class FieldContext:
         _ffi.check(rc, 'split_rng')
         return out
 
+    def gate(self, rows_a: Sequence[DevArray], lam_a: Sequence[int], rows_b: Optional[Sequence[DevArray]],
+             lam_b: Optional[Sequence[int]], t: int, m: int, key: Optional[bytes] = None, nonce: int = 0,
+             rounds: int = 20, state: Optional['RngState'] = None, out: Optional[DevMatrix] = None) -> DevMatrix:
+        """Fused chain gate (ffgpu_gate_rng): shares of A*B with A = sum lam_a[j]*rows_a[j], B likewise
+        (rows_b None: B = A); recombination, product and share generation in one pass."""
+        import secrets as _secrets
+        n = rows_a[0].n
+        ka, pa, la = self._rec_args(rows_a, lam_a, 1)
+        if rows_b:
+            kb, pb, lb = self._rec_args(rows_b, lam_b, 1)
+        else:
+            kb, pb, lb = 0, None, None
+        out = out or self.empty_matrix(m, n)
+        if state is None and key is None:
+            key = _secrets.token_bytes(32)
+        _ffi.check(self._L.ffgpu_gate_rng(self._h, pa, la, ka, pb, lb, kb, key, nonce, rounds,
+                                          state.ptr if state is not None else None, t, m, out.ptr, out.stride, n,
+                                          self._stream()), 'gate_rng')
+        return out
+
     def _rec_args(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int):
         k = len(rows)
         if len(lambdas) != w * k:

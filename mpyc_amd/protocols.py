@@ -57,6 +57,63 @@ def multiply(ctx: FieldContext, field, xs: Shares, ys: Shares, t: int, rng=None)
     return [ctx.recombine([sub[i].row(j) for i in range(k)], lam) for j in range(m)]
 
 
+# ---- chains of multiplications with the recombined share kept in registers ------------------------------
+class Pending:
+    """A secret-shared value each party holds as a RECOMBINATION it has not performed yet: party j's share
+    is sum_i lam[i] * rows[j][i] (rows[j] = the sub-shares party j received).  A materialised sharing is the
+    1-row case with lam = [1]."""
+
+    __slots__ = ('rows', 'lam')
+
+    def __init__(self, rows, lam):
+        self.rows, self.lam = rows, lam
+
+    @classmethod
+    def of(cls, xs: Shares) -> 'Pending':
+        return cls([[x] for x in xs], [1])
+
+
+def materialize(ctx: FieldContext, x) -> Shares:
+    """Pending -> the parties' shares (the recombination of runtime._reshare, runtime.py:677-689)."""
+    if not isinstance(x, Pending):
+        return x
+    if len(x.lam) == 1 and x.lam[0] == 1:
+        return [r[0] for r in x.rows]
+    return [ctx.recombine(r, x.lam) for r in x.rows]
+
+
+def multiply_pending(ctx: FieldContext, field, x, y, t: int, rng=None) -> Pending:
+    """multiply() for operands that may be Pending (y is x: a squaring): the first 2t+1 parties recombine both
+    factors, multiply and re-share in ONE kernel (ffgpu_gate_rng); the result stays Pending, so the next
+    multiplication consumes the new sub-shares directly.  Needs t <= 3."""
+    px = x if isinstance(x, Pending) else Pending.of(x)
+    py = None if y is x else (y if isinstance(y, Pending) else Pending.of(y))
+    m = len(px.rows)
+    k = 2 * t + 1
+    if m < k:
+        raise ValueError('multiplication needs m >= 2t+1 parties')
+    lam = _lagrange(field, range(1, k + 1))
+    sub = [ctx.gate(px.rows[i], px.lam, py.rows[i] if py else None, py.lam if py else None, t, m, state=rng)
+           for i in range(k)]
+    return Pending([[sub[i].row(j) for i in range(k)] for j in range(m)], lam)
+
+
+def pow254_fused(ctx: FieldContext, field, xs: Shares, t: int, rng=None) -> Shares:
+    """pow254() with every intermediate share kept Pending: 11 fused gate kernels + 1 recombination per party
+    instead of 11 x (share generation + recombination)."""
+    mul = lambda a, b: multiply_pending(ctx, field, a, b, t, rng)
+    d = Pending.of(xs)
+    c = mul(d, d)
+    c = mul(c, c)
+    c = mul(c, c)
+    c = mul(c, d)
+    c = mul(c, c)
+    c, d = mul(c, c), mul(c, d)
+    c, d = mul(c, c), mul(c, d)
+    c = mul(c, d)
+    return materialize(ctx, mul(c, c))
+
+
 def matmul(ctx: FieldContext, field, xs: Shares, ys: Shares, M: int, K: int, N: int, t: int, rng=None) -> Shares:
     """runtime.np_matmul (runtime.py:2481-2541): every party multiplies its share matrices locally
     (`A @ B` then one reduction, :2531 -- the dense-product kernel) and the degree-2t result is re-shared as
@@ -103,10 +160,10 @@ def from_bits(ctx: FieldContext, bits: Shares, l: int = 8) -> Shares:
 
 
 def sbox_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A: Sequence[Sequence[int]],
-               B: Sequence[int], fused: bool = True, rng=None) -> Shares:
+               B: Sequence[int], fused: bool = True, rng=None, chain: bool = True) -> Shares:
     """The AES S-box on secret-shared bytes, as demos/np_aes.py:37-43:
     x = np_to_bits(x**254); x = A @ x + B over GF(2) (on bit shares, local); x = np_from_bits(x)."""
-    y = pow254(ctx, field, xs, t, rng)
+    y = pow254_fused(ctx, field, xs, t, rng) if chain and t <= 3 else pow254(ctx, field, xs, t, rng)
     bits = to_bits_gf256(ctx, field, y, rbits, t)
     if fused:
         return [ctx.bit_affine(b, A, B, from_bits=True) for b in bits]           # both local steps in one pass

@@ -260,3 +260,68 @@ def test_secure_matmul_opens_to_product(mods, modulus, t, m):
     zs = protocols.matmul(ctx, F, xs, ys, M, K, N, t)
     want = [sum(A[i][k] * B[k][j] for k in range(K)) % modulus for i in range(M) for j in range(N)]
     assert unpack(protocols.open_(ctx, F, zs, t).to_numpy(), eb) == want
+
+
+@pytest.mark.parametrize('modulus,binary,t,m', [(2**61 - 1, False, 1, 3), (2**61 - 1, False, 3, 7), (2**96 - 17, False, 2, 5),
+                                                (2**128 - 173, False, 1, 4), (0x11b, True, 1, 3), (0x11b, True, 2, 6),
+                                                (258797994007609146293811961253269568351, False, 1, 3),
+                                                ((1 << 64) | 0x1b, True, 1, 3)])
+def test_fused_chain_gate(mods, modulus, binary, t, m):
+    """ffgpu_gate_rng: recombination of both factors + product + share generation in one kernel, against
+    the three separate kernels on the same sub-shares and generator state (bit-exact), and through a chain
+    of Pending values against plaintext arithmetic.  n = 5003 takes the vector path with a ragged tail;
+    offset views take the scalar path."""
+    engine, finfields, gfpx, protocols = mods
+    F = finfields.GF(gfpx.BinaryPolynomial(modulus)) if binary else finfields.GF(modulus)
+    Fo = po.Field(modulus, binary)
+    ctx = engine.FieldContext(modulus, binary, device=0)
+    eb = ctx.elem_bytes
+    rng = random.Random(t * 100 + m)
+    n = 5003
+    a = [rng.randrange(Fo.order) for _ in range(n)]
+    b = [rng.randrange(Fo.order) for _ in range(n)]
+    k = 2 * t + 1
+    xs = protocols.share(ctx, ctx.from_numpy(pack(a, eb)), t, m)
+    ys = protocols.share(ctx, ctx.from_numpy(pack(b, eb)), t, m)
+    px = protocols.multiply_pending(ctx, F, xs, ys, t)              # Pending x*y
+    assert isinstance(px, protocols.Pending) and len(px.lam) == k
+    want_xy = [po.mul(Fo, u, v) for u, v in zip(a, b)]
+    assert unpack(protocols.open_(ctx, F, protocols.materialize(ctx, px), t).to_numpy(), eb) == want_xy
+    # one gate on Pending operands vs the unfused kernels, same generator state -> identical share rows
+    key = bytes(range(32))
+    for square in (True, False):
+        st1, st2 = ctx.rng_state(key=key, nonce=5), ctx.rng_state(key=key, nonce=5)
+        py = None if square else protocols.Pending.of(ys)
+        got = ctx.gate(px.rows[0], px.lam, py.rows[0] if py else None, py.lam if py else None, t, m, state=st1)
+        rec = ctx.recombine(px.rows[0], px.lam)
+        want = ctx.split_rng(rec, t, m, mul_by=rec if square else ys[0], state=st2)
+        assert torch.equal(got.t[:, :n], want.t[:, :n]), square
+        assert st1.nonce() == st2.nonce() == 6
+        # unaligned row views: scalar path, same result
+        off_rows = [engine.DevArray(ctx, r.t[1:], n - 1) for r in px.rows[0]]
+        st3 = ctx.rng_state(key=key, nonce=5)
+        got2 = ctx.gate(off_rows, px.lam, None if square else [engine.DevArray(ctx, ys[0].t[1:], n - 1)],
+                        None if square else [1], t, m, state=st3)
+        rec2 = engine.DevArray(ctx, rec.t[1:].clone(), n - 1)
+        want2 = ctx.split_rng(rec2, t, m, mul_by=rec2 if square else engine.DevArray(ctx, ys[0].t[1:].clone(), n - 1),
+                              state=ctx.rng_state(key=key, nonce=5))
+        assert torch.equal(got2.t[:, :n - 1], want2.t[:, :n - 1]), ('unaligned', square)
+    # a chain: ((x*y)^2 * x)^2 stays Pending throughout
+    c = protocols.multiply_pending(ctx, F, px, px, t)
+    c = protocols.multiply_pending(ctx, F, c, xs, t)
+    c = protocols.multiply_pending(ctx, F, c, c, t)
+    want = [po.mul(Fo, v, v) for v in want_xy]
+    want = [po.mul(Fo, v, u) for v, u in zip(want, a)]
+    want = [po.mul(Fo, v, v) for v in want]
+    assert unpack(protocols.open_(ctx, F, protocols.materialize(ctx, c), t).to_numpy(), eb) == want
+
+
+def test_pow254_fused_equals_unfused(mods):
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    x = list(range(256)) * 3 + [7]
+    xs = protocols.share(ctx, ctx.from_numpy(np.array(x, dtype=np.uint8)), 1, 3)
+    y = protocols.pow254_fused(ctx, F, xs, 1)
+    assert unpack(protocols.open_(ctx, F, y, 1).to_numpy(), 1) == [g['pow254'][v] for v in x]
