@@ -574,12 +574,12 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
-            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, true, false>',
+            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, true, false, false>',
                      'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
-                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true, false>',
+                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true, false, false>',
                      'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
                      'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
-                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true, false>',
+                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true, false, false>',
                      'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
                      'device_copy': 'k_copy16'}
             for q, kn in names.items():

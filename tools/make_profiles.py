@@ -22,7 +22,7 @@ with open('profiles/r01_kernel_stats.md', 'w') as fh:
     fh.write('# Round 1 -- `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (MI355X)\n\n')
     fh.write('Raw file: profiles/r01_kernel_stats.csv (rocprofv3 `*_kernel_stats.csv`). Library kernels only below; the rest are '
              'torch RNG/fill kernels that create the synthetic inputs outside the timed region.\n')
-    fh.write('Template arguments of k_split: <field policy, T, fused local product, non-temporal, lazy single reduction, in-kernel CSPRNG>.\n\n')
+    fh.write('Template arguments of k_split: <field policy, T, fused local product, non-temporal, lazy single reduction, in-kernel CSPRNG, factors given as recombinations (chain gate)>.\n\n')
     fh.write('| kernel | calls | avg us | min us | max us | total ms |\n|---|---|---|---|---|---|\n')
     for r in rows:
         if any(s in r['Name'] for s in ('ffgpu::', 'k_copy16', 'k_sbox', 'k_gf')):
