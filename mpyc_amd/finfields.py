@@ -413,6 +413,33 @@ def _context(field, device: Optional[int] = None) -> FieldContext:
 # --------------------------------------------------------------------------------------------
 # arrays
 # --------------------------------------------------------------------------------------------
+class _Rec:
+    """A deferred Lagrange recombination sum_j lam[j] * rows[j] (thresha.np_recombine with a single target):
+    kept symbolic so that a following product + share generation can recombine in registers
+    (ffgpu_gate_rng).  Materialised at most once."""
+
+    __slots__ = ('rows', 'lam', '_val')
+
+    def __init__(self, rows, lam):
+        self.rows, self.lam, self._val = list(rows), [int(v) for v in lam], None
+
+    @property
+    def ctx(self):
+        return self.rows[0].ctx
+
+    def materialize(self) -> DevArray:
+        if self._val is None:
+            self._val = self.ctx.recombine(self.rows, self.lam)
+        return self._val
+
+    def reads(self, ptr: int) -> bool:
+        return any(r.t.data_ptr() == ptr for r in self.rows)
+
+
+def _src_dev(src) -> DevArray:
+    return src.materialize() if isinstance(src, _Rec) else src
+
+
 class FieldArray:
     """GPU-backed counterpart of finfields.FiniteFieldArray (finfields.py:695-1368).
 
@@ -501,7 +528,8 @@ class FieldArray:
     def _dev(self) -> DevArray:
         if self._devv is None:
             a, b = self._lazy
-            self._devv = a.ctx.mul(a, b)
+            A = _src_dev(a)
+            self._devv = A if b is None else A.ctx.mul(A, A if b is a else _src_dev(b))
             self._lazy = None
         return self._devv
 
@@ -523,20 +551,33 @@ class FieldArray:
             if arr is None or arr._devv is not None:
                 continue
             lz = arr._lazy
-            if lz[0].t.data_ptr() == ptr or lz[1].t.data_ptr() == ptr:
+            if any(src is not None and (src.reads(ptr) if isinstance(src, _Rec) else src.t.data_ptr() == ptr)
+                   for src in lz):
                 arr._dev            # noqa: B018  (property access materialises)
             else:
                 alive.append(ref)
         _pending_products[:] = alive
 
     def _take_lazy_product(self):
-        """(a, b) device operands if this array is an unmaterialised product, else None."""
+        """(a, b) operands if this array is unmaterialised, else None.  Each operand is a DevArray or a
+        deferred recombination (_Rec); b is None for a bare deferred recombination."""
         return self._lazy if self._devv is None else None
+
+    def _source(self):
+        """What a product should read for this array: the deferred recombination if that is all it is, else
+        the device data (materialising a deferred product)."""
+        if self._devv is None and self._lazy is not None and self._lazy[1] is None and isinstance(self._lazy[0], _Rec):
+            return self._lazy[0]
+        return self._dev
+
+    @classmethod
+    def _wrap_lazy_rec(cls, rows, lam, shape) -> 'FieldArray':
+        return cls._wrap_lazy_product(_Rec(rows, lam), None, shape)
 
     # ---- representation --------------------------------------------------------------
     @property
     def ctx(self) -> FieldContext:
-        return (self._lazy[0] if self._devv is None else self._devv).ctx
+        return (self._lazy[0] if self._devv is None else self._devv).ctx        # DevArray and _Rec both have .ctx
 
     @property
     def value(self) -> np.ndarray:
@@ -763,7 +804,8 @@ class FieldArray:
     def __mul__(self, other):
         if isinstance(other, FieldArray) and other.field is type(self).field and other._shape == self._shape \
                 and self.size > 1 and lazy_products:
-            return self._wrap_lazy_product(self._dev, other._dev, self._shape)
+            a = self._source()
+            return self._wrap_lazy_product(a, a if other is self else other._source(), self._shape)
         return self._binop(other, FieldContext.mul, FieldContext.mul_scalar)
 
     __rmul__ = __mul__

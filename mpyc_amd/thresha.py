@@ -26,7 +26,7 @@ from math import prod
 import numpy as np
 
 from .engine import DevArray, DevMatrix
-from .finfields import FieldArray, _context, _fops, _matrix_to_array
+from .finfields import FieldArray, _Rec, _context, _fops, _matrix_to_array, _src_dev
 
 __all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector',
            'pseudorandom_share', 'pseudorandom_share_zero', 'np_pseudorandom_share', 'np_pseudorandom_share_0', 'PRF']
@@ -34,6 +34,9 @@ __all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_rec
 randbelow = None      # parity hook: callable(order) -> int, else device CSPRNG
 rng_rounds = 20       # ChaCha rounds of the device CSPRNG (20, 12 or 8)
 _nonce = 0
+
+
+lazy_recombine = True     # np_recombine defers single-target recombinations of <= 7 rows (see FieldArray._source)
 
 
 def _next_nonce():
@@ -55,7 +58,17 @@ def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
     n = S.size
     lazy = S._take_lazy_product()          # unmaterialised a*b: fuse the product into the split kernel
     if lazy is not None:
-        dev, mul_by = lazy
+        a, b = lazy
+        if (b is not None and randbelow is None and 1 <= t <= 3 and n
+                and (isinstance(a, _Rec) or isinstance(b, _Rec))
+                and all(len(src.rows) <= 7 for src in (a, b) if isinstance(src, _Rec))):
+            # a chain of multiplications: the factors are still the sub-shares received in the previous gate
+            # -> recombine in registers, multiply, re-share (ffgpu_gate_rng); nothing is written in between
+            ra, la = (a.rows, a.lam) if isinstance(a, _Rec) else ([a], [1])
+            rb, lb = (None, None) if b is a else ((b.rows, b.lam) if isinstance(b, _Rec) else ([b], [1]))
+            return ctx.gate(ra, la, rb, lb, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds)
+        dev = _src_dev(a)
+        mul_by = None if b is None else (dev if b is a else _src_dev(b))
     else:
         dev, mul_by = (S.device_array if S.ndim == 1 else S.reshape(-1).device_array), None
     if t == 0 or n == 0:
@@ -177,6 +190,10 @@ def np_recombine(field, points, x_rs=0):
     lam = [v for x_r in xr for v in _recombination_vector(field, tuple(xs), x_r)]
     rows = _rows_on_device(field, shares)
     ctx = rows[0].ctx
+    if scalar and lazy_recombine and 1 < len(rows) <= 7 and rows[0].n > 1:
+        # deferred: a product + share generation that follows recombines in registers; any other use
+        # performs the recombination then (FieldArray._dev)
+        return field.array._wrap_lazy_rec(rows, lam, (rows[0].n,))
     out = ctx.recombine(rows, lam, w=len(xr))
     if scalar:
         return field.array._wrap(out, (rows[0].n,))

@@ -592,3 +592,55 @@ def test_twelve_byte_field_through_the_mirror(api):
         assert ints(back) == ints(s)
         # negative / oversized host inputs reduce like the reference (finfields.py:724)
         same(F.array([-1, p, p + 5, 2**200 + 3]), np.array([p - 1, 0, 5, (2**200 + 3) % p], dtype=object))
+
+
+def test_recombine_multiply_split_chain_stays_in_registers(api):
+    """np_recombine defers; `y * y` / `y * z` of deferred recombinations defers; np_random_split of that
+    issues ONE fused kernel (ffgpu_gate_rng) and never materialises y.  Results equal plain arithmetic, and
+    every other use of a deferred array materialises it transparently."""
+    finfields, gfpx, thresha = api
+    rng = random.Random(77)
+    for F, t, m in ((finfields.GF(2**61 - 1), 1, 3), (finfields.GF(2**96 - 17), 2, 5),
+                    (finfields.GF(gfpx.GFpX(2)(0x11b)), 1, 3)):
+        q = F.order
+        n = 3001
+        a = [rng.randrange(q) for _ in range(n)]
+        b = [rng.randrange(q) for _ in range(n)]
+        A, B = F.array(a), F.array(b)
+        k = 2 * t + 1
+        sa = thresha.np_random_split(F, A, t, m)
+        sb = thresha.np_random_split(F, B, t, m)
+        # party 1's view of a multiplication chain: recombine the rows it "received", square, re-share
+        y = thresha.np_recombine(F, [(x, sa[x - 1]) for x in range(1, t + 2)])
+        z = thresha.np_recombine(F, [(x, sb[x - 1]) for x in range(1, t + 2)])
+        assert y._take_lazy_product() is not None and y._devv is None          # deferred
+        sq = y * y
+        sh = thresha.np_random_split(F, sq, t, m)                             # fused chain gate
+        assert y._devv is None and sq._devv is None                            # nothing was materialised
+        back = thresha.np_recombine(F, [(x, sh[x - 1]) for x in range(1, t + 2)])
+        assert ints(back) == ints(A * A)
+        yz = thresha.np_random_split(F, y * z, t, m)
+        assert y._devv is None and z._devv is None
+        assert ints(thresha.np_recombine(F, [(x, yz[x - 1]) for x in range(m, m - t - 1, -1)])) == ints(A * B)
+        mixed = thresha.np_random_split(F, y * B, t, m)                       # one deferred, one plain operand
+        assert ints(thresha.np_recombine(F, [(x, mixed[x - 1]) for x in range(1, t + 2)])) == ints(A * B)
+        # any other use materialises: arithmetic, indexing, .value, in-place updates of a row
+        assert ints(y + 1) == ints(A + 1) and y._devv is not None
+        assert int(z[5].value) == b[5] and z._devv is not None
+        w = thresha.np_recombine(F, [(x, sa[x - 1]) for x in range(1, t + 2)])
+        p = w * w
+        row = sa[0]
+        row += 1                                                               # mutates a row w still reads
+        assert ints(p) == ints(A * A)                                          # ... after p was flushed
+    # parity mode (randbelow hook) never takes the fused path but still accepts deferred operands
+    F = finfields.GF(2**61 - 1)
+    A = F.array([3, 5, 7, 11])
+    sa = thresha.np_random_split(F, A, 1, 3)
+    y = thresha.np_recombine(F, [(1, sa[0]), (2, sa[1])])
+    draws = iter(range(100, 200))
+    thresha.randbelow = lambda order: next(draws)
+    try:
+        sh = thresha.np_random_split(F, y * y, 1, 3)
+    finally:
+        thresha.randbelow = None
+    assert ints(sh[0]) == [(v * v + 100 + i) % F.order for i, v in enumerate([3, 5, 7, 11])]
