@@ -316,6 +316,25 @@ def main():
         kern['device_copy'] = dict(roof(2 * eb * n, ms_copy), kernel='k_copy16 (80 MB -> 80 MB, rotating sets)')
         def optional_measurements():
             """Everything beyond the step's own kernels; a failure here must not cost the headline line."""
+            # A gate INSIDE a chain of multiplications (production mode): the k = 3 sub-share rows received in the
+            # previous gate are recombined in registers, squared and re-shared with the device CSPRNG in ONE kernel
+            # (ffgpu_gate_rng): 3 reads + 3 writes per element, all three stages of the headline step.
+            st_chain = ctx.rng_state()
+            outs = [ctx.empty_matrix(m, n) for _ in range(2)]
+            chain_sets = [(sets[i].shares, outs[i % 2]) for i in range(len(sets))]
+            for rounds in (20, 8):
+                stc = ctx.rng_state(rounds=rounds)
+                ms = time_launches(lambda s_: ctx.gate([s_[0].row(j) for j in range(k)], lam, None, None, t, m, state=stc,
+                                                       out=s_[1]), chain_sets, reps)
+                bpu = (k + m) * eb
+                kern[f'chain_gate_p61_m3t1_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                                   units_per_s=round(n / (ms * 1e-3), 1),
+                                                                   field_ops_per_s=round(3 * n / (ms * 1e-3), 1))
+            chk = ctx.gate([sets[0].shares.row(j) for j in range(k)], lam, None, None, t, m, state=st_chain, out=outs[0])
+            y0 = sets[0].rec()
+            if not torch.equal(ctx.recombine([chk.row(j) for j in range(k)], lam).t, ctx.mul(y0, y0).t):
+                raise SystemExit('bench parity check failed for the chain gate')
+            del outs, chain_sets
             # second-tier element-wise ops (finfields.py:1278-1281,1424-1458): batched inverse, sqrt = pow by (p+1)/4
             ms = time_launches(lambda s: ctx.inv(s.a, out=s.c, check_zero=False), sets, 3)
             kern['inv_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',

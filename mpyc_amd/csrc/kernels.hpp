@@ -268,6 +268,8 @@ struct RngArgs {
     // antilogs; misc.hip Gf8Tables).  When set, the product of the fused kernel goes through LDS lookups,
     // which run beside the ChaCha VALU work instead of adding ~110 VALU ops per word to it.
     const void* aux;
+    int release;  // 1: the kernel's last workgroup advances the device-resident nonce (small grids only: one
+                  // atomic per workgroup on one address serialises, ~25 ns each); 0: k_rng_advance follows
 };
 
 
@@ -285,6 +287,7 @@ struct GateSrc {
     typename F::word lamA[GATE_MAXK], lamB[GATE_MAXK];   // prepared (f.prep)
     int kA, kB;
     int square;                                          // 1: second factor = first factor
+    int plainA, plainB;                                  // 1: a single row with lambda = 1 (an existing array)
 };
 
 template <class F, bool NT>
@@ -323,7 +326,7 @@ __device__ __forceinline__ typename F::word gate_load_elem(const F& f, const typ
 // Device-resident generator state: the LAST workgroup to finish advances the nonce (every workgroup has read
 // the state by then; the next launch on the stream starts after this one ends).  pad_ counts finished groups.
 __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
-    if (!ra.dev_key) return;
+    if (!ra.dev_key || !ra.release) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         RngKey* st = const_cast<RngKey*>(ra.dev_key);
@@ -336,6 +339,15 @@ __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
         }
     }
 }
+
+// large grids: a one-thread kernel after the share-generation kernel (stream order) advances the nonce
+template <int UNUSED>
+__global__ void k_rng_advance(RngKey* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (++st->nonce[0] == 0) st->nonce[1] += 65536u;
+    }
+}
+enum { RNG_RELEASE_MAX_GRID = 512 };
 
 template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG, bool REC = false>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
@@ -372,8 +384,11 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
         P s, s2;
         if constexpr (REC) {
-            s = gate_load<F, NT>(f, gs.rowsA, gs.lamA, gs.kA, i);
-            s2 = gs.square ? s : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, i);
+            s = gs.plainA ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsA[0]) + i)
+                          : gate_load<F, NT>(f, gs.rowsA, gs.lamA, gs.kA, i);
+            s2 = gs.square ? s
+                           : (gs.plainB ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsB[0]) + i)
+                                        : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, i));
         } else {
             s = ldg<NT>(av + i);
             if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
@@ -464,8 +479,10 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     for (size_t e = done + gid; e < n; e += gsz) {
         W s;
         if constexpr (REC) {
-            s = gate_load_elem<F>(f, gs.rowsA, gs.lamA, gs.kA, e);
-            s = f.mul(s, gs.square ? s : gate_load_elem<F>(f, gs.rowsB, gs.lamB, gs.kB, e));
+            s = gs.plainA ? ld_elem<F>(gs.rowsA[0], e) : gate_load_elem<F>(f, gs.rowsA, gs.lamA, gs.kA, e);
+            s = f.mul(s, gs.square ? s
+                                   : (gs.plainB ? ld_elem<F>(gs.rowsB[0], e)
+                                                : gate_load_elem<F>(f, gs.rowsB, gs.lamB, gs.kB, e)));
         } else {
             s = ld_elem<F>(a, e);
             if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
@@ -1554,10 +1571,13 @@ struct Launchers {
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
                        int t, int m, E* out, size_t ostride, size_t n, hipStream_t st, const RngArgs& ra_in) {
         if (t > MAXT) {
-            const RngArgs& ra = ra_in;
+            RngArgs ra = ra_in;
             unsigned grid = grid_for(n, lc);
+            ra.release = grid <= RNG_RELEASE_MAX_GRID;
             hipLaunchKernelGGL((k_split_any<F, FUSE, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
                                t, m, out, ostride, n, ra);
+            if (RNG && ra.dev_key && !ra.release)
+                hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
             return 0;
         }
         bool vec = al(a) && (!FUSE || al(b)) && al(out) &&
@@ -1570,6 +1590,7 @@ struct Launchers {
         const bool spread = RNG && nvec > 0 && nvec < 262144;
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (RNG && !spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
+        ra.release = grid <= RNG_RELEASE_MAX_GRID;
         bool nt = lc.nt != 0;
         GateSrc<F> gs;
         memset(&gs, 0, sizeof(gs));
@@ -1581,6 +1602,8 @@ struct Launchers {
             case 4: go_split<4, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
             default: return 1;
         }
+        if (RNG && t > 0 && ra.dev_key && !ra.release)
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
         return 0;
     }
     // fused chain gate: both factors given as recombinations (GateSrc), product re-shared with the device CSPRNG
@@ -1606,17 +1629,22 @@ struct Launchers {
         gs.kA = kA;
         gs.kB = kB;
         gs.square = kB == 0;
+        gs.plainA = kA == 1 && lamA2[0] == 1 && lamA2[1] == 0;
+        gs.plainB = kB == 1 && lamB2[0] == 1 && lamB2[1] == 0;
         size_t nvec = vec ? n / EPV : 0;
         RngArgs ra = *rng;
         const bool spread = nvec > 0 && nvec < 262144;
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (!spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
+        ra.release = grid <= RNG_RELEASE_MAX_GRID;
         E* o = (E*)out;
         switch (t) {
             case 1: go_split<1, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
             case 2: go_split<2, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
             default: go_split<3, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
         }
+        if (ra.dev_key && !ra.release)
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
         FFGPU_CHECK_LAUNCH();
         return 0;
     }
