@@ -159,6 +159,16 @@ def test_rng_state_matches_host_key_and_advances(mods):
             assert st.nonce() == 42 + i
         ctx.split_rng(s, 0, 1, state=st)                                            # t = 0 draws nothing
         assert st.nonce() == 44
+        # large grids (> 512 workgroups) advance the nonce with a follow-up kernel instead of in-kernel atomics
+        nb = 1_500_007
+        big = ctx.from_numpy(pack([rng.randrange(F.order) for _ in range(1000)] * (nb // 1000 + 1), ctx.elem_bytes)[:nb])
+        for t_, m_ in ((1, 3), (6, 8)):
+            if m_ >= F.order:
+                continue
+            before = st.nonce()
+            got = ctx.split_rng(big, t_, m_, state=st)
+            want = ctx.split_rng(big, t_, m_, key=key, nonce=before, rounds=12)
+            assert torch.equal(got.t[:, :nb], want.t[:, :nb]) and st.nonce() == before + 1
 
 
 def test_secure_sbox_layer_in_a_hip_graph(mods):
