@@ -150,8 +150,8 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--n', type=int, default=10_000_000, help='elements per GPU')
     ap.add_argument('--sets', type=int, default=4, help='rotating buffer sets')
     ap.add_argument('--no-cpu-baseline', action='store_true')
