@@ -101,3 +101,37 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_ffi, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_ffi.FfgpuError):
         _ffi.lib()
+
+
+def test_empty_inputs_are_ok_everywhere(L):
+    """n = 0 (empty arrays, tests/test_thresha.py and finfields edge cases): every compute entry point
+    returns FFGPU_OK before touching a device (so this runs without a GPU) and without reading pointers."""
+    from mpyc_amd import _ffi
+    rc, h = mk(L, _ffi.PRIME, 2**61 - 1)
+    assert rc == 0
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    two = (ctypes.c_uint64 * 2)(1, 0)
+    rows = (ctypes.c_void_p * 3)(p.value, p.value, p.value)
+    lam = (ctypes.c_uint64 * 6)(1, 0, 1, 0, 1, 0)
+    key = bytes(32)
+    assert L.ffgpu_add(h, p, p, p, 0, None) == 0
+    assert L.ffgpu_mul(h, p, p, p, 0, None) == 0
+    assert L.ffgpu_neg(h, p, p, 0, None) == 0
+    assert L.ffgpu_reduce(h, p, p, 0, None) == 0
+    assert L.ffgpu_mul_scalar(h, p, two, p, 0, None) == 0
+    assert L.ffgpu_muladd(h, p, p, p, p, 0, None) == 0
+    assert L.ffgpu_pow(h, p, two, 1, p, 0, None) == 0
+    assert L.ffgpu_inv(h, p, p, 0, p, None) == 0
+    assert L.ffgpu_split(h, p, p, 0, 1, 3, p, 0, 0, None) == 0
+    assert L.ffgpu_mul_split(h, p, p, p, 0, 1, 3, p, 0, 0, None) == 0
+    assert L.ffgpu_split_rng(h, p, key, 0, 20, 1, 3, p, 0, 0, None) == 0
+    assert L.ffgpu_recombine(h, rows, lam, 3, 1, p, 0, 0, None) == 0
+    assert L.ffgpu_gate_rng(h, rows, lam, 3, None, None, 0, key, 0, 20, None, 1, 3, p, 0, 0, None) == 0
+    assert L.ffgpu_group_matvec(h, lam, None, 1, 3, p, p, 0, None) == 0
+    assert L.ffgpu_gauss(h, p, 3, 3, 0, 0, None, p, None) == 0
+    assert L.ffgpu_shake128_expand(None, None, 0, 10, None, 1) == 0
+    # and bad shapes are still rejected when n = 0
+    assert L.ffgpu_split(h, p, p, 0, 3, 3, p, 0, 0, None) == _ffi.EINVAL      # t must be < m
+    assert L.ffgpu_gate_rng(h, rows, lam, 3, None, None, 0, key, 0, 20, None, 4, 9, p, 0, 0, None) == _ffi.ENOTSUP
+    L.ffgpu_ctx_destroy(h)
