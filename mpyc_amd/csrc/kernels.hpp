@@ -314,11 +314,7 @@ __device__ __forceinline__ typename F::word gate_load_elem(const F& f, const typ
     typename F::acc acc;
     f.acc_zero(acc);
     for (int j = 0; j < k; ++j) {
-        typename F::word x = ld_elem<F>(rows[j], e);
-        if constexpr (F::EPW > 1) {
-            // packed fields: acc_mac works on words; a single element sits in the low byte
-        }
-        f.acc_mac(acc, lam[j], x);
+        f.acc_mac(acc, lam[j], ld_elem<F>(rows[j], e));     // packed fields: the element sits in the low byte of the word
     }
     return f.acc_reduce(acc);
 }
