@@ -61,6 +61,8 @@ struct ffgpu_ctx {
     uint8_t sbox_lut[256];
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
+    void* scratch;          // grow-only device scratch for split-K partial sums (skinny products); one stream at a time
+    size_t scratch_bytes;
     void* gf8_tables_dev;   // device copy of gf8_tables (lazily, for the fused GF(2^n<=8) product)
     // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
     int timing, timed;
@@ -266,6 +268,10 @@ static const void* gf8_tables_on_device(ffgpu_ctx* ctx) {
 }
 
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
+    if (ctx && ctx->scratch) {
+        DeviceGuard g(ctx->device);
+        (void)hipFree(ctx->scratch);
+    }
     if (ctx && ctx->gf8_tables_dev) {
         DeviceGuard g(ctx->device);
         (void)hipFree(ctx->gf8_tables_dev);
@@ -711,8 +717,23 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
     ARGCHK(K == 0 || (A && B && lda >= K && ldb >= N));
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
-    return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N,
-                                          (hipStream_t)stream));
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    if (K >= 128 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) {   // shapes that may split K: partial sums need scratch
+        const size_t want = (size_t)64 << 20;
+        if (ctx->scratch_bytes < want) {
+            // queued work on this stream may still read the old buffer
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            if (ctx->scratch) (void)hipFree(ctx->scratch);
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+            if (hipMalloc(&ctx->scratch, want) == hipSuccess) ctx->scratch_bytes = want;
+        }
+        ws = ctx->scratch;
+        ws_bytes = ctx->scratch_bytes;
+    }
+    return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N, ws,
+                                          ws_bytes, (hipStream_t)stream));
 }
 
 int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int r, int g,

@@ -957,12 +957,24 @@ __device__ __forceinline__ W ff_keep_if(W v, bool ok) {
     }
 }
 
+// kchunk > 0: split-K -- slice blockIdx.z multiplies columns [z*kchunk, (z+1)*kchunk) of A by the matching rows of
+// B into its own (M x N) slab of C (slab stride zstride elements); k_splitk_sum adds the slabs.  Shapes whose
+// output gives fewer tiles than the chip has CUs (a batch of 64 activations times a 4096^2 weight matrix) would
+// otherwise leave most of it idle.
 template <class F, int TM, int TN>
 __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* __restrict__ A, size_t lda,
                                                    const typename F::elem* __restrict__ B, size_t ldb,
-                                                   typename F::elem* __restrict__ C, size_t ldc, int M, int K, int N) {
+                                                   typename F::elem* __restrict__ C, size_t ldc, int M, int K, int N,
+                                                   int kchunk, size_t zstride) {
     typedef typename F::word W;
     static_assert(F::EPW == 1, "packed fields use the byte-wise instantiation");
+    if (kchunk > 0) {
+        const int kz = blockIdx.z * kchunk;
+        A += kz;
+        B += (size_t)kz * ldb;
+        C += (size_t)blockIdx.z * zstride;
+        K = K - kz < kchunk ? K - kz : kchunk;
+    }
     constexpr int BK = 16, BM = 16 * TM, BN = 16 * TN, FLUSH = 192;
     __shared__ W As[BK][BM + 1];
     __shared__ W Bs[BK][BN + 1];
@@ -1310,6 +1322,181 @@ __global__ __launch_bounds__(BLOCK) void k_gauss_elim(F f, typename F::elem* __r
     }
 }
 
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_splitk_sum(F f, const typename F::elem* __restrict__ part, int KS, int M, int N,
+                                                       typename F::elem* __restrict__ C, size_t ldc) {
+    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    typename F::word r = ld_elem<F>(part, idx);
+    for (int s = 1; s < KS; ++s) r = f.add(r, ld_elem<F>(part, (size_t)s * M * N + idx));
+    st_elem<F>(C, (idx / N) * ldc + idx % N, r);
+}
+
+// ---- skinny products: matrix x few columns, few rows x matrix ---------------------------------------------
+// The tiled k_matmul needs both output dimensions to fill the chip; the shapes MPyC's author flags as the
+// bottleneck (demos/np_bnnmnist.py:10-15: `L @ W` with a 1 x 4096 activation row and a 4096 x 4096 weight
+// matrix, finfields.py:1126-1135) have one output dimension of 1..8.  Both are HBM-bound: the big operand is
+// read exactly once, coalesced, the small one stays in L2; products are accumulated unreduced (flush every
+// 192 terms, as k_dot_partial) and reduced once.
+enum { SKINNY_MAX = 8, SKINNY_FLUSH = 192 };
+
+// C (M x N) = A (M x K) @ B (K x N), N <= SKINNY_MAX: one workgroup per row of A
+template <class F, int NN>
+__global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                        const typename F::elem* __restrict__ B, size_t ldb,
+                                                        typename F::elem* __restrict__ C, size_t ldc, int K, int N,
+                                                        int vec, int bvec) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    __shared__ W sm[BLOCK];
+    const size_t row = blockIdx.x;
+    const typename F::elem* __restrict__ a = A + row * lda;
+    typename F::acc acc[NN];
+    W total[NN];
+    bool have = false;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NN; ++j) f.acc_zero(acc[j]);
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            W part = f.acc_reduce(acc[j]);
+            total[j] = have ? f.add(total[j], part) : part;
+            f.acc_zero(acc[j]);
+        }
+        have = true;
+        cnt = 0;
+    };
+    auto term = [&](W x, size_t kk) {
+        const W xp = f.prep(x);
+        if (bvec) {          // the N values of row kk of B with 16-byte loads (N a multiple of the pack width)
+            const MP* __restrict__ br = reinterpret_cast<const MP*>(B + kk * ldb);
+#pragma unroll
+            for (int jp = 0; jp < (NN + P::N - 1) / P::N; ++jp) {
+                if (jp * P::N < N) {
+                    const P bp = ldg<false>(br + jp);
+#pragma unroll
+                    for (int q = 0; q < P::N; ++q)
+                        if (jp * P::N + q < NN) f.acc_mac(acc[jp * P::N + q], xp, bp.w[q]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+                if (j < N) f.acc_mac(acc[j], xp, ld_elem<F>(B, kk * ldb + j));
+        }
+        if (++cnt >= SKINNY_FLUSH) flush();
+    };
+    constexpr int EPV = P::N;
+    const int nvec = vec ? K / EPV : 0;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    for (int i = threadIdx.x; i < nvec; i += BLOCK) {
+        const P x = ldg<true>(av + i);
+#pragma unroll
+        for (int q = 0; q < P::N; ++q) term(x.w[q], (size_t)i * EPV + q);
+    }
+    for (int kk = nvec * EPV + threadIdx.x; kk < K; kk += BLOCK) term(ld_elem<F>(a, kk), (size_t)kk);
+    flush();
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        if (j < N) {
+            const W r = block_reduce_add(f, total[j], sm);
+            if (threadIdx.x == 0) st_elem<F>(C, row * ldc + j, r);
+            __syncthreads();
+        }
+    }
+}
+
+// C (M x N) = A (M x K) @ B (K x N), M <= SKINNY_MAX: a pack of columns per thread, K split over blockIdx.y;
+// partial[(ks * M + m) * N + j], summed by k_vecmat_final
+template <class F, int MM, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                           const typename F::elem* __restrict__ B, size_t ldb,
+                                                           typename F::word* __restrict__ partial, int M, int K, int N,
+                                                           int kchunk) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    constexpr int CW = VEC ? P::N : 1;                              // columns per thread
+    const int j = (blockIdx.x * BLOCK + threadIdx.x) * CW;
+    if (j >= N) return;
+    const int k0 = blockIdx.y * kchunk;
+    const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
+    typename F::acc acc[MM][CW];
+    W total[MM][CW];
+    bool have = false;
+    int cnt = 0;
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+        for (int q = 0; q < CW; ++q) f.acc_zero(acc[mi][q]);
+    auto flush = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                W part = f.acc_reduce(acc[mi][q]);
+                total[mi][q] = have ? f.add(total[mi][q], part) : part;
+                f.acc_zero(acc[mi][q]);
+            }
+        have = true;
+        cnt = 0;
+    };
+    auto load_b = [&](int kk, W (&b)[CW]) {
+        if constexpr (VEC) {
+            const P bp = ldg<true>(reinterpret_cast<const MP*>(B + (size_t)kk * ldb + j));     // coalesced across the block
+#pragma unroll
+            for (int q = 0; q < CW; ++q) b[q] = bp.w[q];
+        } else {
+            b[0] = ld_elem<F>(B, (size_t)kk * ldb + j);
+        }
+    };
+    auto macs = [&](int kk, const W (&b)[CW]) {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+            if (mi < M) {
+                const W ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                      // wave-uniform operand
+#pragma unroll
+                for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, b[q]);
+            }
+    };
+    int kk = k0;
+    for (; kk + 4 <= k1; kk += 4) {                  // four rows of B in flight per thread
+        W b0[CW], b1[CW], b2[CW], b3[CW];
+        load_b(kk, b0); load_b(kk + 1, b1); load_b(kk + 2, b2); load_b(kk + 3, b3);
+        macs(kk, b0); macs(kk + 1, b1); macs(kk + 2, b2); macs(kk + 3, b3);
+        cnt += 4;
+        if (cnt >= SKINNY_FLUSH) flush();
+    }
+    for (; kk < k1; ++kk) {
+        W b0[CW];
+        load_b(kk, b0);
+        macs(kk, b0);
+        if (++cnt >= SKINNY_FLUSH) flush();
+    }
+    flush();
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi)
+        if (mi < M)
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = total[mi][q];
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_vecmat_final(F f, const typename F::word* __restrict__ partial, int KS, int M,
+                                                         int N, typename F::elem* __restrict__ C, size_t ldc) {
+    typedef typename F::word W;
+    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    const int mi = (int)(idx / N), j = (int)(idx % N);
+    W r = partial[idx];
+    for (int s = 1; s < KS; ++s) r = f.add(r, partial[(size_t)s * M * N + idx]);
+    st_elem<F>(C, (size_t)mi * ldc + j, r);
+}
+
 // ---- small public matrix applied to every group of g consecutive elements --------------------------
 // out[i*r + a] = bias[a] + sum_{c<g} M[a][c] * in[i*g + c],   a < r,  i < ngroups   (r, g <= 16)
 // The array-of-structs sibling of k_recombine: finfields `A @ x[..., np.newaxis]` with a public A
@@ -1411,7 +1598,7 @@ struct FieldOps {
     int (*inv)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
                hipStream_t st);
     int (*matmul)(const void* F, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
-                  size_t ldc, int M, int K, int N, hipStream_t st);
+                  size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
     int (*gate)(const void* F, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
@@ -1787,40 +1974,109 @@ struct Launchers {
         return 0;
     }
 
+    // skinny shapes (one output dimension <= 8): HBM-bound kernels that read the big operand once
+    template <int NN>
+    static void go_matvec(const F& f, const E* A, size_t lda, const E* B, size_t ldb, E* C, size_t ldc, int M, int K,
+                          int N, hipStream_t st) {
+        const int vec = al(A) && stride_ok(lda);
+        const int bvec = al(B) && stride_ok(ldb) && (N % (int)(16 / sizeof(W)) == 0) && sizeof(E) != 12;
+        hipLaunchKernelGGL((k_matvec_rows<F, NN>), dim3((unsigned)M), dim3(BLOCK), 0, st, f, A, lda, B, ldb, C, ldc, K, N, vec,
+                           bvec);
+    }
+    template <int MM>
+    static void go_vecmat(const F& f, const E* A, size_t lda, const E* B, size_t ldb, W* part, int M, int K, int N,
+                          int ks, int kchunk, hipStream_t st) {
+        constexpr int CW = 16 / sizeof(W);
+        const bool vec = sizeof(E) != 12 && CW > 1 && al(B) && stride_ok(ldb) && N % CW == 0;
+        if (vec) {
+            dim3 grid((N / CW + BLOCK - 1) / BLOCK, ks);
+            hipLaunchKernelGGL((k_vecmat_partial<F, MM, true>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
+        } else {
+            dim3 grid((N + BLOCK - 1) / BLOCK, ks);
+            hipLaunchKernelGGL((k_vecmat_partial<F, MM, false>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
+        }
+    }
     static int matmul(const void* Fp, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
-                      size_t ldc, int M, int K, int N, hipStream_t st) {
+                      size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
+        if constexpr (F::EPW == 1) {
+            if (N <= SKINNY_MAX && M >= 64 && K >= 1) {
+                const E* a = (const E*)A; const E* b = (const E*)B; E* c = (E*)C;
+                if (N == 1) go_matvec<1>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
+                else if (N == 2) go_matvec<2>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
+                else if (N <= 4) go_matvec<4>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
+                else go_matvec<8>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
+                FFGPU_CHECK_LAUNCH();
+                return 0;
+            }
+            if (M <= SKINNY_MAX && N >= 64 && K >= 1 && workspace) {
+                // split K so that about 2^18 threads are in flight; each chunk at least 8 rows
+                const int cols_blocks = (N / (int)(16 / sizeof(W)) + BLOCK - 1) / BLOCK;
+                int ks = (1024 + cols_blocks - 1) / cols_blocks;
+                if (ks > (K + 7) / 8) ks = (K + 7) / 8;
+                if (ks < 1) ks = 1;
+                while (ks > 1 && (size_t)ks * M * N * sizeof(W) > workspace_bytes) ks /= 2;
+                if ((size_t)ks * M * N * sizeof(W) <= workspace_bytes) {
+                    const int kchunk = (K + ks - 1) / ks;
+                    ks = (K + kchunk - 1) / kchunk;
+                    W* part = (W*)workspace;
+                    const E* a = (const E*)A; const E* b = (const E*)B;
+                    if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    else if (M == 2) go_vecmat<2>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    else if (M <= 4) go_vecmat<4>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    else go_vecmat<8>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    hipLaunchKernelGGL((k_vecmat_final<F>), dim3((unsigned)(((size_t)M * N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                                       st, f, (const W*)part, ks, M, N, (E*)C, ldc);
+                    FFGPU_CHECK_LAUNCH();
+                    return 0;
+                }
+            }
+        }
         if constexpr (F::EPW > 1) {
             dim3 grid((N + 31) / 32, (M + 31) / 32);
             hipLaunchKernelGGL((k_matmul_bytes<F>), grid, dim3(BLOCK), 0, st, f, (const uint8_t*)A, lda,
                                (const uint8_t*)B, ldb, (uint8_t*)C, ldc, M, K, N);
-        } else if constexpr (sizeof(W) == 16) {
-            dim3 grid((N + 31) / 32, (M + 31) / 32);
-            hipLaunchKernelGGL((k_matmul<F, 2, 2>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B, ldb,
-                               (E*)C, ldc, M, K, N);
         } else {
             static int tile = -1;
             if (tile < 0) {
                 const char* e = getenv("FFGPU_MM_TILE");
                 tile = e ? atoi(e) : 42;   // 4x2 per thread: measured best (1.93 T MAC/s at 4096^3 over GF(2^61-1))
             }
-            if (tile == 42) {
-                dim3 grid((N + 31) / 32, (M + 63) / 64);
-                hipLaunchKernelGGL((k_matmul<F, 4, 2>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B,
-                                   ldb, (E*)C, ldc, M, K, N);
-            } else if (tile == 22) {
-                dim3 grid((N + 31) / 32, (M + 31) / 32);
-                hipLaunchKernelGGL((k_matmul<F, 2, 2>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B,
-                                   ldb, (E*)C, ldc, M, K, N);
-            } else if (tile == 84) {
-                dim3 grid((N + 63) / 64, (M + 127) / 128);
-                hipLaunchKernelGGL((k_matmul<F, 8, 4>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B,
-                                   ldb, (E*)C, ldc, M, K, N);
-            } else {
-                dim3 grid((N + 63) / 64, (M + 63) / 64);
-                hipLaunchKernelGGL((k_matmul<F, 4, 4>), grid, dim3(BLOCK), 0, st, f, (const E*)A, lda, (const E*)B,
-                                   ldb, (E*)C, ldc, M, K, N);
+            const int tcode = sizeof(W) == 16 ? 22 : tile;
+            const int bm = tcode == 42 ? 64 : tcode == 22 ? 32 : tcode == 84 ? 128 : 64;
+            const int bn = tcode == 42 ? 32 : tcode == 22 ? 32 : tcode == 84 ? 64 : 64;
+            dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm);
+            // too few output tiles to fill 256 CUs: split K over blockIdx.z into slabs of the workspace
+            int ks = 1, kchunk = 0;
+            const size_t tiles = (size_t)grid.x * grid.y;
+            E* out = (E*)C;
+            size_t out_ld = ldc, zstride = 0;
+            if (tiles < 512 && K >= 128 && workspace) {
+                ks = (int)((1024 + tiles - 1) / tiles);
+                if (ks > K / 64) ks = K / 64;
+                while (ks > 1 && (size_t)ks * M * N * sizeof(E) > workspace_bytes) ks /= 2;
+                if (ks > 1) {
+                    kchunk = ((K + ks - 1) / ks + 15) / 16 * 16;
+                    ks = (K + kchunk - 1) / kchunk;
+                    grid.z = ks;
+                    out = (E*)workspace;
+                    out_ld = N;
+                    zstride = (size_t)M * N;
+                }
             }
+            if (ks <= 1) kchunk = 0;
+            const E* a = (const E*)A; const E* b = (const E*)B;
+            if (tcode == 42)
+                hipLaunchKernelGGL((k_matmul<F, 4, 2>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, out, out_ld, M, K, N, kchunk, zstride);
+            else if (tcode == 22)
+                hipLaunchKernelGGL((k_matmul<F, 2, 2>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, out, out_ld, M, K, N, kchunk, zstride);
+            else if (tcode == 84)
+                hipLaunchKernelGGL((k_matmul<F, 8, 4>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, out, out_ld, M, K, N, kchunk, zstride);
+            else
+                hipLaunchKernelGGL((k_matmul<F, 4, 4>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, out, out_ld, M, K, N, kchunk, zstride);
+            if (ks > 1)
+                hipLaunchKernelGGL((k_splitk_sum<F>), dim3((unsigned)(((size_t)M * N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, f,
+                                   (const E*)workspace, ks, M, N, (E*)C, ldc);
         }
         FFGPU_CHECK_LAUNCH();
         return 0;

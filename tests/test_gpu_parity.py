@@ -571,6 +571,43 @@ def test_matmul(eng, coracle):
             assert (got == want).all(), (hex(modulus), M, K, N)
 
 
+def test_skinny_products(eng, coracle):
+    """Matrix x few columns and few rows x matrix (the np_bnnmnist shape, demos/np_bnnmnist.py:10-15) take
+    dedicated HBM-bound kernels: one output dimension <= 8, the other >= 64.  Against the oracle for every
+    reduction strategy, with worst-case accumulation (all operands p-1), K beyond the 192-term accumulator
+    flush, ragged sizes, and sub-matrix views with a leading dimension larger than the row length."""
+    cases = [(200, 333, 1), (100, 257, 3), (64, 1000, 8), (77, 5, 2), (1, 500, 300), (3, 1000, 129), (8, 2100, 64), (2, 7, 1000),
+             (64, 300, 200), (40, 1000, 90), (130, 2000, 70), (9, 129, 9)]      # the last four: tiled kernel with split-K
+    for modulus, binary in [(P61, False), (P64, False), (2**96 - 17, False), (P128, False), (6616326157076047771, False),
+                            (2**31 - 1, False), (258797994007609146293811961253269568351, False),
+                            ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]:
+        F = po.Field(modulus, binary)
+        ctx = ctx_for(eng, modulus, binary)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, binary)
+        for (M, K, N) in cases if eb < 12 else cases[:2] + cases[4:6] + cases[8:10]:
+            A, B = rand_np(F, eb, M * K, 91), rand_np(F, eb, K * N, 92)
+            if not binary:
+                A[:K] = pack([F.order - 1] * K, eb)
+                B[::N] = pack([F.order - 1] * K, eb)
+            got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A, B, M, K, N)
+            coracle.set_threads(1)
+            assert (got == want).all(), (hex(modulus), M, K, N)
+    # through the mirror: 2-D @ 1-D, 1-D @ 2-D and a batch of two rows
+    from mpyc_amd import finfields
+    Fm = finfields.GF(P61)
+    rng = random.Random(8)
+    W_ = [[rng.randrange(P61) for _ in range(300)] for _ in range(150)]
+    x = [rng.randrange(P61) for _ in range(150)]
+    y = [rng.randrange(P61) for _ in range(300)]
+    got = Fm.array(x) @ Fm.array(W_)
+    assert [int(v) for v in got.value] == [sum(x[k] * W_[k][j] for k in range(150)) % P61 for j in range(300)]
+    got = Fm.array(W_) @ Fm.array(y)
+    assert [int(v) for v in got.value] == [sum(W_[i][k] * y[k] for k in range(300)) % P61 for i in range(150)]
+
+
 def test_gf2n_table_multiplication(eng, coracle):
     """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
     answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""
