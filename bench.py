@@ -391,6 +391,22 @@ def main():
                                              'achieved': round(macs / (ms * 1e-3) / 1e9, 1),
                                              'frac': 0.0, 'units_per_s': round(macs / (ms * 1e-3), 1)}
                 del Am, Bm, Cm
+            # the shape the reference's author names as the np_bnnmnist bottleneck (demos/np_bnnmnist.py:10-15): a
+            # 1 x 4096 activation row times a 4096 x 4096 weight matrix, and the transposed (matrix x vector) form
+            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4096, 4096, 1), (64, 4096, 4096)):
+                big = [DevArray(ctx, uniform_field(gen, 4096 * 4096, P61, ctx.torch_device), 4096 * 4096) for _ in range(3)]
+                small = DevArray(ctx, uniform_field(gen, 64 * 4096, P61, ctx.torch_device), 64 * 4096)
+                outm = ctx.empty(mm_ * nn_)
+                if mm_ <= 64 and nn_ == 4096:
+                    a_ = DevArray(ctx, small.t[:mm_ * kk_], mm_ * kk_)
+                    ms = time_launches(lambda w_: ctx.matmul(a_, w_, mm_, kk_, nn_, out=outm), big, 3)
+                else:
+                    b_ = DevArray(ctx, small.t[:kk_ * nn_], kk_ * nn_)
+                    ms = time_launches(lambda w_: ctx.matmul(w_, b_, mm_, kk_, nn_, out=outm), big, 3)
+                byts = eb * (mm_ * kk_ + kk_ * nn_ + mm_ * nn_)
+                kern[f'matmul_p61_{mm_}x{kk_}x{nn_}'] = dict(roof(byts, ms), units_per_s=round(mm_ * kk_ * nn_ / (ms * 1e-3), 1),
+                                                            algorithmic_bytes_per_unit=None)
+                del big, small, outm
             # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
             del sets[1:]
             torch.cuda.empty_cache()

@@ -1328,8 +1328,16 @@ __global__ __launch_bounds__(BLOCK) void k_splitk_sum(F f, const typename F::ele
                                                        typename F::elem* __restrict__ C, size_t ldc) {
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= (size_t)M * N) return;
-    typename F::word r = ld_elem<F>(part, idx);
-    for (int s = 1; s < KS; ++s) r = f.add(r, ld_elem<F>(part, (size_t)s * M * N + idx));
+    typedef typename F::word W;
+    const size_t mn = (size_t)M * N;
+    W r = ld_elem<F>(part, idx);
+    int s = 1;
+    for (; s + 4 <= KS; s += 4) {                     // four loads in flight
+        const W t0 = ld_elem<F>(part, (size_t)s * mn + idx), t1 = ld_elem<F>(part, (size_t)(s + 1) * mn + idx);
+        const W t2 = ld_elem<F>(part, (size_t)(s + 2) * mn + idx), t3 = ld_elem<F>(part, (size_t)(s + 3) * mn + idx);
+        r = f.add(f.add(r, f.add(t0, t1)), f.add(t2, t3));
+    }
+    for (; s < KS; ++s) r = f.add(r, ld_elem<F>(part, (size_t)s * mn + idx));
     st_elem<F>(C, (idx / N) * ldc + idx % N, r);
 }
 
@@ -1492,9 +1500,27 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_final(F f, const typename F::w
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= (size_t)M * N) return;
     const int mi = (int)(idx / N), j = (int)(idx % N);
-    W r = partial[idx];
-    for (int s = 1; s < KS; ++s) r = f.add(r, partial[(size_t)s * M * N + idx]);
-    st_elem<F>(C, (size_t)mi * ldc + j, r);
+    // KS can be ~128: eight independent chains so that the loads overlap instead of forming one dependent sequence
+    W r[8];
+    const size_t mn = (size_t)M * N;
+    int s = 0;
+    if (KS >= 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = partial[(size_t)u * mn + idx];
+        for (s = 8; s + 8 <= KS; s += 8) {
+            W t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(s + u) * mn + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = f.add(r[u], t[u]);
+        }
+        r[0] = f.add(f.add(f.add(r[0], r[1]), f.add(r[2], r[3])), f.add(f.add(r[4], r[5]), f.add(r[6], r[7])));
+    } else {
+        r[0] = partial[idx];
+        s = 1;
+    }
+    for (; s < KS; ++s) r[0] = f.add(r[0], partial[(size_t)s * mn + idx]);
+    st_elem<F>(C, (size_t)mi * ldc + j, r[0]);
 }
 
 // ---- small public matrix applied to every group of g consecutive elements --------------------------
