@@ -1417,6 +1417,33 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::el
     }
 }
 
+// Same product for SHORT rows (K <= 32, many rows: sums over a trailing axis, tall-thin least squares): one
+// thread per row -- a row is K contiguous elements, neighbouring threads read neighbouring rows, and B[k][j] is
+// wave-uniform (scalar loads).
+template <class F, int NN>
+__global__ __launch_bounds__(BLOCK) void k_matvec_short_rows(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                              const typename F::elem* __restrict__ B, size_t ldb,
+                                                              typename F::elem* __restrict__ C, size_t ldc, int M, int K,
+                                                              int N) {
+    typedef typename F::word W;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    for (size_t row = gid; row < (size_t)M; row += gsz) {
+        typename F::acc acc[NN];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) f.acc_zero(acc[j]);
+        for (int kk = 0; kk < K; ++kk) {                                  // K <= 32 < SKINNY_FLUSH: no flush needed
+            const W x = ld_elem<F>(A, row * lda + kk);
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+                if (j < N) f.acc_mac(acc[j], f.prep(ld_elem<F>(B, (size_t)kk * ldb + j)), x);
+        }
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+            if (j < N) st_elem<F>(C, row * ldc + j, f.acc_reduce(acc[j]));
+    }
+}
+
 // C (M x N) = A (M x K) @ B (K x N), M <= SKINNY_MAX: a pack of columns per thread, K split over blockIdx.y;
 // partial[(ks * M + m) * N + j], summed by k_vecmat_final
 template <class F, int MM, bool VEC>
@@ -2004,6 +2031,11 @@ struct Launchers {
     template <int NN>
     static void go_matvec(const F& f, const E* A, size_t lda, const E* B, size_t ldb, E* C, size_t ldc, int M, int K,
                           int N, hipStream_t st) {
+        if (K <= 32 && M >= 1024) {               // short rows: one thread per row
+            unsigned grid = (unsigned)(((size_t)M + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL((k_matvec_short_rows<F, NN>), dim3(grid), dim3(BLOCK), 0, st, f, A, lda, B, ldb, C, ldc, M, K, N);
+            return;
+        }
         const int vec = al(A) && stride_ok(lda);
         const int bvec = al(B) && stride_ok(ldb) && (N % (int)(16 / sizeof(W)) == 0) && sizeof(E) != 12;
         hipLaunchKernelGGL((k_matvec_rows<F, NN>), dim3((unsigned)M), dim3(BLOCK), 0, st, f, A, lda, B, ldb, C, ldc, K, N, vec,

@@ -987,15 +987,36 @@ class FieldArray:
         """Sum of all elements as a field element (np.sum on a field array, finfields.py:766-819)."""
         if axis is None or self.ndim == 1:
             return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
-        # reduce one axis: move it last, then (rows, k) @ ones(k) through the product kernel
+        # reduce one axis: move it last ON THE DEVICE (a permuted copy of the limb tensor), then per row of k
+        # elements: k <= 16 -> one thread per row (ffgpu_group_matvec with a row of ones); many rows -> matrix x
+        # ones(k) (the HBM-bound matvec kernels); few long rows -> one two-stage reduction (ffgpu_sum) per row
         axis = axis if axis >= 0 else axis + self.ndim
-        moved = _np_movement(np.moveaxis, (self, axis, -1), {})
+        if axis == self.ndim - 1:
+            moved = self
+        else:
+            perm = [d for d in range(self.ndim) if d != axis] + [axis]
+            t = self._limb_view().permute(*(perm + ([self.ndim] if self.ctx.limbs else [])))
+            moved = self._from_limb_view(t)
         k = moved.shape[-1]
         rows = moved.size // k if k else 0
+        cls, ctx = type(self), self.ctx
         if k == 0:
-            return type(self)(np.zeros(moved.shape[:-1], dtype=object))
-        ones = type(self)._wrap(self.ctx.from_ints([1] * k), (k,))
-        return (moved.reshape(rows, k) @ ones).reshape(moved.shape[:-1])
+            return cls(np.zeros(moved.shape[:-1], dtype=object))
+        if rows == 0:
+            return cls(np.zeros(moved.shape[:-1], dtype=object))
+        flat = moved._dev
+        if k <= 16:
+            out = ctx.group_matvec(flat, [[1] * k])
+        elif rows >= 64:
+            ones = ctx.from_ints([1] * k)
+            out = ctx.matmul(flat, ones, rows, k, 1)
+        else:
+            out = ctx.empty(rows)
+            lv = flat.t.reshape(rows, k, ctx.limbs) if ctx.limbs else flat.t.reshape(rows, k)
+            ov = out.t.reshape(rows, ctx.limbs) if ctx.limbs else out.t.reshape(rows)
+            for r in range(rows):
+                ov[r:r + 1].copy_(ctx.sum(DevArray(ctx, lv[r].reshape(-1, ctx.limbs) if ctx.limbs else lv[r], k)).t)
+        return cls._wrap(out, moved.shape[:-1])
 
     def prod(self):
         """Product of all elements (finfields.py:1339-1349): log2(n) halving passes of the mul kernel."""

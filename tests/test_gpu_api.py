@@ -644,3 +644,24 @@ def test_recombine_multiply_split_chain_stays_in_registers(api):
     finally:
         thresha.randbelow = None
     assert ints(sh[0]) == [(v * v + 100 + i) % F.order for i, v in enumerate([3, 5, 7, 11])]
+
+
+def test_sum_along_an_axis_regimes(api):
+    """np.sum(a, axis): short rows (one thread per row), many long rows (matrix x ones), few long rows (one
+    reduction per row), for scalar-limb, 3-limb and 2-limb fields and for every axis of a 3-D array."""
+    finfields, gfpx, _ = api
+    rng = np.random.default_rng(11)
+    for F in (finfields.GF(2**61 - 1), finfields.GF(2**96 - 17), finfields.GF(2**127 - 1), finfields.GF(gfpx.GFpX(2)(0x11b))):
+        q = F.order
+        binary = not isinstance(F.modulus, int)
+        for shape in ((300, 9), (100, 40), (5, 700), (6, 5, 33)):
+            vals = np.array([int(v) % q for v in rng.integers(0, 2**62, size=int(np.prod(shape)))], dtype=object).reshape(shape)
+            a = F.array(vals)
+            for ax in range(len(shape)):
+                got = np.sum(a, axis=ax)
+                if binary:
+                    want = np.bitwise_xor.reduce(vals.astype(np.int64), axis=ax)
+                else:
+                    want = vals.sum(axis=ax) % q
+                assert got.shape == want.shape, (shape, ax)
+                assert ints(got) == [int(v) for v in np.asarray(want, dtype=object).reshape(-1)], (F.order, shape, ax)
