@@ -1036,7 +1036,7 @@ class FieldArray:
         return cls.field(cur.to_ints()[0])
 
     def trace(self, offset=0):
-        return _np_movement(np.diagonal, (self, offset), {}).sum()
+        return _np_diagonal(self, offset).sum()
 
     # ---- linear algebra (finfields.py:872-978) --------------------------------------------------
     @classmethod
@@ -1337,14 +1337,15 @@ def _np_convolve(a, v, mode='full'):
     if a.size < v.size:
         a, v = v, a
     na, nv = a.size, v.size
-    k = np.arange(na + nv - 1, dtype=np.int64)[:, None] - np.arange(nv, dtype=np.int64)[None, :]
-    idx = np.where((k >= 0) & (k < na), k + 1, 0)                    # T[k][j] = a[k - j]
     ctx, eb = a.ctx, a.ctx.elem_bytes
     lb = ctx.limbs
     flat = a._dev.t.reshape(-1, lb) if lb else a._dev.t.reshape(-1)
-    zero = torch.zeros((1, lb) if lb else (1,), dtype=flat.dtype, device=flat.device)
-    t = torch.cat([zero, flat]).index_select(0, torch.from_numpy(idx.reshape(-1)).to(flat.device))
-    T = cls._wrap(DevArray(ctx, t, idx.size), idx.shape)
+    dev = flat.device
+    k = torch.arange(na + nv - 1, device=dev).unsqueeze(1) - torch.arange(nv, device=dev).unsqueeze(0)    # T[k][j] = a[k - j]
+    idx = torch.where((k >= 0) & (k < na), k + 1, torch.zeros_like(k))                                    # 0 = the zero element
+    zero = torch.zeros((1, lb) if lb else (1,), dtype=flat.dtype, device=dev)
+    t = torch.cat([zero, flat]).index_select(0, idx.reshape(-1))
+    T = cls._wrap(DevArray(ctx, t, idx.numel()), tuple(idx.shape))
     full = T @ v
     if mode == 'full':
         return full
@@ -1360,6 +1361,80 @@ def _np_nonzero_mask(a):
     return (~a._zero_mask()).cpu().numpy().reshape(a.shape)
 
 
+
+# ---- data movement with a torch equivalent: done on the device limb tensors (the generic index-gather path
+#      above costs a host index array of 8 bytes per element) -------------------------------------------------
+def _limb_dims(a, t_fn):
+    """apply t_fn to the limb view, which has one trailing limb axis for multi-limb fields"""
+    return a._from_limb_view(t_fn(a._limb_view()))
+
+
+def _np_where(cond, x=None, y=None):
+    if x is None or y is None:
+        raise NotImplementedError('np.where(condition) alone: use np.nonzero')
+    cls = type(x) if isinstance(x, FieldArray) else type(y)
+    x = x if isinstance(x, FieldArray) else cls(x)
+    y = y if isinstance(y, FieldArray) else cls(y)
+    if isinstance(cond, FieldArray):
+        cond = _np_nonzero_mask(cond)
+    shape = np.broadcast_shapes(np.shape(cond), x.shape, y.shape)
+    c = torch.from_numpy(np.array(np.broadcast_to(np.asarray(cond, dtype=bool), shape))).to(x._dev.t.device)   # a copy: writable
+    lb = x.ctx.limbs
+    tx = x._limb_view().expand(*shape, *((lb,) if lb else ()))
+    ty = y._limb_view().expand(*shape, *((lb,) if lb else ()))
+    return x._from_limb_view(torch.where(c.unsqueeze(-1) if lb else c, tx, ty))
+
+
+def _np_tile(a, reps):
+    reps = (reps,) if isinstance(reps, (int, np.integer)) else tuple(reps)
+    nd = max(a.ndim, len(reps))
+    reps = (1,) * (nd - len(reps)) + reps
+    t = a._limb_view().reshape((1,) * (nd - a.ndim) + tuple(a.shape) + ((a.ctx.limbs,) if a.ctx.limbs else ()))
+    return a._from_limb_view(t.repeat(*reps, *((1,) if a.ctx.limbs else ())))
+
+
+def _np_repeat(a, repeats, axis=None):
+    if not isinstance(repeats, (int, np.integer)):
+        return _np_movement(np.repeat, (a, repeats), {'axis': axis})
+    if axis is None:
+        a, axis = a.reshape(-1), 0
+    axis = axis if axis >= 0 else axis + a.ndim
+    return _limb_dims(a, lambda t: torch.repeat_interleave(t, int(repeats), dim=axis))
+
+
+def _np_take(a, indices, axis=None):
+    idx = torch.from_numpy(np.ascontiguousarray(np.asarray(indices, dtype=np.int64))).to(a._dev.t.device)
+    if axis is None:
+        src, axis, out_shape = a.reshape(-1), 0, tuple(idx.shape)
+    else:
+        axis = axis if axis >= 0 else axis + a.ndim
+        src, out_shape = a, None
+    n_ax = src.shape[axis]
+    flat_idx = torch.where(idx < 0, idx + n_ax, idx).reshape(-1)
+    r = _limb_dims(src, lambda t: torch.index_select(t, axis, flat_idx))
+    if out_shape is not None:
+        return r.reshape(out_shape) if out_shape else r.reshape(())
+    return r.reshape(src.shape[:axis] + tuple(idx.shape) + src.shape[axis + 1:])
+
+
+def _np_diagonal(a, offset=0, axis1=0, axis2=1):
+    return _limb_dims(a, lambda t: torch.diagonal(t, offset, axis1, axis2).movedim(-2, -1) if a.ctx.limbs
+                      else torch.diagonal(t, offset, axis1, axis2))
+
+
+def _np_tri(a, k, upper):
+    if a.ndim < 2:
+        return _np_movement(np.triu if upper else np.tril, (a, k), {})
+    r, c = a.shape[-2], a.shape[-1]
+    mask = (torch.triu if upper else torch.tril)(torch.ones(r, c, dtype=torch.bool, device=a._dev.t.device), diagonal=k)
+    lb = a.ctx.limbs
+    t = a._limb_view()
+    return a._from_limb_view(torch.where(mask.unsqueeze(-1) if lb else mask, t, torch.zeros_like(t)))
+
+
+def _np_axes(a, fn):
+    return _limb_dims(a, fn)
+
 _ARRAY_FUNCTIONS = {
     'shape': lambda a: a.shape, 'ndim': lambda a: a.ndim, 'size': lambda a: a.size,
     'reshape': lambda a, *shape, **kw: a.reshape(*shape if shape else (kw.get('newshape', kw.get('shape')),)),
@@ -1369,6 +1444,13 @@ _ARRAY_FUNCTIONS = {
     'vstack': lambda arrays: _np_concatenate([a.reshape(1, -1) if a.ndim == 1 else a for a in arrays], 0),
     'hstack': lambda arrays: _np_concatenate(list(arrays), 0 if list(arrays)[0].ndim == 1 else 1),
     'roll': _np_roll, 'flip': _np_flip,
+    'where': _np_where, 'tile': _np_tile, 'repeat': _np_repeat, 'take': _np_take, 'diagonal': _np_diagonal,
+    'tril': lambda a, k=0: _np_tri(a, k, False), 'triu': lambda a, k=0: _np_tri(a, k, True),
+    'swapaxes': lambda a, a1, a2: _np_axes(a, lambda t: t.transpose(a1 if a1 >= 0 else a1 + a.ndim, a2 if a2 >= 0 else a2 + a.ndim)),
+    'moveaxis': lambda a, src, dst: _np_axes(a, lambda t: t.movedim(src if src >= 0 else src + a.ndim, dst if dst >= 0 else dst + a.ndim))
+    if isinstance(src, (int, np.integer)) else _np_movement(np.moveaxis, (a, src, dst), {}),
+    'expand_dims': lambda a, axis: a.reshape(np.expand_dims(np.empty(a.shape, dtype=np.int8), axis).shape),
+    'squeeze': lambda a, axis=None: a.reshape(np.squeeze(np.empty(a.shape, dtype=np.int8), axis).shape),
     'sum': lambda a, axis=None, **kw: a.sum(axis),
     'dot': lambda a, b: a @ b, 'matmul': lambda a, b: a @ b,
     'outer': _np_outer, 'convolve': _np_convolve, 'prod': lambda a, axis=None, **kw: a.prod(),
