@@ -532,6 +532,23 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_sum(self._h, a.ptr, out.ptr, self._workspace().data_ptr(), a.n, self._stream()), 'sum')
         return out
 
+    def _stage(self, nbytes: int) -> torch.Tensor:
+        """grow-only pinned host staging buffer of this context (uint8)"""
+        stage = getattr(self, '_pinned_stage', None)
+        if stage is None or stage.numel() < nbytes:
+            stage = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            self._pinned_stage = stage
+        return stage
+
+    def download_bytes(self, t: torch.Tensor) -> np.ndarray:
+        """Device tensor -> uint8 numpy VIEW of the pinned staging buffer (valid until the next staged
+        transfer): a pinned copy runs at PCIe speed, a pageable one at a third of it."""
+        flat = t.contiguous().view(torch.uint8).reshape(-1)
+        stage = self._stage(flat.numel())
+        stage[:flat.numel()].copy_(flat, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return stage[:flat.numel()].numpy()
+
     def shake128_streams(self, msgs: Sequence[bytes], out_len: int, threads: int = 0) -> List[torch.Tensor]:
         """SHAKE128(msg).digest(out_len) for every msg, expanded in parallel on host threads into pinned
         buffers (libffgpu's ffgpu_shake128_expand) and uploaded: the XOF streams of a PRSS call
@@ -543,10 +560,7 @@ class FieldContext:
         # the expansion itself), rows padded to 256 bytes
         pitch = (out_len + 255) // 256 * 256
         need = k * pitch
-        stage = getattr(self, '_pinned_stage', None)
-        if stage is None or stage.numel() < need:
-            stage = torch.empty(need, dtype=torch.uint8).pin_memory()
-            self._pinned_stage = stage
+        stage = self._stage(need)
         keep = [ctypes.create_string_buffer(mg, max(len(mg), 1)) for mg in msgs]
         mp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in keep])
         ml = (ctypes.c_size_t * k)(*[len(mg) for mg in msgs])

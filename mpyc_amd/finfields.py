@@ -1171,11 +1171,11 @@ class FieldArray:
     def to_wire(self) -> bytes:
         """field.to_bytes(self.value) without boxing Python ints when byte_length == limb width."""
         F, eb = type(self).field, self.ctx.elem_bytes
-        raw = self._dev.to_numpy()
+        raw = self.ctx.download_bytes(self._dev.t)          # pinned staging buffer: PCIe speed
         if F.byte_length == eb:
             return raw.tobytes()
         n = self.size
-        b = np.frombuffer(raw.tobytes(), dtype=np.uint8).reshape(n, eb)
+        b = raw.reshape(n, eb)
         if F.byte_length < eb:
             return np.ascontiguousarray(b[:, :F.byte_length]).tobytes()
         pad = np.zeros((n, F.byte_length - eb), dtype=np.uint8)                # e.g. GF(2^8): 2-byte wire elements
