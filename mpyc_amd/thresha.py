@@ -36,7 +36,19 @@ rng_rounds = 20       # ChaCha rounds of the device CSPRNG (20, 12 or 8)
 _nonce = 0
 
 
+device_rng_state = False  # True: share generation draws from ONE device-resident generator state per context
+#                           (engine.RngState) instead of a fresh host key per call, so that code using this module
+#                           can be captured in a HIP graph (engine.CapturedLaunches) and still get fresh randomness
+#                           on every replay
 lazy_recombine = True     # np_recombine defers single-target recombinations of <= 7 rows (see FieldArray._source)
+
+
+def _ctx_state(ctx):
+    st = getattr(ctx, '_thresha_rng_state', None)
+    if st is None:
+        st = ctx.rng_state(rounds=rng_rounds)            # key from the host CSPRNG, once
+        ctx._thresha_rng_state = st
+    return st
 
 
 def _next_nonce():
@@ -66,6 +78,8 @@ def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
             # -> recombine in registers, multiply, re-share (ffgpu_gate_rng); nothing is written in between
             ra, la = (a.rows, a.lam) if isinstance(a, _Rec) else ([a], [1])
             rb, lb = (None, None) if b is a else ((b.rows, b.lam) if isinstance(b, _Rec) else ([b], [1]))
+            if device_rng_state:
+                return ctx.gate(ra, la, rb, lb, t, m, state=_ctx_state(ctx))
             return ctx.gate(ra, la, rb, lb, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds)
         dev = _src_dev(a)
         mul_by = None if b is None else (dev if b is a else _src_dev(b))
@@ -74,6 +88,8 @@ def _split_device(field, S: FieldArray, t, m, np_convention: bool) -> DevMatrix:
     if t == 0 or n == 0:
         return ctx.split(dev, None, 0, m, mul_by=mul_by)
     if randbelow is None:
+        if device_rng_state:
+            return ctx.split_rng(dev, t, m, mul_by=mul_by, state=_ctx_state(ctx))
         return ctx.split_rng(dev, t, m, key=secrets.token_bytes(32), nonce=_next_nonce(), rounds=rng_rounds,
                              mul_by=mul_by)
     order = field.order

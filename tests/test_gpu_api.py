@@ -665,3 +665,34 @@ def test_sum_along_an_axis_regimes(api):
                     want = vals.sum(axis=ax) % q
                 assert got.shape == want.shape, (shape, ax)
                 assert ints(got) == [int(v) for v in np.asarray(want, dtype=object).reshape(-1)], (F.order, shape, ax)
+
+
+def test_mirror_calls_in_a_hip_graph(api):
+    """With thresha.device_rng_state the mirror's share generation reads a device-resident generator state, so
+    a sequence of mirror calls (a gate: product, share generation, recombination) can be captured once and
+    replayed: same opened values, fresh shares on every replay."""
+    finfields, _, thresha = api
+    from mpyc_amd.engine import CapturedLaunches
+    F = finfields.GF(2**61 - 1)
+    rng = random.Random(4)
+    n = 4096
+    a = [rng.randrange(F.order) for _ in range(n)]
+    b = [rng.randrange(F.order) for _ in range(n)]
+    A, B = F.array(a), F.array(b)
+    thresha.device_rng_state = True
+    try:
+        def gate():
+            sh = thresha.np_random_split(F, A * B, 1, 3)
+            y = thresha.np_recombine(F, [(1, sh[0]), (3, sh[2])])
+            return sh, y + 0                       # `+ 0` materialises the deferred recombination inside the graph
+        cg = CapturedLaunches(gate)
+        seen = []
+        for _ in range(3):
+            cg.replay()
+            torch.cuda.synchronize()
+            sh, y = cg.result
+            assert ints(y) == [u * v % F.order for u, v in zip(a, b)]
+            seen.append(ints(sh[0])[:8])
+        assert seen[0] != seen[1] != seen[2]
+    finally:
+        thresha.device_rng_state = False
