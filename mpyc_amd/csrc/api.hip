@@ -719,21 +719,31 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
     LaunchTimer lt(ctx, (hipStream_t)stream);
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    if (K >= 128 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) {   // shapes that may split K: partial sums need scratch
-        const size_t want = (size_t)64 << 20;
-        if (ctx->scratch_bytes < want) {
-            // queued work on this stream may still read the old buffer
-            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int mod_bits = 128;
+    if (ctx->kind == FFGPU_PRIME) mod_bits = ctx->modulus[1] ? 128 : 64 - __builtin_clzll(ctx->modulus[0] | 1);
+    {
+        // scratch: int8 limb planes for the matrix-core product (10 x (M + N) x K bytes, up to 8 GiB), else 64 MiB of
+        // split-K partial sums
+        size_t want = 0;
+        const size_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
+        if (ctx->kind == FFGPU_PRIME && ctx->elem_bytes <= 8 && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= 1.6e7) {
+            want = (size_t)10 * (Mp + Np) * Kp;
+            if (want > ((size_t)8 << 30)) want = 0;
+        }
+        if (!want && K >= 128 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) want = (size_t)64 << 20;
+        if (want && ctx->scratch_bytes < want) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // queued work may still read the old buffer
             if (ctx->scratch) (void)hipFree(ctx->scratch);
             ctx->scratch = nullptr;
             ctx->scratch_bytes = 0;
             if (hipMalloc(&ctx->scratch, want) == hipSuccess) ctx->scratch_bytes = want;
+            else (void)hipGetLastError();                         // no scratch: the VALU kernels need none
         }
         ws = ctx->scratch;
         ws_bytes = ctx->scratch_bytes;
     }
     return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N, ws,
-                                          ws_bytes, (hipStream_t)stream));
+                                          ws_bytes, mod_bits, (hipStream_t)stream));
 }
 
 int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int r, int g,

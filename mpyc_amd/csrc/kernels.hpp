@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "fields.hpp"
 #include "rng.hpp"
 
@@ -1341,6 +1342,95 @@ __global__ __launch_bounds__(BLOCK) void k_splitk_sum(F f, const typename F::ele
     st_elem<F>(C, (idx / N) * ldc + idx % N, r);
 }
 
+
+// ---- dense product on the int8 matrix cores ---------------------------------------------------------------
+// An exact modular GEMM as integer GEMMs of 7-bit LIMBS: x = sum_l x_l 2^(7l), 0 <= x_l < 128 (int8), so
+//     (A B)[i][j] = sum_d 2^(7d) D_d[i][j],   D_d = sum_{la + lb = d} A_la B_lb     (2L - 1 integer matrices)
+// and every D_d is accumulated by v_mfma_i32_32x32x32_i8 in an i32 accumulator (L * 127^2 * K < 2^31 for a K
+// chunk of 8192).  The epilogue evaluates the sum by Horner in the field (y * 128 + D_d: muladd_small) -- the
+// only place the modulus enters -- so the result is bit-identical to the reduce-once object matmul of
+// finfields.py:1126-1135.  This is the one GEMM-shaped piece of the path and the only use of MFMA here:
+// 81 int8 MFMAs per 61-bit multiply-accumulate still beat 4 quarter-rate v_mad_u64_u32 by 5x
+// (tools/mfma_limb_gemm.hip: 10.8 vs 1.9 T MAC/s at 4096^3).
+// Operand planes are K-contiguous int8: A planes [l][Mp][Kp], B planes TRANSPOSED [l][Np][Kp] (zero padded to
+// multiples of 64 rows / 32 columns), so a lane's MFMA fragment (one row, 16 consecutive k) is one 16-byte load.
+// One wave = one 32x32 output tile with all 2L-1 accumulators resident; 4 waves per workgroup (64x64).
+typedef int ff_v4i __attribute__((ext_vector_type(4)));
+typedef int ff_v16i __attribute__((ext_vector_type(16)));
+enum { LIMB_KCHUNK = 8192 };
+
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* __restrict__ A, size_t lda,
+                                                         int8_t* __restrict__ Ap, int M, int K, int Mp, int Kp) {
+    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (size_t)Mp * Kp) return;
+    const int row = (int)(idx / Kp), kk = (int)(idx % Kp);
+    uint64_t v = 0;
+    if (row < M && kk < K) v = (uint64_t)ld_elem<F>(A, (size_t)row * lda + kk);
+#pragma unroll
+    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = (int8_t)((v >> (7 * l)) & 127);
+}
+// B (K x N, leading dimension ldb) -> planes [l][Np][Kp] through a 32x32 LDS tile (coalesced reads and writes)
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_split_bt(const typename F::elem* __restrict__ B, size_t ldb,
+                                                          int8_t* __restrict__ Bp, int K, int N, int Np, int Kp) {
+    __shared__ uint64_t tile[32][33];
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int kk = k0 + r, nn = n0 + tx;
+        tile[r][tx] = (kk < K && nn < N) ? (uint64_t)ld_elem<F>(B, (size_t)kk * ldb + nn) : 0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {                       // r: column n of the tile, tx: k
+        const uint64_t v = tile[tx][r];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = (int8_t)((v >> (7 * l)) & 127);
+    }
+}
+
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
+                                                      typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
+                                                      int Np, int Kp, int kb, int ke, int accumulate) {
+    typedef typename F::word W;
+    constexpr int ND = 2 * L - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const int r = lane & 31, h = lane >> 5;
+    ff_v16i acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = (ff_v16i){0};
+    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
+    const int8_t* pa = Ap + (size_t)(m0 + r) * Kp + 16 * h;
+    const int8_t* pb = Bp + (size_t)(n0 + r) * Kp + 16 * h;
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        ff_v4i a[L], b[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            a[l] = *reinterpret_cast<const ff_v4i*>(pa + l * planeA + k0);
+            b[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + k0);
+        }
+#pragma unroll
+        for (int la = 0; la < L; ++la)
+#pragma unroll
+            for (int lb = 0; lb < L; ++lb)
+                acc[la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int col = n0 + (lane & 31), row = m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+            W res = f.reduce_raw((W)(uint32_t)acc[ND - 1][q]);
+#pragma unroll
+            for (int d = ND - 2; d >= 0; --d) res = f.muladd_small(res, 128u, f.reduce_raw((W)(uint32_t)acc[d][q]));
+            if (accumulate) res = f.add(res, ld_elem<F>(C, (size_t)row * ldc + col));
+            st_elem<F>(C, (size_t)row * ldc + col, res);
+        }
+    }
+}
+
 // ---- skinny products: matrix x few columns, few rows x matrix ---------------------------------------------
 // The tiled k_matmul needs both output dimensions to fill the chip; the shapes MPyC's author flags as the
 // bottleneck (demos/np_bnnmnist.py:10-15: `L @ W` with a 1 x 4096 activation row and a 4096 x 4096 weight
@@ -1651,7 +1741,8 @@ struct FieldOps {
     int (*inv)(const void* F, int device, const void* a, const ExpArgs* ex, void* out, size_t n, int* flag,
                hipStream_t st);
     int (*matmul)(const void* F, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
-                  size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, hipStream_t st);
+                  size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, int mod_bits,
+                  hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
     int (*gate)(const void* F, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
@@ -2055,7 +2146,8 @@ struct Launchers {
         }
     }
     static int matmul(const void* Fp, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
-                      size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                      size_t ldc, int M, int K, int N, void* workspace, size_t workspace_bytes, int mod_bits,
+                      hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         if constexpr (F::EPW == 1) {
             if (N <= SKINNY_MAX && M >= 64 && K >= 1) {
@@ -2088,6 +2180,39 @@ struct Launchers {
                     FFGPU_CHECK_LAUNCH();
                     return 0;
                 }
+            }
+        }
+        if constexpr (F::EPW == 1 && !F::BINARY && sizeof(W) <= 8) {
+            // large dense products over primes of up to 64 bits: int8 matrix cores (k_limb_gemm).  limbs of 7 bits:
+            // 5 cover 32-bit storage, 9 cover moduli below 2^63, 10 the rest
+            static int use_mfma = -1;
+            if (use_mfma < 0) {
+                const char* e = getenv("FFGPU_MM_MFMA");
+                use_mfma = e ? atoi(e) : 1;
+            }
+            const int L = sizeof(W) == 4 ? 5 : (mod_bits <= 63 ? 9 : 10);
+            const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
+            const size_t need = (size_t)L * ((size_t)Mp + Np) * Kp;
+            if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= 1.6e7 && workspace && need <= workspace_bytes) {
+                int8_t* Ap = (int8_t*)workspace;
+                int8_t* Bp = Ap + (size_t)L * Mp * Kp;
+                const unsigned ga = (unsigned)(((size_t)Mp * Kp + BLOCK - 1) / BLOCK);
+                dim3 gb(Np / 32, Kp / 32), gg(Np / 64, Mp / 64);
+                auto go = [&](auto lc_) {
+                    constexpr int LL = decltype(lc_)::value;
+                    hipLaunchKernelGGL((k_limb_split_a<F, LL>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, Ap, M, K, Mp, Kp);
+                    hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, Bp, K, N, Np, Kp);
+                    for (int kb = 0; kb < Kp; kb += LIMB_KCHUNK) {
+                        const int ke = kb + LIMB_KCHUNK < Kp ? kb + LIMB_KCHUNK : Kp;
+                        hipLaunchKernelGGL((k_limb_gemm<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
+                                           (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
+                    }
+                };
+                if (L == 5) go(std::integral_constant<int, 5>());
+                else if (L == 9) go(std::integral_constant<int, 9>());
+                else go(std::integral_constant<int, 10>());
+                FFGPU_CHECK_LAUNCH();
+                return 0;
             }
         }
         if constexpr (F::EPW > 1) {

@@ -609,6 +609,36 @@ def test_skinny_products(eng, coracle):
     assert [int(v) for v in got.value] == [sum(W_[i][k] * y[k] for k in range(300)) % P61 for i in range(150)]
 
 
+def test_matrix_core_product(eng, coracle):
+    """Large dense products over primes of up to 64 bits run as int8 limb GEMMs on the matrix cores
+    (k_limb_gemm): bit-exact against the oracle for every limb count (5: 32-bit storage, 9: moduli below 2^63,
+    10: 64-bit moduli), ragged shapes (padding), K beyond one 8192 chunk (accumulating launches), worst-case
+    operands (p - 1 everywhere in a row and a column) and sub-matrix views; and equal to the VALU kernel
+    (FFGPU_MM_MFMA=0 in a fresh context is not needed: the small shapes of test_matmul take that path)."""
+    shapes = [(256, 300, 257), (65, 8300, 70), (130, 64, 2000)]
+    for modulus, binary in [(P61, False), (P64, False), (6616326157076047771, False), (2**31 - 1, False), (2**40 - 87, False),
+                            (65537, False)]:
+        F = po.Field(modulus, binary)
+        ctx = ctx_for(eng, modulus, binary)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, binary)
+        for (M, K, N) in shapes:
+            A, B = rand_np(F, eb, M * K, 71), rand_np(F, eb, K * N, 72)
+            A[:K] = pack([F.order - 1] * K, eb)
+            B[::N] = pack([F.order - 1] * K, eb)
+            got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A, B, M, K, N)
+            coracle.set_threads(1)
+            assert (got == want).all(), (hex(modulus), M, K, N)
+    # all-(p-1) operands: every limb product at its maximum
+    ctx = ctx_for(eng, P64, False)
+    M = K = N = 256
+    ones = pack([P64 - 1] * (M * K), 8)
+    got = unpack(ctx.matmul(ctx.from_numpy(ones), ctx.from_numpy(ones), M, K, N).to_numpy(), 8)
+    assert set(got) == {K * (P64 - 1) * (P64 - 1) % P64}
+
+
 def test_gf2n_table_multiplication(eng, coracle):
     """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
     answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""

@@ -5,7 +5,7 @@ import bench
 from mpyc_amd.engine import FieldContext, DevArray
 ctx = FieldContext(bench.P61, device=0)
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
-for (M, K, N) in ((4096, 4096, 1), (4096, 4096, 8), (4096, 4096, 64), (8192, 8192, 1), (1, 4096, 4096), (8, 4096, 4096), (64, 4096, 4096), (256, 4096, 4096), (4096, 4096, 4096)):
+for (M, K, N) in ((4096, 4096, 1), (4096, 4096, 8), (4096, 4096, 64), (8192, 8192, 1), (1, 4096, 4096), (8, 4096, 4096), (64, 4096, 4096), (256, 4096, 4096), (1024, 1024, 1024), (2048, 2048, 2048), (4096, 4096, 4096), (8192, 8192, 8192)):
     As = [DevArray(ctx, bench.uniform_field(gen, M * K, bench.P61, 'cuda:0'), M * K) for _ in range(3)]
     B = DevArray(ctx, bench.uniform_field(gen, K * N, bench.P61, 'cuda:0'), K * N)
     C = ctx.empty(M * N)
