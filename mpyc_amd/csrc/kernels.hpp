@@ -1344,35 +1344,55 @@ __global__ __launch_bounds__(BLOCK) void k_splitk_sum(F f, const typename F::ele
 
 
 // ---- dense product on the int8 matrix cores ---------------------------------------------------------------
-// An exact modular GEMM as integer GEMMs of 7-bit LIMBS: x = sum_l x_l 2^(7l), 0 <= x_l < 128 (int8), so
-//     (A B)[i][j] = sum_d 2^(7d) D_d[i][j],   D_d = sum_{la + lb = d} A_la B_lb     (2L - 1 integer matrices)
-// and every D_d is accumulated by v_mfma_i32_32x32x32_i8 in an i32 accumulator (L * 127^2 * K < 2^31 for a K
-// chunk of 8192).  The epilogue evaluates the sum by Horner in the field (y * 128 + D_d: muladd_small) -- the
+// An exact modular GEMM as integer GEMMs of signed 8-bit DIGITS.  Every operand is first replaced by a
+// representative x' = x or x - p (congruent mod p) that has exactly L = 8 (4 for 32-bit storage) base-256 digits
+// d_l in [-128, 127] (limb_digits); then
+//     (A B)[i][j] = sum_d 256^d D_d[i][j],   D_d = sum_{la + lb = d} A_la B_lb     (2L - 1 integer matrices)
+// and every D_d is accumulated by v_mfma_i32_32x32x32_i8 in an i32 accumulator (L * 128^2 * K < 2^31 for a K chunk
+// of 8192).  The epilogue evaluates the signed sum by Horner in the field (y * 256 +- |D_d|: muladd_small) -- the
 // only place the modulus enters -- so the result is bit-identical to the reduce-once object matmul of
-// finfields.py:1126-1135.  This is the one GEMM-shaped piece of the path and the only use of MFMA here:
-// 81 int8 MFMAs per 61-bit multiply-accumulate still beat 4 quarter-rate v_mad_u64_u32 by 5x
-// (tools/mfma_limb_gemm.hip: 10.8 vs 1.9 T MAC/s at 4096^3).
+// finfields.py:1126-1135.  This is the one GEMM-shaped piece of the path and the only use of MFMA here: 64 int8
+// MFMAs per 64-bit multiply-accumulate still beat 4 quarter-rate v_mad_u64_u32 several times over.
 // Operand planes are K-contiguous int8: A planes [l][Mp][Kp], B planes TRANSPOSED [l][Np][Kp] (zero padded to
 // multiples of 64 rows / 32 columns), so a lane's MFMA fragment (one row, 16 consecutive k) is one 16-byte load.
-// One wave = one 32x32 output tile with all 2L-1 accumulators resident; 4 waves per workgroup (64x64).
+// One wave = one 32x32 output tile with all 2L-1 accumulators (240 registers for L = 8) resident in the
+// accumulator half of the register file; 4 waves per workgroup (64x64).
 typedef int ff_v4i __attribute__((ext_vector_type(4)));
 typedef int ff_v16i __attribute__((ext_vector_type(16)));
 enum { LIMB_KCHUNK = 8192 };
 
+// L signed base-256 digits d_l in [-128, 127] of a representative of x modulo p.  L such digits represent exactly
+// the integers in [-128 S, 127 S], S = (256^L - 1)/255 -- a window of 256^L - 1 >= p consecutive integers -- so the
+// representative is x itself up to 127 S = 0x7f7f..7f and x - p above (not the balanced residue: for p close to
+// 2^64 the value p/2 is NOT representable, the carries would run out of the top digit).
+template <int L>
+__device__ __forceinline__ void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
+    const uint64_t top = 0x7f7f7f7f7f7f7f7full >> (8 * (8 - L));
+    __int128 v = (x > top) ? (__int128)x - (__int128)p : (__int128)x;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int8_t dl = (int8_t)((int)(v & 0xff));
+        d[l] = dl;
+        v = (v >> 8) + (dl < 0 ? 1 : 0);
+    }
+}
+
 template <class F, int L>
-__global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* __restrict__ A, size_t lda,
+__global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* __restrict__ A, size_t lda, uint64_t p,
                                                          int8_t* __restrict__ Ap, int M, int K, int Mp, int Kp) {
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= (size_t)Mp * Kp) return;
     const int row = (int)(idx / Kp), kk = (int)(idx % Kp);
     uint64_t v = 0;
     if (row < M && kk < K) v = (uint64_t)ld_elem<F>(A, (size_t)row * lda + kk);
+    int8_t d[L];
+    limb_digits<L>(v, p, d);
 #pragma unroll
-    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = (int8_t)((v >> (7 * l)) & 127);
+    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = d[l];
 }
 // B (K x N, leading dimension ldb) -> planes [l][Np][Kp] through a 32x32 LDS tile (coalesced reads and writes)
 template <class F, int L>
-__global__ __launch_bounds__(BLOCK) void k_limb_split_bt(const typename F::elem* __restrict__ B, size_t ldb,
+__global__ __launch_bounds__(BLOCK) void k_limb_split_bt(const typename F::elem* __restrict__ B, size_t ldb, uint64_t p,
                                                           int8_t* __restrict__ Bp, int K, int N, int Np, int Kp) {
     __shared__ uint64_t tile[32][33];
     const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
@@ -1383,10 +1403,10 @@ __global__ __launch_bounds__(BLOCK) void k_limb_split_bt(const typename F::elem*
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {                       // r: column n of the tile, tx: k
-        const uint64_t v = tile[tx][r];
+        int8_t d[L];
+        limb_digits<L>(tile[tx][r], p, d);
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-            Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = (int8_t)((v >> (7 * l)) & 127);
+        for (int l = 0; l < L; ++l) Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = d[l];
     }
 }
 
@@ -1405,28 +1425,53 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
     const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
     const int8_t* pa = Ap + (size_t)(m0 + r) * Kp + 16 * h;
     const int8_t* pb = Bp + (size_t)(n0 + r) * Kp + 16 * h;
+    // software pipeline: with all 2L-1 accumulators resident there is ONE wave per SIMD, so nothing else hides the
+    // latency of the fragment loads.  The B fragments of step k+1 are fetched into a second set of registers
+    // before the L*L MFMAs of step k; an A fragment is dead after its row of MFMAs and is refilled in place.
+    ff_v4i a[L], b[L], bn[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        a[l] = *reinterpret_cast<const ff_v4i*>(pa + l * planeA + kb);
+        b[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + kb);
+    }
     for (int k0 = kb; k0 < ke; k0 += 32) {
-        ff_v4i a[L], b[L];
+        const int kn = k0 + 32 < ke ? k0 + 32 : k0;          // last step: harmless reload of the same fragments
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            a[l] = *reinterpret_cast<const ff_v4i*>(pa + l * planeA + k0);
-            b[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + k0);
-        }
+        for (int l = 0; l < L; ++l) bn[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + kn);
 #pragma unroll
-        for (int la = 0; la < L; ++la)
+        for (int la = 0; la < L; ++la) {
 #pragma unroll
             for (int lb = 0; lb < L; ++lb)
                 acc[la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb], 0, 0, 0);
+            a[la] = *reinterpret_cast<const ff_v4i*>(pa + la * planeA + kn);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) b[l] = bn[l];
     }
+    // epilogue: sum_d 256^d D_d mod p, signed digits sums: Horner from the top diagonal, one diagonal at a time for
+    // all 16 results of the lane
+    W res[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int dv = acc[ND - 1][q];
+        const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+        res[q] = dv < 0 ? f.neg(w) : w;
+    }
+#pragma unroll
+    for (int d = ND - 2; d >= 0; --d)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int dv = acc[d][q];
+            const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+            res[q] = f.muladd_small(res[q], 256u, dv < 0 ? f.neg(w) : w);
+        }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int col = n0 + (lane & 31), row = m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
-            W res = f.reduce_raw((W)(uint32_t)acc[ND - 1][q]);
-#pragma unroll
-            for (int d = ND - 2; d >= 0; --d) res = f.muladd_small(res, 128u, f.reduce_raw((W)(uint32_t)acc[d][q]));
-            if (accumulate) res = f.add(res, ld_elem<F>(C, (size_t)row * ldc + col));
-            st_elem<F>(C, (size_t)row * ldc + col, res);
+            W v = res[q];
+            if (accumulate) v = f.add(v, ld_elem<F>(C, (size_t)row * ldc + col));
+            st_elem<F>(C, (size_t)row * ldc + col, v);
         }
     }
 }
@@ -2183,14 +2228,16 @@ struct Launchers {
             }
         }
         if constexpr (F::EPW == 1 && !F::BINARY && sizeof(W) <= 8) {
-            // large dense products over primes of up to 64 bits: int8 matrix cores (k_limb_gemm).  limbs of 7 bits:
-            // 5 cover 32-bit storage, 9 cover moduli below 2^63, 10 the rest
+            // large dense products over primes of up to 64 bits: int8 matrix cores (k_limb_gemm), 8 signed base-256
+            // digits of the balanced residues (4 for 32-bit storage)
             static int use_mfma = -1;
             if (use_mfma < 0) {
                 const char* e = getenv("FFGPU_MM_MFMA");
                 use_mfma = e ? atoi(e) : 1;
             }
-            const int L = sizeof(W) == 4 ? 5 : (mod_bits <= 63 ? 9 : 10);
+            const int L = sizeof(W) == 4 ? 4 : 8;
+            const uint64_t pmod = (uint64_t)f.p;
+            (void)mod_bits;
             const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
             const size_t need = (size_t)L * ((size_t)Mp + Np) * Kp;
             if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= 1.6e7 && workspace && need <= workspace_bytes) {
@@ -2200,17 +2247,16 @@ struct Launchers {
                 dim3 gb(Np / 32, Kp / 32), gg(Np / 64, Mp / 64);
                 auto go = [&](auto lc_) {
                     constexpr int LL = decltype(lc_)::value;
-                    hipLaunchKernelGGL((k_limb_split_a<F, LL>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, Ap, M, K, Mp, Kp);
-                    hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, Bp, K, N, Np, Kp);
+                    hipLaunchKernelGGL((k_limb_split_a<F, LL>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, pmod, Ap, M, K, Mp, Kp);
+                    hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
                     for (int kb = 0; kb < Kp; kb += LIMB_KCHUNK) {
                         const int ke = kb + LIMB_KCHUNK < Kp ? kb + LIMB_KCHUNK : Kp;
                         hipLaunchKernelGGL((k_limb_gemm<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
                                            (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
                     }
                 };
-                if (L == 5) go(std::integral_constant<int, 5>());
-                else if (L == 9) go(std::integral_constant<int, 9>());
-                else go(std::integral_constant<int, 10>());
+                if (L == 4) go(std::integral_constant<int, 4>());
+                else go(std::integral_constant<int, 8>());
                 FFGPU_CHECK_LAUNCH();
                 return 0;
             }

@@ -631,6 +631,27 @@ def test_matrix_core_product(eng, coracle):
             want = coracle.matmul(cf, A, B, M, K, N)
             coracle.set_threads(1)
             assert (got == want).all(), (hex(modulus), M, K, N)
+    # operands cycling through the values where the signed-digit representative switches (0x7f7f..7f and its
+    # neighbours), p/2, and the ends of the range, for moduli at the top of each storage width
+    for modulus in (P64, 2**64 - 59, 2**63 - 25, 2**32 - 5, 2**31 - 1, P61):
+        F = po.Field(modulus, False)
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, False)
+        T8 = 0x7f7f7f7f7f7f7f7f if eb == 8 else 0x7f7f7f7f
+        edge = sorted({v % modulus for v in (0, 1, 127, 128, 255, 256, T8 - 1, T8, T8 + 1, T8 + 2, modulus // 2, modulus // 2 + 1,
+                                              modulus - 1, modulus - 2, modulus - 128, modulus - 129, 2**31, 2**63 % modulus,
+                                              0x8080808080808080 % modulus, 0x80 << 24)})
+        M = K = N = 256
+        rng = random.Random(modulus % 1000)
+        a = [edge[(i * 7 + k_ * 3) % len(edge)] if (i + k_) % 3 else rng.randrange(modulus) for i in range(M) for k_ in range(K)]
+        b = [edge[(k_ * 5 + j) % len(edge)] if (j + k_) % 4 else rng.randrange(modulus) for k_ in range(K) for j in range(N)]
+        A, B = pack(a, eb), pack(b, eb)
+        got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+        coracle.set_threads(coracle.max_threads())
+        want = coracle.matmul(cf, A, B, M, K, N)
+        coracle.set_threads(1)
+        assert (got == want).all(), hex(modulus)
     # all-(p-1) operands: every limb product at its maximum
     ctx = ctx_for(eng, P64, False)
     M = K = N = 256
