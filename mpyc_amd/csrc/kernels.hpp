@@ -1476,6 +1476,95 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
     }
 }
 
+// The same product with the operand tiles staged through LDS: the four waves of a workgroup (64x64 outputs)
+// share one copy of the 64-row A tile and the 64-column B tile per k-step (2 x L x 2 KiB, double buffered), which
+// halves the L2 -> CU traffic that bounds the direct-load variant.  LDS layout [plane][k-half][row][16 bytes]:
+// the 16 lanes a ds_read_b128 phase serves read 256 contiguous bytes (conflict-free).
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
+                                                          typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
+                                                          int Np, int Kp, int kb, int ke, int accumulate) {
+    typedef typename F::word W;
+    constexpr int ND = 2 * L - 1;
+    constexpr int CHUNKS = L * 2 * 64;                 // 16-byte chunks of one operand tile per k-step
+    constexpr int PER_THREAD = CHUNKS / BLOCK;         // = L / 2 (L is 4 or 8)
+    static_assert(CHUNKS % BLOCK == 0, "tile chunks must divide evenly over the workgroup");
+    __shared__ ff_v4i sA[2][CHUNKS];
+    __shared__ ff_v4i sB[2][CHUNKS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int bm0 = blockIdx.y * 64, bn0 = blockIdx.x * 64;
+    const int r = lane & 31, h = lane >> 5;
+    ff_v16i acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = (ff_v16i){0};
+    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
+    // chunk c of a tile: plane l = c / 128, k-half hh = (c / 64) % 2, row = c % 64  (== its LDS index)
+    ff_v4i ga[PER_THREAD], gb[PER_THREAD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int c = threadIdx.x + u * BLOCK;
+            const int l = c >> 7, hh = (c >> 6) & 1, row = c & 63;
+            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + l * planeA + (size_t)(bm0 + row) * Kp + k0 + 16 * hh);
+            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + l * planeB + (size_t)(bn0 + row) * Kp + k0 + 16 * hh);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            sA[buf][threadIdx.x + u * BLOCK] = ga[u];
+            sB[buf][threadIdx.x + u * BLOCK] = gb[u];
+        }
+    };
+    fetch(kb);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        const bool more = k0 + 32 < ke;
+        if (more) fetch(k0 + 32);                      // in flight during the MFMAs below
+        ff_v4i a[L], b[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            a[l] = sA[cur][(l * 2 + h) * 64 + wm + r];
+            b[l] = sB[cur][(l * 2 + h) * 64 + wn + r];
+        }
+#pragma unroll
+        for (int la = 0; la < L; ++la)
+#pragma unroll
+            for (int lb = 0; lb < L; ++lb)
+                acc[la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb], 0, 0, 0);
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    W res[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int dv = acc[ND - 1][q];
+        const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+        res[q] = dv < 0 ? f.neg(w) : w;
+    }
+#pragma unroll
+    for (int d = ND - 2; d >= 0; --d)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int dv = acc[d][q];
+            const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+            res[q] = f.muladd_small(res[q], 256u, dv < 0 ? f.neg(w) : w);
+        }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int col = bn0 + wn + (lane & 31), row = bm0 + wm + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+            W v = res[q];
+            if (accumulate) v = f.add(v, ld_elem<F>(C, (size_t)row * ldc + col));
+            st_elem<F>(C, (size_t)row * ldc + col, v);
+        }
+    }
+}
+
 // ---- skinny products: matrix x few columns, few rows x matrix ---------------------------------------------
 // The tiled k_matmul needs both output dimensions to fill the chip; the shapes MPyC's author flags as the
 // bottleneck (demos/np_bnnmnist.py:10-15: `L @ W` with a 1 x 4096 activation row and a 4096 x 4096 weight
@@ -2251,8 +2340,12 @@ struct Launchers {
                     hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
                     for (int kb = 0; kb < Kp; kb += LIMB_KCHUNK) {
                         const int ke = kb + LIMB_KCHUNK < Kp ? kb + LIMB_KCHUNK : Kp;
-                        hipLaunchKernelGGL((k_limb_gemm<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
-                                           (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
+                        if (use_mfma == 2)
+                            hipLaunchKernelGGL((k_limb_gemm<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
+                                               (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
+                        else
+                            hipLaunchKernelGGL((k_limb_gemm_lds<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
+                                               (const int8_t*)Bp, (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
                     }
                 };
                 if (L == 4) go(std::integral_constant<int, 4>());
