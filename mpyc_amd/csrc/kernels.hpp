@@ -1483,7 +1483,8 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
 template <class F, int L>
 __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
-                                                          int Np, int Kp, int kb, int ke, int accumulate) {
+                                                          int Np, int Kp, int kb, int ke, int accumulate, int kslice,
+                                                          size_t zstride) {
     typedef typename F::word W;
     constexpr int ND = 2 * L - 1;
     constexpr int CHUNKS = L * 2 * 64;                 // 16-byte chunks of one operand tile per k-step
@@ -1491,6 +1492,12 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
     static_assert(CHUNKS % BLOCK == 0, "tile chunks must divide evenly over the workgroup");
     __shared__ ff_v4i sA[2][CHUNKS];
     __shared__ ff_v4i sB[2][CHUNKS];
+    if (kslice > 0) {                                  // split-K: slice blockIdx.z -> its own slab of C
+        kb += blockIdx.z * kslice;
+        ke = kb + kslice < ke ? kb + kslice : ke;
+        C += (size_t)blockIdx.z * zstride;
+        if (kb >= ke) { kb = 0; ke = 0; }              // empty slice: writes zeros
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int bm0 = blockIdx.y * 64, bn0 = blockIdx.x * 64;
@@ -1517,8 +1524,10 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
             sB[buf][threadIdx.x + u * BLOCK] = gb[u];
         }
     };
-    fetch(kb);
-    stash(0);
+    if (kb < ke) {
+        fetch(kb);
+        stash(0);
+    }
     __syncthreads();
     int cur = 0;
     for (int k0 = kb; k0 < ke; k0 += 32) {
@@ -2338,6 +2347,26 @@ struct Launchers {
                     constexpr int LL = decltype(lc_)::value;
                     hipLaunchKernelGGL((k_limb_split_a<F, LL>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, pmod, Ap, M, K, Mp, Kp);
                     hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
+                    // few output tiles (a batch of 64..256 rows against a big matrix): split K over blockIdx.z into
+                    // slabs behind the planes, summed by k_splitk_sum
+                    const size_t tiles = (size_t)gg.x * gg.y;
+                    int ks = 1;
+                    if (use_mfma != 2 && tiles <= 128 && Kp >= 512) {
+                        ks = (int)((768 + tiles - 1) / tiles);
+                        if (ks > Kp / 256) ks = Kp / 256;
+                        while (ks > 1 && need + (size_t)ks * M * N * sizeof(E) > workspace_bytes) --ks;
+                    }
+                    if (ks > 1 && Kp <= LIMB_KCHUNK) {
+                        const int kslice = ((Kp + ks - 1) / ks + 31) / 32 * 32;
+                        ks = (Kp + kslice - 1) / kslice;
+                        E* slabs = (E*)((char*)workspace + ((need + 255) / 256) * 256);
+                        dim3 g3(gg.x, gg.y, ks);
+                        hipLaunchKernelGGL((k_limb_gemm_lds<F, LL>), g3, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
+                                           slabs, (size_t)N, M, N, Mp, Np, Kp, 0, Kp, 0, kslice, (size_t)M * N);
+                        hipLaunchKernelGGL((k_splitk_sum<F>), dim3((unsigned)(((size_t)M * N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, f,
+                                           (const E*)slabs, ks, M, N, (E*)C, ldc);
+                        return;
+                    }
                     for (int kb = 0; kb < Kp; kb += LIMB_KCHUNK) {
                         const int ke = kb + LIMB_KCHUNK < Kp ? kb + LIMB_KCHUNK : Kp;
                         if (use_mfma == 2)
@@ -2345,7 +2374,7 @@ struct Launchers {
                                                (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
                         else
                             hipLaunchKernelGGL((k_limb_gemm_lds<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
-                                               (const int8_t*)Bp, (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
+                                               (const int8_t*)Bp, (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0, 0, (size_t)0);
                     }
                 };
                 if (L == 4) go(std::integral_constant<int, 4>());

@@ -615,7 +615,7 @@ def test_matrix_core_product(eng, coracle):
     10: 64-bit moduli), ragged shapes (padding), K beyond one 8192 chunk (accumulating launches), worst-case
     operands (p - 1 everywhere in a row and a column) and sub-matrix views; and equal to the VALU kernel
     (FFGPU_MM_MFMA=0 in a fresh context is not needed: the small shapes of test_matmul take that path)."""
-    shapes = [(256, 300, 257), (65, 8300, 70), (130, 64, 2000)]
+    shapes = [(256, 300, 257), (65, 8300, 70), (130, 64, 2000), (64, 1030, 300)]     # the last one: split-K slabs
     for modulus, binary in [(P61, False), (P64, False), (6616326157076047771, False), (2**31 - 1, False), (2**40 - 87, False),
                             (65537, False)]:
         F = po.Field(modulus, binary)
