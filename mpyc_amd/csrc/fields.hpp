@@ -1162,3 +1162,21 @@ struct GF2W128 {
         return r;
     }
 };
+
+// ---- operand digits for the matrix-core dense product (kernels.hpp k_limb_gemm) ------------------------------
+// L signed base-256 digits d_l in [-128, 127] of a representative of x modulo p.  L such digits represent exactly
+// the integers in [-128 S, 127 S], S = (256^L - 1)/255 -- a window of 256^L - 1 >= p consecutive integers -- so the
+// representative is x itself up to 127 S = 0x7f7f..7f and x - p above (not the balanced residue: for p close to
+// 2^64 the value p/2 is NOT representable, the carries would run out of the top digit).
+template <int L>
+FF_HD void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
+    const uint64_t top = 0x7f7f7f7f7f7f7f7full >> (8 * (8 - L));
+    __int128 v = (x > top) ? (__int128)x - (__int128)p : (__int128)x;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int8_t dl = (int8_t)((int)(v & 0xff));
+        d[l] = dl;
+        v = (v >> 8) + (dl < 0 ? 1 : 0);
+    }
+}
+

@@ -1361,22 +1361,6 @@ typedef int ff_v4i __attribute__((ext_vector_type(4)));
 typedef int ff_v16i __attribute__((ext_vector_type(16)));
 enum { LIMB_KCHUNK = 8192 };
 
-// L signed base-256 digits d_l in [-128, 127] of a representative of x modulo p.  L such digits represent exactly
-// the integers in [-128 S, 127 S], S = (256^L - 1)/255 -- a window of 256^L - 1 >= p consecutive integers -- so the
-// representative is x itself up to 127 S = 0x7f7f..7f and x - p above (not the balanced residue: for p close to
-// 2^64 the value p/2 is NOT representable, the carries would run out of the top digit).
-template <int L>
-__device__ __forceinline__ void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
-    const uint64_t top = 0x7f7f7f7f7f7f7f7full >> (8 * (8 - L));
-    __int128 v = (x > top) ? (__int128)x - (__int128)p : (__int128)x;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int8_t dl = (int8_t)((int)(v & 0xff));
-        d[l] = dl;
-        v = (v >> 8) + (dl < 0 ? 1 : 0);
-    }
-}
-
 template <class F, int L>
 __global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* __restrict__ A, size_t lda, uint64_t p,
                                                          int8_t* __restrict__ Ap, int M, int K, int Mp, int Kp) {

@@ -211,3 +211,20 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
         default: return 2;
     }
 }
+
+// digits of the matrix-core product's operand representative (fields.hpp limb_digits), L = 4 or 8
+extern "C" int hc_limb_digits(uint64_t x, uint64_t p, int L, int8_t* out) {
+    if (L == 8) {
+        int8_t d[8];
+        limb_digits<8>(x, p, d);
+        memcpy(out, d, 8);
+    } else if (L == 4) {
+        int8_t d[4];
+        limb_digits<4>(x, p, d);
+        memcpy(out, d, 4);
+    } else {
+        return 1;
+    }
+    return 0;
+}
+

@@ -240,3 +240,24 @@ def test_pseudo_mersenne_with_the_largest_admissible_c(hostcheck):
                 rows = [[p - 1] * n for _ in range(t)]
                 got, _ = run(hostcheck, F, HC_SACC, s, None, [v for row in rows for v in row], x=m, k=t, n=n)
                 assert got == [(s[h] + sum(rows[j][h] * m**(j + 1) for j in range(t))) % p for h in range(n)], (k, hex(p), t, m)
+
+
+def test_matrix_core_operand_digits(hostcheck):
+    """limb_digits (fields.hpp): L signed base-256 digits in [-128, 127] that sum to x or x - p, for every x in
+    [0, p) -- in particular around 0x7f7f..7f, where the representative switches, and for moduli at the very top
+    of the 64-bit and 32-bit ranges, where the balanced residue p/2 would NOT be representable."""
+    rng = random.Random(64)
+    for L, moduli in ((8, [2**64 - 59, 2**64 - 189, 2**63 - 25, 2**61 - 1, 6616326157076047771, 2**40 - 87, 2**33 - 9]),
+                      (4, [2**32 - 5, 2**31 - 1, 65537, 19, 2])):
+        T = int.from_bytes(b'\x7f' * L, 'little')
+        for p in moduli:
+            xs = {0, 1, p - 1, p // 2, p // 2 + 1, (p - 2) % p} | {v % p for v in (T - 1, T, T + 1, T + 2, 255, 256, 2**31, 2**63)}
+            xs |= {rng.randrange(p) for _ in range(300)}
+            buf = (ctypes.c_int8 * L)()
+            for x in xs:
+                assert hostcheck.hc_limb_digits(ctypes.c_uint64(x), ctypes.c_uint64(p), L, buf) == 0
+                d = list(buf)
+                assert all(-128 <= v <= 127 for v in d)
+                val = sum(v << (8 * i) for i, v in enumerate(d))
+                assert val == (x if x <= T else x - p), (L, hex(p), hex(x), d)
+                assert -128 * (256**L - 1) // 255 <= val <= 127 * (256**L - 1) // 255
