@@ -2311,7 +2311,7 @@ struct Launchers {
         }
         if constexpr (F::EPW == 1 && !F::BINARY && sizeof(W) <= 8) {
             // large dense products over primes of up to 64 bits: int8 matrix cores (k_limb_gemm), 8 signed base-256
-            // digits of the balanced residues (4 for 32-bit storage)
+            // digits per operand (4 for 32-bit storage)
             static int use_mfma = -1;
             if (use_mfma < 0) {
                 const char* e = getenv("FFGPU_MM_MFMA");
@@ -2338,7 +2338,7 @@ struct Launchers {
                     if (use_mfma != 2 && tiles <= 128 && Kp >= 512) {
                         ks = (int)((768 + tiles - 1) / tiles);
                         if (ks > Kp / 256) ks = Kp / 256;
-                        while (ks > 1 && need + (size_t)ks * M * N * sizeof(E) > workspace_bytes) --ks;
+                        while (ks > 1 && need + 256 + (size_t)ks * M * N * sizeof(E) > workspace_bytes) --ks;
                     }
                     if (ks > 1 && Kp <= LIMB_KCHUNK) {
                         const int kslice = ((Kp + ks - 1) / ks + 31) / 32 * 32;
