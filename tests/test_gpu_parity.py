@@ -660,6 +660,36 @@ def test_matrix_core_product(eng, coracle):
     assert set(got) == {K * (P64 - 1) * (P64 - 1) % P64}
 
 
+def test_matmul_leading_dimensions(eng, coracle):
+    """ffgpu_matmul on sub-matrix views: lda > K, ldb > N, ldc > N (the C ABI takes leading dimensions; the
+    engine wrapper always passes contiguous operands), through every kernel family: skinny matvec / vecmat,
+    tiled, split-K, and the matrix-core product whose split kernels read the strided operands."""
+    from mpyc_amd import _ffi
+    for modulus in (P61, P64, 2**31 - 1, P128):
+        F = po.Field(modulus, False)
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, False)
+        shapes = [(70, 33, 1), (1, 200, 130), (40, 50, 45), (9, 300, 20), (260, 270, 250)] if eb < 12 else \
+            [(70, 33, 1), (1, 200, 130), (20, 50, 25)]
+        for (M, K, N) in shapes:
+            lda, ldb, ldc = K + 5, N + 3, N + 7
+            Abig, Bbig = rand_np(F, eb, M * lda, 5), rand_np(F, eb, K * ldb, 6)
+            dA, dB = ctx.from_numpy(Abig), ctx.from_numpy(Bbig)
+            dC = ctx.from_numpy(rand_np(F, eb, M * ldc, 7))                   # pre-filled: the padding must survive
+            before = dC.to_numpy().copy()
+            _ffi.check(ctx._L.ffgpu_matmul(ctx._h, dA.ptr, lda, dB.ptr, ldb, dC.ptr, ldc, M, K, N, ctx._stream()), 'matmul')
+            got = dC.to_numpy().reshape((M, ldc) + ((2,) if eb == 16 else ()))
+            A = np.ascontiguousarray(Abig.reshape((M, lda) + ((2,) if eb == 16 else ()))[:, :K])
+            B = np.ascontiguousarray(Bbig.reshape((K, ldb) + ((2,) if eb == 16 else ()))[:, :N])
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A.reshape((M * K,) + ((2,) if eb == 16 else ())), B.reshape((K * N,) + ((2,) if eb == 16 else ())), M, K, N)
+            coracle.set_threads(1)
+            assert (got[:, :N].reshape(want.shape) == want).all(), (hex(modulus), M, K, N)
+            keep = before.reshape(got.shape)[:, N:]
+            assert (got[:, N:] == keep).all(), ('padding overwritten', hex(modulus), M, K, N)
+
+
 def test_gf2n_table_multiplication(eng, coracle):
     """Large GF(2^n<=8) arrays multiply through log/antilog tables in LDS (k_gf8_mul_tab): same
     answers as the shift-xor kernel and the oracle, for every small binary field, all 256x256 pairs."""
