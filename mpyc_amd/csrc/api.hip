@@ -726,7 +726,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
         // split-K partial sums
         size_t want = 0;
         const size_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
-        if (ctx->kind == FFGPU_PRIME && ctx->elem_bytes <= 8 && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= 1.6e7) {
+        if (ctx->kind == FFGPU_PRIME && ctx->elem_bytes <= 8 && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= ffgpu::mfma_min_macs()) {
             want = (size_t)8 * (Mp + Np) * Kp + ((size_t)64 << 20);      // 8 digit planes per operand + split-K slabs
             if (want > ((size_t)8 << 30)) want = 0;
         }

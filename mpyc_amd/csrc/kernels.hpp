@@ -1343,6 +1343,16 @@ __global__ __launch_bounds__(BLOCK) void k_splitk_sum(F f, const typename F::ele
 }
 
 
+// smallest M*N*K that goes to the matrix cores (FFGPU_MM_MFMA_MIN overrides; tuned with tools/mm_threshold.py)
+inline double mfma_min_macs() {
+    static double v = -1;
+    if (v < 0) {
+        const char* e = getenv("FFGPU_MM_MFMA_MIN");
+        v = e ? atof(e) : 1.6e7;
+    }
+    return v;
+}
+
 // ---- dense product on the int8 matrix cores ---------------------------------------------------------------
 // An exact modular GEMM as integer GEMMs of signed 8-bit DIGITS.  Every operand is first replaced by a
 // representative x' = x or x - p (congruent mod p) that has exactly L = 8 (4 for 32-bit storage) base-256 digits
@@ -2322,7 +2332,7 @@ struct Launchers {
             (void)mod_bits;
             const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
             const size_t need = (size_t)L * ((size_t)Mp + Np) * Kp;
-            if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= 1.6e7 && workspace && need <= workspace_bytes) {
+            if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= mfma_min_macs() && workspace && need <= workspace_bytes) {
                 int8_t* Ap = (int8_t*)workspace;
                 int8_t* Bp = Ap + (size_t)L * Mp * Kp;
                 const unsigned ga = (unsigned)(((size_t)Mp * Kp + BLOCK - 1) / BLOCK);
