@@ -1180,3 +1180,33 @@ FF_HD void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
     }
 }
 
+// The same for two-limb values (primes of 65..128 bits): L = 12 (96-bit storage) or 16 digits.  x - p can be as
+// low as -128 S ~ -0.502 * 2^128, so the running value is kept in three 64-bit words (two's complement).
+template <int L>
+FF_HD void limb_digits_wide(uint64_t xlo, uint64_t xhi, uint64_t plo, uint64_t phi, int8_t (&d)[L]) {
+    static_assert(L > 8 && L <= 16, "two-limb operands have 9..16 digits");
+    const uint64_t tlo = 0x7f7f7f7f7f7f7f7full, thi = 0x7f7f7f7f7f7f7f7full >> (8 * (16 - L));
+    const bool above = xhi > thi || (xhi == thi && xlo > tlo);
+    uint64_t w0 = xlo, w1 = xhi, w2 = 0;
+    if (above) {                                   // v = x - p  (negative)
+        const uint64_t b0 = xlo < plo;
+        w0 = xlo - plo;
+        const uint64_t t1 = xhi - phi, b1 = (xhi < phi) || (t1 < b0);
+        w1 = t1 - b0;
+        w2 = 0 - b1;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int8_t dl = (int8_t)(int)(w0 & 0xff);
+        d[l] = dl;
+        // v = (v >> 8) + (dl < 0), arithmetic shift over the three words
+        w0 = (w0 >> 8) | (w1 << 56);
+        w1 = (w1 >> 8) | (w2 << 56);
+        w2 = (uint64_t)((int64_t)w2 >> 8);
+        if (dl < 0) {
+            if (++w0 == 0)
+                if (++w1 == 0) ++w2;
+        }
+    }
+}
+

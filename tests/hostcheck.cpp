@@ -228,3 +228,18 @@ extern "C" int hc_limb_digits(uint64_t x, uint64_t p, int L, int8_t* out) {
     return 0;
 }
 
+extern "C" int hc_limb_digits_wide(const uint64_t* x2, const uint64_t* p2, int L, int8_t* out) {
+    if (L == 16) {
+        int8_t d[16];
+        limb_digits_wide<16>(x2[0], x2[1], p2[0], p2[1], d);
+        memcpy(out, d, 16);
+    } else if (L == 12) {
+        int8_t d[12];
+        limb_digits_wide<12>(x2[0], x2[1], p2[0], p2[1], d);
+        memcpy(out, d, 12);
+    } else {
+        return 1;
+    }
+    return 0;
+}
+

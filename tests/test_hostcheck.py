@@ -261,3 +261,23 @@ def test_matrix_core_operand_digits(hostcheck):
                 val = sum(v << (8 * i) for i, v in enumerate(d))
                 assert val == (x if x <= T else x - p), (L, hex(p), hex(x), d)
                 assert -128 * (256**L - 1) // 255 <= val <= 127 * (256**L - 1) // 255
+
+
+def test_matrix_core_operand_digits_two_limbs(hostcheck):
+    """limb_digits_wide: 12 digits for 65..96-bit primes, 16 for 97..128-bit primes (three-word arithmetic)."""
+    rng = random.Random(128)
+    for L, moduli in ((16, [2**128 - 173, 2**128 - 159, 2**127 - 1, 258797994007609146293811961253269568351, 2**97 - 141, 2**100 - 15]),
+                      (12, [2**96 - 17, 2**80 - 65, 2**65 - 49, 2**89 - 1])):
+        T = int.from_bytes(b'\x7f' * L, 'little')
+        for p in moduli:
+            xs = {0, 1, p - 1, p // 2, p // 2 + 1, p - 2, 2**64 - 1, 2**64, 2**64 + 1} | \
+                 {v % p for v in (T - 1, T, T + 1, T + 2, 255, 256, 2**63, 2**127, (T >> 64) << 64, ((T >> 64) << 64) - 1)}
+            xs |= {rng.randrange(p) for _ in range(300)}
+            buf = (ctypes.c_int8 * L)()
+            for x in xs:
+                x2 = (ctypes.c_uint64 * 2)(x & (2**64 - 1), x >> 64)
+                p2 = (ctypes.c_uint64 * 2)(p & (2**64 - 1), p >> 64)
+                assert hostcheck.hc_limb_digits_wide(x2, p2, L, buf) == 0
+                d = list(buf)
+                val = sum(v << (8 * i) for i, v in enumerate(d))
+                assert val == (x if x <= T else x - p), (L, hex(p), hex(x), d)
