@@ -726,8 +726,8 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
         // split-K partial sums
         size_t want = 0;
         const size_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
-        if (ctx->kind == FFGPU_PRIME && ctx->elem_bytes <= 8 && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= ffgpu::mfma_min_macs()) {
-            want = (size_t)8 * (Mp + Np) * Kp + ((size_t)64 << 20);      // 8 digit planes per operand + split-K slabs
+        if (ctx->kind == FFGPU_PRIME && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= ffgpu::mfma_min_macs()) {
+            want = (size_t)(ctx->elem_bytes <= 8 ? 8 : 16) * (Mp + Np) * Kp + ((size_t)64 << 20);   // digit planes per operand + split-K slabs
             if (want > ((size_t)8 << 30)) want = 0;
         }
         if (!want && K >= 128 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) want = (size_t)64 << 20;

@@ -1568,6 +1568,142 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
     }
 }
 
+// ---- the matrix-core product for primes of 65..128 bits ---------------------------------------------------------
+// L = 12 digits (96-bit storage) or 16: 2L-1 = 23 / 31 diagonals do not fit the register file at once, so the
+// product runs in PASSES over ranges of diagonals [D0, D0+NDP): a pass issues only the MFMAs whose digit pair lies
+// on its diagonals (the work adds up to L^2 per k-step over all passes), evaluates its part by Horner and adds
+// 256^D0 times it to C.  K chunks of 4096 keep the i32 accumulators exact (16 * 128^2 * 4096 = 2^30).
+enum { LIMB_KCHUNK_WIDE = 4096 };
+
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_split_a_wide(const typename F::elem* __restrict__ A, size_t lda, uint64_t plo,
+                                                              uint64_t phi, int8_t* __restrict__ Ap, int M, int K, int Mp,
+                                                              int Kp) {
+    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (size_t)Mp * Kp) return;
+    const int row = (int)(idx / Kp), kk = (int)(idx % Kp);
+    uint64_t lo = 0, hi = 0;
+    if (row < M && kk < K) {
+        const typename F::word w = ld_elem<F>(A, (size_t)row * lda + kk);
+        lo = w.lo;
+        hi = w.hi;
+    }
+    int8_t d[L];
+    limb_digits_wide<L>(lo, hi, plo, phi, d);
+#pragma unroll
+    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = d[l];
+}
+template <class F, int L>
+__global__ __launch_bounds__(BLOCK) void k_limb_split_bt_wide(const typename F::elem* __restrict__ B, size_t ldb, uint64_t plo,
+                                                               uint64_t phi, int8_t* __restrict__ Bp, int K, int N, int Np,
+                                                               int Kp) {
+    __shared__ uint64_t tlo[32][33];
+    __shared__ uint64_t thi[32][33];
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int kk = k0 + r, nn = n0 + tx;
+        uint64_t lo = 0, hi = 0;
+        if (kk < K && nn < N) {
+            const typename F::word w = ld_elem<F>(B, (size_t)kk * ldb + nn);
+            lo = w.lo;
+            hi = w.hi;
+        }
+        tlo[r][tx] = lo;
+        thi[r][tx] = hi;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int8_t d[L];
+        limb_digits_wide<L>(tlo[tx][r], thi[tx][r], plo, phi, d);
+#pragma unroll
+        for (int l = 0; l < L; ++l) Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = d[l];
+    }
+}
+
+// one pass: diagonals D0 .. D0+NDP-1; scale = 256^D0 mod p (prepared); accumulate: add to C instead of writing it
+template <class F, int L, int D0, int NDP>
+__global__ __launch_bounds__(BLOCK) void k_limb_gemm_wide(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
+                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
+                                                           int Np, int Kp, int kb, int ke, int accumulate,
+                                                           typename F::word scale) {
+    typedef typename F::word W;
+    constexpr int CHUNKS = L * 2 * 64;
+    constexpr int PER_THREAD = CHUNKS / BLOCK;
+    static_assert(CHUNKS % BLOCK == 0, "tile chunks must divide evenly over the workgroup");
+    __shared__ ff_v4i sA[2][CHUNKS];
+    __shared__ ff_v4i sB[2][CHUNKS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int bm0 = blockIdx.y * 64, bn0 = blockIdx.x * 64;
+    const int r = lane & 31, h = lane >> 5;
+    ff_v16i acc[NDP];
+#pragma unroll
+    for (int d = 0; d < NDP; ++d) acc[d] = (ff_v16i){0};
+    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
+    ff_v4i ga[PER_THREAD], gb[PER_THREAD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int c = threadIdx.x + u * BLOCK;
+            const int l = c >> 7, hh = (c >> 6) & 1, row = c & 63;
+            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + l * planeA + (size_t)(bm0 + row) * Kp + k0 + 16 * hh);
+            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + l * planeB + (size_t)(bn0 + row) * Kp + k0 + 16 * hh);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            sA[buf][threadIdx.x + u * BLOCK] = ga[u];
+            sB[buf][threadIdx.x + u * BLOCK] = gb[u];
+        }
+    };
+    if (kb < ke) {
+        fetch(kb);
+        stash(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        const bool more = k0 + 32 < ke;
+        if (more) fetch(k0 + 32);
+        ff_v4i a[L], b[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            a[l] = sA[cur][(l * 2 + h) * 64 + wm + r];
+            b[l] = sB[cur][(l * 2 + h) * 64 + wn + r];
+        }
+#pragma unroll
+        for (int la = 0; la < L; ++la)
+#pragma unroll
+            for (int lb = 0; lb < L; ++lb)
+                if (la + lb >= D0 && la + lb < D0 + NDP)
+                    acc[la + lb - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb - D0], 0, 0, 0);
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    auto to_field = [&](int dv) -> W {
+        W w;
+        w.lo = (uint64_t)(uint32_t)(dv < 0 ? -dv : dv);
+        w.hi = 0;
+        w = f.reduce_raw(w);
+        return dv < 0 ? f.neg(w) : w;
+    };
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int col = bn0 + wn + (lane & 31), row = bm0 + wm + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+            W res = to_field(acc[NDP - 1][q]);
+#pragma unroll
+            for (int d = NDP - 2; d >= 0; --d) res = f.muladd_small(res, 256u, to_field(acc[d][q]));
+            if (D0 > 0) res = f.mul(res, scale);
+            if (accumulate) res = f.add(res, ld_elem<F>(C, (size_t)row * ldc + col));
+            st_elem<F>(C, (size_t)row * ldc + col, res);
+        }
+    }
+}
+
 // ---- skinny products: matrix x few columns, few rows x matrix ---------------------------------------------
 // The tiled k_matmul needs both output dimensions to fill the chip; the shapes MPyC's author flags as the
 // bottleneck (demos/np_bnnmnist.py:10-15: `L @ W` with a 1 x 4096 activation row and a 4096 x 4096 weight
@@ -2373,6 +2509,56 @@ struct Launchers {
                 };
                 if (L == 4) go(std::integral_constant<int, 4>());
                 else go(std::integral_constant<int, 8>());
+                FFGPU_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+        if constexpr (F::EPW == 1 && !F::BINARY && sizeof(W) == 16) {
+            // primes of 65..128 bits: the matrix-core product in passes over the diagonals (k_limb_gemm_wide)
+            static int use_mfma_w = -1;
+            if (use_mfma_w < 0) {
+                const char* e = getenv("FFGPU_MM_MFMA");
+                use_mfma_w = e ? atoi(e) : 1;
+            }
+            constexpr int LW = sizeof(E) == 12 ? 12 : 16;
+            const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
+            const size_t need = (size_t)LW * ((size_t)Mp + Np) * Kp;
+            if (use_mfma_w && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= mfma_min_macs() && workspace &&
+                need <= workspace_bytes) {
+                int8_t* Ap = (int8_t*)workspace;
+                int8_t* Bp = Ap + (size_t)LW * Mp * Kp;
+                const unsigned ga = (unsigned)(((size_t)Mp * Kp + BLOCK - 1) / BLOCK);
+                dim3 gb(Np / 32, Kp / 32), gg(Np / 64, Mp / 64);
+                hipLaunchKernelGGL((k_limb_split_a_wide<F, LW>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, f.p_lo, f.p_hi, Ap, M,
+                                   K, Mp, Kp);
+                hipLaunchKernelGGL((k_limb_split_bt_wide<F, LW>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, f.p_lo, f.p_hi, Bp, K, N,
+                                   Np, Kp);
+                // 256^D0 mod p by repeated doubling of the canonical 1 (host, canonical arithmetic of the policy)
+                auto pow256 = [&](int d0) {
+                    W v;
+                    v.lo = 1;
+                    v.hi = 0;
+                    for (int i = 0; i < 8 * d0; ++i) v = f.add(v, v);
+                    return v;
+                };
+                bool first = true;
+                for (int kb = 0; kb < Kp; kb += LIMB_KCHUNK_WIDE) {
+                    const int ke = kb + LIMB_KCHUNK_WIDE < Kp ? kb + LIMB_KCHUNK_WIDE : Kp;
+                    auto pass = [&](auto d0_, auto ndp_) {
+                        constexpr int D0 = decltype(d0_)::value, NDP = decltype(ndp_)::value;
+                        hipLaunchKernelGGL((k_limb_gemm_wide<F, LW, D0, NDP>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
+                                           (const int8_t*)Bp, (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, first ? 0 : 1, pow256(D0));
+                        first = false;
+                    };
+                    if constexpr (LW == 12) {            // 23 diagonals: 12 + 11
+                        pass(std::integral_constant<int, 0>(), std::integral_constant<int, 12>());
+                        pass(std::integral_constant<int, 12>(), std::integral_constant<int, 11>());
+                    } else {                              // 31 diagonals: 11 + 10 + 10
+                        pass(std::integral_constant<int, 0>(), std::integral_constant<int, 11>());
+                        pass(std::integral_constant<int, 11>(), std::integral_constant<int, 10>());
+                        pass(std::integral_constant<int, 21>(), std::integral_constant<int, 10>());
+                    }
+                }
                 FFGPU_CHECK_LAUNCH();
                 return 0;
             }

@@ -660,6 +660,37 @@ def test_matrix_core_product(eng, coracle):
     assert set(got) == {K * (P64 - 1) * (P64 - 1) % P64}
 
 
+def test_matrix_core_product_two_limb_primes(eng, coracle):
+    """Primes of 65..128 bits: 12 / 16 signed digits, the diagonals in 2 / 3 passes (k_limb_gemm_wide), K beyond one
+    4096 chunk, worst-case operands, every two-limb reduction strategy (pseudo-Mersenne k = 128 and k < 128,
+    Montgomery, 12-byte storage), and operands at the representative switch 0x7f7f..7f."""
+    for modulus in (P128, 2**127 - 1, 258797994007609146293811961253269568351, 2**96 - 17, 2**80 - 65):
+        F = po.Field(modulus, False)
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(modulus, False)
+        nb = 12 if eb == 12 else 16
+        T = int.from_bytes(b'\x7f' * nb, 'little')
+        edge = sorted({v % modulus for v in (0, 1, T - 1, T, T + 1, modulus // 2, modulus // 2 + 1, modulus - 1, modulus - 2,
+                                              2**64 - 1, 2**64, 2**127 % modulus, modulus - 128)})
+        for (M, K, N) in ((128, 1000, 130), (65, 4200, 70)):
+            A, B = rand_np(F, eb, M * K, 61), rand_np(F, eb, K * N, 62)
+            a = unpack(A, eb)
+            b = unpack(B, eb)
+            for i in range(K):
+                a[i] = modulus - 1                                   # row 0 of A and column 0 of B: worst case
+                b[i * N] = modulus - 1
+            for i in range(len(edge)):
+                a[K + i] = edge[i]                                   # row 1 of A: the edge values
+                b[N * i + 1] = edge[(3 * i) % len(edge)]             # column 1 of B
+            A, B = pack(a, eb), pack(b, eb)
+            got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A, B, M, K, N)
+            coracle.set_threads(1)
+            assert (got == want).all(), (hex(modulus), M, K, N)
+
+
 def test_matmul_leading_dimensions(eng, coracle):
     """ffgpu_matmul on sub-matrix views: lda > K, ldb > N, ldc > N (the C ABI takes leading dimensions; the
     engine wrapper always passes contiguous operands), through every kernel family: skinny matvec / vecmat,
