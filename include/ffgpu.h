@@ -223,7 +223,13 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 
 /* ---- dense matrix product ---------------------------------------------- */
 /* C (M x N) = A (M x K) @ B (K x N) over the field, row-major with leading dimensions lda/ldb/ldc in
- * ELEMENTS.  Products are accumulated unreduced and reduced once per 192 terms.
+ * ELEMENTS.  The result is that of the reference's object matmul followed by one `%` (exact integer
+ * accumulation, reduced at the end).  Kernel families, chosen by shape and field: one output dimension <= 8 ->
+ * HBM-bound matrix x vector / vector x matrix kernels; prime fields with M, N, K >= 64 and M*N*K >= 1.6e7 ->
+ * exact signed-digit GEMMs on the int8 matrix cores; otherwise an LDS-tiled vector-ALU kernel (split over K when
+ * the output has few tiles).  The matrix-core and split-K paths keep digit planes / partial sums in a grow-only
+ * scratch buffer owned by the context: the first call of a larger shape allocates it (and synchronises the stream),
+ * so issue one such call before capturing launches in a HIP graph, and use one stream per context.
  * replaces: finfields.py:1126-1146 (__matmul__: object matmul then one `%`), the local product of
  * runtime.py:2481-2541 np_matmul (A @ B at :2531).                                             */
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,
