@@ -407,6 +407,22 @@ def main():
                 kern[f'matmul_p61_{mm_}x{kk_}x{nn_}'] = dict(roof(byts, ms), units_per_s=round(mm_ * kk_ * nn_ / (ms * 1e-3), 1),
                                                             algorithmic_bytes_per_unit=None)
                 del big, small, outm
+            # dense products over two-limb primes (12 / 16 signed digits, diagonals in passes on the matrix cores)
+            for nm_, pw_ in (('p96', 2**96 - 17), ('p128', 2**128 - 173)):
+                cw = FieldContext(pw_, device=local_rank)
+                dim = 2048
+                dtw = torch.int32 if cw.elem_bytes == 12 else torch.int64
+                hiw = 2**31 - 1 if cw.elem_bytes == 12 else 2**62
+                Aw = DevArray(cw, torch.randint(0, hiw, (dim * dim, cw.limbs), dtype=dtw, device=ctx.torch_device, generator=gen), dim * dim)
+                Bw = DevArray(cw, torch.randint(0, hiw, (dim * dim, cw.limbs), dtype=dtw, device=ctx.torch_device, generator=gen), dim * dim)
+                cw.reduce(Aw, out=Aw)
+                cw.reduce(Bw, out=Bw)
+                Cw = cw.empty(dim * dim)
+                ms = time_launches(lambda s_: cw.matmul(Aw, Bw, dim, dim, dim, out=Cw), [0], 2)
+                kern[f'matmul_{nm_}_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'int8 MFMA (signed-digit limb GEMM, passes)',
+                                               'unit': 'GMAC/s', 'achieved': round(float(dim) ** 3 / (ms * 1e-3) / 1e9, 1), 'frac': 0.0,
+                                               'units_per_s': round(float(dim) ** 3 / (ms * 1e-3), 1)}
+                del Aw, Bw, Cw
             # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
             del sets[1:]
             torch.cuda.empty_cache()
