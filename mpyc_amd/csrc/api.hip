@@ -730,7 +730,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
             want = (size_t)(ctx->elem_bytes <= 8 ? 8 : 16) * (Mp + Np) * Kp + ((size_t)64 << 20);   // digit planes per operand + split-K slabs
             if (want > ((size_t)8 << 30)) want = 0;
         }
-        if (!want && K >= 128 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) want = (size_t)64 << 20;
+        if (!want && K >= 64 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) want = (size_t)64 << 20;
         if (want && ctx->scratch_bytes < want) {
             HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // queued work may still read the old buffer
             if (ctx->scratch) (void)hipFree(ctx->scratch);

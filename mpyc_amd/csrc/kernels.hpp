@@ -1348,7 +1348,7 @@ inline double mfma_min_macs() {
     static double v = -1;
     if (v < 0) {
         const char* e = getenv("FFGPU_MM_MFMA_MIN");
-        v = e ? atof(e) : 1.6e7;
+        v = e ? atof(e) : 8e7;
     }
     return v;
 }
@@ -2573,7 +2573,9 @@ struct Launchers {
                 const char* e = getenv("FFGPU_MM_TILE");
                 tile = e ? atoi(e) : 42;   // 4x2 per thread: measured best (1.93 T MAC/s at 4096^3 over GF(2^61-1))
             }
-            const int tcode = sizeof(W) == 16 ? 22 : tile;
+            // small outputs (a 64 x 64 product is two 64 x 32 tiles): 32 x 32 tiles give four times as many workgroups
+            const bool small_out = ((M + 63) / 64) * ((N + 31) / 32) < 64;
+            const int tcode = (sizeof(W) == 16 || small_out) ? 22 : tile;
             const int bm = tcode == 42 ? 64 : tcode == 22 ? 32 : tcode == 84 ? 128 : 64;
             const int bn = tcode == 42 ? 32 : tcode == 22 ? 32 : tcode == 84 ? 64 : 64;
             dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm);
@@ -2582,9 +2584,9 @@ struct Launchers {
             const size_t tiles = (size_t)grid.x * grid.y;
             E* out = (E*)C;
             size_t out_ld = ldc, zstride = 0;
-            if (tiles < 512 && K >= 128 && workspace) {
+            if (tiles < 512 && K >= 64 && workspace) {
                 ks = (int)((1024 + tiles - 1) / tiles);
-                if (ks > K / 64) ks = K / 64;
+                if (ks > K / 32) ks = K / 32;
                 while (ks > 1 && (size_t)ks * M * N * sizeof(E) > workspace_bytes) ks /= 2;
                 if (ks > 1) {
                     kchunk = ((K + ks - 1) / ks + 15) / 16 * 16;

@@ -1,6 +1,9 @@
 import ctypes
 import json
 import os
+
+# the parity tests use modest shapes: send them to the matrix-core product already (production default: 8e7 MACs)
+os.environ.setdefault('FFGPU_MM_MFMA_MIN', '1.6e7')
 import subprocess
 import sys
 
