@@ -7,20 +7,90 @@ Layout:
     engine.py      field context + device-resident limb arrays
     finfields.py   host-side mirror of mpyc.finfields GF()/array types on the engine
     thresha.py     host-side mirror of mpyc.thresha (np_)random_split / (np_)recombine
+    install()      substitution of both into an importable mpyc
 """
-__version__ = '0.1.0'
+__version__ = '0.2.0'
+
+list_path_min = 256     # install(): thresha.random_split / recombine (the per-element list path, thresha.py:23-44,
+#                         88-116) go to the device from this many secrets on; below it the reference's own
+#                         pure-Python function runs (a kernel launch + two PCIe hops per scalar is not a speed-up)
+_installed = None
 
 
 def install():
     """Substitute the GPU array type and sharing functions into an importable `mpyc`
     (INTEGRATION.md section 2).  Must run before any field is created: mpyc caches array types
-    per field (finfields.py:45,347).  Returns the list of substituted names."""
+    per field (finfields.py:45,347).  Returns the list of substituted names.
+
+    * `finfields.arrayGF` (finfields.py:45-60) is wrapped: for every prime field of up to 128 bits and every
+      GF(2^n), n <= 128, the array type derives from BOTH mpyc_amd.finfields.FieldArray (behaviour, device
+      storage) and mpyc's own finfields.FiniteFieldArray (so `isinstance(x, finfields.FiniteFieldArray)`,
+      sectypes.py:1372, holds); its inherited `value` slot is shadowed by the lazy device-backed property.
+      Fields the device path does not cover (wider primes, odd-characteristic extension fields) keep the
+      reference's own array classes.
+    * `thresha.np_random_split / np_recombine / np_pseudorandom_share(_0)` are replaced for those fields; the
+      list-path functions from `list_path_min` secrets on.
+    """
+    global _installed
+    if _installed is not None:
+        return list(_installed)
+    import functools
     from mpyc import finfields, thresha          # ImportError if mpyc is not installed
     from . import finfields as gff, thresha as gth
-    finfields.PrimeFieldArray = gff.FieldArray
-    finfields.BinaryFieldArray = gff.FieldArray
-    done = ['finfields.PrimeFieldArray', 'finfields.BinaryFieldArray']
-    for name in ('np_random_split', 'np_recombine', 'random_split', 'recombine', '_recombination_vector'):
-        setattr(thresha, name, getattr(gth, name))
+
+    class DeviceFieldArray(gff.FieldArray, finfields.FiniteFieldArray):
+        """field.array base class under install(): mpyc_amd behaviour on mpyc's own class hierarchy."""
+        __slots__ = gff._STORAGE_SLOTS
+
+    DeviceFieldArray._mix_types = (int, gff.np.integer)
+    orig_arrayGF = finfields.arrayGF
+
+    def supported(field):
+        try:
+            ops = gff._fops(field)
+        except NotImplementedError:
+            return False
+        return ops.modulus.bit_length() <= (129 if ops.binary else 128)
+
+    @functools.cache
+    def arrayGF(field, modulus):
+        if not supported(field):
+            return orig_arrayGF(field, modulus)
+        array = type(f'Array{field.__name__}', (DeviceFieldArray,), {'__slots__': ()})
+        array.field = field
+        return array
+
+    finfields.arrayGF = arrayGF
+    finfields.DeviceFieldArray = DeviceFieldArray
+    done = ['finfields.arrayGF']
+
+    def on_device(field):
+        arr = getattr(field, 'array', None)
+        return arr is not None and issubclass(arr, gff.FieldArray)
+
+    def route(name, min_len=None):
+        ref_fn, gpu_fn = getattr(thresha, name), getattr(gth, name)
+
+        @functools.wraps(ref_fn)
+        def fn(field, *args, **kwargs):
+            if not on_device(field):
+                return ref_fn(field, *args, **kwargs)
+            if min_len is not None:
+                first = args[0]
+                n = len(first) if name == 'random_split' else len(first[0][1])
+                if n < list_path_min:
+                    return ref_fn(field, *args, **kwargs)
+            return gpu_fn(field, *args, **kwargs)
+        fn.reference = ref_fn
+        setattr(thresha, name, fn)
         done.append('thresha.' + name)
-    return done
+
+    for name in ('np_random_split', 'np_recombine', 'np_pseudorandom_share', 'np_pseudorandom_share_0'):
+        route(name)
+    for name in ('random_split', 'recombine'):
+        route(name, min_len=list_path_min)
+    _installed = done
+    import os
+    if os.environ.get('MPYC_AMD_TRACE_INSTALL') == '1':
+        print(f'mpyc_amd.install: {len(done)} names substituted (pid {os.getpid()})', flush=True)
+    return list(done)

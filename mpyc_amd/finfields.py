@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import functools
 import random as _random
+import sys
 from typing import Optional
 
 import numpy as np
@@ -293,7 +294,7 @@ def GF(modulus):
 
 
 def _make_array(field):
-    arr = type(f'Array{field.__name__}', (FieldArray,), {'__slots__': ()})     # finfields.py:45-60
+    arr = type(f'Array{field.__name__}', (_MirrorFieldArray,), {'__slots__': ()})     # finfields.py:45-60
     arr.field = field
     field.array = arr
     return arr
@@ -379,18 +380,41 @@ def _fops(field) -> _FieldOps:
     ops = _fops_cache.get(field)
     if ops is None:
         ops = _fops_cache[field] = _FieldOps(field)
+        _field_registry[(ops.binary, ops.modulus)] = field
     return ops
 
 
 def _scalar_value(x):
     """field element (this module's or the reference's) -> canonical int, else None"""
+    if isinstance(x, (np.ndarray, FieldArray)):
+        return None
     v = getattr(x, 'value', None)
-    if v is None or isinstance(x, (np.ndarray, FieldArray)):
+    if v is None:
         return None
     try:
         return int(v)
     except (TypeError, ValueError):
         return None
+
+
+def _ctx_add(ctx, a, b, out=None):
+    return ctx.add(a, b, out)
+
+
+def _ctx_sub(ctx, a, b, out=None):
+    return ctx.sub(a, b, out)
+
+
+def _ctx_mul(ctx, a, b, out=None):
+    return ctx.mul(a, b, out)
+
+
+def _ctx_add_scalar(ctx, a, s, out=None):
+    return ctx.add_scalar(a, s, out)
+
+
+def _ctx_mul_scalar(ctx, a, s, out=None):
+    return ctx.mul_scalar(a, s, out)
 
 
 _ctx_cache = {}
@@ -432,12 +456,156 @@ class _Rec:
             self._val = self.ctx.recombine(self.rows, self.lam)
         return self._val
 
-    def reads(self, ptr: int) -> bool:
-        return any(r.t.data_ptr() == ptr for r in self.rows)
+    def reads(self, sid: int) -> bool:
+        """does this deferred recombination read (or has it materialised into) the storage `sid`?"""
+        return any(_storage_id(r) == sid for r in self.rows) or (self._val is not None and _storage_id(self._val) == sid)
+
+
+def _storage_id(dev: DevArray) -> int:
+    """Identity of the allocation behind a device array: views (slices, reshapes, rows of a share matrix) share it,
+    so hazards between a deferred product and an in-place update are detected for every alias, not only for
+    equal base pointers."""
+    return dev.t.untyped_storage().data_ptr()
 
 
 def _src_dev(src) -> DevArray:
     return src.materialize() if isinstance(src, _Rec) else src
+
+
+_POISON = np.array(None, dtype=object)
+_HV_OWN = frozenset(('_fa', '_real', '_is_lazy', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
+                     '__reduce_ex__', '__setitem__', '__array_function__', '__array_ufunc__', '__array_finalize__',
+                     '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
+
+
+class HostView(np.ndarray):
+    """What `FieldArray.value` returns: an np.ndarray (so `isinstance(v, np.ndarray)`, sectypes.py:1366,
+    holds) that stands for the reference's object ndarray but keeps the data on the device for what the
+    runtime does on its hot path --
+
+        x = a.value; shape = x.shape; x = x.reshape(-1)          runtime.py:561-563, 643-645
+        thresha.np_random_split(field, x, t, m)                  runtime.py:495, 662
+        pickle.dumps(x) / points.append((pid + 1, x))            runtime.py:571-585
+
+    -- and resolves to the real object ndarray of canonical ints (materialised once per array, read-only:
+    FieldArray._host_value) for everything else: methods and attributes (__getattribute__), operators,
+    indexing, NumPy functions and ufuncs (__array_function__ / __array_ufunc__).  Its OWN buffer is a
+    zero-stride broadcast of None (no allocation): C-level code that bypasses every Python hook
+    (np.asarray(v), ndarray.__setitem__ from it) sees None entries, which fail loudly in the next integer
+    operation instead of yielding wrong numbers."""
+
+    __array_priority__ = 0
+
+    lazy_min = None     # None: `.value` is lazy only when read by the runtime's three hot-path methods (below) and
+    #                     carries the REAL values in its buffer everywhere else, so that it behaves like the
+    #                     reference's ndarray in every context, including C-level ones that no Python hook can
+    #                     intercept (`b[mask] = x.value`, runtime.py:1285).  An int: also lazy from that size on.
+    lazy_callers = frozenset(('_reshare', 'output', '_distribute'))     # runtime.py:643, 561, 494: `.value` is only
+    #                     reshaped, handed to thresha and pickled there
+
+    def __new__(cls, fa, lazy=None):
+        if lazy is None:
+            lazy = cls.lazy_min is not None and fa.size >= cls.lazy_min
+        if lazy:
+            obj = np.broadcast_to(_POISON, fa._shape).view(cls)
+        else:
+            obj = fa._host_value().view(cls)
+        obj._fa = fa
+        obj._is_lazy = bool(lazy)
+        return obj
+
+    def __array_finalize__(self, obj):
+        pass
+
+    def _real(self) -> np.ndarray:
+        return object.__getattribute__(self, '_fa')._host_value()
+
+    def __getattribute__(self, name):
+        if name in _HV_OWN:
+            return object.__getattribute__(self, name)
+        return getattr(object.__getattribute__(self, '_fa')._host_value(), name)
+
+    # -- stays on the device --
+    def reshape(self, *shape, **kw):
+        return HostView(self._fa.reshape(*shape, **kw), lazy=self._is_lazy or None)
+
+    def __setitem__(self, key, value):
+        """`a.value[key] = v` writes through to the array, as it does in the reference where `.value` IS the
+        storage (e.g. runtime.py:3975)."""
+        fa = self._fa
+        real = fa._host_value()
+        real.flags.writeable = True
+        try:
+            real[key] = _hv_unwrap(value)
+        finally:
+            real.flags.writeable = False
+        fa[key] = real[key]
+        fa._cache = real
+
+    def __reduce__(self):
+        return self._fa.__reduce__()
+
+    def __reduce_ex__(self, protocol):
+        return self._fa.__reduce__()
+
+    def __copy__(self):
+        return HostView(self._fa)
+
+    def __deepcopy__(self, memo):
+        return HostView(self._fa.copy())
+
+    # -- everything else: the materialised ndarray --
+    def __array_function__(self, func, types, args, kwargs):
+        return func(*_hv_unwrap(args), **_hv_unwrap(kwargs))
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return getattr(ufunc, method)(*_hv_unwrap(inputs), **_hv_unwrap(kwargs))
+
+    __hash__ = None
+
+
+def _hv_unwrap(x):
+    if isinstance(x, HostView):
+        return x._real()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_hv_unwrap(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _hv_unwrap(v) for k, v in x.items()}
+    return x
+
+
+def _hv_delegate(name):
+    def op(self, *args):
+        return getattr(self._real(), name)(*_hv_unwrap(args))
+    op.__name__ = name
+    return op
+
+
+for _n in ('add', 'sub', 'mul', 'matmul', 'truediv', 'floordiv', 'mod', 'divmod', 'pow', 'lshift', 'rshift',
+           'and', 'or', 'xor'):
+    setattr(HostView, f'__{_n}__', _hv_delegate(f'__{_n}__'))
+    setattr(HostView, f'__r{_n}__', _hv_delegate(f'__r{_n}__'))
+    setattr(HostView, f'__i{_n}__', _hv_delegate(f'__{_n}__'))      # the snapshot is read-only: x op= y rebinds
+for _n in ('neg', 'pos', 'abs', 'invert', 'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'getitem', 'iter', 'contains', 'bool',
+           'repr', 'str', 'int', 'float', 'index', 'array', 'format'):
+    setattr(HostView, f'__{_n}__', _hv_delegate(f'__{_n}__'))
+del _n
+
+
+_field_registry = {}      # (binary, modulus) -> field class: where unpickled share rows find their array type
+
+
+def _register_field(field):
+    ops = _fops(field)
+    _field_registry[(ops.binary, ops.modulus)] = field
+
+
+def _array_from_wire(binary, modulus, shape, data):
+    """Unpickle hook: rebuild a device array from field.to_bytes-format limb bytes (see FieldArray.__reduce__)."""
+    field = _field_registry.get((binary, modulus))
+    if field is None:
+        raise TypeError(f'no field with modulus {modulus:#x} has been created in this process')
+    return field.array.from_wire(data, shape)
 
 
 class FieldArray:
@@ -447,7 +615,8 @@ class FieldArray:
     of ints (any integer dtype or object), another FieldArray, or an engine DevArray; with
     check=True inputs are reduced into canonical form (negative ints wrap Python-style)."""
 
-    __slots__ = ('_devv', '_shape', '_cache', '_lazy', '__weakref__')
+    __slots__ = ()          # behaviour only: the storage slots live in the concrete leaf classes (_STORAGE_SLOTS),
+    #                         so that install() can derive the array type from mpyc's own FiniteFieldArray as well
     field = None            # set per field by GF()
     __array_priority__ = 100
 
@@ -455,6 +624,8 @@ class FieldArray:
         F = type(self).field
         ctx = _context(F)
         self._cache = None
+        if isinstance(value, HostView):
+            value = value._fa                 # `.value` of an array handed back (runtime.py:508): still on the device
         if isinstance(value, FieldArray):
             if value.field is not F:
                 raise TypeError('array over a different field')
@@ -469,7 +640,11 @@ class FieldArray:
             raise TypeError('wrap raw limb tensors in an engine.DevArray')
         # lists go through dtype=object so that big Python ints are never coerced to float64
         a = value if isinstance(value, np.ndarray) else np.array(value, dtype=object)
-        if a.dtype.kind == 'f' or a.dtype.kind == 'c':
+        if a.dtype.kind == 'f' and not check:
+            # `Zp.array(np.empty(N), check=False)` (demos/np_lpsolver.py): an uninitialised placeholder that the
+            # caller fills by item assignment; the reference keeps the float garbage, limbs start from zero
+            a = np.zeros(a.shape, dtype=np.int64)
+        if (a.dtype.kind == 'f' or a.dtype.kind == 'c') and a.size:               # np.array([]) is float64: allowed
             raise TypeError('float values are not field elements')            # tests/test_finfields.py:372-382
         shape = a.shape
         flat = a.reshape(-1)
@@ -544,14 +719,14 @@ class FieldArray:
         reads that buffer, so that deferred evaluation never observes the later mutation."""
         if not _pending_products:
             return
-        ptr = dev.t.data_ptr()
+        ptr = _storage_id(dev)
         alive = []
         for ref in _pending_products:
             arr = ref()
             if arr is None or arr._devv is not None:
                 continue
             lz = arr._lazy
-            if any(src is not None and (src.reads(ptr) if isinstance(src, _Rec) else src.t.data_ptr() == ptr)
+            if any(src is not None and (src.reads(ptr) if isinstance(src, _Rec) else _storage_id(src) == ptr)
                    for src in lz):
                 arr._dev            # noqa: B018  (property access materialises)
             else:
@@ -580,9 +755,17 @@ class FieldArray:
         return (self._lazy[0] if self._devv is None else self._devv).ctx        # DevArray and _Rec both have .ctx
 
     @property
-    def value(self) -> np.ndarray:
-        """Object ndarray of canonical Python ints (BinaryPolynomial objects for GF(2^n)), as the
-        reference stores it.  Materialised on first use, read-only snapshot."""
+    def value(self) -> 'HostView':
+        """The reference's representation (finfields.py:703-709: object ndarray of canonical Python ints,
+        BinaryPolynomial objects for GF(2^n)) as a lazy HostView: shape / reshape / pickling / being handed back to
+        thresha or the array ctor stay on the device; any other use materialises the object ndarray once
+        (read-only snapshot)."""
+        code = sys._getframe(1).f_code
+        if code.co_name in HostView.lazy_callers and code.co_filename.endswith('runtime.py'):
+            return HostView(self, lazy=True)
+        return HostView(self)
+
+    def _host_value(self) -> np.ndarray:
         if self._cache is None:
             ints = self._dev.to_ints()
             ops = _fops(type(self).field)
@@ -637,10 +820,13 @@ class FieldArray:
         _pending_products.append(weakref.ref(o))
         return o
 
-    def copy(self):
+    def copy(self, order='C'):
         return self._wrap(self._dev.clone(), self._shape)
 
-    def reshape(self, *shape):
+    def reshape(self, *shape, order='C'):
+        if order in ('F', 'f'):
+            rs = self._reshape_shape(shape)
+            return self.transpose().reshape(tuple(reversed(rs))).transpose()
         if self._devv is None and self._lazy is not None:
             # keep the product deferred through the "in-place flatten" the runtime does before sharing
             o = self._wrap_lazy_product(self._lazy[0], self._lazy[1], self._shape)
@@ -659,29 +845,49 @@ class FieldArray:
             raise ValueError(f'cannot reshape array of size {n} into shape {shape}')
         return tuple(shape)
 
-    def flatten(self):
+    def flatten(self, order='C'):
+        if order in ('F', 'f'):
+            return self.transpose().flatten()
         return self._wrap(self._dev.clone(), (self.size,))
 
-    def ravel(self):
-        return self.reshape(-1)
+    def ravel(self, order='C'):
+        return self.reshape(-1, order=order)
 
     def _limb_view(self):
         """limb tensor shaped like the array (+ trailing 2 for two-limb fields)."""
         t = self._dev.t
         return t.reshape(tuple(self._shape) + ((self.ctx.limbs,) if self.ctx.limbs else ()))
 
+    def _index_key(self, key):
+        """NumPy-style index -> torch index on the limb view (index arrays / masks move to the device)."""
+        dev = self._dev.t.device
+
+        def conv(k):
+            if isinstance(k, np.ndarray):
+                return torch.from_numpy(np.ascontiguousarray(k)).to(dev)
+            if isinstance(k, (np.integer,)):
+                return int(k)
+            if isinstance(k, list):
+                a = np.asarray(k)
+                if a.dtype.kind in 'iub':          # (nested) lists of indices / booleans index like arrays
+                    return torch.from_numpy(a if a.dtype.kind == 'b' else a.astype(np.int64)).to(dev)
+            return k
+        if isinstance(key, tuple):
+            key = tuple(conv(k) for k in key)
+            if self.ctx.limbs and Ellipsis not in key:
+                key = key + (Ellipsis, slice(None))
+            elif self.ctx.limbs:
+                key = key + (slice(None),)
+            return key
+        key = conv(key)
+        return (key, Ellipsis, slice(None)) if self.ctx.limbs and key is not Ellipsis else key
+
     def __getitem__(self, key):
-        t = self._limb_view()
-        if self.ctx.limbs:
-            key = key if isinstance(key, tuple) else (key,)
-            sub = t[key + (Ellipsis, slice(None))] if Ellipsis not in key else t[key]
-            shape = sub.shape[:-1]
-        else:
-            sub = t[key]
-            shape = sub.shape
+        sub = self._limb_view()[self._index_key(key)]
+        shape = sub.shape[:-1] if self.ctx.limbs else sub.shape
         if len(shape) == 0:
             flat = sub.reshape(1, self.ctx.limbs) if self.ctx.limbs else sub.reshape(1)
-            return type(self).field(DevArray(self.ctx, flat, 1).to_ints()[0])
+            return type(self).field(_fops(type(self).field).box(DevArray(self.ctx, flat, 1).to_ints()[0]))
         n = int(np.prod(shape, dtype=np.int64))
         flat = sub.reshape(n, self.ctx.limbs) if self.ctx.limbs else sub.reshape(n)
         if not flat.is_contiguous():
@@ -690,19 +896,36 @@ class FieldArray:
 
     def __setitem__(self, key, value):
         cls = type(self)
+        if isinstance(value, HostView):
+            value = value._fa
         if isinstance(value, (int, np.integer)) or _scalar_value(value) is not None:
             value = cls([int(value) if isinstance(value, (int, np.integer)) else _scalar_value(value)]).reshape(())
         elif not isinstance(value, FieldArray):
             value = cls(value)
+        # shape check as the reference does it (finfields.py:1019-1027): object ndarrays would not complain
+        target = np.broadcast_to(np.int8(0), self._shape)[key].shape
+        try:
+            ok = np.broadcast_shapes(value._shape, target) == tuple(target)
+        except ValueError:
+            ok = False
+        if not ok:
+            raise ValueError(f'could not broadcast input array from shape {value._shape} into shape {tuple(target)}')
         src = value._limb_view()
         self._flush_products_reading(self._dev)
-        t = self._limb_view()
-        if self.ctx.limbs:
-            key = key if isinstance(key, tuple) else (key,)
-            t[key + (Ellipsis, slice(None))] = src
-        else:
-            t[key] = src
+        self._limb_view()[self._index_key(key)] = src
         self._cache = None
+
+    def __contains__(self, value):
+        """NumPy's `in`: any element equal, after broadcasting (finfields.py:995-1005)."""
+        if isinstance(value, HostView):
+            value = value._fa
+        return bool(np.any(self == value))
+
+    @property
+    def flat(self):
+        field = type(self).field
+        for a in self._host_value().flat:
+            yield field(a)
 
     def __iter__(self):
         for i in range(len(self)):
@@ -717,9 +940,7 @@ class FieldArray:
             if other.field is not F:
                 raise TypeError('arrays over different fields')
             return ('array', other) if other.size != 1 or other.ndim > self.ndim else ('scalar', other._dev.to_ints()[0])
-        if isinstance(other, bool):
-            return None
-        if isinstance(other, (int, np.integer)):
+        if isinstance(other, (int, np.integer, np.bool_)):          # bool is an int (the reference's _mix_types)
             return 'scalar', ops.reduce_int(int(other))
         if isinstance(other, float):
             raise TypeError('float operand')
@@ -775,17 +996,17 @@ class FieldArray:
 
     # ---- arithmetic (finfields.py:1056-1124, 1189-1197) --------------------------------------
     def __add__(self, other):
-        return self._binop(other, FieldContext.add, FieldContext.add_scalar)
+        return self._binop(other, _ctx_add, _ctx_add_scalar)
 
     __radd__ = __add__
 
     def __iadd__(self, other):
-        return self._binop(other, FieldContext.add, FieldContext.add_scalar, inplace=True)
+        return self._binop(other, _ctx_add, _ctx_add_scalar, inplace=True)
 
     def __sub__(self, other):
         def sub_scalar(ctx, a, s, out):
             return ctx.add_scalar(a, _fops(type(self).field).sub(0, s), out)
-        return self._binop(other, FieldContext.sub, sub_scalar)
+        return self._binop(other, _ctx_sub, sub_scalar)
 
     def __rsub__(self, other):
         opd = self._operand(other)
@@ -799,19 +1020,19 @@ class FieldArray:
     def __isub__(self, other):
         def sub_scalar(ctx, a, s, out):
             return ctx.add_scalar(a, _fops(type(self).field).sub(0, s), out)
-        return self._binop(other, FieldContext.sub, sub_scalar, inplace=True)
+        return self._binop(other, _ctx_sub, sub_scalar, inplace=True)
 
     def __mul__(self, other):
         if isinstance(other, FieldArray) and other.field is type(self).field and other._shape == self._shape \
                 and self.size > 1 and lazy_products:
             a = self._source()
             return self._wrap_lazy_product(a, a if other is self else other._source(), self._shape)
-        return self._binop(other, FieldContext.mul, FieldContext.mul_scalar)
+        return self._binop(other, _ctx_mul, _ctx_mul_scalar)
 
     __rmul__ = __mul__
 
     def __imul__(self, other):
-        return self._binop(other, FieldContext.mul, FieldContext.mul_scalar, inplace=True)
+        return self._binop(other, _ctx_mul, _ctx_mul_scalar, inplace=True)
 
     def __neg__(self):
         return self._wrap(self.ctx.neg(self._dev), self._shape)
@@ -894,7 +1115,7 @@ class FieldArray:
         """A @ self for a small public/host matrix A (w, k) and self (k, n): the shape of the
         Vandermonde and Lagrange products in thresha (one pass over HBM, unreduced accumulation)."""
         if self.ndim != 2:
-            raise NotImplementedError('left operand @ array needs a 2-D array on the right')
+            return (other if isinstance(other, FieldArray) else type(self)(other)).__matmul__(self)
         F = type(self).field
         A = np.asarray(other.value if isinstance(other, FieldArray) else other, dtype=object)
         vec = A.ndim == 1
@@ -919,7 +1140,11 @@ class FieldArray:
         """Matrix product over the field on the device (finfields.py:1126-1135): 1-D / 2-D operands
         with NumPy's matmul shape rules; the right operand may be anything the ctor accepts."""
         cls = type(self)
+        if isinstance(other, HostView):
+            other = other._fa
         if not isinstance(other, FieldArray):
+            if not isinstance(other, (np.ndarray, list, tuple)):
+                return NotImplemented                   # e.g. a secure array: its __rmatmul__ takes over
             other = cls(other)
         elif other.field is not cls.field:
             raise TypeError('arrays over different fields')
@@ -931,8 +1156,29 @@ class FieldArray:
             A = [int(v) for v in self._dev.to_ints()]
             out = self.ctx.group_matvec(other._dev, [A[i * g:(i + 1) * g] for i in range(r)])
             return self._wrap(out, other._shape[:-2] + (r, 1))
-        if self.ndim not in (1, 2) or other.ndim not in (1, 2):
-            raise NotImplementedError('matmul of arrays with more than 2 dimensions is not accelerated')
+        if self.ndim == 0 or other.ndim == 0:
+            raise ValueError('matmul: Input operand does not have enough dimensions')
+        if self.ndim > 2 or other.ndim > 2:
+            # stacks of matrices (NumPy's matmul broadcasting over the leading dimensions): one product per matrix
+            A = self.reshape(1, -1) if self.ndim == 1 else self
+            B = other.reshape(-1, 1) if other.ndim == 1 else other
+            if A._shape[-1] != B._shape[-2]:
+                raise ValueError(f'matmul: shapes {self._shape} and {other._shape} not aligned')
+            batch = tuple(np.broadcast_shapes(A._shape[:-2], B._shape[:-2]))
+            lb = (self.ctx.limbs,) if self.ctx.limbs else ()
+            At = A._limb_view().expand(*batch, *A._shape[-2:], *lb).reshape(-1, *A._shape[-2:], *lb)
+            Bt = B._limb_view().expand(*batch, *B._shape[-2:], *lb).reshape(-1, *B._shape[-2:], *lb)
+            outs = [self._from_limb_view(At[i]) @ self._from_limb_view(Bt[i]) for i in range(At.shape[0])]
+            mshape = (A._shape[-2], B._shape[-1])
+            if not outs:
+                res = cls(np.zeros(batch + mshape, dtype=object))
+            else:
+                res = _np_stack(outs, 0).reshape(batch + mshape)
+            if self.ndim == 1:
+                res = res.reshape(res._shape[:-2] + res._shape[-1:])
+            elif other.ndim == 1:
+                res = res.reshape(res._shape[:-1])
+            return res
         M, K = (1, self._shape[0]) if self.ndim == 1 else self._shape
         K2, N = (other._shape[0], 1) if other.ndim == 1 else other._shape
         if K != K2:
@@ -983,10 +1229,34 @@ class FieldArray:
             return a.unsigned_()
         return a.signed_() if cls.field.is_signed else a.unsigned_()
 
-    def sum(self, axis=None):
-        """Sum of all elements as a field element (np.sum on a field array, finfields.py:766-819)."""
-        if axis is None or self.ndim == 1:
-            return type(self).field(self.ctx.sum(self._dev).to_ints()[0])
+    def sum(self, axis=None, keepdims=False, initial=None, **kw):
+        """Sum of all elements as a field element / along axes (np.sum on a field array, finfields.py:1332-1337)."""
+        if kw.get('where') is not None or kw.get('out') is not None:
+            raise NotImplementedError('sum: where / out')
+        if initial is not None:
+            r = self.sum(axis=axis, keepdims=keepdims)
+            return r + initial
+        if isinstance(axis, (tuple, list)):
+            axes = sorted((a if a >= 0 else a + self.ndim) for a in axis)
+            r = self
+            for a in reversed(axes):
+                r = r.sum(axis=a)
+            if keepdims:
+                shape = tuple(1 if d in axes else s for d, s in enumerate(self._shape))
+                r = (r if isinstance(r, FieldArray) else type(self)([r])).reshape(shape)
+            return r
+        if keepdims:
+            r = self.sum(axis=axis)
+            if axis is None:
+                return type(self)([r]).reshape((1,) * self.ndim)
+            axis = axis if axis >= 0 else axis + self.ndim
+            r = r if isinstance(r, FieldArray) else type(self)([r])
+            return r.reshape(self._shape[:axis] + (1,) + self._shape[axis + 1:])
+        if axis is None or self.ndim <= 1:
+            F = type(self).field
+            if self.size == 0:
+                return F(_fops(F).box(0))
+            return F(_fops(F).box(self.ctx.sum(self._dev).to_ints()[0]))
         # reduce one axis: move it last ON THE DEVICE (a permuted copy of the limb tensor), then per row of k
         # elements: k <= 16 -> one thread per row (ffgpu_group_matvec with a row of ones); many rows -> matrix x
         # ones(k) (the HBM-bound matvec kernels); few long rows -> one two-stage reduction (ffgpu_sum) per row
@@ -1018,25 +1288,42 @@ class FieldArray:
                 ov[r:r + 1].copy_(ctx.sum(DevArray(ctx, lv[r].reshape(-1, ctx.limbs) if ctx.limbs else lv[r], k)).t)
         return cls._wrap(out, moved.shape[:-1])
 
-    def prod(self):
-        """Product of all elements (finfields.py:1339-1349): log2(n) halving passes of the mul kernel."""
+    def prod(self, axis=None, **kw):
+        """Product of all elements / along one axis (finfields.py:1339-1349): log2(k) halving passes of the
+        element-wise product kernel."""
         cls, ctx = type(self), self.ctx
-        if self.size == 0:
-            return cls.field(1)
-        cur, n = self._dev, self.size
-        while n > 1:
-            h = n // 2
-            lo = DevArray(ctx, cur.t[:h], h)
-            hi = DevArray(ctx, cur.t[h:2 * h], h)
-            nxt = ctx.empty(h + (n & 1))
-            ctx.mul(lo, hi, out=DevArray(ctx, nxt.t[:h], h))
-            if n & 1:
-                nxt.t[h:].copy_(cur.t[2 * h:])
-            cur, n = nxt, h + (n & 1)
-        return cls.field(cur.to_ints()[0])
+        if kw.get('initial') is not None or kw.get('keepdims'):
+            raise NotImplementedError('prod: initial / keepdims')
+        if axis is not None and self.ndim > 1:
+            axis = axis if axis >= 0 else axis + self.ndim
+            perm = [axis] + [d for d in range(self.ndim) if d != axis]        # reduced axis FIRST: halves are contiguous
+            t = self._limb_view().permute(*(perm + ([self.ndim] if ctx.limbs else [])))
+            moved = self._from_limb_view(t)
+            k, rest = moved._shape[0], moved._shape[1:]
+            inner = int(np.prod(rest, dtype=np.int64))
+            if k == 0:
+                return cls(np.ones(rest, dtype=object))
+            cur = moved._dev
+        else:
+            if self.size == 0:
+                return cls.field(1)
+            k, rest, inner, cur = self.size, (), 1, self._dev
+        while k > 1:
+            h = k // 2
+            lo = DevArray(ctx, cur.t[:h * inner], h * inner)
+            hi = DevArray(ctx, cur.t[h * inner:2 * h * inner], h * inner)
+            nxt = ctx.empty((h + (k & 1)) * inner)
+            ctx.mul(lo, hi, out=DevArray(ctx, nxt.t[:h * inner], h * inner))
+            if k & 1:
+                nxt.t[h * inner:].copy_(cur.t[2 * h * inner:k * inner])
+            cur, k = nxt, h + (k & 1)
+        if rest == () and (axis is None or self.ndim <= 1):
+            return cls.field(_fops(cls.field).box(DevArray(ctx, cur.t[:1], 1).to_ints()[0]))
+        return cls._wrap(DevArray(ctx, cur.t[:inner], inner), rest)
 
-    def trace(self, offset=0):
-        return _np_diagonal(self, offset).sum()
+    def trace(self, offset=0, axis1=0, axis2=1, **kw):
+        d = _np_diagonal(self, offset, axis1, axis2)
+        return d.sum() if d.ndim == 1 else d.sum(axis=-1)
 
     # ---- linear algebra (finfields.py:872-978) --------------------------------------------------
     @classmethod
@@ -1107,13 +1394,29 @@ class FieldArray:
 
     # ---- NumPy protocol (finfields.py:728-819): data movement on the device limb tensors, arithmetic
     #      through the kernels; anything not listed raises instead of silently computing on the host ----
-    def __array__(self, dtype=None, copy=None):
-        return np.array(self.value, dtype=object if dtype is None else dtype)
+    # NB no __array__: like the reference's class, np.asarray(a) goes through the sequence protocol and yields an
+    # object ndarray of field ELEMENTS (what np.vectorize / np.testing rely on); the raw values are `a.value`.
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        name = ufunc.__name__
+        if method == 'at':
+            # in-place ufunc.at(a, indices[, b]) (finfields.py:759-761): gather, apply, scatter on the device
+            a, idx = inputs[0], inputs[1]
+            sub = a[idx]
+            res = getattr(np, name)(sub, *inputs[2:])
+            a[idx] = res
+            return None
+        if method == 'reduce' and name in ('add', 'multiply'):
+            a, axis = inputs[0], (inputs[1] if len(inputs) > 1 else kwargs.get('axis', 0))
+            return a.sum(axis=axis) if name == 'add' else a.prod(axis=axis)
+        if method == 'accumulate' and name in ('add', 'multiply'):
+            a, axis = inputs[0], (inputs[1] if len(inputs) > 1 else kwargs.get('axis', 0))
+            return _np_scan(a, axis, name == 'multiply')
+        if method == 'outer' and name in ('add', 'subtract', 'multiply'):
+            cls, a, b = _pair(inputs[0], inputs[1])
+            return getattr(np, name)(a.reshape(tuple(a.shape) + (1,) * b.ndim), b)
         if method != '__call__' or kwargs.get('out') is not None:
             return NotImplemented
-        name = ufunc.__name__
         a = inputs[0]
         b = inputs[1] if len(inputs) > 1 else None
         first = isinstance(a, FieldArray)
@@ -1136,22 +1439,150 @@ class FieldArray:
         return NotImplemented
 
     def __array_function__(self, func, types, args, kwargs):
-        impl = _ARRAY_FUNCTIONS.get(func.__name__)
-        if impl is None and func.__name__ in _MOVEMENT_FUNCTIONS:
+        # `self` is a field ELEMENT when the reference's element class redirects here (finfields.py:83-85)
+        cls = type(self) if isinstance(self, FieldArray) else type(self).array
+        name = func.__name__
+        args = _lift_elements(cls, args)
+        kwargs = {k: _lift_elements(cls, v) for k, v in kwargs.items()}
+        impl = _ARRAY_FUNCTIONS.get(name)
+        if impl is None and name in _MOVEMENT_FUNCTIONS:
             return _np_movement(func, args, kwargs)
         if impl is None:
-            raise NotImplementedError(f'numpy.{func.__name__} is not supported on GPU field arrays')
+            raise NotImplementedError(f'numpy.{name} is not supported on GPU field arrays')
         return impl(*args, **kwargs)
+
+    # ---- in-place variants and reflected stubs of the reference (finfields.py:1148-1157, 1170-1271) ----
+    def _assign(self, res: 'FieldArray'):
+        if res._shape != self._shape:
+            raise ValueError('non-broadcastable output operand')
+        self._flush_products_reading(self._dev)
+        self._dev.t.copy_(res._dev.t.reshape(self._dev.t.shape))       # views of this array see the update
+        self._cache = None
+        return self
+
+    def __itruediv__(self, other):
+        r = self.__truediv__(other)
+        return r if r is NotImplemented else self._assign(r)
+
+    def __ilshift__(self, other):
+        r = self.__lshift__(other)
+        return r if r is NotImplemented else self._assign(r)
+
+    def __irshift__(self, other):
+        r = self.__rshift__(other)
+        return r if r is NotImplemented else self._assign(r)
+
+    def __ipow__(self, other):
+        r = self.__pow__(other)
+        return r if r is NotImplemented else self._assign(r)
+
+    def __imatmul__(self, other):
+        r = self.__matmul__(other)
+        if r is NotImplemented:
+            return r
+        if isinstance(r, FieldArray) and r._shape == self._shape:
+            return self._assign(r)
+        raise ValueError('in-place matmul needs a result of the same shape')
+
+    def __rpow__(self, other):
+        return NotImplemented
+
+    def __rlshift__(self, other):
+        return NotImplemented
+
+    def __rrshift__(self, other):
+        return NotImplemented
+
+    def __int__(self):
+        """(signed) integer value of a size-1 array (finfields.py:1385-1392)."""
+        return self.intarray(self).__int__()
+
+    def __abs__(self):
+        return abs(self.signed_())                                     # finfields.py:1394-1396
+
+    # ---- class-level primitives on RAW values (finfields.py:1408-1470, 1550-1563): the runtime calls e.g.
+    #      field.array._sqrt(r2, INV=True) on `.value` arrays (runtime.py:4265); computed on the device, returned
+    #      as the object ndarray (or int) the reference returns ----
+    @classmethod
+    def _raw(cls, a):
+        if isinstance(a, HostView):
+            return a._fa, True
+        if isinstance(a, FieldArray):
+            return a, True
+        if isinstance(a, np.ndarray):
+            return cls(a, check=False), True
+        return cls([int(a)], check=False), False
+
+    @staticmethod
+    def _unraw(r, is_array):
+        if is_array:
+            return np.array(r._host_value())             # writable copy, as the reference returns a fresh array
+        return r._host_value().reshape(-1)[0]
+
+    @classmethod
+    def _pow(cls, a, b):
+        A, arr = cls._raw(a)
+        if isinstance(b, np.ndarray) or isinstance(b, (list, tuple)):
+            b = np.asarray(b)
+            shape = np.broadcast_shapes(A._shape, b.shape)
+            vals = np.broadcast_to(b, shape).reshape(-1)
+            Ab = A._from_limb_view(A._limb_view().expand(*shape, *((A.ctx.limbs,) if A.ctx.limbs else ())))
+            out = Ab.copy()
+            for e in set(int(v) for v in vals):       # one kernel per distinct public exponent
+                mask = np.array([int(v) == e for v in vals]).reshape(shape)
+                out[mask] = Ab[mask] ** e
+            return cls._unraw(out, True)
+        return cls._unraw(A ** int(b), arr)
+
+    @classmethod
+    def _reciprocal(cls, a):
+        A, arr = cls._raw(a)
+        return cls._unraw(A.reciprocal(), arr)
+
+    @classmethod
+    def _sqrt(cls, a, INV=False):
+        A, arr = cls._raw(a)
+        return cls._unraw(A.sqrt(INV=INV), arr)
+
+    @classmethod
+    def _is_sqr(cls, a):
+        A, arr = cls._raw(a)
+        r = A.is_sqr()
+        return r if arr else bool(r.reshape(-1)[0])
+
+    # ---- ndarray-style methods of the reference class (finfields.py:1308-1368) on the device ----
+    def compress(self, condition, axis=None):
+        return _np_movement(np.compress, (condition, self), {'axis': axis})
+
+    def nonzero(self):
+        return np.nonzero(_np_nonzero_mask(self))
+
+    def take(self, indices, axis=None, **kw):
+        return _np_take(self, indices, axis)
+
+    def repeat(self, repeats, axis=None):
+        return _np_repeat(self, repeats, axis)
+
+    def diagonal(self, offset=0, axis1=0, axis2=1):
+        return _np_diagonal(self, offset, axis1, axis2)
+
+    def swapaxes(self, axis1, axis2):
+        return _ARRAY_FUNCTIONS['swapaxes'](self, axis1, axis2)
+
+    @staticmethod
+    def diag(a, k=0):
+        return _np_movement(np.diag, (a, k), {})
 
     @property
     def T(self):
         return self.transpose()
 
     def transpose(self, *axes):
-        if len(axes) == 1 and isinstance(axes[0], (tuple, list)):
-            axes = tuple(axes[0])
+        if len(axes) == 1 and (axes[0] is None or isinstance(axes[0], (tuple, list))):
+            axes = tuple(axes[0] or ())
         if not axes:
             axes = tuple(reversed(range(self.ndim)))
+        axes = tuple(a if a >= 0 else a + self.ndim for a in axes)
         t = self._limb_view()
         perm = tuple(axes) + ((self.ndim,) if self.ctx.limbs else ())
         return self._from_limb_view(t.permute(*perm))
@@ -1165,7 +1596,15 @@ class FieldArray:
         return self._wrap(DevArray(self.ctx, flat, n), shape)
 
     def tolist(self):
-        return self.unsigned_().tolist()
+        """(nested) list of field elements (finfields.py:1320-1321)."""
+        return np.vectorize(type(self).field, otypes='O')(self._host_value()).tolist()
+
+    def __reduce__(self):
+        """pickle.dumps(row) -- how the runtime marshals arrays (runtime.py:484,571,655) -- ships the
+        field.to_bytes-format limb bytes from the pinned staging buffer instead of a graph of PyLongs; the receiving
+        party rebuilds a device array (no Python integers on either side)."""
+        ops = _fops(type(self).field)
+        return _array_from_wire, (ops.binary, ops.modulus, self._shape, self.to_wire())
 
     # ---- wire format (finfields.py:91-102) straight from device limbs ------------------------------
     def to_wire(self) -> bytes:
@@ -1182,22 +1621,43 @@ class FieldArray:
         return np.concatenate([b, pad], axis=1).tobytes()
 
     @classmethod
-    def from_wire(cls, data: bytes, shape=None) -> 'FieldArray':
+    def from_wire(cls, data: bytes, shape=None, check=True) -> 'FieldArray':
+        """field.from_bytes (finfields.py:97-102) straight into device limbs.  The length must be a whole number of
+        byte_length-sized elements (and match `shape`); with check=True (default: the bytes come from a peer) the
+        values are reduced on the device like `field.array(...)` does (finfields.py:724), so that kernels never
+        see a non-canonical element."""
         F = cls.field
         ctx = _context(F)
         eb, r = ctx.elem_bytes, F.byte_length
+        if len(data) % r:
+            raise ValueError(f'{len(data)} bytes is not a whole number of {r}-byte field elements')
         n = len(data) // r
+        if shape is not None and int(np.prod(shape, dtype=np.int64)) != n:
+            raise ValueError(f'{n} elements on the wire do not fill shape {tuple(shape)}')
         b = np.frombuffer(data, dtype=np.uint8).reshape(n, r)
         if r < eb:
             b = np.concatenate([b, np.zeros((n, eb - r), dtype=np.uint8)], axis=1)
         elif r > eb:
+            if check and n and b[:, eb:].any():
+                raise ValueError('field element on the wire exceeds the element width')
             b = b[:, :eb]
         raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb])
         raw = raw.reshape(n, ctx.limbs) if ctx.limbs else raw.reshape(n)
-        return cls._wrap(ctx.from_numpy(raw), shape if shape is not None else (n,))
+        dev = ctx.from_numpy(raw)
+        if check and n:
+            dev = ctx.reduce(dev, out=dev)
+        return cls._wrap(dev, shape if shape is not None else (n,))
 
     def __repr__(self):
         return f'{self.intarray(self)}'
+
+
+_STORAGE_SLOTS = ('_devv', '_shape', '_cache', '_lazy', '__weakref__')
+
+
+class _MirrorFieldArray(FieldArray):
+    """Concrete base of the array types this module's GF() creates."""
+    __slots__ = _STORAGE_SLOTS
 
 
 def _matrix_to_array(cls, mtx: DevMatrix) -> FieldArray:
@@ -1214,7 +1674,7 @@ def _matrix_to_array(cls, mtx: DevMatrix) -> FieldArray:
 def _np_concatenate(arrays, axis=0):
     arrays = list(arrays)
     cls = type(next(a for a in arrays if isinstance(a, FieldArray)))
-    arrays = [a if isinstance(a, FieldArray) else cls(a) for a in arrays]
+    arrays = [_as_arr(cls, a) for a in arrays]
     if axis is None:
         arrays, axis = [a.reshape(-1) for a in arrays], 0
     t = torch.cat([a._limb_view() for a in arrays], dim=axis if axis >= 0 else axis + arrays[0].ndim)
@@ -1224,7 +1684,7 @@ def _np_concatenate(arrays, axis=0):
 def _np_stack(arrays, axis=0):
     arrays = list(arrays)
     cls = type(next(a for a in arrays if isinstance(a, FieldArray)))
-    arrays = [a if isinstance(a, FieldArray) else cls(a) for a in arrays]
+    arrays = [_as_arr(cls, a) for a in arrays]
     nd = arrays[0].ndim + 1
     t = torch.stack([a._limb_view() for a in arrays], dim=axis if axis >= 0 else axis + nd)
     return arrays[0]._from_limb_view(t)
@@ -1255,7 +1715,7 @@ _MOVEMENT_FUNCTIONS = frozenset((
     'triu', 'delete', 'append', 'broadcast_to', 'compress', 'pad', 'where', 'copy', 'resize', 'select', 'choose'))
 
 
-def _np_movement(func, args, kwargs):
+def _np_movement(func, args, kwargs, keep=()):
     name = func.__name__
     if name == 'pad' and ('constant_values' in kwargs or 'end_values' in kwargs or len(args) > 3):
         raise NotImplementedError('np.pad on GPU field arrays: only zero / element-copy padding')
@@ -1287,7 +1747,7 @@ def _np_movement(func, args, kwargs):
         if isinstance(x, (list, tuple)) and find_cls(x) is not None:
             return type(x)(sub(y, True) for y in x)
         if inside and not isinstance(x, FieldArray):
-            return index_of(cls(x))                       # plain ints / lists next to field arrays
+            return index_of(_as_arr(cls, x))              # plain ints / lists next to field arrays
         return x
 
     args = list(args)
@@ -1295,7 +1755,7 @@ def _np_movement(func, args, kwargs):
         args[1] = cls(args[1])
     if name == 'where' and len(args) == 3:
         args[1:] = [a if isinstance(a, FieldArray) else cls(a) for a in args[1:]]
-    iargs = [sub(a) for a in args]
+    iargs = [a if i in keep else sub(a) for i, a in enumerate(args)]
     ikw = {k: sub(v) for k, v in kwargs.items()}
     res = func(*iargs, **ikw)
     ctx = pool[0].ctx
@@ -1307,7 +1767,7 @@ def _np_movement(func, args, kwargs):
 
     def back(r):
         if isinstance(r, np.ndarray):
-            idx = torch.from_numpy(np.ascontiguousarray(r, dtype=np.int64).reshape(-1)).to(table.device)
+            idx = torch.from_numpy(np.array(r, dtype=np.int64).reshape(-1)).to(table.device)
             t = table.index_select(0, idx)
             return cls._wrap(DevArray(ctx, t, idx.shape[0]), tuple(r.shape))
         if isinstance(r, (list, tuple)):
@@ -1435,9 +1895,158 @@ def _np_tri(a, k, upper):
 def _np_axes(a, fn):
     return _limb_dims(a, fn)
 
+def _lift_elements(cls, x):
+    """field elements among the arguments of a NumPy function -> 0-d arrays (the reference unwraps them to raw
+    values, finfields.py:778-797)."""
+    if isinstance(x, cls.field):
+        return cls([int(x.value)], check=False).reshape(())
+    if isinstance(x, HostView):
+        return x._fa
+    if isinstance(x, (list, tuple)) and not isinstance(x, FieldArray):
+        y = [_lift_elements(cls, v) for v in x]
+        if any(a is not b for a, b in zip(x, y)):
+            return type(x)(y) if type(x) in (list, tuple) else y
+    return x
+
+
+def _as_arr(cls, x):
+    if isinstance(x, FieldArray):
+        return x
+    if isinstance(x, HostView):
+        return x._fa
+    if isinstance(x, np.ndarray) and x.dtype.kind == 'f':
+        # a float ndarray combined with field arrays (tests/test_runtime.py:475-478): the reference lets NumPy mix
+        # the float objects into the share array (meaningless values, only the metadata of the secure array is
+        # used afterwards); limbs cannot hold floats, so they are truncated
+        x = x.astype(np.int64)
+    return cls(x)
+
+
+def _pair(a, b):
+    cls = type(a) if isinstance(a, FieldArray) else type(b)
+    return cls, _as_arr(cls, a), _as_arr(cls, b)
+
+
+def _scalar_out(r):
+    """0-d result -> field element, as NumPy returns scalars"""
+    if isinstance(r, FieldArray) and r.ndim == 0:
+        return r[()]
+    return r
+
+
+def _np_dot(a, b):
+    cls, a, b = _pair(a, b)
+    if a.ndim == 0 or b.ndim == 0:
+        return a * b
+    if a.ndim <= 2 and b.ndim <= 2:
+        return a @ b
+    return _np_tensordot(a, b, axes=((a.ndim - 1,), (b.ndim - 2,)))
+
+
+def _np_vdot(a, b):
+    cls, a, b = _pair(a, b)
+    return a.reshape(-1) @ b.reshape(-1)
+
+
+def _np_tensordot(a, b, axes=2):
+    cls, a, b = _pair(a, b)
+    if isinstance(axes, (int, np.integer)):
+        ax_a, ax_b = list(range(a.ndim - axes, a.ndim)), list(range(axes))
+    else:
+        ax_a, ax_b = axes
+        ax_a = [ax_a] if isinstance(ax_a, (int, np.integer)) else list(ax_a)
+        ax_b = [ax_b] if isinstance(ax_b, (int, np.integer)) else list(ax_b)
+    ax_a = [x if x >= 0 else x + a.ndim for x in ax_a]
+    ax_b = [x if x >= 0 else x + b.ndim for x in ax_b]
+    if [a.shape[x] for x in ax_a] != [b.shape[x] for x in ax_b]:
+        raise ValueError('shape-mismatch for sum')
+    free_a = [d for d in range(a.ndim) if d not in ax_a]
+    free_b = [d for d in range(b.ndim) if d not in ax_b]
+    K = int(np.prod([a.shape[x] for x in ax_a], dtype=np.int64))
+    M = int(np.prod([a.shape[x] for x in free_a], dtype=np.int64))
+    N = int(np.prod([b.shape[x] for x in free_b], dtype=np.int64))
+    A2 = a.transpose(*(free_a + ax_a)).reshape(M, K)
+    B2 = b.transpose(*(ax_b + free_b)).reshape(K, N)
+    out_shape = tuple(a.shape[x] for x in free_a) + tuple(b.shape[x] for x in free_b)
+    if K == 0:
+        return cls(np.zeros(out_shape, dtype=object))
+    return (A2 @ B2).reshape(out_shape)
+
+
+def _np_inner(a, b):
+    cls, a, b = _pair(a, b)
+    if a.ndim == 0 or b.ndim == 0:
+        return a * b
+    return _scalar_out(_np_tensordot(a, b, axes=((a.ndim - 1,), (b.ndim - 1,))))
+
+
+def _np_kron(a, b):
+    cls, a, b = _pair(a, b)
+    nd = max(a.ndim, b.ndim, 1)
+    sa = (1,) * (nd - a.ndim) + tuple(a.shape)
+    sb = (1,) * (nd - b.ndim) + tuple(b.shape)
+    A = a.reshape(tuple(x for s_ in sa for x in (s_, 1)))
+    B = b.reshape(tuple(x for s_ in sb for x in (1, s_)))
+    return (A * B).reshape(tuple(x * y for x, y in zip(sa, sb)))
+
+
+def _np_vander(x, N=None, increasing=False):
+    """np.vander on a 1-D field array: one exponentiation kernel per column (runtime.py:4931)."""
+    if x.ndim != 1:
+        raise ValueError('x must be a one-dimensional array or sequence.')
+    N = len(x) if N is None else N
+    if N == 0:
+        return type(x)(np.empty((len(x), 0), dtype=object))
+    cols = [x ** e for e in range(N)]
+    if not increasing:
+        cols.reverse()
+    return _np_stack(cols, axis=1)
+
+
+def _np_insert(arr, obj, values, axis=None):
+    cls = type(arr) if isinstance(arr, FieldArray) else type(values)
+    return _np_movement(np.insert, (_as_arr(cls, arr), obj, _as_arr(cls, values)), {'axis': axis}, keep=(1,))
+
+
+def _np_trim_zeros(filt, trim='fb', **kw):
+    nz = np.flatnonzero(_np_nonzero_mask(filt))
+    if nz.size == 0:
+        return filt[:0]
+    lo = int(nz[0]) if 'f' in trim.lower() else 0
+    hi = int(nz[-1]) + 1 if 'b' in trim.lower() else len(filt)
+    return filt[lo:hi]
+
+
+def _np_scan(a, axis, mul: bool, include_initial=False):
+    """np.cumsum / np.cumprod along one axis: Hillis-Steele scan, ceil(log2 k) passes of the add / mul kernel."""
+    if axis is None:
+        a, axis = a.reshape(-1), 0
+    axis = axis if axis >= 0 else axis + a.ndim
+    if include_initial:                                   # np.cumulative_sum/prod: leading 0 / 1 along the axis
+        init = type(a)(np.full(a.shape[:axis] + (1,) + a.shape[axis + 1:], 1 if mul else 0, dtype=object))
+        return _np_concatenate([init, _np_scan(a, axis, mul)], axis)
+    perm = [axis] + [d for d in range(a.ndim) if d != axis]
+    inv = [perm.index(d) for d in range(a.ndim)]
+    moved = a.transpose(*perm) if a.ndim > 1 else a.copy()
+    ctx = a.ctx
+    k = moved.shape[0] if moved.ndim else 1
+    inner = moved.size // k if k else 0
+    cur = moved._dev if moved._dev is not a._dev else moved._dev.clone()
+    step = 1
+    while step < k and inner:
+        nxt = cur.clone()
+        m = (k - step) * inner
+        lo = DevArray(ctx, cur.t[:m], m)
+        hi = DevArray(ctx, cur.t[step * inner:k * inner], m)
+        (ctx.mul if mul else ctx.add)(lo, hi, out=DevArray(ctx, nxt.t[step * inner:k * inner], m))
+        cur, step = nxt, step * 2
+    res = a._wrap(cur, moved.shape)
+    return res.transpose(*inv) if a.ndim > 1 else res
+
+
 _ARRAY_FUNCTIONS = {
     'shape': lambda a: a.shape, 'ndim': lambda a: a.ndim, 'size': lambda a: a.size,
-    'reshape': lambda a, *shape, **kw: a.reshape(*shape if shape else (kw.get('newshape', kw.get('shape')),)),
+    'reshape': lambda a, *shape, order='C', **kw: a.reshape(*shape if shape else (kw.get('newshape', kw.get('shape')),), order=order or 'C'),
     'ravel': lambda a: a.ravel(), 'copy': lambda a: a.copy(),
     'transpose': lambda a, axes=None: a.transpose(*([axes] if axes is not None else [])),
     'concatenate': _np_concatenate, 'stack': _np_stack,
@@ -1451,10 +2060,16 @@ _ARRAY_FUNCTIONS = {
     if isinstance(src, (int, np.integer)) else _np_movement(np.moveaxis, (a, src, dst), {}),
     'expand_dims': lambda a, axis: a.reshape(np.expand_dims(np.empty(a.shape, dtype=np.int8), axis).shape),
     'squeeze': lambda a, axis=None: a.reshape(np.squeeze(np.empty(a.shape, dtype=np.int8), axis).shape),
-    'sum': lambda a, axis=None, **kw: a.sum(axis),
-    'dot': lambda a, b: a @ b, 'matmul': lambda a, b: a @ b,
-    'outer': _np_outer, 'convolve': _np_convolve, 'prod': lambda a, axis=None, **kw: a.prod(),
-    'trace': lambda a, offset=0, **kw: a.trace(offset),
+    'sum': lambda a, axis=None, **kw: a.sum(axis, **{k: v for k, v in kw.items() if k in ('keepdims', 'initial') and v is not np._NoValue}),
+    'dot': _np_dot, 'matmul': lambda a, b: _pair(a, b)[1] @ _pair(a, b)[2], 'vdot': _np_vdot, 'inner': _np_inner,
+    'tensordot': _np_tensordot, 'kron': _np_kron, 'vander': _np_vander, 'insert': _np_insert,
+    'trim_zeros': _np_trim_zeros,
+    'cumsum': lambda a, axis=None, **kw: _np_scan(a, axis, False),
+    'cumprod': lambda a, axis=None, **kw: _np_scan(a, axis, True),
+    'cumulative_sum': lambda a, axis=None, include_initial=False, **kw: _np_scan(a, axis, False, include_initial),
+    'cumulative_prod': lambda a, axis=None, include_initial=False, **kw: _np_scan(a, axis, True, include_initial),
+    'outer': _np_outer, 'convolve': _np_convolve, 'prod': lambda a, axis=None, **kw: a.prod(axis),
+    'trace': lambda a, offset=0, axis1=0, axis2=1, **kw: a.trace(offset, axis1, axis2),
     'nonzero': lambda a: np.nonzero(_np_nonzero_mask(a)), 'flatnonzero': lambda a: np.flatnonzero(_np_nonzero_mask(a)),
     'count_nonzero': lambda a, **kw: int(np.count_nonzero(_np_nonzero_mask(a))),
     'any': lambda a, **kw: bool(_np_nonzero_mask(a).any()), 'all': lambda a, **kw: bool(_np_nonzero_mask(a).all()),

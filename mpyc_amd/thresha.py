@@ -26,7 +26,7 @@ from math import prod
 import numpy as np
 
 from .engine import DevArray, DevMatrix
-from .finfields import FieldArray, _Rec, _context, _fops, _matrix_to_array, _src_dev
+from .finfields import FieldArray, HostView, _Rec, _context, _fops, _matrix_to_array, _src_dev
 
 __all__ = ['random_split', 'recombine', 'np_random_split', 'np_recombine', '_recombination_vector',
            'pseudorandom_share', 'pseudorandom_share_zero', 'np_pseudorandom_share', 'np_pseudorandom_share_0', 'PRF']
@@ -58,6 +58,8 @@ def _next_nonce():
 
 
 def _as_field_array(field, s) -> FieldArray:
+    if isinstance(s, HostView):
+        s = s._fa
     if isinstance(s, FieldArray):
         return s
     vals = [v if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v)) for v in s] \
@@ -136,7 +138,7 @@ class ShareMatrix:
         """The reference's return value: plain object ndarray (m, n) of canonical ints."""
         out = np.empty(self.shape, dtype=object)
         for i in range(self.shape[0]):
-            out[i] = self[i].value
+            out[i] = self[i]._host_value()
         return out
 
     def __array__(self, dtype=None, copy=None):
@@ -188,6 +190,8 @@ def _recombination_vector(field, xs, x_r):
 def _rows_on_device(field, shares):
     rows = []
     for sh in shares:
+        if isinstance(sh, HostView):
+            sh = sh._fa
         if isinstance(sh, FieldArray):
             rows.append((sh if sh.ndim == 1 else sh.reshape(-1)).device_array)
         elif isinstance(sh, DevArray):
@@ -310,6 +314,9 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
     if l == 0 or (mask_bits == 0 and bound & (bound - 1) == 0):   # bound == 1: all draws are 0
         return ctx.mul_scalar(ctx.from_ints([0] * n), 0)
     d = (m - len(items[0][0])) if zero else 1
+    if d == 0:                                   # t = 0: the zero sharing has no random part (thresha.py:208-216)
+        out.t.zero_()
+        return out
     i1 = ops.reduce_int(i + 1)
     weights = []
     for S, prf in items:

@@ -57,3 +57,12 @@ def coracle():
     if _newer(src, dst):
         co.build()
     return co
+
+
+# Development aid (build container, no GPU): MPYC_AMD_CPUCTX=1 runs the API-level `-m gpu` tests of the mirror on
+# tests/cpuctx.py's Python-integer context, to debug HOST logic before spending GPU time.  Never set on the GPU box.
+if os.environ.get('MPYC_AMD_CPUCTX') == '1':
+    import torch as _torch
+    from cpuctx import use_cpu_contexts as _use
+    _use()
+    _torch.cuda.is_available = lambda: True

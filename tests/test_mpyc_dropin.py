@@ -1,0 +1,128 @@
+"""The drop-in behind the real MPyC runtime.
+
+mpyc_amd.install() substitutes the device array type (derived from mpyc's own FiniteFieldArray) and the
+sharing functions into an importable mpyc; these tests then run the REFERENCE's own unit tests and its
+np_aes demo, unmodified, on top of it:
+
+  * build container (reference in /root/reference, no GPU): `-m "not gpu"`, on the Python-integer context of
+    tests/cpuctx.py -- checks the HOST logic of the substitution;
+  * GPU box: `-m gpu`, on libffgpu's kernels.  The reference does not exist there unless a copy was staged
+    into the untracked scratch directory `_refstage/` (tools/stage_reference.sh, build container only; it is
+    git-ignored, never committed); without it these tests skip.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE = os.path.join(ROOT, '_refstage')
+FIPS197 = '69c4e0d86a7b0430d8cdb78070b4c55a'        # docs/demos.rst:611, FIPS-197 appendix C.1
+
+
+def _ref_root(gpu: bool):
+    if gpu:
+        return STAGE if os.path.isdir(os.path.join(STAGE, 'mpyc')) else None
+    return '/root/reference' if os.path.isdir('/root/reference/mpyc') else None
+
+
+def _env(ref, cpuctx: bool, site: str):
+    env = dict(os.environ)
+    env['PYTHONPATH'] = os.pathsep.join([site, os.path.join(ROOT, 'tests'), ROOT, ref])
+    env['MPYC_GPU'] = '1'
+    env.pop('MPYC_AMD_CPUCTX', None)
+    if cpuctx:
+        env['MPYC_AMD_CPUCTX'] = '1'
+    return env
+
+
+def _run_reference_tests(ref, cpuctx, files, extra_env=None, k=None):
+    env = _env(ref, cpuctx, os.path.join(ROOT, 'tests', 'devsite'))
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'pytest', '-p', 'refplugin', '-p', 'no:cacheprovider', '-q', '--tb=short']
+    cmd += [os.path.join(ref, 'tests', f) for f in files]
+    if k:
+        cmd += ['-k', k]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=3000)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    return r.stdout
+
+
+def _run_np_aes(ref, cpuctx, args):
+    site = os.path.join(ROOT, 'tests', 'devsite') if cpuctx else os.path.join(ROOT, 'mpyc_amd', 'autoinstall')
+    env = _env(ref, cpuctx, site)
+    env['MPYC_AMD_TRACE_INSTALL'] = '1'
+    r = subprocess.run([sys.executable, 'np_aes.py'] + args, capture_output=True, text=True,
+                       cwd=os.path.join(ref, 'demos'), env=env, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and FIPS197 in out, out[-3000:]
+    assert 'mpyc_amd.install' in out, out[-3000:]          # the substitution really was active in this process
+    return out
+
+
+REF_FILES = ['test_finfields.py', 'test_thresha.py', 'test_gfpx.py', 'test_runtime.py', 'test_secpols.py',
+             'test_seclists.py', 'test_mpctools.py', 'test_random.py', 'test_statistics.py']
+
+
+# ---------------------------------------------------------------------------------------------------
+# build container: host logic under the real runtime
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_install_substitutes_array_type_and_sharing_functions():
+    code = '''
+import mpyc_amd
+names = mpyc_amd.install()
+from mpyc import finfields, thresha
+import mpyc_amd.finfields as gff
+F = finfields.GF(2**61 - 1)                      # created AFTER install -> device array type ...
+assert issubclass(F.array, gff.FieldArray) and issubclass(F.array, finfields.FiniteFieldArray), F.array.__mro__
+assert F.array.field is F
+G = finfields.GF(finfields.find_irreducible(2, 8))
+assert issubclass(G.array, gff.FieldArray)
+W = finfields.GF(finfields.find_prime_root(200)[0])       # wider than the device path: the reference's own class
+assert not issubclass(W.array, gff.FieldArray) and issubclass(W.array, finfields.PrimeFieldArray)
+X = finfields.GF(finfields.find_irreducible(3, 2))        # odd-characteristic extension field: reference class
+assert not issubclass(X.array, gff.FieldArray)
+assert 'thresha.np_random_split' in names and thresha.np_random_split.reference is not thresha.np_random_split
+import mpyc_amd.thresha as gth
+assert gth._recombination_vector(F, (1, 2, 3), 0) == [3, F.modulus - 3, 1]
+ops = gff._fops(G)
+assert ops.binary and ops.modulus == 0x11b and ops.mul(57, 67) == 137 and ops.order == 256
+print("WIRING_OK", len(names))
+'''
+    env = _env('/root/reference', False, os.path.join(ROOT, 'tests', 'devsite'))
+    env['MPYC_GPU'] = '0'
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=env, timeout=300)
+    assert r.returncode == 0 and 'WIRING_OK' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_reference_suite_under_install_host_logic():
+    """lschoe/mpyc's own tests, unmodified, with install() active (list path routed to the device functions too)."""
+    out = _run_reference_tests('/root/reference', True, REF_FILES, {'MPYC_AMD_LIST_MIN': '0'})
+    assert ' passed' in out and 'failed' not in out
+
+
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_np_aes_demo_under_install_host_logic():
+    _run_np_aes('/root/reference', True, ['-1'])
+    _run_np_aes('/root/reference', True, ['-1', '-M3'])          # 3 party processes, TCP on localhost
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU box (needs the staged reference copy)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
+def test_reference_suite_under_install_on_gpu():
+    out = _run_reference_tests(STAGE, False, REF_FILES, {'MPYC_AMD_LIST_MIN': '0'})
+    assert ' passed' in out and 'failed' not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
+def test_np_aes_demo_under_install_on_gpu():
+    _run_np_aes(STAGE, False, ['-1'])
+    _run_np_aes(STAGE, False, ['-1', '-M3'])
