@@ -27,7 +27,7 @@ import numpy as np
 
 from mpyc import finfields, gfpx, thresha
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('GOLDEN_OUT') or os.path.dirname(os.path.abspath(__file__))     # GOLDEN_OUT: regenerate elsewhere (tests)
 rng = random.Random(20260925)
 
 P61 = 2**61 - 1
@@ -300,6 +300,7 @@ def prss_cases():
 def matmul_cases():
     """F.array @ F.array from the reference (finfields.py:1126-1135; tests/test_finfields.py:389-404)."""
     out = {}
+    rng = random.Random(79)          # own stream: this file does not depend on what ran before it
     for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P127', finfields.GF(P127)),
                     ('P128', finfields.GF(P128)), ('P128G', finfields.GF(P128G)), ('P63G', finfields.GF(P63G)),
                     ('GF19', finfields.GF(19)), ('P31', finfields.GF(P31)),
@@ -431,7 +432,80 @@ def npfunc_cases():
     print('wrote npfuncs.json', os.path.getsize(os.path.join(OUT, 'npfuncs.json')))
 
 
+def wire_cases():
+    """The reference's marshalled forms of share rows:
+      * field.to_bytes / from_bytes (finfields.py:91-102): byte_length little-endian bytes per element, incl. the
+        2-byte elements of GF(2^8) (order.bit_length() = 9, finfields.py:524) and the 12-byte ones of 2^96-17;
+      * the message frame `<qI{n}s` = pc (8 bytes signed) | payload size (4 bytes) | payload written by
+        asyncoro.MessageExchanger.send (asyncoro.py:54-64), produced here by the reference's own send() on a
+        recording transport, and its reassembly by data_received (asyncoro.py:66-106) from odd-sized chunks."""
+    from mpyc import asyncoro
+    r = random.Random(80)
+    out = {'fields': {}, 'frames': []}
+    for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P96', finfields.GF(P96)),
+                    ('P80', finfields.GF(P80)), ('P128', finfields.GF(P128)), ('P128G', finfields.GF(P128G)),
+                    ('P31', finfields.GF(P31)), ('P40', finfields.GF(P40)), ('GF19', finfields.GF(19)),
+                    ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))), ('GF2_16', finfields.GF(GF2X(BINARIES['GF2_16']))),
+                    ('GF2_64', finfields.GF(GF2X(BINARIES['GF2_64']))), ('GF2_100', finfields.GF(GF2X(BINARIES['GF2_100']))),
+                    ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
+        q = F.order
+        vals = [0, 1, q - 1, q - 2, q >> 1] + [r.randrange(q) for _ in range(12)]
+        data = F.to_bytes(vals)
+        assert F.from_bytes(data) == vals
+        # the same bytes from a field array's representation (what runtime.py:480,567,650 marshal in mix32-64bit mode)
+        arr = F.array(vals)
+        assert F.to_bytes([int(v) for v in arr.value]) == data
+        out['fields'][name] = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int),
+                               'byte_length': F.byte_length, 'values': hxl(vals), 'bytes': data.hex()}
+
+    class Recorder:
+        def __init__(self):
+            self.chunks = []
+
+        def write(self, data):
+            self.chunks.append(bytes(data))
+
+    class FakeRuntime:
+        class options:
+            no_prss = True
+
+        def set_protocol(self, pid, proto):
+            pass
+
+    tx = asyncoro.MessageExchanger(FakeRuntime(), peer_pid=1)
+    tx.transport = Recorder()
+    msgs = [(0, b''), (1, b'\x00'), (-1, bytes(range(7))), (2**63 - 1, bytes(r.randrange(256) for _ in range(40))),
+            (-2**63, out['fields']['P64']['bytes'] and bytes.fromhex(out['fields']['P64']['bytes'])),
+            (123456789, bytes.fromhex(out['fields']['GF2_8']['bytes']))]
+    for pc, payload in msgs:
+        tx.send(pc, payload)
+    stream = b''.join(tx.transport.chunks)
+    assert tx.nbytes_sent == len(stream)
+    # reassembly by the reference's receiver from chunks of 1, 2, 3, ... bytes
+    rx = asyncoro.MessageExchanger(FakeRuntime(), peer_pid=0)
+    pos, step = 0, 1
+    while pos < len(stream):
+        rx.data_received(stream[pos:pos + step])
+        pos += step
+        step += 1
+    assert {pc: bytes(p) for pc, p in rx.buffers.items()} == dict(msgs)
+    out['frames'] = [{'pc': pc, 'payload': payload.hex(), 'frame': chunk.hex()}
+                     for (pc, payload), chunk in zip(msgs, tx.transport.chunks)]
+    with open(os.path.join(OUT, 'wire.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote wire.json', os.path.getsize(os.path.join(OUT, 'wire.json')))
+
+
+ALL = ('main', 'prss', 'matmul', 'linalg', 'npfuncs', 'sqrt', 'wire')
+
 if __name__ == '__main__':
+    args = sys.argv[1:]
+    if 'wire' in args:
+        wire_cases()
+        sys.exit(0)
+    if 'matmul' in args:
+        matmul_cases()
+        sys.exit(0)
     if 'sqrt' in sys.argv[1:]:
         sqrt_cases()
         sys.exit(0)
@@ -447,3 +521,4 @@ if __name__ == '__main__':
     linalg_cases()
     npfunc_cases()
     sqrt_cases()
+    wire_cases()
