@@ -100,6 +100,19 @@ def roof(bytes_per_launch, ms):
             'bytes_per_launch': int(bytes_per_launch), 'traffic': None}
 
 
+I8_MFMA_PEAK_TOPS = 3944.0   # measured dense int8 MFMA ceiling (MI355X_MICROARCH.md, matrix-core table; 2 ops per MAC)
+
+
+def roof_mfma(field_macs, digits, ms):
+    """Matrix-core product: every field MAC is digits x digits int8 MACs on the MFMA pipe (signed base-256 digit
+    planes, all 2L-1 diagonals); achieved = int8 ops actually issued / time, against the int8 MFMA ceiling."""
+    tops = 2.0 * field_macs * digits * digits / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(tops, 1), 'peak': I8_MFMA_PEAK_TOPS, 'unit': 'TOP/s (int8)',
+            'frac': round(tops / I8_MFMA_PEAK_TOPS, 4), 'ms_per_launch': round(ms, 4), 'traffic': None,
+            'int8_macs_per_field_mac': digits * digits, 'units_per_s': round(field_macs / (ms * 1e-3), 1),
+            'field_GMAC_per_s': round(field_macs / (ms * 1e-3) / 1e9, 1)}
+
+
 def cpu_baseline(n_full, t, m, lam, seed=20260925):
     """C port of the reference path (oracle/fforacle.c) on this host: the same 3-stage pass
     over the same workload shape.  Also times the reference-style NumPy object-array path
@@ -147,15 +160,177 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
             'reference_style_sample': f'n={ns} of the same pass with NumPy dtype=object arrays (oracle/nporacle.py)'}
 
 
+def u128_rows(rows, n, device, gen):
+    """(rows, n, 2) int64 limb pairs: uniform canonical elements of GF(2^128 - 173)."""
+    x = torch.randint(-2**63, 2**63 - 1, (rows, n, 2), dtype=torch.int64, device=device, generator=gen)
+    # (hi, lo) >= p only if hi == 2^64-1 and lo >= 2^64-173: fold those few
+    bad = (x[..., 1] == -1) & (x[..., 0] < 0) & (x[..., 0] >= -173)
+    x[..., 0] = torch.where(bad, x[..., 0] + 173, x[..., 0])
+    x[..., 1] = torch.where(bad, torch.zeros_like(x[..., 1]), x[..., 1])
+    return x
+
+
+def multi_gpu_leg(dist, rank, world, local_rank, backend, n, steps, warmup, lagrange):
+    """configs[3] on N GPUs (every rank runs this): 128-bit prime 2^128-173, m = 7, t = 3, n gates per GPU.
+
+    gate_sharded    the production layout: gates sharded by element, every rank runs fused mul+split and the
+                    recombination from 2t+1 = 7 rows on its own shard -- no collective.
+    party_major_*   the one layout with an exchange step: share row j lives whole on rank j % N (the GPUs stand in
+                    for the parties); before recombining, every rank needs its column range of all 7 rows.
+                    `all_to_all`: multigpu.exchange_party_major (batched point-to-point of column slices, 1/N of
+                    the all-gather traffic); `allgather`: multigpu.PartyMajorGather (ONE all_gather_into_tensor of
+                    whole rows -- the north star's wording).  Both are followed by the same k = 7 recombination of
+                    the rank's own column range.  Rows have N*n elements (weak scaling: n secrets per GPU).
+    Times are wall clock between barriers, MAX over ranks; `exchange_share` = the exchange timed alone / the step."""
+    from mpyc_amd.engine import DevArray, FieldContext
+    from mpyc_amd import multigpu
+    P128 = 2**128 - 173
+    t, m = 3, 7
+    k = 2 * t + 1
+    eb = 16
+    ctx = FieldContext(P128, device=local_rank)
+    dev = ctx.torch_device
+    lam = lagrange(P128, range(1, k + 1))
+    red_dev = dev if backend == 'nccl' else 'cpu'
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / steps * 1e3          # ms per step
+
+    res = {'config': {'workload': 'configs[3]: GF(2^128-173) (two limbs), m=7, t=3, gate = modmul + np_random_split + '
+                                  'np_recombine(k=7)', 'n_per_gpu': n, 'n_gpus': world, 'backend': backend,
+                      'steps': steps, 'warmup': warmup}}
+    gen = torch.Generator(device=dev)
+
+    # ---- element-sharded gate: no collective -----------------------------------------------------------------
+    gen.manual_seed(977 + rank)
+    sets = []
+    for _ in range(2):
+        ab = u128_rows(2 + t, n, dev, gen)
+        coef = ctx.empty_matrix(t, n)
+        for j in range(t):
+            coef.row(j).t.copy_(ab[2 + j])
+        shares = ctx.empty_matrix(m, n)
+        y = ctx.empty(n)
+        sets.append({'a': DevArray(ctx, ab[0].contiguous(), n), 'b': DevArray(ctx, ab[1].contiguous(), n), 'coef': coef,
+                     'shares': shares, 'y': y, 'rec': ctx.recombine_plan([shares.row(j) for j in range(k)], lam, y)})
+        del ab
+    it = [0]
+
+    def gate():
+        s_ = sets[it[0] % len(sets)]
+        it[0] += 1
+        ctx.split(s_['a'], s_['coef'], t, m, out=s_['shares'], mul_by=s_['b'])
+        s_['rec']()
+    ms = timed(gate)
+    torch.cuda.synchronize()
+    if not torch.equal(sets[0]['y'].t, ctx.mul(sets[0]['a'], sets[0]['b']).t):
+        raise SystemExit('bench parity check failed: P128 gate does not open to a*b')
+    bpu = (2 + t + m) * eb + (k + 1) * eb
+    res['gate_sharded'] = {'ms_per_step': round(ms, 5), 'gates_per_s': round(n * world / (ms * 1e-3), 1),
+                           'algorithmic_bytes_per_gate': bpu, 'GBps_per_gpu': round(bpu * n / (ms * 1e-3) / 1e9, 1),
+                           'frac_of_hbm_peak': round(bpu * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'collective': None}
+    del sets
+    torch.cuda.empty_cache()
+
+    # ---- party-major rows: exchange + recombination of the own column range -------------------------------
+    ntot = n * world
+    lo, hi = multigpu.shard_range(ntot, rank, world)
+
+    def row_slice(j, r):
+        """columns of rank r of share row j: reproducible anywhere from (j, r) -- lets every rank check what it receives"""
+        g = torch.Generator(device=dev)
+        g.manual_seed(1_000_003 * (j + 1) + r)
+        return u128_rows(1, multigpu.shard_range(ntot, r, world)[1] - multigpu.shard_range(ntot, r, world)[0], dev, g)[0]
+
+    template = torch.empty((0, 2), dtype=torch.int64, device=dev)
+    local = {j: torch.cat([row_slice(j, r) for r in range(world)]) for j in range(k) if multigpu.row_owner(j, world) == rank}
+    want = [row_slice(j, rank) for j in range(k)]
+    recv = [torch.empty((hi - lo, 2), dtype=torch.int64, device=dev) for _ in range(k)]
+    y = ctx.empty(hi - lo)
+    row_ids = list(range(k))
+    got = multigpu.exchange_party_major(local, row_ids, ntot, template=template, recv=recv)
+    torch.cuda.synchronize()
+    for j in range(k):
+        if not torch.equal(got[j], want[j]):
+            raise SystemExit(f'bench parity check failed: exchanged slice of row {j} differs on rank {rank}')
+    y_want = ctx.recombine([DevArray(ctx, w_, hi - lo) for w_ in want], lam)
+
+    def a2a_exchange():
+        return multigpu.exchange_party_major(local, row_ids, ntot, template=template, recv=recv)
+
+    def a2a_step():
+        sl = a2a_exchange()
+        ctx.recombine([DevArray(ctx, s_, hi - lo) for s_ in sl], lam, out=y)
+    ms_step = timed(a2a_step)
+    torch.cuda.synchronize()
+    if not torch.equal(y.t, y_want.t):
+        raise SystemExit('bench parity check failed: party-major recombination (all-to-all)')
+    ms_x = timed(a2a_exchange)
+    owned = len(local)
+    sent = owned * (ntot - (hi - lo)) * eb                         # bytes this rank sends to its peers per step
+    rcvd = (k - owned) * (hi - lo) * eb
+    res['party_major_all_to_all'] = {
+        'ms_per_step': round(ms_step, 5), 'ms_exchange_alone': round(ms_x, 5),
+        'exchange_share': round(ms_x / ms_step, 4), 'secrets_per_s': round(ntot / (ms_step * 1e-3), 1),
+        'rank0_bytes_sent': sent, 'rank0_bytes_received': rcvd,
+        'rank0_exchange_GBps': round((sent + rcvd) / (ms_x * 1e-3) / 1e9, 1) if world > 1 else 0.0,
+        'collective': 'batched isend/irecv of column slices (exchange_party_major)'}
+    del recv, got
+
+    pg = multigpu.PartyMajorGather(k, ntot, template)
+    for j, row in local.items():
+        pg.block_row(j).copy_(row)
+    del local
+    torch.cuda.empty_cache()
+    rows_view = None
+
+    def ag_step():
+        pg.gather()
+        ctx.recombine([DevArray(ctx, pg.row(j)[lo:hi], hi - lo) for j in range(k)], lam, out=y)
+    y.t.zero_()
+    ms_step = timed(ag_step)
+    torch.cuda.synchronize()
+    if not torch.equal(y.t, y_want.t):
+        raise SystemExit('bench parity check failed: party-major recombination (all-gather)')
+    ms_x = timed(pg.gather)
+    res['party_major_allgather'] = {
+        'ms_per_step': round(ms_step, 5), 'ms_exchange_alone': round(ms_x, 5),
+        'exchange_share': round(ms_x / ms_step, 4), 'secrets_per_s': round(ntot / (ms_step * 1e-3), 1),
+        'bytes_received_per_rank': pg.bytes_received,
+        'exchange_GBps_per_rank': round(pg.bytes_received / (ms_x * 1e-3) / 1e9, 1) if world > 1 else 0.0,
+        'collective': 'all_gather_into_tensor of whole rows (PartyMajorGather)'}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--n', type=int, default=10_000_000, help='elements per GPU')
+    ap.add_argument('--n', type=int, default=int(os.environ.get('FFGPU_BENCH_N', 10_000_000)), help='elements per GPU')
     ap.add_argument('--sets', type=int, default=4, help='rotating buffer sets')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-multi-gpu-leg', action='store_true', help='skip the configs[3] / party-major section')
+    ap.add_argument('--layout', choices=('element', 'party-major'), default='element',
+                    help="'party-major': only the configs[3] section (gate sharded + party-major exchange), more steps")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -284,6 +459,20 @@ def main():
                       'ms_per_step': round(elapsed_unfused / args.steps * 1e3, 5),
                       'note': 'same step as three kernels (mul, split, recombine) with c written to HBM'}
 
+    # configs[3] on all N ranks: element-sharded P128 gate and the party-major exchange (the one collective)
+    if not args.no_multi_gpu_leg:
+        full = args.layout == 'party-major'
+        try:
+            leg = multi_gpu_leg(dist, rank, world, local_rank, backend, n,
+                                args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else 2, lagrange)
+        except torch.OutOfMemoryError as exc:
+            leg = {'error': f'OutOfMemoryError: {exc}'}
+        out['multi_gpu'] = leg
+        torch.cuda.empty_cache()
+    if args.layout == 'party-major':
+        args.no_extras = True
+        args.no_cpu_baseline = True
+
     if rank == 0 and not args.no_extras:
         eb = 8
         reps = 10
@@ -316,6 +505,7 @@ def main():
         kern['device_copy'] = dict(roof(2 * eb * n, ms_copy), kernel='k_copy16 (80 MB -> 80 MB, rotating sets)')
         def optional_measurements():
             """Everything beyond the step's own kernels; a failure here must not cost the headline line."""
+            from mpyc_amd import gfpx as ggx, protocols
             # A gate INSIDE a chain of multiplications (production mode): the k = 3 sub-share rows received in the
             # previous gate are recombined in registers, squared and re-shared with the device CSPRNG in ONE kernel
             # (ffgpu_gate_rng): 3 reads + 3 writes per element, all three stages of the headline step.
@@ -387,9 +577,7 @@ def main():
                 Cm = ctx.empty(dim * dim)
                 ms = time_launches(lambda s: ctx.matmul(Am, Bm, dim, dim, dim, out=Cm), [0], 2)
                 macs = float(dim) ** 3
-                kern[f'matmul_p61_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'int8 MFMA (signed-digit limb GEMM)', 'unit': 'GMAC/s',
-                                             'achieved': round(macs / (ms * 1e-3) / 1e9, 1),
-                                             'frac': 0.0, 'units_per_s': round(macs / (ms * 1e-3), 1)}
+                kern[f'matmul_p61_{dim}'] = dict(roof_mfma(macs, 8, ms), kernel='k_limb_gemm<PM64,8> (8 signed base-256 digits)')
                 del Am, Bm, Cm
             # the shape the reference's author names as the np_bnnmnist bottleneck (demos/np_bnnmnist.py:10-15): a
             # 1 x 4096 activation row times a 4096 x 4096 weight matrix, and the transposed (matrix x vector) form
@@ -406,6 +594,8 @@ def main():
                 byts = eb * (mm_ * kk_ + kk_ * nn_ + mm_ * nn_)
                 kern[f'matmul_p61_{mm_}x{kk_}x{nn_}'] = dict(roof(byts, ms), units_per_s=round(mm_ * kk_ * nn_ / (ms * 1e-3), 1),
                                                             algorithmic_bytes_per_unit=None)
+                if mm_ == 64:
+                    kern[f'matmul_p61_{mm_}x{kk_}x{nn_}']['mfma'] = roof_mfma(float(mm_) * kk_ * nn_, 8, ms)
                 del big, small, outm
             # dense products over two-limb primes (12 / 16 signed digits, diagonals in passes on the matrix cores)
             for nm_, pw_ in (('p96', 2**96 - 17), ('p128', 2**128 - 173)):
@@ -419,9 +609,8 @@ def main():
                 cw.reduce(Bw, out=Bw)
                 Cw = cw.empty(dim * dim)
                 ms = time_launches(lambda s_: cw.matmul(Aw, Bw, dim, dim, dim, out=Cw), [0], 2)
-                kern[f'matmul_{nm_}_{dim}'] = {'ms_per_launch': round(ms, 4), 'bound': 'int8 MFMA (signed-digit limb GEMM, passes)',
-                                               'unit': 'GMAC/s', 'achieved': round(float(dim) ** 3 / (ms * 1e-3) / 1e9, 1), 'frac': 0.0,
-                                               'units_per_s': round(float(dim) ** 3 / (ms * 1e-3), 1)}
+                kern[f'matmul_{nm_}_{dim}'] = dict(roof_mfma(float(dim) ** 3, 12 if cw.elem_bytes == 12 else 16, ms),
+                                                   kernel='k_limb_gemm_wide (12 / 16 signed digits, diagonals in passes)')
                 del Aw, Bw, Cw
             # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
             del sets[1:]
@@ -444,14 +633,38 @@ def main():
                 bpu = (1 + m2) * eb
                 kern[f'split_rng_p64_m7t3_chacha{rounds}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                                                   units_per_s=round(n / (ms * 1e-3), 1))
+            plans64 = {}
             for kk in (t2 + 1, 2 * t2 + 1):
                 lam64 = lagrange(P64, range(1, kk + 1))
-                for s in sets64:
-                    s.rec = ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y)
-                ms = time_launches(lambda s: s.rec(), sets64, reps)
+                plans64[kk] = [ctx64.recombine_plan([s.shares.row(j) for j in range(kk)], lam64, s.y) for s in sets64]
+                ms = time_launches(lambda pl: pl(), plans64[kk], reps)
                 bpu = (kk + 1) * eb
                 kern[f'recombine_p64_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
                                                     units_per_s=round(n / (ms * 1e-3), 1))
+            # second headline: configs[2] as ONE timed pass per secret -- share generation (m=7,t=3, coefficients
+            # supplied: the parity mode) followed by recombination from t+1 = 4 rows (and from 2t+1 = 7 rows)
+            cfg2 = {'metric': 'secrets/sec (Shamir share m=7,t=3 + Lagrange recombine) on 10^7 secrets, 64-bit prime',
+                    'config': {'workload': 'configs[2]: GF(2^64-189), n = 10^7 secrets, np_random_split(m=7,t=3, coefficients '
+                                           'supplied) then np_recombine from k rows', 'n': n, 'prime': '2^64-189', 'm': m2, 't': t2},
+                    'unit': 'secrets/s', 'dtype': 'u64'}
+            for kk in (t2 + 1, 2 * t2 + 1):
+                pairs = list(zip(sets64, plans64[kk]))
+
+                def share_and_recombine(sp):
+                    ctx64.split(sp[0].a, sp[0].coef, t2, m2, out=sp[0].shares)
+                    sp[1]()
+                ms = time_launches(share_and_recombine, pairs, reps)
+                bpu = (1 + t2 + m2) * eb + (kk + 1) * eb
+                cfg2[f'k{kk}'] = dict(roof(bpu * n, ms), value=round(n / (ms * 1e-3), 1), algorithmic_bytes_per_unit=bpu,
+                                      ms_per_pass=round(ms, 5))
+                if not torch.equal(sets64[0].y.t, sets64[0].a.t):
+                    raise SystemExit('bench parity check failed: recombine(split(s)) != s for configs[2]')
+            cfg2['value'] = cfg2[f'k{t2 + 1}']['value']
+            cfg2['roofline'] = dict({q: kern['split_p64_m7t3'][q] for q in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')},
+                                    kernel='k_split<PM64<true,false>,3> (dominant: 88 of the 128 B per secret)',
+                                    ms_per_launch=kern['split_p64_m7t3']['ms_per_launch'])
+            out['configs2'] = cfg2
+            del plans64
             # generic (non pseudo-Mersenne) primes: reciprocal / Montgomery reductions, u32 storage
             from mpyc_amd.engine import DevArray as _DA
             for label, modulus in (('rc64_generic63', 6616326157076047771), ('rc32_p31', 2**31 - 1),
@@ -472,29 +685,55 @@ def main():
                                             units_per_s=round(n / (ms * 1e-3), 1))
                 del bufs
                 torch.cuda.empty_cache()
+            # configs[4] names GF(2^128) next to GF(2^8): wide binary fields (carry-less products on the integer
+            # multiplier; gfpx.py:988-1045), mul / share generation / recombination at the m=7,t=3 setting
+            for label, modulus, tail, ebg in (('gf2_64', (1 << 64) | 0x1b, (), 8), ('gf2_128', (1 << 128) | 0x87, (2,), 16)):
+                cb_ = FieldContext(modulus, binary=True, device=local_rank)
+                bufs = []
+                for _ in range(3):
+                    x = torch.randint(-2**63, 2**63 - 1, (3, n) + tail, dtype=torch.int64, device=ctx.torch_device, generator=gen)
+                    bufs.append(tuple(_DA(cb_, x[i], n) for i in range(3)))
+                ms = time_launches(lambda s: cb_.mul(s[0], s[1], out=s[2]), bufs, reps)
+                kern[f'mul_{label}'] = dict(roof(3 * ebg * n, ms), algorithmic_bytes_per_unit=3 * ebg, bound_note='integer ALU (carry-less product)',
+                                            units_per_s=round(n / (ms * 1e-3), 1))
+                cfb = cb_.empty_matrix(t2, n)
+                for j in range(t2):
+                    cfb.row(j).t.copy_(bufs[j][1].t)
+                shb = [cb_.empty_matrix(m2, n) for _ in range(2)]
+                ms = time_launches(lambda i_: cb_.split(bufs[i_][0], cfb, t2, m2, out=shb[i_ % 2]), [0, 1, 2], reps)
+                bpu = (1 + t2 + m2) * ebg
+                kern[f'split_{label}_m7t3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+                Fb = gff.GF(ggx.GFpX(2)(modulus))
+                for kk in (t2 + 1, 2 * t2 + 1):
+                    lamb = [int(v) for v in gth._recombination_vector(Fb, tuple(range(1, kk + 1)), 0)]
+                    plans = [cb_.recombine_plan([shb[i_].row(j) for j in range(kk)], lamb, bufs[i_][2]) for i_ in range(2)]
+                    ms = time_launches(lambda pl: pl(), plans, reps)
+                    bpu = (kk + 1) * ebg
+                    kern[f'recombine_{label}_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu, bound_note='LDS tables / ALU',
+                                                            units_per_s=round(n / (ms * 1e-3), 1))
+                cb_.split(bufs[0][0], cfb, t2, m2, out=shb[0])
+                lamb = [int(v) for v in gth._recombination_vector(Fb, tuple(range(1, t2 + 2)), 0)]
+                if not torch.equal(cb_.recombine([shb[0].row(j) for j in range(t2 + 1)], lamb).t, bufs[0][0].t):
+                    raise SystemExit(f'bench parity check failed for {label} split/recombine')
+                del bufs, cfb, shb, plans
+                torch.cuda.empty_cache()
             # configs[3] shape on ONE GPU: 128-bit prime (two limbs), gate = mul + split(m=7,t=3) + recombine(k=7)
             del sets64[:]
             torch.cuda.empty_cache()
             P128 = 2**128 - 173
             ctx128 = FieldContext(P128, device=local_rank)
 
-            def u128_rows(rows):
-                x = torch.randint(-2**63, 2**63 - 1, (rows, n, 2), dtype=torch.int64, device=ctx.torch_device,
-                                  generator=gen)
-                # canonical: (hi,lo) >= p only if hi == 2^64-1 and lo >= 2^64-173: fold those few
-                bad = (x[..., 1] == -1) & (x[..., 0] < 0) & (x[..., 0] >= -173)
-                x[..., 0] = torch.where(bad, x[..., 0] + 173, x[..., 0])
-                x[..., 1] = torch.where(bad, torch.zeros_like(x[..., 1]), x[..., 1])
-                return x
+            def u128(rows):
+                return u128_rows(rows, n, ctx.torch_device, gen)
 
             class Set128:
                 def __init__(s):
                     from mpyc_amd.engine import DevArray
-                    ab = u128_rows(2)
+                    ab = u128(2)
                     s.a, s.b = DevArray(ctx128, ab[0], n), DevArray(ctx128, ab[1], n)
                     s.c = ctx128.empty(n)
                     s.coef = ctx128.empty_matrix(t2, n)
-                    cf_ = u128_rows(t2)
+                    cf_ = u128(t2)
                     for j in range(t2):
                         s.coef.row(j).t.copy_(cf_[j])
                     s.shares = ctx128.empty_matrix(m2, n)
@@ -550,40 +789,51 @@ def main():
             # multiplications, bit decomposition with shared random bits, GF(2) affine map on bit shares,
             # recomposition -- the compute of all m = 3 parties (t = 1) on this GPU, no networking
             # (mpyc_amd/protocols.py; opened result checked against the public S-box kernel).
-            from mpyc_amd import finfields as gff, gfpx as ggx, protocols
             F8 = gff.GF(ggx.GFpX(2)(0x11b))
             A8 = [[(rows8[r__] >> c__) & 1 for c__ in range(8)] for r__ in range(8)]
             B8 = [(b8 >> r__) & 1 for r__ in range(8)]
             for n8, tag in ((1_000_000, '1e6'), (100_000_000, '1e8')):
                 xpub = DevArray(ctx8, torch.randint(0, 256, (n8,), dtype=torch.uint8, device=ctx.torch_device, generator=gen), n8)
-                xs = protocols.share(ctx8, xpub, 1, 3)
+                xs = protocols.as_matrix(ctx8, protocols.share(ctx8, xpub, 1, 3))
                 rb = DevArray(ctx8, torch.randint(0, 2, (8 * n8,), dtype=torch.uint8, device=ctx.torch_device, generator=gen), 8 * n8)
-                rbits = protocols.share(ctx8, rb, 1, 3)
-                res = protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8)
-                if not torch.equal(protocols.open_(ctx8, F8, res, 1).t, ctx8.sbox(xpub, rows8, b8).t):
+                rbits = protocols.as_matrix(ctx8, protocols.share(ctx8, rb, 1, 3))
+                del rb
+                want8 = ctx8.sbox(xpub, rows8, b8).t
+
+                def opened(mtx):
+                    return protocols.open_(ctx8, F8, [mtx.row(i_) for i_ in range(3)], 1).t
+                res = protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8)
+                if not torch.equal(opened(res), want8):
                     raise SystemExit('bench parity check failed for the secure S-box layer')
                 del res
-                ms = time_launches(lambda s_: protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
-                # algorithmic bytes per secure byte over all 3 parties: x^254 as 11 fused chain gates (operands read
-                # as 1 or 3 sub-share rows each, 3 rows written) + one final recombination = 76 per party = 228;
-                # bit decomposition 3 x (9 + 3 + 17) + 3 = 90; affine + recomposition 3 x 9 = 27
-                bpu = 345
+                ms = time_launches(lambda s_: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
+                # algorithmic bytes per secure byte, all 3 parties (t = 1, k = 3 senders): x^254 as 11 chain gates, each
+                # sender reading its factors as 1 (plain share) or 3 (pending sub-shares) rows and writing 3 rows:
+                # (4+6+6+7+6+6+7+6+9+9+6) x 3 = 216; opening the masked value from 2 parties: 6 rows + 16 bit shares
+                # + 1 = 23; bits + affine map + recomposition: (1 + 8 + 1) x 3 = 30
+                bpu = 269
                 kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
                                                              units_per_s=round(n8 / (ms * 1e-3), 1),
-                                                             kernels_per_layer=58)
+                                                             kernels_per_layer=13)
                 if n8 <= 10**6:
                     # the same layer captured once in a HIP graph (device-resident generator state: fresh
                     # randomness on every replay) -- the launch-bound regime is where graphs pay
                     st8 = ctx8.rng_state()
-                    cg8 = CapturedLaunches(lambda: protocols.sbox_layer(ctx8, F8, xs, rbits, 1, A8, B8, rng=st8))
+                    cg8 = CapturedLaunches(lambda: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8, rng=st8))
                     cg8.replay()
-                    if not torch.equal(protocols.open_(ctx8, F8, cg8.result, 1).t, ctx8.sbox(xpub, rows8, b8).t):
+                    if not torch.equal(opened(cg8.result), want8):
                         raise SystemExit('bench parity check failed for the graph-replayed secure S-box layer')
                     msg = time_launches(lambda s_: cg8.replay(), [0], 20)
                     kern[f'secure_sbox_layer_m3t1_{tag}_hipgraph'] = dict(roof(bpu * n8, msg), algorithmic_bytes_per_unit=bpu,
                                                                            units_per_s=round(n8 / (msg * 1e-3), 1))
                     del cg8
-                del xs, rbits, rb, xpub
+                    # one launch per party and step (what each MPyC party does in its own process): 49 launches, 345 B
+                    xl, rl = [xs.row(i_) for i_ in range(3)], [rbits.row(i_) for i_ in range(3)]
+                    ms = time_launches(lambda s_: protocols.sbox_layer(ctx8, F8, xl, rl, 1, A8, B8), [0], 5)
+                    kern[f'secure_sbox_layer_m3t1_{tag}_launch_per_party'] = dict(roof(345 * n8, ms), algorithmic_bytes_per_unit=345,
+                                                                                   units_per_s=round(n8 / (ms * 1e-3), 1),
+                                                                                   kernels_per_layer=49)
+                del xs, rbits, xpub, want8
                 torch.cuda.empty_cache()
             # AES-128 encryption of secret-shared blocks under secret-shared round keys (np_aes.py:75-86): 10 S-box
             # layers + ShiftRows/MixColumns (row relabelling + the small-matrix kernel) + AddRoundKey, all 3 parties
@@ -641,6 +891,8 @@ def main():
                 out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
         except (OSError, ValueError):
             pass
+        if 'configs2' in out and 'split_p64_m7t3' in kern:
+            out['configs2']['roofline']['traffic'] = kern['split_p64_m7t3'].get('traffic')
         out['roofline']['bytes_per_launch'] = kern[dom]['bytes_per_launch']
         out['kernels'] = kern
         out['mulmod_per_s_1gpu'] = kern['mul_p61']['units_per_s']

@@ -197,6 +197,20 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
                    uint64_t nonce, int rounds, void* dev_state, int t, int m, void* shares, size_t share_stride,
                    size_t n, void* stream);
 
+/* `nbatch` independent chain gates in ONE launch (grid rows): gate y reads every row of A at element offset
+ * y * batch_stride_a (B: y * batch_stride_b) from the given row pointers and writes its m share rows at
+ * shares + y * batch_stride_out (+ i * share_stride for party i+1); its coefficients come from the call's
+ * generator stream with y added to bits 8..15 of nonce word 1 (nbatch <= 255), so the gates draw independent
+ * randomness.  This is what the 2t+1 re-sharing parties of one `_reshare` (runtime.py:658-666) do when a whole
+ * computation is held on one GPU: with the sub-shares stored [recipient][sender][n] the senders of the next gate
+ * are batch_stride = (2t+1)*n apart and a layer of the np_aes S-box chain (runtime.py:1356-1367) is one launch
+ * instead of 2t+1.  nbatch = 1 is ffgpu_gate_rng.                                                              */
+int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
+                         size_t batch_stride_a, const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb,
+                         size_t batch_stride_b, const uint8_t* host_key32, uint64_t nonce, int rounds, void* dev_state,
+                         int t, int m, void* shares, size_t share_stride, size_t batch_stride_out, size_t n, int nbatch,
+                         void* stream);
+
 /* Device-resident generator state, for launches captured in a HIP graph: the kernels read key / nonce /
  * rounds from `dev_state` (ffgpu_rng_state_bytes() bytes of device memory) when they start, and the nonce is
  * advanced on the device after every use (by the last workgroup of the share-generation kernel itself), so each REPLAY of a captured ffgpu_split_rng_state draws fresh
@@ -308,6 +322,24 @@ int ffgpu_gf256_bit_affine(ffgpu_ctx* ctx, const uint64_t* host_matrix, const ui
  * opened masked value c to its shares of the random bits.
  * replaces: runtime.py:4418-4423 (`c_bits = np.int8(np.right_shift.outer(c, shifts) & 1); return c_bits + r_bits`). */
 int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void* out, size_t n, void* stream);
+
+/* The secure bit decomposition of runtime.np_to_bits over GF(2^8) (runtime.py:4411-4423) with the two local steps
+ * around its opening fused, for a computation whose parties all live on this GPU (mpyc_amd/protocols.py):
+ *
+ * ffgpu_gf256_mask_open: out[h] = sum_r coef[r] * rows[r][h] + sum_p mu[p] * (sum_b 2^b rbits_p[8h + b])
+ *   = the opened masked value c = a + r_modl (runtime.py:4414-4421: `r_modl` by Horner over the bit shares, `a + r_modl`,
+ *   `output`) computed straight from the t+1 opening parties' shares: rows/coef = their shares of a, each possibly
+ *   still a pending recombination of sub-share rows (coef = mu_p * lambda_s, <= 32 rows), rbits_p = their shares of the
+ *   random bits (8 per byte, 16-byte aligned, <= 8 parties).  One pass instead of 3 per party + 1.
+ * ffgpu_gf256_bits_affine_fold: out_y[h] = sum_r 2^r (M (bits(c[h]) + rbits_y[8h..8h+7]) + bias)_r for parties
+ *   y < nbatch (rbits_y = rbits + y*rbits_batch_stride, out_y = out + y*out_batch_stride; one launch, grid rows = y)
+ *   = `c_bits + r_bits` (runtime.py:4422-4423), the public affine map over the bit shares and np_from_bits
+ *   (demos/np_aes.py:40-42, runtime.py:4475-4484) without the 8n-byte bit arrays ever reaching HBM.                */
+int ffgpu_gf256_mask_open(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_coef, int nrows,
+                          const void* const* host_rbits, const uint64_t* host_mu, int np, void* out, size_t n, void* stream);
+int ffgpu_gf256_bits_affine_fold(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, const void* c,
+                                 const void* rbits, size_t rbits_batch_stride, void* out, size_t out_batch_stride, size_t n,
+                                 int nbatch, void* stream);
 
 /* out[h] = A * bits(in[h]^254) + B packed back to a byte, with the 8x8 GF(2)
  * matrix given as 8 row bytes (bit c of host_rows8[r] = A[r][c]) and B as a byte.

@@ -31,6 +31,11 @@ const FieldOps* ffgpu_ops_gf2w128();
 int ffgpu_sbox_build_lut(const void* gf2p8_policy, const uint8_t* rows8, uint8_t b, uint8_t* lut256);
 int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_to_bits(int device, const void* in, const void* addend, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_gf8_mask_open(const void* policy, int device, const void* const* rows, const uint64_t* coef2, int nrows,
+                               const void* const* rbits, const uint64_t* mu2, int np, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, const void* c,
+                                      const void* rbits, size_t ybr, void* out, size_t ybo, size_t n, int nbatch,
+                                      hipStream_t st);
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
@@ -625,7 +630,17 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
                    const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb, const uint8_t* host_key32,
                    uint64_t nonce, int rounds, void* dev_state, int t, int m, void* shares, size_t share_stride,
                    size_t n, void* stream) {
+    return ffgpu_gate_rng_batch(ctx, host_rows_a, host_lambda_a, ka, 0, host_rows_b, host_lambda_b, kb, 0, host_key32, nonce,
+                                rounds, dev_state, t, m, shares, share_stride, 0, n, 1, stream);
+}
+
+int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
+                         size_t batch_stride_a, const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb,
+                         size_t batch_stride_b, const uint8_t* host_key32, uint64_t nonce, int rounds, void* dev_state,
+                         int t, int m, void* shares, size_t share_stride, size_t batch_stride_out, size_t n, int nbatch,
+                         void* stream) {
     ARGCHK(ctx);
+    ARGCHK(nbatch >= 1 && nbatch <= 255);
     ARGCHK(m >= 1 && t >= 1 && t < m && ka >= 1 && kb >= 0);
     if (t > 3 || ka > 7 || kb > 7) return FFGPU_ENOTSUP;
     ARGCHK(host_rows_a && host_lambda_a && (kb == 0 || (host_rows_b && host_lambda_b)));
@@ -648,7 +663,8 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
     LaunchTimer lt(ctx, (hipStream_t)stream);
     ra.aux = gf8_tables_on_device(ctx);
     return launch_status(ctx->ops->gate(ctx->policy, ctx->device, host_rows_a, host_lambda_a, ka, host_rows_b,
-                                        host_lambda_b, kb, t, m, shares, share_stride, n, (hipStream_t)stream, &ra));
+                                        host_lambda_b, kb, t, m, shares, share_stride, n, (hipStream_t)stream, &ra,
+                                        nbatch, batch_stride_a, batch_stride_b, batch_stride_out));
 }
 
 int ffgpu_split(ffgpu_ctx* ctx, const void* secrets, const void* coeffs, size_t coeff_stride, int t, int m,
@@ -828,6 +844,38 @@ int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_gf8_to_bits(ctx->device, in, addend, out, n, (hipStream_t)stream));
+}
+
+int ffgpu_gf256_mask_open(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t* host_coef, int nrows,
+                          const void* const* host_rbits, const uint64_t* host_mu, int np, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;
+    ARGCHK(nrows >= 0 && np >= 0 && nrows + np >= 1);
+    if (nrows > 32 || np > 8) return FFGPU_ENOTSUP;
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(out && (nrows == 0 || (host_rows && host_coef)) && (np == 0 || (host_rbits && host_mu)));
+    for (int r = 0; r < nrows; ++r) ARGCHK(host_rows[r]);
+    for (int p = 0; p < np; ++p) ARGCHK(host_rbits[p]);
+    DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
+    return launch_status(ffgpu_launch_gf8_mask_open(ctx->policy, ctx->device, host_rows, host_coef, nrows, host_rbits, host_mu,
+                                                    np, out, n, (hipStream_t)stream));
+}
+
+int ffgpu_gf256_bits_affine_fold(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, const void* c,
+                                 const void* rbits, size_t rbits_batch_stride, void* out, size_t out_batch_stride, size_t n,
+                                 int nbatch, void* stream) {
+    ARGCHK(ctx && host_matrix);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;
+    ARGCHK(nbatch >= 1 && nbatch <= 65535);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(c && rbits && out);
+    ARGCHK(nbatch == 1 || (rbits_batch_stride >= 8 * n && out_batch_stride >= n));
+    DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
+    return launch_status(ffgpu_launch_gf8_bits_affine_fold(ctx->policy, ctx->device, host_matrix, host_bias, c, rbits,
+                                                           rbits_batch_stride, out, out_batch_stride, n, nbatch,
+                                                           (hipStream_t)stream));
 }
 
 int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b, void* out,

@@ -289,6 +289,10 @@ struct GateSrc {
     int kA, kB;
     int square;                                          // 1: second factor = first factor
     int plainA, plainB;                                  // 1: a single row with lambda = 1 (an existing array)
+    // batched launch (gridDim.y senders in one grid, e.g. all parties of a computation held on one GPU): workgroup
+    // row y reads every row of A at element offset y*yA (B: y*yB) and writes its share rows at offset y*yO; its
+    // generator stream is the call's with y added to bits 8..15 of nonce word 1
+    size_t yA, yB, yO;
 };
 
 template <class F, bool NT>
@@ -329,7 +333,7 @@ __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
         RngKey* st = const_cast<RngKey*>(ra.dev_key);
         __threadfence();
         const uint32_t done = atomicAdd(&st->pad_, 1u);
-        if (done == gridDim.x - 1) {
+        if (done == gridDim.x * gridDim.y - 1) {
             st->pad_ = 0;
             if (++st->nonce[0] == 0) st->nonce[1] += 65536u;   // rows of t > 4 calls use nonce[1] + j + 1, j < 64
             __threadfence();
@@ -353,6 +357,18 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
                                                   size_t nvec, size_t n, RngArgs ra, GateSrc<F> gs) {
     if (ra.dev_key) ra.rk = *ra.dev_key;
+    if constexpr (REC) {
+        const size_t yb = blockIdx.y;                  // wave-uniform: scalar pointer arithmetic
+        if (yb) {
+#pragma unroll
+            for (int j = 0; j < GATE_MAXK; ++j) {
+                gs.rowsA[j] += yb * gs.yA;
+                gs.rowsB[j] += yb * gs.yB;
+            }
+            out += yb * gs.yO;
+            ra.rk.nonce[1] += (uint32_t)yb << 8;
+        }
+    }
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
@@ -1780,6 +1796,93 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::el
     }
 }
 
+// The same product with R rows of A per workgroup: the values of B a thread needs (B is re-read by every workgroup:
+// with one row per workgroup the L2 -> CU traffic for B equals the HBM traffic for A) are loaded ONCE per R rows and
+// the R row packs are all in flight before the first multiply.  `bpack`: N == 1 with unit-stride, aligned B -- the
+// vector is read as 16-byte packs with the same index as A's.
+template <class F, int NN, int R>
+__global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                          const typename F::elem* __restrict__ B, size_t ldb,
+                                                          typename F::elem* __restrict__ C, size_t ldc, int M, int K, int N,
+                                                          int vec, int bpack) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    __shared__ W sm[BLOCK];
+    const size_t row0 = (size_t)blockIdx.x * R;
+    typename F::acc acc[R][NN];
+    W total[R][NN];
+    bool have = false;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) f.acc_zero(acc[r][j]);
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                W part = f.acc_reduce(acc[r][j]);
+                total[r][j] = have ? f.add(total[r][j], part) : part;
+                f.acc_zero(acc[r][j]);
+            }
+        have = true;
+        cnt = 0;
+    };
+    constexpr int EPV = P::N;
+    const int nvec = vec ? K / EPV : 0;
+    for (int i = threadIdx.x; i < nvec; i += BLOCK) {
+        P x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)                                   // rows past M re-read the last row (result discarded)
+            x[r] = ldg<true>(reinterpret_cast<const MP*>(A + (row0 + r < (size_t)M ? row0 + r : (size_t)M - 1) * lda) + i);
+        W b[EPV][NN];
+        if (bpack) {
+            const P bp = ldg<false>(reinterpret_cast<const MP*>(B) + i);
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) b[q][0] = f.prep(bp.w[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < EPV; ++q)
+#pragma unroll
+                for (int j = 0; j < NN; ++j)
+                    if (j < N) b[q][j] = f.prep(ld_elem<F>(B, ((size_t)i * EPV + q) * ldb + j));
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < EPV; ++q)
+#pragma unroll
+                for (int j = 0; j < NN; ++j)
+                    if (j < N) f.acc_mac(acc[r][j], b[q][j], x[r].w[q]);
+        cnt += EPV;
+        if (cnt >= SKINNY_FLUSH) flush();
+    }
+    for (int kk = nvec * EPV + threadIdx.x; kk < K; kk += BLOCK) {
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+            if (j < N) {
+                const W bp = f.prep(ld_elem<F>(B, (size_t)kk * ldb + j));
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    f.acc_mac(acc[r][j], bp, ld_elem<F>(A, (row0 + r < (size_t)M ? row0 + r : (size_t)M - 1) * lda + kk));
+            }
+        if (++cnt >= SKINNY_FLUSH) flush();
+    }
+    flush();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            if (j < N) {
+                const W v = block_reduce_add(f, total[r][j], sm);
+                if (threadIdx.x == 0 && row0 + r < (size_t)M) st_elem<F>(C, (row0 + r) * ldc + j, v);
+                __syncthreads();
+            }
+        }
+}
+
 // Same product for SHORT rows (K <= 32, many rows: sums over a trailing axis, tall-thin least squares): one
 // thread per row -- a row is K contiguous elements, neighbouring threads read neighbouring rows, and B[k][j] is
 // wave-uniform (scalar loads).
@@ -1881,6 +1984,95 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
 #pragma unroll
             for (int q = 0; q < CW; ++q)
                 if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = total[mi][q];
+}
+
+// The same partial product with the four waves of a workgroup on the SAME 64 * CW columns and interleaved rows of
+// the K chunk: a wave reads one contiguous 1 KiB row segment per load, the four per-wave sums meet in LDS, and one
+// partial row per WORKGROUP goes to memory -- a quarter of the slabs (and of the final pass) for the same number of
+// waves in flight.  Vector path only (16-byte loads of B).
+template <class F, int MM>
+__global__ __launch_bounds__(BLOCK) void k_vecmat_slab(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                        const typename F::elem* __restrict__ B, size_t ldb,
+                                                        typename F::word* __restrict__ partial, int M, int K, int N,
+                                                        int kchunk) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    constexpr int CW = P::N;
+    constexpr int NW = BLOCK / 64;
+    __shared__ W sm[NW - 1][MM][CW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + lane) * CW;
+    const bool live = j < N;
+    const int k0 = blockIdx.y * kchunk;
+    const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
+    typename F::acc acc[MM][CW];
+    W total[MM][CW];
+    bool have = false;
+    int cnt = 0;
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+        for (int q = 0; q < CW; ++q) f.acc_zero(acc[mi][q]);
+    auto flush = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                W part = f.acc_reduce(acc[mi][q]);
+                total[mi][q] = have ? f.add(total[mi][q], part) : part;
+                f.acc_zero(acc[mi][q]);
+            }
+        have = true;
+        cnt = 0;
+    };
+    auto macs = [&](int kk, const P& bp) {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+            if (mi < M) {
+                const W ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                      // wave-uniform operand
+#pragma unroll
+                for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, bp.w[q]);
+            }
+    };
+    if (live) {
+        const typename F::elem* __restrict__ bcol = B + j;
+        int kk = k0 + wv;
+        for (; kk + 7 * NW < k1; kk += 8 * NW) {          // eight rows of B in flight per lane
+            P b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b[u] = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)(kk + u * NW) * ldb));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) macs(kk + u * NW, b[u]);
+            cnt += 8;
+            if (cnt >= SKINNY_FLUSH) flush();
+        }
+        for (; kk < k1; kk += NW) {
+            const P b0 = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)kk * ldb));
+            macs(kk, b0);
+            if (++cnt >= SKINNY_FLUSH) flush();
+        }
+    }
+    flush();
+    if (wv > 0) {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) sm[wv - 1][mi][q][lane] = total[mi][q];
+    }
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi)
+            if (mi < M)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    W r = total[mi][q];
+#pragma unroll
+                    for (int w2 = 0; w2 < NW - 1; ++w2) r = f.add(r, sm[w2][mi][q][lane]);
+                    if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = r;
+                }
+    }
 }
 
 template <class F>
@@ -2018,9 +2210,10 @@ struct FieldOps {
                   hipStream_t st);
     int (*dot)(const void* F, int device, const void* a, const void* b, void* out, void* workspace, size_t n,
                hipStream_t st);
+    // nbatch > 1: gridDim.y independent gates in one launch, operands / outputs of gate y at element offsets y*yA, y*yB, y*yO
     int (*gate)(const void* F, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
                 const void* const* rowsB, const uint64_t* lamB2, int kB, int t, int m, void* out, size_t ostride,
-                size_t n, hipStream_t st, const RngArgs* rng);
+                size_t n, hipStream_t st, const RngArgs* rng, int nbatch, size_t yA, size_t yB, size_t yO);
     int (*sqrt_cl)(const void* F, int device, const void* a, const ExpArgs* eleg, const ExpArgs* elad, void* out, size_t n,
                    hipStream_t st);
     int (*gauss)(const void* F, int device, void* A, int n, int ncols, size_t batch, int det_mode, const ExpArgs* ex,
@@ -2146,13 +2339,13 @@ struct Launchers {
     template <int T, bool FUSE, bool RNG, bool REC = false>
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
                          size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st,
-                         const RngArgs& ra, const GateSrc<F>& gs) {
+                         const RngArgs& ra, const GateSrc<F>& gs, unsigned gy = 1) {
         bool lazy = false;
         if constexpr (F::HAS_SACC != 0 && T > 0) lazy = f.sacc_ok(T, m);
         if constexpr (F::HAS_SACC != 0 && T > 0) {
             if (lazy) {
                 if (nt || RNG)
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG, REC>), dim3(grid), dim3(BLOCK), 0, st, f, a,
+                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a,
                                        b, coef, cstride, m, out, ostride, nvec, n, ra, gs);
                 else
                     hipLaunchKernelGGL((k_split<F, T, FUSE, false, true, false>), dim3(grid), dim3(BLOCK), 0, st, f,
@@ -2161,7 +2354,7 @@ struct Launchers {
             }
         }
         if (nt || RNG)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG, REC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a, b,
                                coef, cstride, m, out, ostride, nvec, n, ra, gs);
         else
             hipLaunchKernelGGL((k_split<F, T, FUSE, false, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
@@ -2209,13 +2402,20 @@ struct Launchers {
     // fused chain gate: both factors given as recombinations (GateSrc), product re-shared with the device CSPRNG
     static int gate(const void* Fp, int device, const void* const* rowsA, const uint64_t* lamA2, int kA,
                     const void* const* rowsB, const uint64_t* lamB2, int kB, int t, int m, void* out, size_t ostride,
-                    size_t n, hipStream_t st, const RngArgs* rng) {
+                    size_t n, hipStream_t st, const RngArgs* rng, int nbatch, size_t yA, size_t yB, size_t yO) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         if (t < 1 || t > 3 || kA < 1 || kA > GATE_MAXK || kB < 0 || kB > GATE_MAXK || !rng) return 2;
+        if (nbatch < 1 || nbatch > 255) return 2;
         LaunchCfg lc = launch_cfg(device);
         GateSrc<F> gs;
         memset(&gs, 0, sizeof(gs));
         bool vec = al(out) && (stride_ok(ostride) || m <= 1);
+        if (nbatch > 1) {
+            gs.yA = yA;
+            gs.yB = yB;
+            gs.yO = yO;
+            vec = vec && stride_ok(yA) && stride_ok(yO) && (kB == 0 || stride_ok(yB));
+        }
         for (int j = 0; j < kA; ++j) {
             gs.rowsA[j] = (const E*)rowsA[j];
             gs.lamA[j] = f.prep(word_from_limbs<F>(f, lamA2[2 * j], lamA2[2 * j + 1]));
@@ -2236,12 +2436,13 @@ struct Launchers {
         const bool spread = nvec > 0 && nvec < 262144;
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (!spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
-        ra.release = grid <= RNG_RELEASE_MAX_GRID;
+        const unsigned gy = (unsigned)nbatch;
+        ra.release = (size_t)grid * gy <= RNG_RELEASE_MAX_GRID;
         E* o = (E*)out;
         switch (t) {
-            case 1: go_split<1, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
-            case 2: go_split<2, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
-            default: go_split<3, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs); break;
+            case 1: go_split<1, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
+            case 2: go_split<2, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
+            default: go_split<3, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
         }
         if (ra.dev_key && !ra.release)
             hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
@@ -2391,6 +2592,15 @@ struct Launchers {
         return 0;
     }
 
+    // FFGPU_SKINNY_V2=0 selects the first-generation skinny kernels (A/B measurements)
+    static bool skinny_v2() {
+        static int v = -1;
+        if (v < 0) {
+            const char* e = getenv("FFGPU_SKINNY_V2");
+            v = e ? atoi(e) : 1;
+        }
+        return v != 0;
+    }
     // skinny shapes (one output dimension <= 8): HBM-bound kernels that read the big operand once
     template <int NN>
     static void go_matvec(const F& f, const E* A, size_t lda, const E* B, size_t ldb, E* C, size_t ldc, int M, int K,
@@ -2402,6 +2612,16 @@ struct Launchers {
         }
         const int vec = al(A) && stride_ok(lda);
         const int bvec = al(B) && stride_ok(ldb) && (N % (int)(16 / sizeof(W)) == 0) && sizeof(E) != 12;
+        if constexpr (NN <= 2 && sizeof(E) != 12) {
+            // long rows, one or two columns: R rows per workgroup share every load of B (still >= 4 workgroups per CU)
+            constexpr int R = NN == 1 ? 4 : 2;
+            if (skinny_v2() && vec && K >= 1024 && M >= 1024 * R) {
+                const int bpack = (N == 1 && ldb == 1 && al(B)) ? 1 : 0;
+                hipLaunchKernelGGL((k_matvec_rows_r<F, NN, R>), dim3((unsigned)((M + R - 1) / R)), dim3(BLOCK), 0, st, f, A, lda, B,
+                                   ldb, C, ldc, M, K, N, vec, bpack);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_matvec_rows<F, NN>), dim3((unsigned)M), dim3(BLOCK), 0, st, f, A, lda, B, ldb, C, ldc, K, N, vec,
                            bvec);
     }
@@ -2434,8 +2654,12 @@ struct Launchers {
             }
             if (M <= SKINNY_MAX && N >= 64 && K >= 1 && workspace) {
                 // split K so that about 2^18 threads are in flight; each chunk at least 8 rows
-                const int cols_blocks = (N / (int)(16 / sizeof(W)) + BLOCK - 1) / BLOCK;
+                constexpr int CWs = (int)(16 / sizeof(W));
+                const bool slab = skinny_v2() && sizeof(E) != 12 && CWs > 1 && al(B) && stride_ok(ldb) && N % CWs == 0 && K >= 256;
+                // slab kernel: a workgroup covers 64 * CW columns (its four waves split the K chunk)
+                const int cols_blocks = slab ? (N / CWs + 63) / 64 : (N / CWs + BLOCK - 1) / BLOCK;
                 int ks = (1024 + cols_blocks - 1) / cols_blocks;
+                if (slab && ks > K / 32) ks = K / 32;                       // at least 8 rows per wave
                 if (ks > (K + 7) / 8) ks = (K + 7) / 8;
                 if (ks < 1) ks = 1;
                 while (ks > 1 && (size_t)ks * M * N * sizeof(W) > workspace_bytes) ks /= 2;
@@ -2444,7 +2668,13 @@ struct Launchers {
                     ks = (K + kchunk - 1) / kchunk;
                     W* part = (W*)workspace;
                     const E* a = (const E*)A; const E* b = (const E*)B;
-                    if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    if (slab) {
+                        dim3 grid((unsigned)cols_blocks, (unsigned)ks);
+                        if (M == 1) hipLaunchKernelGGL((k_vecmat_slab<F, 1>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
+                        else if (M == 2) hipLaunchKernelGGL((k_vecmat_slab<F, 2>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
+                        else if (M <= 4) hipLaunchKernelGGL((k_vecmat_slab<F, 4>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
+                        else hipLaunchKernelGGL((k_vecmat_slab<F, 8>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
+                    } else if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M == 2) go_vecmat<2>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M <= 4) go_vecmat<4>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else go_vecmat<8>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);

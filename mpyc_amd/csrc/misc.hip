@@ -226,15 +226,12 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_group8(GF2P8 f, Gf8Group8Args ga,
     }
 }
 
-// matrix: (8, 8) field constants (low byte of each 2-limb scalar), bias: 8 constants or NULL
-int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
-                            const void* in, void* out, size_t ngroups, hipStream_t st) {
-    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
-    Gf8Group8Args ga;
+// matrix: (8, 8) field constants (low byte of each 2-limb scalar; NULL = identity), bias: 8 constants or NULL
+static bool gf8_group8_args(const GF2P8& f, const uint64_t* m2, const uint64_t* bias2, int fold, Gf8Group8Args& ga) {
     memset(&ga, 0, sizeof(ga));
     for (int r = 0; r < 8; ++r) {
         for (int c = 0; c < 8; ++c) {
-            const uint32_t w = (uint32_t)(m2[2 * (r * 8 + c)] & 0xffu);
+            const uint32_t w = m2 ? (uint32_t)(m2[2 * (r * 8 + c)] & 0xffu) : (uint32_t)(r == c);
             const int d = (c - r + 8) & 7;                   // out_r takes x_{(r+d)%8}
             for (int b = 0; b < 8; ++b)
                 if ((w >> b) & 1) {
@@ -260,6 +257,14 @@ int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, 
     }
     bool general = false;
     for (int d = 0; d < 8; ++d) general = general || ga.nplanes[d] > 1;
+    return general;
+}
+
+int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
+                            const void* in, void* out, size_t ngroups, hipStream_t st) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    Gf8Group8Args ga;
+    const bool general = gf8_group8_args(f, m2, bias2, fold, ga);
     LaunchCfg lc = launch_cfg(device);
     const bool vec = (((uintptr_t)in) & 15u) == 0 && (((uintptr_t)out) & (fold ? 1u : 15u)) == 0;
     const size_t npack = vec ? ngroups / 2 : 0;
@@ -270,6 +275,158 @@ int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, 
     else if (fold) hipLaunchKernelGGL((k_gf8_group8<true, false>), dim3(grid), dim3(BLOCK), 0, st, f, ga, iv, ov, npack, ngroups);
     else if (general) hipLaunchKernelGGL((k_gf8_group8<false, true>), dim3(grid), dim3(BLOCK), 0, st, f, ga, iv, ov, npack, ngroups);
     else hipLaunchKernelGGL((k_gf8_group8<false, false>), dim3(grid), dim3(BLOCK), 0, st, f, ga, iv, ov, npack, ngroups);
+    FFGPU_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- GF(2^8) secure bit decomposition, fused (runtime.py:4411-4423 + demos/np_aes.py:40-42) --------------
+// np_to_bits over a binary field: r_modl = sum_b 2^b r_b; c = open(a + r_modl); bits = bits(c) + r_bits.  With
+// all parties of a computation on one GPU the steps before and after the opening are one kernel each:
+//
+//   k_gf8_mask_open:        c[h] = sum_r coef[r] * rows[r][h]  +  sum_p mu[p] * (sum_b 2^b R_p[8h + b])
+//       rows / coef: the shares of `a` of the t+1 opening parties, each possibly still a pending recombination of
+//       sub-share rows (coef = mu_p * lambda_s, multiplied on the host); R_p: their shares of the random bits.
+//   k_gf8_bits_affine_fold: out_y[h] = sum_r 2^r (M (bits(c[h]) + R_y[8h..8h+7]) + bias)_r   for party y = blockIdx.y
+//       the public 8x8 matrix M over the bit shares (np_aes.py:40-41) and np_from_bits (runtime.py:4475-4484).
+//
+// A lane takes 2 output bytes = 16 bytes of bit shares (one dwordx4, fully coalesced); bytes and rows travel as
+// 16-bit accesses (they are 1/8 of the traffic).  Two units per lane, half the array apart, as in k_gf8_group8.
+enum { GF8_MO_MAXROWS = 32, GF8_MO_MAXP = 8 };
+struct Gf8MaskOpenArgs {
+    const uint8_t* rows[GF8_MO_MAXROWS];
+    const uint8_t* rbits[GF8_MO_MAXP];
+    uint32_t coef[GF8_MO_MAXROWS];
+    uint32_t mu[GF8_MO_MAXP];
+    int nrows, np;
+};
+
+__device__ __forceinline__ uint32_t gf8_mask_open_pair(const GF2P8& f, const Gf8Group8Args& ga, const Gf8MaskOpenArgs& a,
+                                                        size_t i) {
+    GF2P8::acc acc;
+    f.acc_zero(acc);
+    for (int r = 0; r < a.nrows; ++r)
+        f.acc_mac(acc, a.coef[r], (uint32_t)reinterpret_cast<const uint16_t*>(a.rows[r])[i]);
+    for (int p = 0; p < a.np; ++p) {
+        const uint4 v = ldg<true>(reinterpret_cast<const uint4*>(a.rbits[p]) + i);
+        const uint32_t b0 = (uint32_t)gf8_group8_one<true, false>(f, ga, v.x, v.y);
+        const uint32_t b1 = (uint32_t)gf8_group8_one<true, false>(f, ga, v.z, v.w);
+        f.acc_mac(acc, a.mu[p], b0 | (b1 << 8));
+    }
+    return f.acc_reduce(acc) & 0xffffu;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gf8_mask_open(GF2P8 f, Gf8Group8Args ga, Gf8MaskOpenArgs a, uint8_t* __restrict__ out,
+                                                          size_t npair, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    uint16_t* __restrict__ o16 = reinterpret_cast<uint16_t*>(out);
+    const size_t half = (npair + 1) / 2;
+    for (size_t i = gid; i < half; i += gsz) {
+        const size_t i2 = i + half;
+        o16[i] = (uint16_t)gf8_mask_open_pair(f, ga, a, i);
+        if (i2 < npair) o16[i2] = (uint16_t)gf8_mask_open_pair(f, ga, a, i2);
+    }
+    for (size_t e = 2 * npair + gid; e < n; e += gsz) {            // odd tail / unaligned buffers: one byte at a time
+        GF2P8::acc acc;
+        f.acc_zero(acc);
+        for (int r = 0; r < a.nrows; ++r) f.acc_mac(acc, a.coef[r], (uint32_t)a.rows[r][e]);
+        for (int p = 0; p < a.np; ++p) {
+            uint32_t lo = 0, hi = 0;
+            for (int b = 0; b < 4; ++b) {
+                lo |= (uint32_t)a.rbits[p][8 * e + b] << (8 * b);
+                hi |= (uint32_t)a.rbits[p][8 * e + 4 + b] << (8 * b);
+            }
+            f.acc_mac(acc, a.mu[p], (uint32_t)gf8_group8_one<true, false>(f, ga, lo, hi));
+        }
+        out[e] = (uint8_t)(f.acc_reduce(acc) & 0xffu);
+    }
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(BLOCK) void k_gf8_bits_affine_fold(GF2P8 f, Gf8Group8Args ga, const uint8_t* __restrict__ c,
+                                                                 const uint8_t* __restrict__ rbits, size_t ybr,
+                                                                 uint8_t* __restrict__ out, size_t ybo, size_t npair, size_t n) {
+    rbits += (size_t)blockIdx.y * ybr;
+    out += (size_t)blockIdx.y * ybo;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    const uint16_t* __restrict__ c16 = reinterpret_cast<const uint16_t*>(c);
+    const uint4* __restrict__ rv = reinterpret_cast<const uint4*>(rbits);
+    uint16_t* __restrict__ o16 = reinterpret_cast<uint16_t*>(out);
+    const size_t half = (npair + 1) / 2;
+    auto one = [&](size_t i) -> uint16_t {
+        const uint32_t v = c16[i];
+        const uint4 r = ldg<true>(rv + i);
+        const uint64_t lo = spread_bits(v & 0xffu) ^ ((uint64_t)r.x | ((uint64_t)r.y << 32));
+        const uint64_t hi = spread_bits(v >> 8) ^ ((uint64_t)r.z | ((uint64_t)r.w << 32));
+        const uint32_t b0 = (uint32_t)gf8_group8_one<true, GENERAL>(f, ga, (uint32_t)lo, (uint32_t)(lo >> 32));
+        const uint32_t b1 = (uint32_t)gf8_group8_one<true, GENERAL>(f, ga, (uint32_t)hi, (uint32_t)(hi >> 32));
+        return (uint16_t)(b0 | (b1 << 8));
+    };
+    for (size_t i = gid; i < half; i += gsz) {
+        const size_t i2 = i + half;
+        const uint16_t r0 = one(i);
+        if (i2 < npair) o16[i2] = one(i2);
+        o16[i] = r0;
+    }
+    for (size_t e = 2 * npair + gid; e < n; e += gsz) {
+        const uint64_t b = spread_bits(c[e]);
+        uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+        for (int j = 0; j < 4; ++j) {
+            lo ^= (uint32_t)rbits[8 * e + j] << (8 * j);
+            hi ^= (uint32_t)rbits[8 * e + 4 + j] << (8 * j);
+        }
+        out[e] = (uint8_t)gf8_group8_one<true, GENERAL>(f, ga, lo, hi);
+    }
+}
+
+// rows / rbits: host arrays of device pointers; coef2 / mu2: canonical 2-limb host scalars
+int ffgpu_launch_gf8_mask_open(const void* policy, int device, const void* const* rows, const uint64_t* coef2, int nrows,
+                               const void* const* rbits, const uint64_t* mu2, int np, void* out, size_t n, hipStream_t st) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    if (nrows < 0 || nrows > GF8_MO_MAXROWS || np < 0 || np > GF8_MO_MAXP) return 2;
+    Gf8Group8Args ga;
+    gf8_group8_args(f, nullptr, nullptr, 1, ga);                     // identity matrix + fold = sum_b 2^b x_b
+    Gf8MaskOpenArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nrows = nrows;
+    a.np = np;
+    bool vec = (((uintptr_t)out) & 1u) == 0;
+    for (int r = 0; r < nrows; ++r) {
+        a.rows[r] = (const uint8_t*)rows[r];
+        a.coef[r] = (uint32_t)(coef2[2 * r] & 0xffu);
+        vec = vec && (((uintptr_t)rows[r]) & 1u) == 0;
+    }
+    for (int p = 0; p < np; ++p) {
+        a.rbits[p] = (const uint8_t*)rbits[p];
+        a.mu[p] = (uint32_t)(mu2[2 * p] & 0xffu);
+        vec = vec && (((uintptr_t)rbits[p]) & 15u) == 0;
+    }
+    const size_t npair = vec ? n / 2 : 0;
+    LaunchCfg lc = launch_cfg(device);
+    unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
+    hipLaunchKernelGGL(k_gf8_mask_open, dim3(grid), dim3(BLOCK), 0, st, f, ga, a, (uint8_t*)out, npair, n);
+    FFGPU_CHECK_LAUNCH();
+    return 0;
+}
+
+int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, const void* c,
+                                      const void* rbits, size_t ybr, void* out, size_t ybo, size_t n, int nbatch,
+                                      hipStream_t st) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    Gf8Group8Args ga;
+    const bool general = gf8_group8_args(f, m2, bias2, 1, ga);
+    bool vec = (((uintptr_t)c) & 1u) == 0 && (((uintptr_t)rbits) & 15u) == 0 && (((uintptr_t)out) & 1u) == 0;
+    if (nbatch > 1) vec = vec && (ybr % 16 == 0) && (ybo % 2 == 0);
+    const size_t npair = vec ? n / 2 : 0;
+    LaunchCfg lc = launch_cfg(device);
+    unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
+    if (general)
+        hipLaunchKernelGGL((k_gf8_bits_affine_fold<true>), dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, f, ga,
+                           (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
+    else
+        hipLaunchKernelGGL((k_gf8_bits_affine_fold<false>), dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, f, ga,
+                           (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
 }

@@ -261,10 +261,31 @@ class FieldContext:
             mtx.row(i).t.copy_(self.from_numpy(a[i]).t)
         return mtx
 
+    # ---- operand checks ---------------------------------------------------
+    # The kernels take raw pointers and ONE element count: every operand (and a caller-supplied output) must have
+    # exactly that many elements and belong to this field, otherwise a launch would read or write past an
+    # allocation.  Share rows arrive from peers (from_wire derives their length from the message size), so a short
+    # or ragged row must be refused here -- the reference's field.array(shares) raises on the same input.
+    def _same(self, n: int, *arrays, what: str = 'operand'):
+        for a in arrays:
+            if a is None:
+                continue
+            if a.ctx is not self and (a.ctx.modulus != self.modulus or a.ctx.binary != self.binary
+                                      or a.ctx.device != self.device):
+                raise ValueError(f'{what} belongs to a different field context')
+            if a.n != n:
+                raise ValueError(f'{what} has {a.n} elements, expected {n}')
+
+    def _out_matrix(self, out: Optional[DevMatrix], rows: int, n: int) -> DevMatrix:
+        if out is None:
+            return self.empty_matrix(rows, n)
+        if out.rows < rows or out.n != n:
+            raise ValueError(f'output matrix is ({out.rows}, {out.n}), need ({rows}, {n})')
+        return out
+
     # ---- element-wise -----------------------------------------------------
     def _ew2(self, fn, a: DevArray, b: DevArray, out: Optional[DevArray]) -> DevArray:
-        if a.n != b.n:
-            raise ValueError('length mismatch')
+        self._same(a.n, b, out)
         out = out or self.empty(a.n)
         _ffi.check(fn(self._h, a.ptr, b.ptr, out.ptr, a.n, self._stream()), fn.__name__)
         return out
@@ -279,16 +300,19 @@ class FieldContext:
         return self._ew2(self._L.ffgpu_mul, a, b, out)
 
     def neg(self, a, out=None):
+        self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
         _ffi.check(self._L.ffgpu_neg(self._h, a.ptr, out.ptr, a.n, self._stream()), 'neg')
         return out
 
     def reduce(self, raw: DevArray, out=None):
+        self._same(raw.n, out, what='output')
         out = out or self.empty(raw.n)
         _ffi.check(self._L.ffgpu_reduce(self._h, raw.ptr, out.ptr, raw.n, self._stream()), 'reduce')
         return out
 
     def _ews(self, fn, a, scalar: int, out):
+        self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
         _ffi.check(fn(self._h, a.ptr, _ffi.limbs(scalar, 2), out.ptr, a.n, self._stream()), fn.__name__)
         return out
@@ -303,6 +327,7 @@ class FieldContext:
         return self._ews(self._L.ffgpu_rsub_scalar, a, s, out)
 
     def muladd(self, a, b, c, out=None):
+        self._same(a.n, b, c, out)
         out = out or self.empty(a.n)
         _ffi.check(self._L.ffgpu_muladd(self._h, a.ptr, b.ptr, c.ptr, out.ptr, a.n, self._stream()), 'muladd')
         return out
@@ -311,6 +336,7 @@ class FieldContext:
         """a ** e for a public exponent 0 <= e < 2^128, one kernel (finfields.py:1159-1187)."""
         if e < 0 or e >> 128:
             raise ValueError('exponent out of range')
+        self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
         _ffi.check(self._L.ffgpu_pow(self._h, a.ptr, _ffi.limbs(e, 2), 2, out.ptr, a.n, self._stream()), 'pow')
         return out
@@ -318,6 +344,7 @@ class FieldContext:
     def inv(self, a, out=None, check_zero: bool = True):
         """Element-wise inverse (batched, one kernel).  Raises ZeroDivisionError like the reference
         if any element is zero (costs one device->host flag read); check_zero=False skips that."""
+        self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
         flag = torch.zeros(1, dtype=torch.int32, device=self.torch_device) if check_zero else None
         _ffi.check(self._L.ffgpu_inv(self._h, a.ptr, out.ptr, a.n, flag.data_ptr() if check_zero else None,
@@ -328,6 +355,7 @@ class FieldContext:
 
     def beaver_combine(self, z, x, y, d, e, add_de: bool, out=None):
         """z + d*y + e*x (+ d*e): local step of Beaver multiplication (not a reference function; see ffgpu.h)."""
+        self._same(z.n, x, y, d, e, out)
         out = out or self.empty(z.n)
         _ffi.check(self._L.ffgpu_beaver_combine(self._h, z.ptr, x.ptr, y.ptr, d.ptr, e.ptr, int(bool(add_de)), out.ptr,
                                                 z.n, self._stream()), 'beaver_combine')
@@ -341,7 +369,8 @@ class FieldContext:
         n = secrets.n
         if t and (coeffs is None or coeffs.rows < t or coeffs.n != n):
             raise ValueError('coefficient matrix must be (t, n)')
-        out = out or self.empty_matrix(m, n)
+        self._same(n, mul_by)
+        out = self._out_matrix(out, m, n)
         cptr = coeffs.ptr if t else None
         cstride = coeffs.stride if t else 0
         if mul_by is None:
@@ -386,8 +415,9 @@ class FieldContext:
         (the reference draws from `secrets` too, thresha.py:58)."""
         import secrets as _secrets
         n = secrets.n
+        self._same(n, mul_by)
+        out = self._out_matrix(out, m, n)
         if state is not None:
-            out = out or self.empty_matrix(m, n)
             _ffi.check(self._L.ffgpu_split_rng_state(self._h, secrets.ptr, mul_by.ptr if mul_by is not None else None,
                                                      state.ptr, t, m, out.ptr, out.stride, n, self._stream()),
                        'split_rng_state')
@@ -396,7 +426,6 @@ class FieldContext:
             key = _secrets.token_bytes(32)
         if len(key) != 32:
             raise ValueError('key must be 32 bytes')
-        out = out or self.empty_matrix(m, n)
         if mul_by is None:
             rc = self._L.ffgpu_split_rng(self._h, secrets.ptr, key, nonce, rounds, t, m, out.ptr, out.stride, n,
                                          self._stream())
@@ -418,7 +447,8 @@ class FieldContext:
             kb, pb, lb = self._rec_args(rows_b, lam_b, 1)
         else:
             kb, pb, lb = 0, None, None
-        out = out or self.empty_matrix(m, n)
+        self._same(n, *(rows_b or ()), what='share row')
+        out = self._out_matrix(out, m, n)
         if state is None and key is None:
             key = _secrets.token_bytes(32)
         _ffi.check(self._L.ffgpu_gate_rng(self._h, pa, la, ka, pb, lb, kb, key, nonce, rounds,
@@ -426,10 +456,41 @@ class FieldContext:
                                           self._stream()), 'gate_rng')
         return out
 
+    def gate_batch(self, rows_a: Sequence[DevArray], lam_a: Sequence[int], stride_a: int,
+                   rows_b: Optional[Sequence[DevArray]], lam_b: Optional[Sequence[int]], stride_b: int,
+                   t: int, m: int, nbatch: int, out: DevMatrix, out_rows_per_party: int,
+                   key: Optional[bytes] = None, nonce: int = 0, rounds: int = 20,
+                   state: Optional['RngState'] = None) -> DevMatrix:
+        """`nbatch` chain gates in one launch (ffgpu_gate_rng_batch): rows_a / rows_b are the operand rows of gate 0;
+        gate y reads them `y * stride_a` (`y * stride_b`) elements further on.  `out` is a DevMatrix of
+        m * out_rows_per_party rows used as [recipient][sender]: gate y writes the share row for party i+1 into row
+        i * out_rows_per_party + y.  The caller owns the layout (mpyc_amd/protocols.py); operand rows of gate 0
+        and the output are length-checked here."""
+        import secrets as _secrets
+        n = rows_a[0].n
+        if nbatch < 1 or out_rows_per_party < nbatch or out.rows < m * out_rows_per_party or out.n != n:
+            raise ValueError('output block does not hold m x nbatch share rows of n elements')
+        ka, pa, la = self._rec_args(rows_a, lam_a, 1)
+        if rows_b:
+            kb, pb, lb = self._rec_args(rows_b, lam_b, 1)
+            self._same(n, *rows_b, what='share row')
+        else:
+            kb, pb, lb = 0, None, None
+        if state is None and key is None:
+            key = _secrets.token_bytes(32)
+        _ffi.check(self._L.ffgpu_gate_rng_batch(self._h, pa, la, ka, stride_a, pb, lb, kb, stride_b, key, nonce, rounds,
+                                                state.ptr if state is not None else None, t, m, out.ptr,
+                                                out.stride * out_rows_per_party, out.stride, n, nbatch,
+                                                self._stream()), 'gate_rng_batch')
+        return out
+
     def _rec_args(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int):
         k = len(rows)
+        if not k:
+            raise ValueError('no share rows')
         if len(lambdas) != w * k:
             raise ValueError('need w*k lambda values')
+        self._same(rows[0].n, *rows, what='share row')
         ptrs = (ctypes.c_void_p * k)(*[r.ptr for r in rows])
         lam = (ctypes.c_uint64 * (2 * w * k))()
         for i, v in enumerate(lambdas):
@@ -443,10 +504,11 @@ class FieldContext:
         k, ptrs, lam = self._rec_args(rows, lambdas, w)
         n = rows[0].n
         if w == 1:
+            self._same(n, out, what='output')
             out = out or self.empty(n)
             stride = n
         else:
-            out = out or self.empty_matrix(w, n)
+            out = self._out_matrix(out, w, n)
             stride = out.stride
         _ffi.check(self._L.ffgpu_recombine(self._h, ptrs, lam, k, w, out.ptr, stride, n, self._stream()),
                    'recombine')
@@ -457,6 +519,10 @@ class FieldContext:
         the returned callable only issues the kernel (hot loops, benchmarks)."""
         k, ptrs, lam = self._rec_args(rows, lambdas, w)
         n = rows[0].n
+        if w == 1:
+            self._same(n, out, what='output')
+        else:
+            self._out_matrix(out, w, n)
         stride = n if w == 1 else out.stride
         fn, h, optr = self._L.ffgpu_recombine, self._h, out.ptr
         keep = (rows, out)
@@ -617,6 +683,43 @@ class FieldContext:
                 b[2 * i] = int(v)
         _ffi.check(self._L.ffgpu_gf256_bit_affine(self._h, m, b, 1 if from_bits else 0, bits.ptr, out.ptr, ng,
                                                   self._stream()), 'bit_affine')
+        return out
+
+    @staticmethod
+    def _scalars(vals: Sequence[int]):
+        w = (ctypes.c_uint64 * (2 * max(1, len(vals))))()
+        for i, v in enumerate(vals):
+            w[2 * i], w[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        return w
+
+    def gf256_mask_open(self, rows: Sequence[DevArray], coefs: Sequence[int], rbits: Sequence[DevArray],
+                        mus: Sequence[int], out: Optional[DevArray] = None) -> DevArray:
+        """GF(2^8): c = sum_r coefs[r] * rows[r] + sum_p mus[p] * from_bits(rbits[p]) -- the opened masked value of
+        np_to_bits (runtime.py:4414-4421) in one pass (ffgpu_gf256_mask_open)."""
+        if len(rows) != len(coefs) or len(rbits) != len(mus) or not (rows or rbits):
+            raise ValueError('one coefficient per row')
+        n = rows[0].n if rows else rbits[0].n // 8
+        self._same(n, *rows, out, what='share row')
+        self._same(8 * n, *rbits, what='bit-share row')
+        out = out or self.empty(n)
+        pr = (ctypes.c_void_p * max(1, len(rows)))(*[r.ptr for r in rows])
+        pb = (ctypes.c_void_p * max(1, len(rbits)))(*[r.ptr for r in rbits])
+        _ffi.check(self._L.ffgpu_gf256_mask_open(self._h, pr, self._scalars(coefs), len(rows), pb, self._scalars(mus),
+                                                 len(rbits), out.ptr, n, self._stream()), 'gf256_mask_open')
+        return out
+
+    def gf256_bits_affine_fold(self, c: DevArray, rbits: DevMatrix, matrix: Sequence[Sequence[int]],
+                               bias: Optional[Sequence[int]] = None, out: Optional[DevMatrix] = None) -> DevMatrix:
+        """GF(2^8), all parties in one launch: out[y] = from_bits(M (bits(c) + rbits[y]) + bias) for every row y of
+        the (parties, 8n) matrix of bit shares (runtime.py:4422-4423 + np_aes.py:40-42; ffgpu_gf256_bits_affine_fold)."""
+        n = c.n
+        if rbits.n != 8 * n:
+            raise ValueError('need 8 bit shares per byte')
+        out = self._out_matrix(out, rbits.rows, n)
+        mm = self._scalars([v for row in matrix for v in row])
+        bb = self._scalars(bias) if bias is not None else None
+        _ffi.check(self._L.ffgpu_gf256_bits_affine_fold(self._h, mm, bb, c.ptr, rbits.ptr, rbits.stride, out.ptr, out.stride,
+                                                        n, rbits.rows, self._stream()), 'gf256_bits_affine_fold')
         return out
 
     def to_bits(self, x: DevArray, addend: Optional[DevArray] = None, out: Optional[DevArray] = None) -> DevArray:

@@ -159,6 +159,98 @@ def from_bits(ctx: FieldContext, bits: Shares, l: int = 8) -> Shares:
     return [ctx.group_matvec(b, weights) for b in bits]
 
 
+# ---- the same layer with ALL parties in every launch ---------------------------------------------------------
+# The per-party functions above issue one launch per party and step (what each MPyC party does in its own
+# process).  When all m parties of a computation sit on one GPU the parties' launches of a step are identical
+# up to pointers, so they become grid rows of ONE launch: shares of all parties are the rows of one DevMatrix,
+# sub-shares live in an (m * k)-row block used as [recipient][sender], and a layer of the x^254 chain is one
+# ffgpu_gate_rng_batch.  The two local steps around the opening inside np_to_bits are one kernel each
+# (ffgpu_gf256_mask_open, ffgpu_gf256_bits_affine_fold).  13 launches per S-box layer instead of 49.
+def as_matrix(ctx: FieldContext, xs: Shares):
+    """The parties' shares as the rows of one DevMatrix: a view when they already are equally spaced rows of one
+    allocation (what share() / split return), else a copy."""
+    import torch
+    from .engine import DevMatrix, limbs_of
+    m, n, eb = len(xs), xs[0].n, ctx.elem_bytes
+    unit = 4 if eb == 12 else eb                      # bytes of one tensor element
+    step = (xs[1].ptr - xs[0].ptr) if m > 1 else 0
+    lb = limbs_of(eb)
+    same_storage = all(x.t.untyped_storage().data_ptr() == xs[0].t.untyped_storage().data_ptr() for x in xs)
+    if m > 1 and same_storage and step > 0 and step % eb == 0 and step // eb >= n and \
+            all(xs[i].ptr - xs[0].ptr == i * step for i in range(m)) and all(x.n == n for x in xs) and \
+            xs[0].t.storage_offset() * unit + (m - 1) * step + n * eb <= xs[0].t.untyped_storage().nbytes():
+        stride = step // eb
+        shape, strides = ((m, stride, lb), (stride * lb, lb, 1)) if lb else ((m, stride), (stride, 1))
+        span = xs[0].t.storage_offset() + ((m - 1) * stride + stride) * (lb or 1)
+        if span * unit <= xs[0].t.untyped_storage().nbytes():
+            return DevMatrix(ctx, torch.as_strided(xs[0].t, shape, strides, xs[0].t.storage_offset()), m, n, stride)
+    mtx = ctx.empty_matrix(m, n)
+    for i, x in enumerate(xs):
+        mtx.row(i).t.copy_(x.t)
+    return mtx
+
+
+class _Block:
+    """Sub-shares of one re-sharing round, all parties: row j * k + s of `mtx` = the sub-share sender s+1 dealt to
+    party j+1."""
+
+    __slots__ = ('mtx', 'k', 'lam')
+
+    def __init__(self, mtx, k, lam):
+        self.mtx, self.k, self.lam = mtx, k, lam
+
+    def rows_of(self, j: int):
+        return [self.mtx.row(j * self.k + s) for s in range(self.k)]
+
+
+def _gate_all(ctx: FieldContext, x, y, t: int, m: int, lam, rng):
+    """One secure multiplication (runtime.py:1096-1141 + :603-689) for all parties: the k = 2t+1 senders recombine
+    their factors (pending _Blocks or plain share matrices), multiply and re-share in ONE launch."""
+    k = 2 * t + 1
+
+    def operand(v):
+        if isinstance(v, _Block):
+            return v.rows_of(0), v.lam, v.k * v.mtx.stride
+        return [v.row(0)], [1], v.stride
+    ra, la, sa = operand(x)
+    rb, lb, sb = (None, None, 0) if y is x else operand(y)
+    n = ra[0].n
+    out = ctx.empty_matrix(m * k, n)
+    ctx.gate_batch(ra, la, sa, rb, lb, sb, t, m, k, out, k, state=rng)
+    return _Block(out, k, lam)
+
+
+def sbox_layer_all(ctx: FieldContext, field, xs, rbits, t: int, A: Sequence[Sequence[int]], B: Sequence[int], rng=None):
+    """sbox_layer() with all parties in every launch (see above): xs / rbits are Shares lists or DevMatrix (one row
+    per party); returns a DevMatrix of the parties' shares of S-box(x).  GF(2^8), t <= 3."""
+    from .engine import DevMatrix
+    X = xs if isinstance(xs, DevMatrix) else as_matrix(ctx, xs)
+    R = rbits if isinstance(rbits, DevMatrix) else as_matrix(ctx, rbits)
+    m, k = X.rows, 2 * t + 1
+    if m < k or R.rows != m:
+        raise ValueError('multiplication needs m >= 2t+1 parties, and bit shares for each of them')
+    lam = _lagrange(field, range(1, k + 1))
+    mul = lambda a, b: _gate_all(ctx, a, b, t, m, lam, rng)
+    d = X                                               # x^254 by the reference's addition chain, runtime.py:1356-1367
+    c = mul(d, d)
+    c = mul(c, c)
+    c = mul(c, c)
+    c = mul(c, d)
+    c = mul(c, c)
+    c, d = mul(c, c), mul(c, d)
+    c, d = mul(c, c), mul(c, d)
+    c = mul(c, d)
+    y = mul(c, c)                                       # pending: party j holds sum_s lam[s] * y.rows_of(j)[s]
+    mu = _lagrange(field, range(1, t + 2))              # opening from the first t+1 parties (runtime.py:582-585)
+    rows, coefs = [], []
+    for p in range(t + 1):
+        for s, r in enumerate(y.rows_of(p)):
+            rows.append(r)
+            coefs.append(int(field(mu[p]) * field(lam[s])))
+    opened = ctx.gf256_mask_open(rows, coefs, [R.row(p) for p in range(t + 1)], mu[:t + 1])
+    return ctx.gf256_bits_affine_fold(opened, R, A, B)
+
+
 def sbox_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A: Sequence[Sequence[int]],
                B: Sequence[int], fused: bool = True, rng=None, chain: bool = True) -> Shares:
     """The AES S-box on secret-shared bytes, as demos/np_aes.py:37-43:
@@ -169,6 +261,14 @@ def sbox_layer(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A: S
         return [ctx.bit_affine(b, A, B, from_bits=True) for b in bits]           # both local steps in one pass
     bits = [ctx.group_matvec(b, A, B) for b in bits]
     return from_bits(ctx, bits)
+
+
+def _sbox_any(ctx: FieldContext, field, xs: Shares, rbits: Shares, t: int, A, B, rng) -> Shares:
+    """S-box layer for the AES functions below: all parties per launch when the fused chain applies (t <= 3)."""
+    if t <= 3:
+        out = sbox_layer_all(ctx, field, xs, rbits, t, A, B, rng)
+        return [out.row(i) for i in range(out.rows)]
+    return sbox_layer(ctx, field, xs, rbits, t, A, B, rng=rng)
 
 
 # ---- AES-128 on secret-shared blocks (demos/np_aes.py:55-86) ------------------------------------------
@@ -209,7 +309,7 @@ def aes128_key_expansion(ctx: FieldContext, field, key: Shares, nblk: int, rbits
     for i in range(4, 44):
         prev = w[i - 1]
         if i % 4 == 0:
-            sub = sbox_layer(ctx, field, [_cat(ctx, prev[pi]) for pi in range(m)], rbits_fn(4 * nblk), t, A, B, rng=rng)
+            sub = _sbox_any(ctx, field, [_cat(ctx, prev[pi]) for pi in range(m)], rbits_fn(4 * nblk), t, A, B, rng)
             tcol = [[_row(ctx, sub[pi], (r + 1) % 4, nblk) for r in range(4)] for pi in range(m)]        # RotWord
             rcon = _xpow(ctx.modulus, i // 4 - 1)                   # f256(1) << i//Nk - 1  (np_aes.py:67)
             for pi in range(m):
@@ -228,7 +328,7 @@ def aes128_encrypt(ctx: FieldContext, field, K, state: Shares, nblk: int, rbits_
     lam = [v for row in _MIX for v in row]
     s = [ctx.add(state[pi], K[0][pi]) for pi in range(m)]
     for rnd in range(1, 11):
-        s = sbox_layer(ctx, field, s, rbits_fn(16 * nblk), t, A, B, rng=rng)
+        s = _sbox_any(ctx, field, s, rbits_fn(16 * nblk), t, A, B, rng)
         nxt = []
         for pi in range(m):
             # ShiftRows: s'[r][c] = s[r][(c + r) % 4]  (np.roll(s[r], -r))

@@ -232,7 +232,8 @@ int orc_sbox(const unsigned char* in, const uint8_t* rows8, uint8_t b, unsigned 
  * Device CSPRNG restatement (mpyc_amd/csrc/rng.hpp).  The reference has no counterpart (it calls
  * secrets.randbelow per coefficient, thresha.py:37,58-60); this pins the *published algorithm*:
  * ChaCha block function (RFC 8439 section 2.3, checked against its test vector 2.3.2 in
- * tests/test_rng.py) + "W+64 uniform bits mod p" sampling + the documented keystream layout.
+ * tests/test_rng.py) + rejection sampling with per-sample re-draw blocks / "W+64 uniform bits mod p" sampling
+ * + the documented keystream layout.
  * ------------------------------------------------------------------------------------------ */
 static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
 static void qround(uint32_t* s, int a, int b, int c, int d) {
@@ -289,7 +290,6 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
     int kbits = 0;
     const int pm = orc_is_pm(f, &kbits);
     const int S = packed ? 4 : (f->binary ? eb : (pm ? eb : (eb == 16 ? 32 : 16)));
-    const int SPARE = pm ? 2 : 0;
     const u128 kmask = kbits >= 128 ? ~(u128)0 : ((((u128)1) << kbits) - 1);
     uint32_t key[8];
     memcpy(key, key32, 32);
@@ -308,10 +308,10 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
         /* group size: G in 1..4 with the fewest blocks per pack (smallest G on ties) */
         int G = 1;
         for (int g = 2; g <= 4; ++g) {
-            int bg = ((g * NS + SPARE) * S + 63) / 64, bG = ((G * NS + SPARE) * S + 63) / 64;
+            int bg = (g * NS * S + 63) / 64, bG = (G * NS * S + 63) / 64;
             if (bg * G < bG * g) G = g;
         }
-        const int B = ((G * NS + SPARE) * S + 63) / 64;
+        const int B = (G * NS * S + 63) / 64;
         uint32_t n0 = (uint32_t)nonce, n1 = (uint32_t)(nonce >> 32);
         if (t > 4) n1 += (uint32_t)(d + 1);
         const size_t ngroups = (npacks + G - 1) / G;
@@ -322,7 +322,6 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
                 uint32_t w[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), n0, n1};
                 orc_chacha_block(key, w, rounds, ks + 16 * b);
             }
-            const uint32_t* spare = ks + G * NS * (S / 4);
             for (int u = 0; u < G; ++u) {
                 size_t i = (size_t)u * ngroups + grp;   /* pack index: group g serves g, g+NG, g+2NG, ... */
                 if (i >= npacks) continue;
@@ -344,11 +343,18 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
                     } else if (pm) {
                         v = ld_words(w, eb / 4) & kmask;
                         if (v >= f->p) {
-                            v = ld_words(spare, eb / 4) & kmask;
-                            if (v >= f->p) {
-                                v = ld_words(spare + eb / 4, eb / 4) & kmask;
-                                if (v >= f->p) v -= f->p;
+                            /* rejected: the sample's own re-draw block, counter 2^63 + its global index; first
+                             * candidate below p wins, the last one is conditionally reduced if none is */
+                            uint64_t sidx = (uint64_t)grp * (uint64_t)(G * NS) + (uint64_t)(u * NS + sn);
+                            uint32_t wr[4] = {(uint32_t)sidx, (uint32_t)(sidx >> 32) | 0x80000000u, n0, n1};
+                            uint32_t blk[16];
+                            orc_chacha_block(key, wr, rounds, blk);
+                            int nc = 64 / S, found = 0;
+                            for (int ci = 0; ci < nc && !found; ++ci) {
+                                v = ld_words(blk + ci * (S / 4), eb / 4) & kmask;
+                                if (v < f->p) found = 1;
                             }
+                            if (!found) v -= f->p;
                         }
                     } else if (eb == 4) {
                         v = ld_words(w, 3) % f->p;                      /* 96 bits */

@@ -35,6 +35,29 @@ def main():
             mine = got[0]
             gathered = [torch.empty_like(full[0][slice(*multigpu.shard_range(n, r, world))]) for r in range(world)]
             dist.all_gather(gathered, mine) if all(g.shape == mine.shape for g in gathered) else None
+            # the inverse exchange puts the slices back into whole rows on their owners
+            back = {j: torch.zeros_like(full[j]) for j in local}
+            multigpu.scatter_party_major(got, row_ids, n, back)
+            for j in local:
+                assert torch.equal(back[j], full[j]), (rank, j)
+            # all-gather form: owners write their rows into the block, everyone reads whole rows afterwards
+            pg = multigpu.PartyMajorGather(k, n, full[0])
+            for j in local:
+                pg.block_row(j).copy_(full[j])
+            pg.gather()
+            for j in range(k):
+                assert torch.equal(pg.row(j), full[j]), (rank, j)
+            assert pg.bytes_received == (world - 1) * pg.rows_per_rank * full[0].numel() * 8
+            # ragged rows are refused before anything is sent
+            if local:
+                bad = dict(local)
+                j0 = next(iter(bad))
+                bad[j0] = bad[j0][:-1]
+                try:
+                    multigpu.exchange_party_major(bad, row_ids, n)
+                    raise AssertionError('ragged row accepted')
+                except ValueError:
+                    pass
     rows = multigpu.allgather_rows(torch.full((11,), rank, dtype=torch.int64))
     assert [int(r[0]) for r in rows] == list(range(world))
     # MAX-over-ranks reduction used by bench.py

@@ -578,7 +578,9 @@ def test_skinny_products(eng, coracle):
     flush, ragged sizes, and sub-matrix views with a leading dimension larger than the row length."""
     cases = [(200, 333, 1), (100, 257, 3), (64, 1000, 8), (77, 5, 2), (1, 500, 300), (3, 1000, 129), (8, 2100, 64), (2, 7, 1000),
              (64, 300, 200), (40, 1000, 90), (130, 2000, 70), (9, 129, 9),      # these four: tiled kernel with split-K
-             (5000, 7, 1), (3000, 32, 3)]                                        # short rows: one thread per row
+             (5000, 7, 1), (3000, 32, 3),                                        # short rows: one thread per row
+             (4096, 1024, 1), (4101, 1030, 2), (8192, 2050, 1),                  # several rows per workgroup (k_matvec_rows_r)
+             (1, 4096, 4096), (2, 300, 4098), (5, 1111, 640)]                    # waves of a workgroup split K (k_vecmat_slab)
     for modulus, binary in [(P61, False), (P64, False), (2**96 - 17, False), (P128, False), (6616326157076047771, False),
                             (2**31 - 1, False), (258797994007609146293811961253269568351, False),
                             ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]:
@@ -586,7 +588,7 @@ def test_skinny_products(eng, coracle):
         ctx = ctx_for(eng, modulus, binary)
         eb = ctx.elem_bytes
         cf = coracle.CField(modulus, binary)
-        for (M, K, N) in cases if eb < 12 else cases[:2] + cases[4:6] + cases[8:10] + cases[12:13]:
+        for (M, K, N) in cases if eb < 12 else cases[:2] + cases[4:6] + cases[8:10] + cases[12:13] + cases[14:15] + cases[17:18]:
             A, B = rand_np(F, eb, M * K, 91), rand_np(F, eb, K * N, 92)
             if not binary:
                 A[:K] = pack([F.order - 1] * K, eb)

@@ -335,3 +335,137 @@ def test_pow254_fused_equals_unfused(mods):
     xs = protocols.share(ctx, ctx.from_numpy(np.array(x, dtype=np.uint8)), 1, 3)
     y = protocols.pow254_fused(ctx, F, xs, 1)
     assert unpack(protocols.open_(ctx, F, y, 1).to_numpy(), 1) == [g['pow254'][v] for v in x]
+
+
+# ---- all parties in one launch (protocols.sbox_layer_all) --------------------------------------------------------
+def _gf8_mul(a, b):
+    return po.mul(po.Field(0x11b, True), a, b)
+
+
+@pytest.mark.gpu
+def test_gf256_mask_open_and_bits_affine_fold_match_the_step_by_step_kernels(mods):
+    """The two fused kernels of the secure bit decomposition against (a) Python integers (oracle arithmetic) and
+    (b) the composition of the single-step kernels they replace, bit for bit, incl. odd lengths and unaligned views."""
+    engine, finfields, gfpx, protocols = mods
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    rng = np.random.default_rng(11)
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    for n in (1, 2, 15, 4098, 100_003):
+        nrows, npar = 6, 2
+        rows = [rng.integers(0, 256, size=n, dtype=np.uint8) for _ in range(nrows)]
+        coefs = [int(v) for v in rng.integers(1, 256, size=nrows)]
+        coefs[1] = 0                                                      # a zero coefficient is skipped
+        rb = [rng.integers(0, 256, size=8 * n, dtype=np.uint8) for _ in range(npar)]
+        mus = [3, 2]
+        drows = [ctx.from_numpy(r) for r in rows]
+        drb = [ctx.from_numpy(r) for r in rb]
+        got = ctx.gf256_mask_open(drows, coefs, drb, mus).to_numpy()
+        # (b) step by step: scalar multiples, from_bits through the small-matrix kernel, adds
+        acc = None
+        for r, cf in zip(drows, coefs):
+            term = ctx.mul_scalar(r, cf)
+            acc = term if acc is None else ctx.add(acc, term)
+        for r, mu in zip(drb, mus):
+            acc = ctx.add(acc, ctx.mul_scalar(ctx.group_matvec(r, [[1 << j for j in range(8)]]), mu))
+        assert (got == acc.to_numpy()).all(), n
+        # (a) Python integers on a sample
+        for h in list(range(min(n, 40))) + [n - 1]:
+            v = 0
+            for r, cf in zip(rows, coefs):
+                v ^= _gf8_mul(int(r[h]), cf)
+            for r, mu in zip(rb, mus):
+                fb = 0
+                for b in range(8):
+                    fb ^= _gf8_mul(int(r[8 * h + b]), 1 << b)
+                v ^= _gf8_mul(fb, mu)
+            assert int(got[h]) == v, (n, h)
+        # bits(c) + r_bits -> affine -> from_bits, all parties in one launch
+        m = 3
+        R = ctx.empty_matrix(m, 8 * n)
+        rr = [rng.integers(0, 256, size=8 * n, dtype=np.uint8) for _ in range(m)]
+        for i in range(m):
+            R.row(i).t.copy_(ctx.from_numpy(rr[i]).t)
+        c = ctx.from_numpy(rng.integers(0, 256, size=n, dtype=np.uint8))
+        out = ctx.gf256_bits_affine_fold(c, R, A, B)
+        for i in range(m):
+            want = ctx.bit_affine(ctx.to_bits(c, addend=R.row(i)), A, B, from_bits=True)
+            assert (out.row(i).to_numpy() == want.to_numpy()).all(), (n, i)
+        # a general (non 0/1) matrix takes the other instantiation
+        M2 = [[int(v) for v in rng.integers(0, 256, size=8)] for _ in range(8)]
+        out2 = ctx.gf256_bits_affine_fold(c, R, M2, None)
+        want2 = ctx.bit_affine(ctx.to_bits(c, addend=R.row(1)), M2, None, from_bits=True)
+        assert (out2.row(1).to_numpy() == want2.to_numpy()).all(), n
+        if n > 16:      # unaligned operands: scalar path, same values
+            sub = [engine.DevArray(ctx, r.t[1:], n - 1) for r in drows]
+            subb = [engine.DevArray(ctx, r.t[8:], 8 * (n - 1)) for r in drb]
+            got_u = ctx.gf256_mask_open(sub, coefs, subb, mus).to_numpy()
+            assert (got_u == got[1:]).all()
+    with pytest.raises(ValueError):
+        ctx.gf256_mask_open(drows, coefs, [engine.DevArray(ctx, drb[0].t[:-8], drb[0].n - 8)], mus[:1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('t,m', [(1, 3), (2, 5), (1, 4), (3, 7)])
+def test_sbox_layer_all_parties_in_one_launch(mods, t, m):
+    """protocols.sbox_layer_all (13 launches: 11 batched chain gates + 2 fused bit-decomposition kernels) opens to
+    the FIPS-197 S-box of every byte value, like the per-party layer."""
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    for x in (list(range(256)) * 5 + [0x53, 0x00, 0xff], list(range(256)) * 1100, [0x53]):
+        n = len(x)
+        xpub = ctx.from_numpy(np.array(x, dtype=np.uint8))
+        xs = protocols.share(ctx, xpub, t, m)
+        rb = torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0')
+        rbits = protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m)
+        X = protocols.as_matrix(ctx, xs)
+        assert X.t.data_ptr() == xs[0].ptr                                   # a view, not a copy
+        out = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B)
+        shares = [out.row(i) for i in range(m)]
+        want = [g['table'][v] for v in x]
+        assert unpack(protocols.open_(ctx, F, shares, t).to_numpy(), 1) == want
+        # any t+1 parties open it, and the shares are not the value itself
+        sub = shares[m - t - 1:]
+        lam = [int(v) for v in __import__('mpyc_amd.thresha', fromlist=['x'])._recombination_vector(F, tuple(range(m - t, m + 1)), 0)]
+        assert unpack(ctx.recombine(sub, lam).to_numpy(), 1) == want
+        if n > 100:
+            assert unpack(shares[0].to_numpy(), 1) != want
+    # scattered shares (not rows of one matrix) are copied into one
+    lone = [ctx.from_numpy(np.array([1, 2, 3], dtype=np.uint8)) for _ in range(m)]
+    M = protocols.as_matrix(ctx, lone)
+    assert M.rows == m and unpack(M.row(m - 1).to_numpy(), 1) == [1, 2, 3]
+
+
+@pytest.mark.gpu
+def test_batched_chain_gate_opens_to_products(mods):
+    """ffgpu_gate_rng_batch over a prime field: k senders in one launch, operands as plain share matrices and as
+    pending blocks; every party's recombined share opens to a*b (and the senders drew different randomness)."""
+    engine, finfields, gfpx, protocols = mods
+    p = 2**61 - 1
+    F = finfields.GF(p)
+    ctx = engine.FieldContext(p, device=0)
+    t, m = 1, 3
+    k = 2 * t + 1
+    n = 70_001
+    r = np.random.default_rng(3)
+    a = r.integers(0, p, size=n, dtype=np.uint64)
+    b = r.integers(0, p, size=n, dtype=np.uint64)
+    As = protocols.as_matrix(ctx, protocols.share(ctx, ctx.from_numpy(a), t, m))
+    Bs = protocols.as_matrix(ctx, protocols.share(ctx, ctx.from_numpy(b), t, m))
+    lam = protocols._lagrange(F, range(1, k + 1))
+    blk = protocols._gate_all(ctx, As, Bs, t, m, lam, None)                     # plain x plain
+    want_ab = [(int(x) * int(y)) % p for x, y in zip(a[:200], b[:200])]
+    shares = [ctx.recombine(blk.rows_of(j), lam) for j in range(m)]
+    assert protocols.open_(ctx, F, shares, t).to_ints()[:200] == want_ab
+    assert blk.mtx.row(0).to_ints()[:50] != blk.mtx.row(1).to_ints()[:50]      # sender 1 and sender 2 -> party 1 differ
+    blk2 = protocols._gate_all(ctx, blk, blk, t, m, lam, None)                  # pending squared
+    shares2 = [ctx.recombine(blk2.rows_of(j), lam) for j in range(m)]
+    assert protocols.open_(ctx, F, shares2, t).to_ints()[:200] == [(v * v) % p for v in want_ab]
+    blk3 = protocols._gate_all(ctx, blk2, As, t, m, lam, None)                  # pending x plain
+    shares3 = [ctx.recombine(blk3.rows_of(j), lam) for j in range(m)]
+    assert protocols.open_(ctx, F, shares3, t).to_ints()[:200] == [(v * v * int(x)) % p for v, x in zip(want_ab, a[:200])]

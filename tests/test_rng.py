@@ -77,7 +77,7 @@ def test_sampler_by_hand(hostcheck, coracle):
 def test_rejection_branch(hostcheck, coracle):
     """Rejection is rare for the default primes (2^-56), so exercise the branch on an admissible
     pseudo-Mersenne prime with the largest possible c: p = 2^33 - c, c just below 2^16 (rejection
-    probability ~2^-17 per sample -> dozens of hits in 2^21 samples, including spare re-use)."""
+    probability ~2^-17 per sample -> a handful of hits in the groups restated below)."""
     from mpyc_amd.finfields import is_prime
     from oracle import pyoracle as po
     c = 65535
@@ -92,16 +92,33 @@ def test_rejection_branch(hostcheck, coracle):
     want = coracle.rng_coeffs(cf, KEY, 123, 8, 2, n)
     assert (got == want).all()
     assert int(got.max()) < p
-    # count how many primary samples were rejected, from the raw keystream (pack = 2 elements, t = 2:
-    # 4 primary words + 2 spares = 48 bytes -> G = 1, one block per pack)
+    # Independent restatement in Python of the documented layout for this case (S = 8, pack = 2 elements, t = 2:
+    # NS = 4 samples per pack, G = 2 packs per 64-byte block, group g serves packs g and g + NG) and of the
+    # re-draw rule: a rejected sample takes the first candidate < p of ITS OWN block (counter 2^63 + global sample
+    # index), so no two rejected samples can ever receive the same replacement.
+    mask, NS, G = 2**33 - 1, 4, 2
+    npacks = n // 2
+    ng = (npacks + G - 1) // G
     hits = 0
-    for i in range(0, 4096):
-        blk = coracle.chacha_block(KEY, [i, 0, 123, 0], 8)
-        for sn in range(4):
-            v = (blk[2 * sn] | (blk[2 * sn + 1] << 32)) & (2**33 - 1)
-            hits += v >= p
-    expected = 4096 * 4 * c / 2**33
-    assert hits >= 0 and abs(hits - expected) < 6 * max(1.0, expected) ** 0.5 + 3
+    for g in list(range(0, 3000)) + list(range(ng - 50, ng)):
+        blk = coracle.chacha_block(KEY, [g, 0, 123, 0], 8)
+        for u in range(G):
+            pack = u * ng + g
+            for sn in range(NS):
+                w = blk[2 * (u * NS + sn):2 * (u * NS + sn) + 2]
+                v = (w[0] | (w[1] << 32)) & mask
+                if v >= p:
+                    hits += 1
+                    sidx = g * G * NS + u * NS + sn
+                    rb = coracle.chacha_block(KEY, [sidx & 0xffffffff, (sidx >> 32) | 0x80000000, 123, 0], 8)
+                    cands = [(rb[2 * i] | (rb[2 * i + 1] << 32)) & mask for i in range(8)]
+                    ok = [x for x in cands if x < p]
+                    v = ok[0] if ok else cands[-1] - p
+                assert int(got[sn // 2, pack * 2 + sn % 2]) == v, (g, u, sn)
+    expected = 3050 * G * NS * c / 2**33
+    assert abs(hits - expected) < 6 * max(1.0, expected) ** 0.5 + 3
+    # the re-draw counter is a function of the sample index alone: distinct samples -> distinct blocks
+    assert coracle.chacha_block(KEY, [7, 0x80000000, 123, 0], 8) != coracle.chacha_block(KEY, [8, 0x80000000, 123, 0], 8)
     for q in (2**61 - 1, 2**64 - 189, 2**40 - 87, 2**127 - 1, 2**128 - 173, 2**96 - 17):
         got = hc_coeffs(hostcheck, po.Field(q), KEY, 77, 20, 3, 4099)
         assert (got == coracle.rng_coeffs(coracle.CField(q), KEY, 77, 20, 3, 4099)).all(), q

@@ -14,6 +14,13 @@ if has bench; then
   (time timeout 900 python bench.py --steps 50 --warmup 5 $BENCH_ARGS) > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
   tail -4 $O/bench.log | cut -c1-600
 fi
+if has bench2; then
+  # N = 2 control flow of bench.py on a 1-GPU box: two ranks share GPU 0, gloo (device tensors staged through the host)
+  (FFGPU_BENCH_BACKEND=gloo FFGPU_BENCH_DEVICE=0 FFGPU_BENCH_N=2000000 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+     --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 --steps 5 --warmup 2 --no-extras) > $O/bench2.log 2>&1
+  echo "bench2 rc=$?" >> $O/bench2.log
+  tail -3 $O/bench2.log | cut -c1-1500
+fi
 export TMPDIR=/tmp
 if has prof; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o $T -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline) > $O/rocprof_$T.log 2>&1
