@@ -201,15 +201,22 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
  * y * batch_stride_a (B: y * batch_stride_b) from the given row pointers and writes its m share rows at
  * shares + y * batch_stride_out (+ i * share_stride for party i+1); its coefficients come from the call's
  * generator stream with y added to bits 8..15 of nonce word 1 (nbatch <= 255), so the gates draw independent
- * randomness.  This is what the 2t+1 re-sharing parties of one `_reshare` (runtime.py:658-666) do when a whole
+ * randomness (dev_state / nonce / defer_advance: see ffgpu_rng_state_advance below).  This is what the 2t+1 re-sharing parties of one `_reshare` (runtime.py:658-666) do when a whole
  * computation is held on one GPU: with the sub-shares stored [recipient][sender][n] the senders of the next gate
  * are batch_stride = (2t+1)*n apart and a layer of the np_aes S-box chain (runtime.py:1356-1367) is one launch
  * instead of 2t+1.  nbatch = 1 is ffgpu_gate_rng.                                                              */
 int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
                          size_t batch_stride_a, const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb,
                          size_t batch_stride_b, const uint8_t* host_key32, uint64_t nonce, int rounds, void* dev_state,
-                         int t, int m, void* shares, size_t share_stride, size_t batch_stride_out, size_t n, int nbatch,
-                         void* stream);
+                         int defer_advance, int t, int m, void* shares, size_t share_stride, size_t batch_stride_out,
+                         size_t n, int nbatch, void* stream);
+
+/* Deferred advance of a device-resident generator state: with dev_state != NULL, ffgpu_gate_rng_batch draws from
+ * (state nonce + `nonce`) -- `nonce` < 2^32 is then an OFFSET -- and, if defer_advance != 0, leaves the state alone.
+ * A sequence of N launches uses offsets 0..N-1 and ends with ONE ffgpu_rng_state_advance(state, N), instead of one
+ * nonce update (a one-thread kernel for large grids, ~4 us) after every launch; captured in a HIP graph the offsets
+ * are constants and the single advance keeps every replay on fresh nonces.                                        */
+int ffgpu_rng_state_advance(ffgpu_ctx* ctx, void* dev_state, uint32_t by, void* stream);
 
 /* Device-resident generator state, for launches captured in a HIP graph: the kernels read key / nonce /
  * rounds from `dev_state` (ffgpu_rng_state_bytes() bytes of device memory) when they start, and the nonce is

@@ -65,7 +65,8 @@ _SIGS = {
     'ffgpu_gate_rng': [_vp, ctypes.POINTER(_vp), _u64p, _int, ctypes.POINTER(_vp), _u64p, _int, ctypes.c_char_p,
                        ctypes.c_uint64, _int, _vp, _int, _int, _vp, _sz, _sz, _vp],
     'ffgpu_gate_rng_batch': [_vp, ctypes.POINTER(_vp), _u64p, _int, _sz, ctypes.POINTER(_vp), _u64p, _int, _sz, ctypes.c_char_p,
-                             ctypes.c_uint64, _int, _vp, _int, _int, _vp, _sz, _sz, _sz, _int, _vp],
+                             ctypes.c_uint64, _int, _vp, _int, _int, _int, _vp, _sz, _sz, _sz, _int, _vp],
+    'ffgpu_rng_state_advance': [_vp, _vp, ctypes.c_uint32, _vp],
     'ffgpu_rng_state_bytes': [],
     'ffgpu_rng_state_init': [_vp, _vp, ctypes.c_char_p, ctypes.c_uint64, _int, _vp],
     'ffgpu_split_rng_state': [_vp, _vp, _vp, _vp, _int, _int, _vp, _sz, _sz, _vp],

@@ -630,17 +630,26 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
                    const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb, const uint8_t* host_key32,
                    uint64_t nonce, int rounds, void* dev_state, int t, int m, void* shares, size_t share_stride,
                    size_t n, void* stream) {
-    return ffgpu_gate_rng_batch(ctx, host_rows_a, host_lambda_a, ka, 0, host_rows_b, host_lambda_b, kb, 0, host_key32, nonce,
-                                rounds, dev_state, t, m, shares, share_stride, 0, n, 1, stream);
+    return ffgpu_gate_rng_batch(ctx, host_rows_a, host_lambda_a, ka, 0, host_rows_b, host_lambda_b, kb, 0, host_key32,
+                                dev_state ? 0 : nonce, rounds, dev_state, 0, t, m, shares, share_stride, 0, n, 1, stream);
+}
+
+int ffgpu_rng_state_advance(ffgpu_ctx* ctx, void* dev_state, uint32_t by, void* stream) {
+    ARGCHK(ctx && dev_state);
+    if (by == 0) return FFGPU_OK;
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, (hipStream_t)stream, (RngKey*)dev_state, by);
+    return hipGetLastError() == hipSuccess ? FFGPU_OK : FFGPU_EHIP;
 }
 
 int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_t* host_lambda_a, int ka,
                          size_t batch_stride_a, const void* const* host_rows_b, const uint64_t* host_lambda_b, int kb,
                          size_t batch_stride_b, const uint8_t* host_key32, uint64_t nonce, int rounds, void* dev_state,
-                         int t, int m, void* shares, size_t share_stride, size_t batch_stride_out, size_t n, int nbatch,
-                         void* stream) {
+                         int defer_advance, int t, int m, void* shares, size_t share_stride, size_t batch_stride_out,
+                         size_t n, int nbatch, void* stream) {
     ARGCHK(ctx);
     ARGCHK(nbatch >= 1 && nbatch <= 255);
+    ARGCHK(!dev_state || nonce <= 0xffffffffull);
     ARGCHK(m >= 1 && t >= 1 && t < m && ka >= 1 && kb >= 0);
     if (t > 3 || ka > 7 || kb > 7) return FFGPU_ENOTSUP;
     ARGCHK(host_rows_a && host_lambda_a && (kb == 0 || (host_rows_b && host_lambda_b)));
@@ -651,6 +660,8 @@ int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const u
         ra.r0 = ctx->rng_r[0];
         ra.r1 = ctx->rng_r[1];
         ra.dev_key = (const RngKey*)dev_state;
+        ra.nonce_off = (uint32_t)nonce;
+        ra.no_advance = defer_advance ? 1 : 0;
     } else {
         int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
         if (rc != FFGPU_OK) return rc;

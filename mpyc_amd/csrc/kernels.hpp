@@ -269,6 +269,9 @@ struct RngArgs {
     // antilogs; misc.hip Gf8Tables).  When set, the product of the fused kernel goes through LDS lookups,
     // which run beside the ChaCha VALU work instead of adding ~110 VALU ops per word to it.
     const void* aux;
+    uint32_t nonce_off;  // device-resident state: added to the state's nonce for THIS launch (deferred advance: a
+                         // sequence of launches uses offsets 0, 1, 2, ... and ONE ffgpu_rng_state_advance follows)
+    int no_advance;      // 1: this launch leaves the device-resident nonce alone (the caller advances it)
     int release;  // 1: the kernel's last workgroup advances the device-resident nonce (small grids only: one
                   // atomic per workgroup on one address serialises, ~25 ns each); 0: k_rng_advance follows
 };
@@ -343,9 +346,20 @@ __device__ __forceinline__ void rng_state_release(const RngArgs& ra) {
 
 // large grids: a one-thread kernel after the share-generation kernel (stream order) advances the nonce
 template <int UNUSED>
-__global__ void k_rng_advance(RngKey* st) {
+__global__ void k_rng_advance(RngKey* st, uint32_t by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (++st->nonce[0] == 0) st->nonce[1] += 65536u;
+        const uint32_t old = st->nonce[0];
+        st->nonce[0] = old + by;
+        if (st->nonce[0] < old) st->nonce[1] += 65536u;
+    }
+}
+// kernel start: key / nonce / rounds from the device-resident state, plus this launch's offset
+__device__ __forceinline__ void rng_load_state(RngArgs& ra) {
+    if (ra.dev_key) {
+        ra.rk = *ra.dev_key;
+        const uint32_t old = ra.rk.nonce[0];
+        ra.rk.nonce[0] = old + ra.nonce_off;
+        if (ra.rk.nonce[0] < old) ra.rk.nonce[1] += 65536u;
     }
 }
 enum { RNG_RELEASE_MAX_GRID = 512 };
@@ -356,18 +370,17 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
                                                   int m, typename F::elem* __restrict__ out, size_t ostride,
                                                   size_t nvec, size_t n, RngArgs ra, GateSrc<F> gs) {
-    if (ra.dev_key) ra.rk = *ra.dev_key;
+    rng_load_state(ra);
+    // batched launch: gate y = blockIdx.y reads its operand rows yA / yB elements further on and writes yO further on.
+    // (The offsets are added where the rows are indexed: the row-pointer arrays stay read-only kernel arguments --
+    // a modified copy would be demoted to scratch memory, since they are indexed by the runtime row count.)
+    size_t yoffA = 0, yoffB = 0;
     if constexpr (REC) {
-        const size_t yb = blockIdx.y;                  // wave-uniform: scalar pointer arithmetic
-        if (yb) {
-#pragma unroll
-            for (int j = 0; j < GATE_MAXK; ++j) {
-                gs.rowsA[j] += yb * gs.yA;
-                gs.rowsB[j] += yb * gs.yB;
-            }
-            out += yb * gs.yO;
-            ra.rk.nonce[1] += (uint32_t)yb << 8;
-        }
+        const size_t yb = blockIdx.y;                  // wave-uniform
+        yoffA = yb * gs.yA;
+        yoffB = yb * gs.yB;
+        out += yb * gs.yO;
+        ra.rk.nonce[1] += (uint32_t)yb << 8;
     }
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
@@ -397,11 +410,12 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
         P s, s2;
         if constexpr (REC) {
-            s = gs.plainA ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsA[0]) + i)
-                          : gate_load<F, NT>(f, gs.rowsA, gs.lamA, gs.kA, i);
+            const size_t iA = i + yoffA / EPV_, iB = i + yoffB / EPV_;      // batch offsets are whole packs on this path
+            s = gs.plainA ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsA[0]) + iA)
+                          : gate_load<F, NT>(f, gs.rowsA, gs.lamA, gs.kA, iA);
             s2 = gs.square ? s
-                           : (gs.plainB ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsB[0]) + i)
-                                        : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, i));
+                           : (gs.plainB ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsB[0]) + iB)
+                                        : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, iB));
         } else {
             s = ldg<NT>(av + i);
             if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
@@ -492,10 +506,11 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     for (size_t e = done + gid; e < n; e += gsz) {
         W s;
         if constexpr (REC) {
-            s = gs.plainA ? ld_elem<F>(gs.rowsA[0], e) : gate_load_elem<F>(f, gs.rowsA, gs.lamA, gs.kA, e);
+            const size_t eA = e + yoffA, eB = e + yoffB;
+            s = gs.plainA ? ld_elem<F>(gs.rowsA[0], eA) : gate_load_elem<F>(f, gs.rowsA, gs.lamA, gs.kA, eA);
             s = f.mul(s, gs.square ? s
-                                   : (gs.plainB ? ld_elem<F>(gs.rowsB[0], e)
-                                                : gate_load_elem<F>(f, gs.rowsB, gs.lamB, gs.kB, e)));
+                                   : (gs.plainB ? ld_elem<F>(gs.rowsB[0], eB)
+                                                : gate_load_elem<F>(f, gs.rowsB, gs.lamB, gs.kB, eB)));
         } else {
             s = ld_elem<F>(a, e);
             if constexpr (FUSE_MUL) s = f.mul(s, ld_elem<F>(b, e));
@@ -536,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
 template <class F, int T>
 __global__ __launch_bounds__(BLOCK) void k_rng_coeffs(F f, typename F::elem* __restrict__ coef, size_t cstride,
                                                        size_t nvec, size_t n, RngArgs ra) {
-    if (ra.dev_key) ra.rk = *ra.dev_key;
+    rng_load_state(ra);
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
                                                       const typename F::elem* __restrict__ coef, size_t cstride,
                                                       int t, int m, typename F::elem* __restrict__ out,
                                                       size_t ostride, size_t n, RngArgs ra) {
-    if (ra.dev_key) ra.rk = *ra.dev_key;
+    rng_load_state(ra);
     typedef typename F::word W;
     typedef Pack<W> P;
     constexpr int EPV = P::N * F::EPW;
@@ -627,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_any(F f, const typename F::elem
 template <class F>
 __global__ __launch_bounds__(BLOCK) void k_rng_coeffs_any(F f, typename F::elem* __restrict__ coef, size_t cstride,
                                                            int t, size_t n, RngArgs ra) {
-    if (ra.dev_key) ra.rk = *ra.dev_key;
+    rng_load_state(ra);
     typedef typename F::word W;
     typedef Pack<W> P;
     constexpr int EPV = P::N * F::EPW;
@@ -1107,6 +1122,20 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_bytes(F f, const uint8_t* __re
 // multiply-accumulate per thread, flushed every 192 terms, then an LDS tree with field additions) into
 // partial[blockIdx]; a single workgroup then folds the partials.
 enum { DOT_MAX_BLOCKS = 1024 };
+
+// cross-lane exchange of a field word (4, 8 or 16 bytes) within a wave, 32 bits at a time
+template <class W>
+__device__ __forceinline__ W wave_shfl_xor(const W& v, int mask) {
+    static_assert(sizeof(W) % 4 == 0, "word size");
+    union {
+        W w;
+        int d[sizeof(W) / 4];
+    } in, outv;
+    in.w = v;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(W) / 4); ++q) outv.d[q] = __shfl_xor(in.d[q], mask, 64);
+    return outv.w;
+}
 
 template <class F>
 __device__ __forceinline__ typename F::word block_reduce_add(const F& f, typename F::word v, typename F::word* sm) {
@@ -1871,16 +1900,26 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::
         if (++cnt >= SKINNY_FLUSH) flush();
     }
     flush();
+    // R*NN sums over the workgroup: butterfly inside each wave (cross-lane moves, no barrier), then ONE exchange
+    // of the per-wave sums through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < NN; ++j) {
-            if (j < N) {
-                const W v = block_reduce_add(f, total[r][j], sm);
-                if (threadIdx.x == 0 && row0 + r < (size_t)M) st_elem<F>(C, (row0 + r) * ldc + j, v);
-                __syncthreads();
-            }
+            W v = total[r][j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = f.add(v, wave_shfl_xor(v, off));
+            if (lane == 0) sm[(r * NN + j) * (BLOCK / 64) + wv] = v;
         }
+    __syncthreads();
+    if (threadIdx.x < R * NN) {
+        const int r = threadIdx.x / NN, j = threadIdx.x % NN;
+        W v = sm[threadIdx.x * (BLOCK / 64)];
+#pragma unroll
+        for (int w2 = 1; w2 < BLOCK / 64; ++w2) v = f.add(v, sm[threadIdx.x * (BLOCK / 64) + w2]);
+        if (j < N && row0 + r < (size_t)M) st_elem<F>(C, (row0 + r) * ldc + j, v);
+    }
 }
 
 // Same product for SHORT rows (K <= 32, many rows: sums over a trailing axis, tall-thin least squares): one
@@ -1986,8 +2025,8 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
                 if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = total[mi][q];
 }
 
-// The same partial product with the four waves of a workgroup on the SAME 64 * CW columns and interleaved rows of
-// the K chunk: a wave reads one contiguous 1 KiB row segment per load, the four per-wave sums meet in LDS, and one
+// The same partial product with the four waves of a workgroup on the SAME 64 * CW columns and a quarter of the K
+// chunk each: a wave reads one contiguous 1 KiB row segment per load, the four per-wave sums meet in LDS, and one
 // partial row per WORKGROUP goes to memory -- a quarter of the slabs (and of the final pass) for the same number of
 // waves in flight.  Vector path only (16-byte loads of B).
 template <class F, int MM>
@@ -2036,18 +2075,22 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_slab(F f, const typename F::el
             }
     };
     if (live) {
+        // wave wv takes the wv-th quarter of the chunk: its rows are CONSECUTIVE, so the wave-uniform elements of A
+        // that go with eight rows in flight arrive in one scalar load
         const typename F::elem* __restrict__ bcol = B + j;
-        int kk = k0 + wv;
-        for (; kk + 7 * NW < k1; kk += 8 * NW) {          // eight rows of B in flight per lane
+        const int per = (k1 - k0 + NW - 1) / NW;
+        int kk = k0 + wv * per;
+        const int kend = kk + per < k1 ? kk + per : k1;
+        for (; kk + 8 <= kend; kk += 8) {                 // eight rows of B in flight per lane
             P b[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) b[u] = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)(kk + u * NW) * ldb));
+            for (int u = 0; u < 8; ++u) b[u] = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)(kk + u) * ldb));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) macs(kk + u * NW, b[u]);
+            for (int u = 0; u < 8; ++u) macs(kk + u, b[u]);
             cnt += 8;
             if (cnt >= SKINNY_FLUSH) flush();
         }
-        for (; kk < k1; kk += NW) {
+        for (; kk < kend; ++kk) {
             const P b0 = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)kk * ldb));
             macs(kk, b0);
             if (++cnt >= SKINNY_FLUSH) flush();
@@ -2366,11 +2409,11 @@ struct Launchers {
         if (t > MAXT) {
             RngArgs ra = ra_in;
             unsigned grid = grid_for(n, lc);
-            ra.release = grid <= RNG_RELEASE_MAX_GRID;
+            ra.release = !ra.no_advance && grid <= RNG_RELEASE_MAX_GRID;
             hipLaunchKernelGGL((k_split_any<F, FUSE, RNG>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, coef, cstride,
                                t, m, out, ostride, n, ra);
-            if (RNG && ra.dev_key && !ra.release)
-                hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
+            if (RNG && ra.dev_key && !ra.release && !ra.no_advance)
+                hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u);
             return 0;
         }
         bool vec = al(a) && (!FUSE || al(b)) && al(out) &&
@@ -2383,7 +2426,7 @@ struct Launchers {
         const bool spread = RNG && nvec > 0 && nvec < 262144;
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (RNG && !spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
-        ra.release = grid <= RNG_RELEASE_MAX_GRID;
+        ra.release = !ra.no_advance && grid <= RNG_RELEASE_MAX_GRID;
         bool nt = lc.nt != 0;
         GateSrc<F> gs;
         memset(&gs, 0, sizeof(gs));
@@ -2395,8 +2438,8 @@ struct Launchers {
             case 4: go_split<4, FUSE, RNG>(f, grid, nt, a, b, coef, cstride, m, out, ostride, nvec, n, st, ra, gs); break;
             default: return 1;
         }
-        if (RNG && t > 0 && ra.dev_key && !ra.release)
-            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
+        if (RNG && t > 0 && ra.dev_key && !ra.release && !ra.no_advance)
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u);
         return 0;
     }
     // fused chain gate: both factors given as recombinations (GateSrc), product re-shared with the device CSPRNG
@@ -2437,15 +2480,15 @@ struct Launchers {
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (!spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
         const unsigned gy = (unsigned)nbatch;
-        ra.release = (size_t)grid * gy <= RNG_RELEASE_MAX_GRID;
+        ra.release = !ra.no_advance && (size_t)grid * gy <= RNG_RELEASE_MAX_GRID;
         E* o = (E*)out;
         switch (t) {
             case 1: go_split<1, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
             case 2: go_split<2, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
             default: go_split<3, true, true, true>(f, grid, true, nullptr, nullptr, nullptr, 0, m, o, ostride, nvec, n, st, ra, gs, gy); break;
         }
-        if (ra.dev_key && !ra.release)
-            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key));
+        if (ra.dev_key && !ra.release && !ra.no_advance)
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u);
         FFGPU_CHECK_LAUNCH();
         return 0;
     }

@@ -299,53 +299,112 @@ struct Gf8MaskOpenArgs {
     uint32_t mu[GF8_MO_MAXP];
     int nrows, np;
 };
+// Both kernels are GF(2)-linear maps from the 8 bit-share bytes of a group to one byte, so they are XORs of
+// byte-indexed table entries: out = S[c] ^ T_0[r_0] ^ ... ^ T_7[r_7] (T_b[v] = w_b * v for the public constant w_b of
+// column b; S = the same map applied to the bits of the public byte, plus the bias).  The tables (2 KiB + 256 B,
+// built on the host with the field's own packed arithmetic) arrive as a kernel argument and are copied to LDS by
+// every workgroup; 9 LDS byte reads replace ~60 VALU operations per output byte.
+struct Gf8ByteTables {
+    uint8_t t[8][256];
+    uint8_t s[256];
+};
 
-__device__ __forceinline__ uint32_t gf8_mask_open_pair(const GF2P8& f, const Gf8Group8Args& ga, const Gf8MaskOpenArgs& a,
-                                                        size_t i) {
-    GF2P8::acc acc;
-    f.acc_zero(acc);
-    for (int r = 0; r < a.nrows; ++r)
-        f.acc_mac(acc, a.coef[r], (uint32_t)reinterpret_cast<const uint16_t*>(a.rows[r])[i]);
-    for (int p = 0; p < a.np; ++p) {
-        const uint4 v = ldg<true>(reinterpret_cast<const uint4*>(a.rbits[p]) + i);
-        const uint32_t b0 = (uint32_t)gf8_group8_one<true, false>(f, ga, v.x, v.y);
-        const uint32_t b1 = (uint32_t)gf8_group8_one<true, false>(f, ga, v.z, v.w);
-        f.acc_mac(acc, a.mu[p], b0 | (b1 << 8));
-    }
-    return f.acc_reduce(acc) & 0xffffu;
+__device__ __forceinline__ void gf8_tables_to_lds(const Gf8ByteTables& tb, uint32_t* lds) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb);
+    for (int i = threadIdx.x; i < (int)(sizeof(Gf8ByteTables) / 4); i += BLOCK) lds[i] = src[i];
+    __syncthreads();
+}
+// XOR_b T_b[byte b of (lo, hi)]
+__device__ __forceinline__ uint32_t gf8_tab_group(const uint8_t* lds, uint32_t lo, uint32_t hi) {
+    const uint32_t a = lds[0 * 256 + (lo & 0xffu)] ^ lds[1 * 256 + ((lo >> 8) & 0xffu)] ^ lds[2 * 256 + ((lo >> 16) & 0xffu)];
+    const uint32_t b = lds[3 * 256 + (lo >> 24)] ^ lds[4 * 256 + (hi & 0xffu)] ^ lds[5 * 256 + ((hi >> 8) & 0xffu)];
+    return a ^ b ^ lds[6 * 256 + ((hi >> 16) & 0xffu)] ^ lds[7 * 256 + (hi >> 24)];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_gf8_mask_open(GF2P8 f, Gf8Group8Args ga, Gf8MaskOpenArgs a, uint8_t* __restrict__ out,
+// two units (byte pairs i and i2, `half` pairs apart) share one 32-bit SWAR word: the field arithmetic costs the
+// same for 4 packed bytes as for 2.  Rows are loaded eight at a time before the first multiply.
+__device__ __forceinline__ uint32_t gf8_mask_open_word(const GF2P8& f, const uint8_t* lds, const Gf8MaskOpenArgs& a,
+                                                        size_t i, size_t i2, bool two) {
+    GF2P8::acc acc;
+    f.acc_zero(acc);
+    uint4 v[GF8_MO_MAXP > 2 ? 2 : GF8_MO_MAXP], v2[2];
+    const int np0 = a.np < 2 ? a.np : 2;                   // the first two parties' bit shares go out with the rows
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        v[p] = make_uint4(0, 0, 0, 0);
+        v2[p] = make_uint4(0, 0, 0, 0);
+        if (p < np0) {
+            const uint4* __restrict__ rv = reinterpret_cast<const uint4*>(a.rbits[p]);
+            v[p] = ldg<true>(rv + i);
+            if (two) v2[p] = ldg<true>(rv + i2);
+        }
+    }
+    for (int r0 = 0; r0 < a.nrows; r0 += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            w[u] = 0;
+            if (r0 + u < a.nrows) {
+                const uint16_t* __restrict__ row = reinterpret_cast<const uint16_t*>(a.rows[r0 + u]);
+                w[u] = (uint32_t)row[i] | (two ? (uint32_t)row[i2] << 16 : 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + u < a.nrows) f.acc_mac(acc, a.coef[r0 + u], w[u]);
+    }
+    for (int p = 0; p < a.np; ++p) {
+        uint4 x, x2 = make_uint4(0, 0, 0, 0);
+        if (p < 2) {
+            x = p == 0 ? v[0] : v[1];
+            x2 = p == 0 ? v2[0] : v2[1];
+        } else {
+            const uint4* __restrict__ rv = reinterpret_cast<const uint4*>(a.rbits[p]);
+            x = ldg<true>(rv + i);
+            if (two) x2 = ldg<true>(rv + i2);
+        }
+        const uint32_t word = gf8_tab_group(lds, x.x, x.y) | (gf8_tab_group(lds, x.z, x.w) << 8) |
+                              (gf8_tab_group(lds, x2.x, x2.y) << 16) | (gf8_tab_group(lds, x2.z, x2.w) << 24);
+        f.acc_mac(acc, a.mu[p], word);
+    }
+    return f.acc_reduce(acc);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gf8_mask_open(GF2P8 f, Gf8ByteTables tb, Gf8MaskOpenArgs a, uint8_t* __restrict__ out,
                                                           size_t npair, size_t n) {
+    __shared__ uint32_t lds32[sizeof(Gf8ByteTables) / 4];
+    gf8_tables_to_lds(tb, lds32);
+    const uint8_t* lds = reinterpret_cast<const uint8_t*>(lds32);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     uint16_t* __restrict__ o16 = reinterpret_cast<uint16_t*>(out);
     const size_t half = (npair + 1) / 2;
     for (size_t i = gid; i < half; i += gsz) {
         const size_t i2 = i + half;
-        o16[i] = (uint16_t)gf8_mask_open_pair(f, ga, a, i);
-        if (i2 < npair) o16[i2] = (uint16_t)gf8_mask_open_pair(f, ga, a, i2);
+        const bool two = i2 < npair;
+        const uint32_t w = gf8_mask_open_word(f, lds, a, i, i2, two);
+        o16[i] = (uint16_t)w;
+        if (two) o16[i2] = (uint16_t)(w >> 16);
     }
     for (size_t e = 2 * npair + gid; e < n; e += gsz) {            // odd tail / unaligned buffers: one byte at a time
         GF2P8::acc acc;
         f.acc_zero(acc);
         for (int r = 0; r < a.nrows; ++r) f.acc_mac(acc, a.coef[r], (uint32_t)a.rows[r][e]);
         for (int p = 0; p < a.np; ++p) {
-            uint32_t lo = 0, hi = 0;
-            for (int b = 0; b < 4; ++b) {
-                lo |= (uint32_t)a.rbits[p][8 * e + b] << (8 * b);
-                hi |= (uint32_t)a.rbits[p][8 * e + 4 + b] << (8 * b);
-            }
-            f.acc_mac(acc, a.mu[p], (uint32_t)gf8_group8_one<true, false>(f, ga, lo, hi));
+            uint32_t fb = 0;
+            for (int b = 0; b < 8; ++b) fb ^= lds[b * 256 + a.rbits[p][8 * e + b]];
+            f.acc_mac(acc, a.mu[p], fb);
         }
         out[e] = (uint8_t)(f.acc_reduce(acc) & 0xffu);
     }
 }
 
-template <bool GENERAL>
-__global__ __launch_bounds__(BLOCK) void k_gf8_bits_affine_fold(GF2P8 f, Gf8Group8Args ga, const uint8_t* __restrict__ c,
+__global__ __launch_bounds__(BLOCK) void k_gf8_bits_affine_fold(Gf8ByteTables tb, const uint8_t* __restrict__ c,
                                                                  const uint8_t* __restrict__ rbits, size_t ybr,
                                                                  uint8_t* __restrict__ out, size_t ybo, size_t npair, size_t n) {
+    __shared__ uint32_t lds32[sizeof(Gf8ByteTables) / 4];
+    gf8_tables_to_lds(tb, lds32);
+    const uint8_t* lds = reinterpret_cast<const uint8_t*>(lds32);
     rbits += (size_t)blockIdx.y * ybr;
     out += (size_t)blockIdx.y * ybo;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -354,29 +413,55 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_bits_affine_fold(GF2P8 f, Gf8Grou
     const uint4* __restrict__ rv = reinterpret_cast<const uint4*>(rbits);
     uint16_t* __restrict__ o16 = reinterpret_cast<uint16_t*>(out);
     const size_t half = (npair + 1) / 2;
-    auto one = [&](size_t i) -> uint16_t {
-        const uint32_t v = c16[i];
-        const uint4 r = ldg<true>(rv + i);
-        const uint64_t lo = spread_bits(v & 0xffu) ^ ((uint64_t)r.x | ((uint64_t)r.y << 32));
-        const uint64_t hi = spread_bits(v >> 8) ^ ((uint64_t)r.z | ((uint64_t)r.w << 32));
-        const uint32_t b0 = (uint32_t)gf8_group8_one<true, GENERAL>(f, ga, (uint32_t)lo, (uint32_t)(lo >> 32));
-        const uint32_t b1 = (uint32_t)gf8_group8_one<true, GENERAL>(f, ga, (uint32_t)hi, (uint32_t)(hi >> 32));
-        return (uint16_t)(b0 | (b1 << 8));
-    };
     for (size_t i = gid; i < half; i += gsz) {
         const size_t i2 = i + half;
-        const uint16_t r0 = one(i);
-        if (i2 < npair) o16[i2] = one(i2);
-        o16[i] = r0;
+        const bool two = i2 < npair;
+        const uint4 r = ldg<true>(rv + i);
+        uint4 r2 = make_uint4(0, 0, 0, 0);
+        uint32_t v = c16[i], v2 = 0;
+        if (two) {
+            r2 = ldg<true>(rv + i2);
+            v2 = c16[i2];
+        }
+        const uint32_t b0 = lds[2048 + (v & 0xffu)] ^ gf8_tab_group(lds, r.x, r.y);
+        const uint32_t b1 = lds[2048 + (v >> 8)] ^ gf8_tab_group(lds, r.z, r.w);
+        o16[i] = (uint16_t)(b0 | (b1 << 8));
+        if (two) {
+            const uint32_t b2 = lds[2048 + (v2 & 0xffu)] ^ gf8_tab_group(lds, r2.x, r2.y);
+            const uint32_t b3 = lds[2048 + (v2 >> 8)] ^ gf8_tab_group(lds, r2.z, r2.w);
+            o16[i2] = (uint16_t)(b2 | (b3 << 8));
+        }
     }
     for (size_t e = 2 * npair + gid; e < n; e += gsz) {
-        const uint64_t b = spread_bits(c[e]);
-        uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
-        for (int j = 0; j < 4; ++j) {
-            lo ^= (uint32_t)rbits[8 * e + j] << (8 * j);
-            hi ^= (uint32_t)rbits[8 * e + 4 + j] << (8 * j);
+        uint32_t b = lds[2048 + c[e]];
+        for (int j = 0; j < 8; ++j) b ^= lds[j * 256 + rbits[8 * e + j]];
+        out[e] = (uint8_t)b;
+    }
+}
+
+// T_b[v] = w_b * v with w_b = sum_r 2^r * M[r][b] (M = NULL: identity, so w_b = 2^b: np_from_bits alone);
+// S[c] = sum_b bit_b(c) * w_b + sum_r 2^r * bias_r
+static void gf8_byte_tables(const GF2P8& f, const uint64_t* m2, const uint64_t* bias2, Gf8ByteTables& tb) {
+    auto mul1 = [&](uint32_t a, uint32_t b) { return f.mul(a & 0xffu, b & 0xffu) & 0xffu; };
+    uint32_t w[8], pw[8], biasf = 0;
+    pw[0] = 1;
+    for (int r = 1; r < 8; ++r) pw[r] = f.xtime(pw[r - 1]) & 0xffu;        // 2^r in the field
+    for (int b = 0; b < 8; ++b) {
+        w[b] = 0;
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t mrc = m2 ? (uint32_t)(m2[2 * (r * 8 + b)] & 0xffu) : (uint32_t)(r == b);
+            w[b] ^= mul1(pw[r], mrc);
         }
-        out[e] = (uint8_t)gf8_group8_one<true, GENERAL>(f, ga, lo, hi);
+    }
+    if (bias2)
+        for (int r = 0; r < 8; ++r) biasf ^= mul1(pw[r], (uint32_t)(bias2[2 * r] & 0xffu));
+    for (int b = 0; b < 8; ++b)
+        for (uint32_t v = 0; v < 256; ++v) tb.t[b][v] = (uint8_t)mul1(w[b], v);
+    for (uint32_t cv = 0; cv < 256; ++cv) {
+        uint32_t sv = biasf;
+        for (int b = 0; b < 8; ++b)
+            if ((cv >> b) & 1) sv ^= w[b];
+        tb.s[cv] = (uint8_t)sv;
     }
 }
 
@@ -385,8 +470,13 @@ int ffgpu_launch_gf8_mask_open(const void* policy, int device, const void* const
                                const void* const* rbits, const uint64_t* mu2, int np, void* out, size_t n, hipStream_t st) {
     const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
     if (nrows < 0 || nrows > GF8_MO_MAXROWS || np < 0 || np > GF8_MO_MAXP) return 2;
-    Gf8Group8Args ga;
-    gf8_group8_args(f, nullptr, nullptr, 1, ga);                     // identity matrix + fold = sum_b 2^b x_b
+    static thread_local Gf8ByteTables tb;
+    static thread_local uint32_t tb_for[3] = {~0u, 0, 0};
+    if (tb_for[0] != f.n || tb_for[1] != f.red) {                  // sum_b 2^b x_b: depends on the field only
+        gf8_byte_tables(f, nullptr, nullptr, tb);
+        tb_for[0] = f.n;
+        tb_for[1] = f.red;
+    }
     Gf8MaskOpenArgs a;
     memset(&a, 0, sizeof(a));
     a.nrows = nrows;
@@ -404,8 +494,9 @@ int ffgpu_launch_gf8_mask_open(const void* policy, int device, const void* const
     }
     const size_t npair = vec ? n / 2 : 0;
     LaunchCfg lc = launch_cfg(device);
+    if (lc.blocks_per_cu <= 0) lc.blocks_per_cu = table_blocks_per_cu();      // every workgroup copies 2.3 KiB of tables
     unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
-    hipLaunchKernelGGL(k_gf8_mask_open, dim3(grid), dim3(BLOCK), 0, st, f, ga, a, (uint8_t*)out, npair, n);
+    hipLaunchKernelGGL(k_gf8_mask_open, dim3(grid), dim3(BLOCK), 0, st, f, tb, a, (uint8_t*)out, npair, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
 }
@@ -414,19 +505,16 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
                                       const void* rbits, size_t ybr, void* out, size_t ybo, size_t n, int nbatch,
                                       hipStream_t st) {
     const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
-    Gf8Group8Args ga;
-    const bool general = gf8_group8_args(f, m2, bias2, 1, ga);
+    Gf8ByteTables tb;
+    gf8_byte_tables(f, m2, bias2, tb);
     bool vec = (((uintptr_t)c) & 1u) == 0 && (((uintptr_t)rbits) & 15u) == 0 && (((uintptr_t)out) & 1u) == 0;
     if (nbatch > 1) vec = vec && (ybr % 16 == 0) && (ybo % 2 == 0);
     const size_t npair = vec ? n / 2 : 0;
     LaunchCfg lc = launch_cfg(device);
+    if (lc.blocks_per_cu <= 0) lc.blocks_per_cu = table_blocks_per_cu();
     unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
-    if (general)
-        hipLaunchKernelGGL((k_gf8_bits_affine_fold<true>), dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, f, ga,
-                           (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
-    else
-        hipLaunchKernelGGL((k_gf8_bits_affine_fold<false>), dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, f, ga,
-                           (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
+    hipLaunchKernelGGL(k_gf8_bits_affine_fold, dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, tb,
+                       (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
 }

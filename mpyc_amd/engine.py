@@ -138,14 +138,28 @@ class DevMatrix:
 class RngState:
     """Key / nonce / rounds of the device CSPRNG in device memory (FieldContext.rng_state)."""
 
-    __slots__ = ('ctx', 't')
+    __slots__ = ('ctx', 't', 'pending')
 
     def __init__(self, ctx, t):
-        self.ctx, self.t = ctx, t
+        self.ctx, self.t, self.pending = ctx, t, 0
 
     @property
     def ptr(self) -> int:
         return self.t.data_ptr()
+
+    def take_offset(self) -> int:
+        """Deferred advance (ffgpu_rng_state_advance): the next launch of a sequence draws from nonce + offset and
+        leaves the device nonce alone; commit() advances it once by the number of launches."""
+        off = self.pending
+        self.pending += 1
+        return off
+
+    def commit(self):
+        """One nonce update for all deferred launches since the last commit (stream-ordered, capturable).  Every
+        engine call that advances the nonce itself commits first, so offsets never collide with it."""
+        if self.pending:
+            by, self.pending = self.pending, 0
+            _ffi.check(self.ctx._L.ffgpu_rng_state_advance(self.ctx._h, self.ptr, by, self.ctx._stream()), 'rng_state_advance')
 
     def nonce(self) -> int:
         w = self.t.cpu().numpy().view(np.uint32)
@@ -418,6 +432,7 @@ class FieldContext:
         self._same(n, mul_by)
         out = self._out_matrix(out, m, n)
         if state is not None:
+            state.commit()
             _ffi.check(self._L.ffgpu_split_rng_state(self._h, secrets.ptr, mul_by.ptr if mul_by is not None else None,
                                                      state.ptr, t, m, out.ptr, out.stride, n, self._stream()),
                        'split_rng_state')
@@ -451,6 +466,8 @@ class FieldContext:
         out = self._out_matrix(out, m, n)
         if state is None and key is None:
             key = _secrets.token_bytes(32)
+        if state is not None:
+            state.commit()
         _ffi.check(self._L.ffgpu_gate_rng(self._h, pa, la, ka, pb, lb, kb, key, nonce, rounds,
                                           state.ptr if state is not None else None, t, m, out.ptr, out.stride, n,
                                           self._stream()), 'gate_rng')
@@ -478,8 +495,11 @@ class FieldContext:
             kb, pb, lb = 0, None, None
         if state is None and key is None:
             key = _secrets.token_bytes(32)
+        defer = 0
+        if state is not None:
+            nonce, defer = state.take_offset(), 1          # deferred advance: state.commit() follows the sequence
         _ffi.check(self._L.ffgpu_gate_rng_batch(self._h, pa, la, ka, stride_a, pb, lb, kb, stride_b, key, nonce, rounds,
-                                                state.ptr if state is not None else None, t, m, out.ptr,
+                                                state.ptr if state is not None else None, defer, t, m, out.ptr,
                                                 out.stride * out_rows_per_party, out.stride, n, nbatch,
                                                 self._stream()), 'gate_rng_batch')
         return out

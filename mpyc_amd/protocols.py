@@ -247,6 +247,8 @@ def sbox_layer_all(ctx: FieldContext, field, xs, rbits, t: int, A: Sequence[Sequ
         for s, r in enumerate(y.rows_of(p)):
             rows.append(r)
             coefs.append(int(field(mu[p]) * field(lam[s])))
+    if rng is not None:
+        rng.commit()                                    # one nonce update for the 11 gates (deferred advance)
     opened = ctx.gf256_mask_open(rows, coefs, [R.row(p) for p in range(t + 1)], mu[:t + 1])
     return ctx.gf256_bits_affine_fold(opened, R, A, B)
 

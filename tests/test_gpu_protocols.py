@@ -469,3 +469,58 @@ def test_batched_chain_gate_opens_to_products(mods):
     blk3 = protocols._gate_all(ctx, blk2, As, t, m, lam, None)                  # pending x plain
     shares3 = [ctx.recombine(blk3.rows_of(j), lam) for j in range(m)]
     assert protocols.open_(ctx, F, shares3, t).to_ints()[:200] == [(v * v * int(x)) % p for v, x in zip(want_ab, a[:200])]
+
+
+@pytest.mark.gpu
+def test_sbox_layer_all_in_a_hip_graph_deferred_nonce(mods):
+    """The 13-launch layer captured once: the 11 batched gates draw from nonce + 0..10 (offsets frozen into the
+    graph) and ONE advance by 11 follows, so every replay re-shares with fresh randomness and opens to the table."""
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    t, m = 1, 3
+    x = list(range(256)) * 40                         # > 512 workgroups in the batched grid: the path that used a nonce kernel per gate
+    n = len(x)
+    xs = protocols.as_matrix(ctx, protocols.share(ctx, ctx.from_numpy(np.array(x, dtype=np.uint8)), t, m))
+    rb = torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0')
+    rbits = protocols.as_matrix(ctx, protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m))
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    st = ctx.rng_state()
+    cg = engine.CapturedLaunches(lambda: protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, rng=st))
+    assert st.pending == 0
+    n0 = st.nonce()
+    seen = []
+    for _ in range(3):
+        cg.replay()
+        torch.cuda.synchronize()
+        out = cg.result
+        assert unpack(protocols.open_(ctx, F, [out.row(i) for i in range(m)], t).to_numpy(), 1) == [g['table'][v] for v in x]
+        seen.append(out.row(0).t.clone())
+    assert st.nonce() == n0 + 3 * 11
+    # (the OUTPUT shares are a function of the opened masked value and the bit shares only, so they repeat; the
+    # re-sharing randomness shows in the sub-shares of a gate:)
+    assert torch.equal(seen[0], seen[1])
+    lam3 = protocols._lagrange(F, range(1, 4))
+
+    def one_gate():
+        blk_ = protocols._gate_all(ctx, xs, xs, t, m, lam3, st)
+        st.commit()
+        return blk_
+    cg2 = engine.CapturedLaunches(one_gate)
+    subs = []
+    for _ in range(3):
+        cg2.replay()
+        torch.cuda.synchronize()
+        subs.append(cg2.result.mtx.row(0).t.clone())
+        sq = [ctx.recombine(cg2.result.rows_of(j), lam3) for j in range(m)]
+        assert unpack(protocols.open_(ctx, F, sq, t).to_numpy(), 1)[:300] == [po.mul(po.Field(0x11b, True), v, v) for v in x[:300]]
+    assert not torch.equal(subs[0], subs[1]) and not torch.equal(subs[1], subs[2])
+    n0 = st.nonce() - 33
+    # a launch that advances the nonce itself first commits what is pending: offsets never collide with it
+    blk = protocols._gate_all(ctx, xs, xs, t, m, protocols._lagrange(F, range(1, 4)), st)
+    assert st.pending == 1
+    protocols.share(ctx, xs.row(0), t, m, rng=st)
+    torch.cuda.synchronize()
+    assert st.pending == 0 and st.nonce() == n0 + 33 + 2
