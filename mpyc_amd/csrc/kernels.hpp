@@ -1408,13 +1408,59 @@ inline double mfma_min_macs() {
 // only place the modulus enters -- so the result is bit-identical to the reduce-once object matmul of
 // finfields.py:1126-1135.  This is the one GEMM-shaped piece of the path and the only use of MFMA here: 64 int8
 // MFMAs per 64-bit multiply-accumulate still beat 4 quarter-rate v_mad_u64_u32 several times over.
-// Operand planes are K-contiguous int8: A planes [l][Mp][Kp], B planes TRANSPOSED [l][Np][Kp] (zero padded to
-// multiples of 64 rows / 32 columns), so a lane's MFMA fragment (one row, 16 consecutive k) is one 16-byte load.
+// Operand digits are int8 with k contiguous in runs of 16 (a lane's MFMA fragment -- one row, 16 consecutive k -- is
+// one 16-byte load), A by rows and B TRANSPOSED (by columns), zero padded to multiples of 64 rows / 32 k and tiled
+// per (64-row block, k-step) as described at limb_off below.
 // One wave = one 32x32 output tile with all 2L-1 accumulators (240 registers for L = 8) resident in the
 // accumulator half of the register file; 4 waves per workgroup (64x64).
 typedef int ff_v4i __attribute__((ext_vector_type(4)));
 typedef int ff_v16i __attribute__((ext_vector_type(16)));
 enum { LIMB_KCHUNK = 8192 };
+
+// Digit-plane layout: TILED so that what a workgroup fetches per k-step is contiguous.  The digits of a 64-row block
+// for one 32-wide k-step form one block of L x 2 KiB, [digit l][k half][row][16 k] -- byte for byte the LDS image
+// of the tile -- so the 256 threads of a workgroup read it as consecutive 16-byte chunks (1 KiB per wave
+// instruction).  With plain row-major planes [l][row][k] the same fetch touches a different 128-byte line in every
+// lane and each line is re-fetched from L2 for four k-steps: the fetch cost 37 % of the kernel (measured by
+// switching it off).  Rows are padded to multiples of 64, k to multiples of 32.
+template <int L>
+__host__ __device__ __forceinline__ size_t limb_off(int l, int row, int k, int Kp) {
+    return ((((size_t)(row >> 6) * (size_t)(Kp >> 5) + (size_t)(k >> 5)) * L + l) << 11) + (size_t)(((k >> 4) & 1) << 10) +
+           (size_t)((row & 63) << 4) + (size_t)(k & 15);
+}
+
+// Epilogue of the 8-digit product: sum_d 256^d D_d mod p for the 15 signed diagonal sums |D_d| <= 2^30 of one
+// output.  Horner in the field costs a modular multiply-add and a sign fix per diagonal (~800 instructions per
+// output: a quarter of the kernel's time, with one wave per SIMD nothing overlaps it).  Instead the sum is formed
+// as an exact INTEGER first -- diagonals 4 apart are 32 bits apart, so
+//     lo_r = D_r + 2^32 D_{r+4},  hi_r = D_{r+8} + 2^32 D_{r+12}   (int64, r = 0..3)
+//     V = Lo + 2^64 Hi,  Lo = sum_r 2^(8r) lo_r,  Hi = sum_r 2^(8r) hi_r   (|.| < 2^88: __int128)
+// -- and reduced once: X mod p = (X mod 2^64) + (2^64 mod p) * (X >> 64) with the small signed high part.
+template <class F>
+__device__ __forceinline__ typename F::word limb_signed(const F& f, int64_t v) {
+    typedef typename F::word W;
+    const W w = f.reduce_raw((W)(uint64_t)(v < 0 ? -v : v));
+    return v < 0 ? f.neg(w) : w;
+}
+template <class F>
+__device__ __forceinline__ typename F::word limb_red128(const F& f, __int128 x, typename F::word r64) {
+    typedef typename F::word W;
+    return f.add(f.reduce_raw((W)(uint64_t)x), f.mul(r64, limb_signed(f, (int64_t)(x >> 64))));
+}
+template <class F>
+__device__ __forceinline__ typename F::word limb_combine15(const F& f, const int (&d)[15], typename F::word r64) {
+    __int128 lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        const int64_t lr = (int64_t)d[r] + ((int64_t)d[r + 4] << 32);
+        const int64_t hr = (int64_t)d[r + 8] + (r + 12 < 15 ? ((int64_t)d[r + 12] << 32) : (int64_t)0);
+        lo = (lo << 8) + (__int128)lr;
+        hi = (hi << 8) + (__int128)hr;
+    }
+    // V = (lo mod 2^64) + 2^64 T,  T = hi + (lo >> 64)  (|T| < 2^89)
+    const __int128 t = hi + (lo >> 64);
+    return f.add(f.reduce_raw((typename F::word)(uint64_t)lo), f.mul(r64, limb_red128(f, t, r64)));
+}
 
 template <class F, int L>
 __global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* __restrict__ A, size_t lda, uint64_t p,
@@ -1427,7 +1473,7 @@ __global__ __launch_bounds__(BLOCK) void k_limb_split_a(const typename F::elem* 
     int8_t d[L];
     limb_digits<L>(v, p, d);
 #pragma unroll
-    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = d[l];
+    for (int l = 0; l < L; ++l) Ap[limb_off<L>(l, row, kk, Kp)] = d[l];
 }
 // B (K x N, leading dimension ldb) -> planes [l][Np][Kp] through a 32x32 LDS tile (coalesced reads and writes)
 template <class F, int L>
@@ -1445,7 +1491,7 @@ __global__ __launch_bounds__(BLOCK) void k_limb_split_bt(const typename F::elem*
         int8_t d[L];
         limb_digits<L>(tile[tx][r], p, d);
 #pragma unroll
-        for (int l = 0; l < L; ++l) Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = d[l];
+        for (int l = 0; l < L; ++l) Bp[limb_off<L>(l, n0 + r, k0 + tx, Kp)] = d[l];
     }
 }
 
@@ -1461,28 +1507,27 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
     ff_v16i acc[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) acc[d] = (ff_v16i){0};
-    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
-    const int8_t* pa = Ap + (size_t)(m0 + r) * Kp + 16 * h;
-    const int8_t* pb = Bp + (size_t)(n0 + r) * Kp + 16 * h;
+    auto pa = [&](int l, int k) { return Ap + limb_off<L>(l, m0 + r, k + 16 * h, Kp); };
+    auto pb = [&](int l, int k) { return Bp + limb_off<L>(l, n0 + r, k + 16 * h, Kp); };
     // software pipeline: with all 2L-1 accumulators resident there is ONE wave per SIMD, so nothing else hides the
     // latency of the fragment loads.  The B fragments of step k+1 are fetched into a second set of registers
     // before the L*L MFMAs of step k; an A fragment is dead after its row of MFMAs and is refilled in place.
     ff_v4i a[L], b[L], bn[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        a[l] = *reinterpret_cast<const ff_v4i*>(pa + l * planeA + kb);
-        b[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + kb);
+        a[l] = *reinterpret_cast<const ff_v4i*>(pa(l, kb));
+        b[l] = *reinterpret_cast<const ff_v4i*>(pb(l, kb));
     }
     for (int k0 = kb; k0 < ke; k0 += 32) {
         const int kn = k0 + 32 < ke ? k0 + 32 : k0;          // last step: harmless reload of the same fragments
 #pragma unroll
-        for (int l = 0; l < L; ++l) bn[l] = *reinterpret_cast<const ff_v4i*>(pb + l * planeB + kn);
+        for (int l = 0; l < L; ++l) bn[l] = *reinterpret_cast<const ff_v4i*>(pb(l, kn));
 #pragma unroll
         for (int la = 0; la < L; ++la) {
 #pragma unroll
             for (int lb = 0; lb < L; ++lb)
                 acc[la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb], 0, 0, 0);
-            a[la] = *reinterpret_cast<const ff_v4i*>(pa + la * planeA + kn);
+            a[la] = *reinterpret_cast<const ff_v4i*>(pa(la, kn));
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) b[l] = bn[l];
@@ -1518,7 +1563,9 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
 // The same product with the operand tiles staged through LDS: the four waves of a workgroup (64x64 outputs)
 // share one copy of the 64-row A tile and the 64-column B tile per k-step (2 x L x 2 KiB, double buffered), which
 // halves the L2 -> CU traffic that bounds the direct-load variant.  LDS layout [plane][k-half][row][16 bytes]:
-// the 16 lanes a ds_read_b128 phase serves read 256 contiguous bytes (conflict-free).
+// the 16 lanes a ds_read_b128 phase serves read 256 contiguous bytes (conflict-free).  (A variant that also
+// double-buffers the FRAGMENT registers -- LDS reads of step s+1 issued before the MFMAs of step s -- measured the
+// same: the LDS latency is not what the loop waits for; profiles/r02_limb_gemm.md.)
 template <class F, int L>
 __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
@@ -1544,7 +1591,6 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
     ff_v16i acc[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) acc[d] = (ff_v16i){0};
-    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
     // chunk c of a tile: plane l = c / 128, k-half hh = (c / 64) % 2, row = c % 64  (== its LDS index)
     ff_v4i ga[PER_THREAD], gb[PER_THREAD];
     auto fetch = [&](int k0) {
@@ -1552,8 +1598,8 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
         for (int u = 0; u < PER_THREAD; ++u) {
             const int c = threadIdx.x + u * BLOCK;
             const int l = c >> 7, hh = (c >> 6) & 1, row = c & 63;
-            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + l * planeA + (size_t)(bm0 + row) * Kp + k0 + 16 * hh);
-            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + l * planeB + (size_t)(bn0 + row) * Kp + k0 + 16 * hh);
+            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + limb_off<L>(l, bm0 + row, k0 + 16 * hh, Kp));
+            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + limb_off<L>(l, bn0 + row, k0 + 16 * hh, Kp));
         }
     };
     auto stash = [&](int buf) {
@@ -1588,20 +1634,32 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
         cur ^= 1;
     }
     W res[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int dv = acc[ND - 1][q];
-        const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
-        res[q] = dv < 0 ? f.neg(w) : w;
-    }
-#pragma unroll
-    for (int d = ND - 2; d >= 0; --d)
+    if constexpr (L == 8 && sizeof(W) == 8) {
+        const W t32 = f.reduce_raw((W)(1ull << 32));
+        const W r64 = f.mul(t32, t32);                 // 2^64 mod p
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int dv = acc[d][q];
-            const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
-            res[q] = f.muladd_small(res[q], 256u, dv < 0 ? f.neg(w) : w);
+            int dq[15];
+#pragma unroll
+            for (int d = 0; d < 15; ++d) dq[d] = acc[d][q];
+            res[q] = limb_combine15(f, dq, r64);
         }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int dv = acc[ND - 1][q];
+            const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+            res[q] = dv < 0 ? f.neg(w) : w;
+        }
+#pragma unroll
+        for (int d = ND - 2; d >= 0; --d)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int dv = acc[d][q];
+                const W w = f.reduce_raw((W)(uint32_t)(dv < 0 ? -dv : dv));
+                res[q] = f.muladd_small(res[q], 256u, dv < 0 ? f.neg(w) : w);
+            }
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int col = bn0 + wn + (lane & 31), row = bm0 + wm + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -1636,7 +1694,7 @@ __global__ __launch_bounds__(BLOCK) void k_limb_split_a_wide(const typename F::e
     int8_t d[L];
     limb_digits_wide<L>(lo, hi, plo, phi, d);
 #pragma unroll
-    for (int l = 0; l < L; ++l) Ap[(size_t)l * Mp * Kp + idx] = d[l];
+    for (int l = 0; l < L; ++l) Ap[limb_off<L>(l, row, kk, Kp)] = d[l];
 }
 template <class F, int L>
 __global__ __launch_bounds__(BLOCK) void k_limb_split_bt_wide(const typename F::elem* __restrict__ B, size_t ldb, uint64_t plo,
@@ -1662,7 +1720,7 @@ __global__ __launch_bounds__(BLOCK) void k_limb_split_bt_wide(const typename F::
         int8_t d[L];
         limb_digits_wide<L>(tlo[tx][r], thi[tx][r], plo, phi, d);
 #pragma unroll
-        for (int l = 0; l < L; ++l) Bp[(size_t)l * Np * Kp + (size_t)(n0 + r) * Kp + k0 + tx] = d[l];
+        for (int l = 0; l < L; ++l) Bp[limb_off<L>(l, n0 + r, k0 + tx, Kp)] = d[l];
     }
 }
 
@@ -1685,15 +1743,14 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_wide(F f, const int8_t* __r
     ff_v16i acc[NDP];
 #pragma unroll
     for (int d = 0; d < NDP; ++d) acc[d] = (ff_v16i){0};
-    const size_t planeA = (size_t)Mp * Kp, planeB = (size_t)Np * Kp;
     ff_v4i ga[PER_THREAD], gb[PER_THREAD];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < PER_THREAD; ++u) {
             const int c = threadIdx.x + u * BLOCK;
             const int l = c >> 7, hh = (c >> 6) & 1, row = c & 63;
-            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + l * planeA + (size_t)(bm0 + row) * Kp + k0 + 16 * hh);
-            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + l * planeB + (size_t)(bn0 + row) * Kp + k0 + 16 * hh);
+            ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + limb_off<L>(l, bm0 + row, k0 + 16 * hh, Kp));
+            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + limb_off<L>(l, bn0 + row, k0 + 16 * hh, Kp));
         }
     };
     auto stash = [&](int buf) {
@@ -1951,7 +2008,7 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_short_rows(F f, const typename
 
 // C (M x N) = A (M x K) @ B (K x N), M <= SKINNY_MAX: a pack of columns per thread, K split over blockIdx.y;
 // partial[(ks * M + m) * N + j], summed by k_vecmat_final
-template <class F, int MM, bool VEC>
+template <class F, int MM, bool VEC, int UNR = 4>
 __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F::elem* __restrict__ A, size_t lda,
                                                            const typename F::elem* __restrict__ B, size_t ldb,
                                                            typename F::word* __restrict__ partial, int M, int K, int N,
@@ -2003,11 +2060,13 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
             }
     };
     int kk = k0;
-    for (; kk + 4 <= k1; kk += 4) {                  // four rows of B in flight per thread
-        W b0[CW], b1[CW], b2[CW], b3[CW];
-        load_b(kk, b0); load_b(kk + 1, b1); load_b(kk + 2, b2); load_b(kk + 3, b3);
-        macs(kk, b0); macs(kk + 1, b1); macs(kk + 2, b2); macs(kk + 3, b3);
-        cnt += 4;
+    for (; kk + UNR <= k1; kk += UNR) {              // UNR rows of B in flight per thread
+        W b[UNR][CW];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) load_b(kk + u, b[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) macs(kk + u, b[u]);
+        cnt += UNR;
         if (cnt >= SKINNY_FLUSH) flush();
     }
     for (; kk < k1; ++kk) {
@@ -2023,99 +2082,6 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
 #pragma unroll
             for (int q = 0; q < CW; ++q)
                 if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = total[mi][q];
-}
-
-// The same partial product with the four waves of a workgroup on the SAME 64 * CW columns and a quarter of the K
-// chunk each: a wave reads one contiguous 1 KiB row segment per load, the four per-wave sums meet in LDS, and one
-// partial row per WORKGROUP goes to memory -- a quarter of the slabs (and of the final pass) for the same number of
-// waves in flight.  Vector path only (16-byte loads of B).
-template <class F, int MM>
-__global__ __launch_bounds__(BLOCK) void k_vecmat_slab(F f, const typename F::elem* __restrict__ A, size_t lda,
-                                                        const typename F::elem* __restrict__ B, size_t ldb,
-                                                        typename F::word* __restrict__ partial, int M, int K, int N,
-                                                        int kchunk) {
-    typedef Pack<typename F::word> P;
-    typedef typename MemPack<F>::type MP;
-    typedef typename F::word W;
-    constexpr int CW = P::N;
-    constexpr int NW = BLOCK / 64;
-    __shared__ W sm[NW - 1][MM][CW][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = (blockIdx.x * 64 + lane) * CW;
-    const bool live = j < N;
-    const int k0 = blockIdx.y * kchunk;
-    const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
-    typename F::acc acc[MM][CW];
-    W total[MM][CW];
-    bool have = false;
-    int cnt = 0;
-#pragma unroll
-    for (int mi = 0; mi < MM; ++mi)
-#pragma unroll
-        for (int q = 0; q < CW; ++q) f.acc_zero(acc[mi][q]);
-    auto flush = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < MM; ++mi)
-#pragma unroll
-            for (int q = 0; q < CW; ++q) {
-                W part = f.acc_reduce(acc[mi][q]);
-                total[mi][q] = have ? f.add(total[mi][q], part) : part;
-                f.acc_zero(acc[mi][q]);
-            }
-        have = true;
-        cnt = 0;
-    };
-    auto macs = [&](int kk, const P& bp) {
-#pragma unroll
-        for (int mi = 0; mi < MM; ++mi)
-            if (mi < M) {
-                const W ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                      // wave-uniform operand
-#pragma unroll
-                for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, bp.w[q]);
-            }
-    };
-    if (live) {
-        // wave wv takes the wv-th quarter of the chunk: its rows are CONSECUTIVE, so the wave-uniform elements of A
-        // that go with eight rows in flight arrive in one scalar load
-        const typename F::elem* __restrict__ bcol = B + j;
-        const int per = (k1 - k0 + NW - 1) / NW;
-        int kk = k0 + wv * per;
-        const int kend = kk + per < k1 ? kk + per : k1;
-        for (; kk + 8 <= kend; kk += 8) {                 // eight rows of B in flight per lane
-            P b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) b[u] = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)(kk + u) * ldb));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) macs(kk + u, b[u]);
-            cnt += 8;
-            if (cnt >= SKINNY_FLUSH) flush();
-        }
-        for (; kk < kend; ++kk) {
-            const P b0 = ldg<true>(reinterpret_cast<const MP*>(bcol + (size_t)kk * ldb));
-            macs(kk, b0);
-            if (++cnt >= SKINNY_FLUSH) flush();
-        }
-    }
-    flush();
-    if (wv > 0) {
-#pragma unroll
-        for (int mi = 0; mi < MM; ++mi)
-#pragma unroll
-            for (int q = 0; q < CW; ++q) sm[wv - 1][mi][q][lane] = total[mi][q];
-    }
-    __syncthreads();
-    if (wv == 0 && live) {
-#pragma unroll
-        for (int mi = 0; mi < MM; ++mi)
-            if (mi < M)
-#pragma unroll
-                for (int q = 0; q < CW; ++q) {
-                    W r = total[mi][q];
-#pragma unroll
-                    for (int w2 = 0; w2 < NW - 1; ++w2) r = f.add(r, sm[w2][mi][q][lane]);
-                    if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = r;
-                }
-    }
 }
 
 template <class F>
@@ -2697,12 +2663,8 @@ struct Launchers {
             }
             if (M <= SKINNY_MAX && N >= 64 && K >= 1 && workspace) {
                 // split K so that about 2^18 threads are in flight; each chunk at least 8 rows
-                constexpr int CWs = (int)(16 / sizeof(W));
-                const bool slab = skinny_v2() && sizeof(E) != 12 && CWs > 1 && al(B) && stride_ok(ldb) && N % CWs == 0 && K >= 256;
-                // slab kernel: a workgroup covers 64 * CW columns (its four waves split the K chunk)
-                const int cols_blocks = slab ? (N / CWs + 63) / 64 : (N / CWs + BLOCK - 1) / BLOCK;
+                const int cols_blocks = (N / (int)(16 / sizeof(W)) + BLOCK - 1) / BLOCK;
                 int ks = (1024 + cols_blocks - 1) / cols_blocks;
-                if (slab && ks > K / 32) ks = K / 32;                       // at least 8 rows per wave
                 if (ks > (K + 7) / 8) ks = (K + 7) / 8;
                 if (ks < 1) ks = 1;
                 while (ks > 1 && (size_t)ks * M * N * sizeof(W) > workspace_bytes) ks /= 2;
@@ -2711,13 +2673,7 @@ struct Launchers {
                     ks = (K + kchunk - 1) / kchunk;
                     W* part = (W*)workspace;
                     const E* a = (const E*)A; const E* b = (const E*)B;
-                    if (slab) {
-                        dim3 grid((unsigned)cols_blocks, (unsigned)ks);
-                        if (M == 1) hipLaunchKernelGGL((k_vecmat_slab<F, 1>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
-                        else if (M == 2) hipLaunchKernelGGL((k_vecmat_slab<F, 2>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
-                        else if (M <= 4) hipLaunchKernelGGL((k_vecmat_slab<F, 4>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
-                        else hipLaunchKernelGGL((k_vecmat_slab<F, 8>), grid, dim3(BLOCK), 0, st, f, a, lda, b, ldb, part, M, K, N, kchunk);
-                    } else if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M == 2) go_vecmat<2>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M <= 4) go_vecmat<4>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else go_vecmat<8>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
