@@ -27,9 +27,13 @@
  *     name says so.
  *   - inputs are never written; `out` may alias an input of the same shape for
  *     the element-wise entry points (in-place operators, finfields.py:1068-1124).
- *   - thread-safety: a context is immutable after creation and may be shared
- *     between host threads; the reference only ever calls from one event-loop
- *     thread (asyncoro.py:416-464).
+ *   - thread-safety: the field description of a context is immutable after
+ *     creation and a context may be shared between host threads and streams;
+ *     its only mutable state -- the ffgpu_matmul scratch buffers (one per
+ *     stream, under a mutex) and the lazily built tables -- is internally
+ *     synchronised.  Two host threads must not issue work on the SAME stream
+ *     of a context concurrently.  The reference only ever calls from one
+ *     event-loop thread (asyncoro.py:416-464).
  */
 #ifndef FFGPU_H
 #define FFGPU_H
@@ -248,9 +252,10 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
  * accumulation, reduced at the end).  Kernel families, chosen by shape and field: one output dimension <= 8 ->
  * HBM-bound matrix x vector / vector x matrix kernels; prime fields with M, N, K >= 64 and M*N*K >= 8e7 ->
  * exact signed-digit GEMMs on the int8 matrix cores; otherwise an LDS-tiled vector-ALU kernel (split over K when
- * the output has few tiles).  The matrix-core and split-K paths keep digit planes / partial sums in a grow-only
- * scratch buffer owned by the context: the first call of a larger shape allocates it (and synchronises the stream),
- * so issue one such call before capturing launches in a HIP graph, and use one stream per context.
+ * the output has few tiles).  The matrix-core and split-K paths keep digit planes / partial sums in grow-only
+ * scratch buffers owned by the context, ONE PER STREAM (launches on different streams never share scratch): the
+ * first call of a larger shape on a stream allocates its buffer (and synchronises that stream), so issue one such
+ * call before capturing launches in a HIP graph.
  * replaces: finfields.py:1126-1146 (__matmul__: object matmul then one `%`), the local product of
  * runtime.py:2481-2541 np_matmul (A @ B at :2531).                                             */
 int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_t ldb, void* C, size_t ldc,

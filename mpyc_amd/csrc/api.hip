@@ -66,8 +66,15 @@ struct ffgpu_ctx {
     uint8_t sbox_lut[256];
     alignas(16) unsigned char policy[128];
     uint64_t modulus[3];
-    void* scratch;          // grow-only device scratch for split-K partial sums (skinny products); one stream at a time
-    size_t scratch_bytes;
+    // grow-only device scratch of ffgpu_matmul (digit planes, split-K slabs), ONE BUFFER PER STREAM: launches on
+    // different streams never share scratch, and a buffer is only freed after its own stream has drained
+    struct Scratch {
+        hipStream_t stream;
+        void* ptr;
+        size_t bytes;
+        int used;
+    } scratch[8];
+    std::mutex* scratch_mu;
     void* gf8_tables_dev;   // device copy of gf8_tables (lazily, for the fused GF(2^n<=8) product)
     // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
     int timing, timed;
@@ -197,6 +204,7 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     if (!modulus || !out || nlimbs < 1 || nlimbs > 3 || device < 0) return FFGPU_EINVAL;
     ffgpu_ctx* c = (ffgpu_ctx*)calloc(1, sizeof(ffgpu_ctx));
     if (!c) return FFGPU_ENOMEM;
+    c->scratch_mu = new std::mutex();
     c->kind = kind;
     c->device = device;
     for (int i = 0; i < nlimbs; ++i) c->modulus[i] = modulus[i];
@@ -273,9 +281,12 @@ static const void* gf8_tables_on_device(ffgpu_ctx* ctx) {
 }
 
 int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
-    if (ctx && ctx->scratch) {
+    if (ctx) {
         DeviceGuard g(ctx->device);
-        (void)hipFree(ctx->scratch);
+        for (auto& sc : ctx->scratch)
+            if (sc.ptr) (void)hipFree(sc.ptr);
+        delete ctx->scratch_mu;
+        ctx->scratch_mu = nullptr;
     }
     if (ctx && ctx->gf8_tables_dev) {
         DeviceGuard g(ctx->device);
@@ -758,16 +769,37 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
             if (want > ((size_t)8 << 30)) want = 0;
         }
         if (!want && K >= 64 && ((M + 31) / 32) * ((N + 31) / 32) < 2048) want = (size_t)64 << 20;
-        if (want && ctx->scratch_bytes < want) {
-            HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // queued work may still read the old buffer
-            if (ctx->scratch) (void)hipFree(ctx->scratch);
-            ctx->scratch = nullptr;
-            ctx->scratch_bytes = 0;
-            if (hipMalloc(&ctx->scratch, want) == hipSuccess) ctx->scratch_bytes = want;
-            else (void)hipGetLastError();                         // no scratch: the VALU kernels need none
+        if (want) {
+            std::lock_guard<std::mutex> lk(*ctx->scratch_mu);
+            ffgpu_ctx::Scratch* slot = nullptr;
+            for (auto& sc : ctx->scratch)
+                if (sc.used && sc.stream == (hipStream_t)stream) slot = &sc;
+            if (!slot) {
+                for (auto& sc : ctx->scratch)
+                    if (!sc.used && !slot) slot = &sc;
+                if (!slot) {                                     // more streams than slots: recycle the smallest buffer
+                    slot = &ctx->scratch[0];
+                    for (auto& sc : ctx->scratch)
+                        if (sc.bytes < slot->bytes) slot = &sc;
+                    HIPCHK(hipStreamSynchronize(slot->stream));
+                    if (slot->ptr) (void)hipFree(slot->ptr);
+                    slot->ptr = nullptr;
+                    slot->bytes = 0;
+                }
+                slot->used = 1;
+                slot->stream = (hipStream_t)stream;
+            }
+            if (slot->bytes < want) {
+                HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // queued work may still read the old buffer
+                if (slot->ptr) (void)hipFree(slot->ptr);
+                slot->ptr = nullptr;
+                slot->bytes = 0;
+                if (hipMalloc(&slot->ptr, want) == hipSuccess) slot->bytes = want;
+                else (void)hipGetLastError();                     // no scratch: the VALU kernels need none
+            }
+            ws = slot->ptr;
+            ws_bytes = slot->bytes;
         }
-        ws = ctx->scratch;
-        ws_bytes = ctx->scratch_bytes;
     }
     return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N, ws,
                                           ws_bytes, mod_bits, (hipStream_t)stream));

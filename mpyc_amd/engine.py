@@ -599,9 +599,12 @@ class FieldContext:
         return out
 
     def _workspace(self):
-        ws = getattr(self, '_ws', None)
+        """partial-sum workspace of dot / sum: one per stream (launches on different streams must not share it)"""
+        wss = self.__dict__.setdefault('_ws', {})
+        key = self._stream()
+        ws = wss.get(key)
         if ws is None:
-            ws = self._ws = torch.empty(1024 * 16, dtype=torch.uint8, device=self.torch_device)
+            ws = wss[key] = torch.empty(1024 * 16, dtype=torch.uint8, device=self.torch_device)
         return ws
 
     def dot(self, a: DevArray, b: DevArray) -> DevArray:
@@ -620,10 +623,11 @@ class FieldContext:
 
     def _stage(self, nbytes: int) -> torch.Tensor:
         """grow-only pinned host staging buffer of this context (uint8)"""
-        stage = getattr(self, '_pinned_stage', None)
+        stages = self.__dict__.setdefault('_pinned_stage', {})
+        key = self._stream()                              # one staging buffer per stream
+        stage = stages.get(key)
         if stage is None or stage.numel() < nbytes:
-            stage = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
-            self._pinned_stage = stage
+            stage = stages[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
         return stage
 
     def download_bytes(self, t: torch.Tensor) -> np.ndarray:

@@ -699,3 +699,79 @@ def test_mirror_calls_in_a_hip_graph(api):
         assert seen[0] != seen[1] != seen[2]
     finally:
         thresha.device_rng_state = False
+
+
+@pytest.mark.gpu
+def test_deferred_products_never_see_later_in_place_updates_through_aliases(api):
+    """A deferred `a * b` must be evaluated from the operands as they were when it was written, also when the
+    later in-place update goes through an ALIAS of an operand (a basic-slice view, a row of a share matrix, the
+    materialised value of a deferred recombination) -- the reference is eager NumPy and never does otherwise."""
+    finfields, gfpx, thresha = api
+    F = finfields.GF(2**61 - 1)
+    p = F.order
+    a = [(7 * i + 3) % p for i in range(50)]
+    b = [(11 * i + 5) % p for i in range(50)]
+    want = [x * y % p for x, y in zip(a, b)]
+    # (1) update through an offset view of an operand
+    A, B = F.array(a), F.array(b)
+    c = A * B
+    v = A[2:]
+    v += 1
+    assert ints(c) == want
+    assert ints(A)[2:] == [(x + 1) % p for x in a[2:]] and ints(A)[:2] == a[:2]
+    # (2) product of a view, then item assignment into the base array
+    A = F.array(a)
+    c2 = A[2:] * B[2:]
+    A[3] = 0
+    assert ints(c2) == want[2:]
+    # (3) a deferred recombination that has been materialised, squared lazily, then updated in place
+    t, m = 1, 3
+    sh = thresha.np_random_split(F, F.array(a), t, m)
+    X = thresha.np_recombine(F, [(x, sh[x - 1]) for x in range(1, t + 2)])
+    assert ints(X) == a                                  # materialises the recombination
+    Y = X * X
+    X += 1
+    assert ints(Y) == [x * x % p for x in a]
+    assert ints(X) == [(x + 1) % p for x in a]
+    # the fused path (share generation of a deferred product) sees the same values
+    X2 = thresha.np_recombine(F, [(x, sh[x - 1]) for x in range(1, t + 2)])
+    Y2 = X2 * X2
+    row = sh[0]
+    row *= 2                                             # a row X2 still reads
+    s2 = thresha.np_random_split(F, Y2, t, m)
+    assert ints(thresha.np_recombine(F, [(x, s2[x - 1]) for x in range(1, t + 2)])) == [x * x % p for x in a]
+
+
+@pytest.mark.gpu
+def test_matmul_scratch_is_per_stream():
+    """Two streams issue matrix-core products of DIFFERENT sizes on one context back to back (the second, larger
+    one makes its stream's scratch grow): each stream has its own digit-plane scratch, so neither product reads
+    planes the other is writing, and growing one buffer never frees memory the other stream still uses."""
+    import torch
+    from mpyc_amd.engine import DevArray, FieldContext
+    p = 2**61 - 1
+    ctx = FieldContext(p, device=0)
+    gen = torch.Generator(device='cuda:0')
+    gen.manual_seed(5)
+
+    def rnd(n):
+        return DevArray(ctx, (torch.randint(0, 2**62, (n,), dtype=torch.int64, device='cuda:0', generator=gen) >> 1) % p, n)
+    shapes = [(512, 512, 512), (768, 1024, 640)]
+    ops = [(rnd(M * K), rnd(K * N)) for (M, K, N) in shapes]
+    want = [ctx.matmul(a, b, M, K, N).t.clone() for (a, b), (M, K, N) in zip(ops, shapes)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [ctx.empty(M * N) for (M, K, N) in shapes]
+    for rep in range(6):
+        with torch.cuda.stream(s1):
+            ctx.matmul(ops[0][0], ops[0][1], *shapes[0], out=outs[0])
+        with torch.cuda.stream(s2):
+            ctx.matmul(ops[1][0], ops[1][1], *shapes[1], out=outs[1])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].t, want[0]) and torch.equal(outs[1].t, want[1])
+    with torch.cuda.stream(s1):
+        d1 = ctx.dot(ops[0][0], ops[0][0])
+    with torch.cuda.stream(s2):
+        d2 = ctx.dot(ops[1][0], ops[1][0])
+    torch.cuda.synchronize()
+    assert d1.to_ints() == ctx.dot(ops[0][0], ops[0][0]).to_ints() and d2.to_ints() == ctx.dot(ops[1][0], ops[1][0]).to_ints()
