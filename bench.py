@@ -871,9 +871,11 @@ def main():
                                ms_per_launch=kern[dom]['ms_per_launch'],
                                frac_of_measured_copy=round(kern[dom]['achieved'] / kern['device_copy']['achieved'], 4))
         # HBM traffic per launch from PMC counters (collected separately with rocprofv3 --pmc, see
-        # profiles/r01_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
+        # profiles/r02_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+            pmc_file = next(f_ for f_ in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                            if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
+            with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                 pmc = json.load(fh)
             names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, true, false, false>',
                      'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
@@ -882,14 +884,17 @@ def main():
                      'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
                      'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true, false, false>',
                      'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
+                     'mul_p128': 'k_ew2<PM128<true>, 2, true>',
+                     'split_p128_m7t3': 'k_split<PM128<true>, 3, false, true, true, false, false>',
+                     'recombine_p128_k7': 'k_recombine<PM128<true>, 7, true>',
                      'device_copy': 'k_copy16'}
             for q, kn in names.items():
                 if q in kern and kn in pmc and n == 10_000_000:
                     kern[q]['traffic'] = pmc[kn]['traffic_bytes']
             if n == 10_000_000 and names.get(dom) in pmc:
                 out['roofline']['traffic'] = pmc[names[dom]]['traffic_bytes']
-                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-        except (OSError, ValueError):
+                out['roofline']['traffic_source'] = f'profiles/{pmc_file[:-5]}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+        except (OSError, ValueError, StopIteration):
             pass
         if 'configs2' in out and 'split_p64_m7t3' in kern:
             out['configs2']['roofline']['traffic'] = kern['split_p64_m7t3'].get('traffic')

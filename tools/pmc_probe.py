@@ -43,4 +43,29 @@ for rep in range(3):
         ctx.mul(b[0], b[1], out=b[2])
         ctx.add(b[0], b[1], out=b[2])
 torch.cuda.synchronize()
+del bufs
+torch.cuda.empty_cache()
+# configs[3]: two-limb prime 2^128-173, m = 7, t = 3 (mul, split, recombine k = 7)
+P128 = 2**128 - 173
+ctx = FieldContext(P128, device=0)
+t, m, k = 3, 7, 7
+lam = list(gth._recombination_vector(gff.GF(P128), tuple(range(1, k + 1)), 0))
+sets = []
+for _ in range(3):
+    ab = bench.u128_rows(2 + t, n, 'cuda:0', gen)
+    coef = ctx.empty_matrix(t, n)
+    for j in range(t):
+        coef.row(j).t.copy_(ab[2 + j])
+    sh = ctx.empty_matrix(m, n)
+    y, c = ctx.empty(n), ctx.empty(n)
+    sets.append((DevArray(ctx, ab[0].contiguous(), n), DevArray(ctx, ab[1].contiguous(), n), coef, sh, y, c,
+                 ctx.recombine_plan([sh.row(j) for j in range(k)], lam, y)))
+    del ab
+for rep in range(3):
+    for a_, b_, coef, sh, y, c, rec in sets:
+        ctx.mul(a_, b_, out=c)
+        ctx.split(c, coef, t, m, out=sh)
+        rec()
+torch.cuda.synchronize()
+assert torch.equal(sets[0][4].t, sets[0][5].t)
 print('pmc probe done')
