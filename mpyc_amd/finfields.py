@@ -72,6 +72,16 @@ def prev_prime(n: int) -> int:
     return n
 
 
+def next_prime(x):
+    """smallest prime above x (gmpy2.next_prime / mpyc.gmpy stub)"""
+    x = max(int(x) + 1, 2)
+    if x > 2 and x % 2 == 0:
+        x += 1
+    while not is_prime(x):
+        x += 1 if x == 2 else 2
+    return x
+
+
 def find_prime_root(l, blum=True, n=1):
     """finfields.py:311-344: prime of bit length l (largest [Blum] prime below 2^l for n <= 2)."""
     if l <= 2:
@@ -84,7 +94,19 @@ def find_prime_root(l, blum=True, n=1):
             while p % 4 != 3:
                 p = prev_prime(p)
         return p, n, (p - 1 if n == 2 else 1)
-    raise NotImplementedError('roots of unity of order n > 2 (finfields.py:331-343) are not on the accelerated path')
+    # finfields.py:331-343: a Blum prime p = 1 (mod 2n) of about l bits and an n-th root of unity w (n rounded up to
+    # a prime): host scalars, as in the reference
+    if not blum:
+        raise AssertionError('roots of unity of order n > 2 need a Blum prime (finfields.py:333)')
+    if not is_prime(n):
+        n = next_prime(n)
+    p = 1 + 2 * n * (3 + 2 * ((1 << l - 3) // n))
+    while not is_prime(p):
+        p += 4 * n
+    a = 2
+    while (w := pow(a, (p - 1) // n, p)) == 1:
+        a += 1
+    return p, n, w
 
 
 def find_irreducible(p, d):

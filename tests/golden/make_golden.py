@@ -496,12 +496,29 @@ def wire_cases():
     print('wrote wire.json', os.path.getsize(os.path.join(OUT, 'wire.json')))
 
 
-ALL = ('main', 'prss', 'matmul', 'linalg', 'npfuncs', 'sqrt', 'wire')
+def roots_cases():
+    """finfields.find_prime_root (finfields.py:311-344) incl. n-th roots of unity for n > 2 (:331-343), the primes
+    SecFld / SecInt pick by default."""
+    out = []
+    for l, blum, n in ((8, True, 1), (8, False, 1), (16, True, 2), (61, True, 1), (64, True, 1), (80, True, 1), (128, True, 1),
+                       (2, True, 1), (2, False, 1), (10, True, 3), (16, True, 5), (32, True, 7), (61, True, 4), (64, True, 17),
+                       (100, True, 257), (128, True, 1000)):
+        p, nn, w = finfields.find_prime_root(l, blum, n)
+        out.append({'l': l, 'blum': blum, 'n': n, 'p': hx(int(p)), 'n_out': int(nn), 'w': hx(int(w))})
+    with open(os.path.join(OUT, 'roots.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('wrote roots.json', os.path.getsize(os.path.join(OUT, 'roots.json')))
+
+
+ALL = ('main', 'prss', 'matmul', 'linalg', 'npfuncs', 'sqrt', 'wire', 'roots')
 
 if __name__ == '__main__':
     args = sys.argv[1:]
     if 'wire' in args:
         wire_cases()
+        sys.exit(0)
+    if 'roots' in args:
+        roots_cases()
         sys.exit(0)
     if 'matmul' in args:
         matmul_cases()
@@ -522,3 +539,4 @@ if __name__ == '__main__':
     npfunc_cases()
     sqrt_cases()
     wire_cases()
+    roots_cases()

@@ -126,3 +126,22 @@ def test_reference_suite_under_install_on_gpu():
 def test_np_aes_demo_under_install_on_gpu():
     _run_np_aes(STAGE, False, ['-1'])
     _run_np_aes(STAGE, False, ['-1', '-M3'])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
+def test_reference_np_demos_under_install_on_gpu():
+    """demos/np-run-all.sh of the reference, unmodified, with and without install(): identical printed results
+    (tools/run_np_demos.sh; profiles/r02_np_demos.md)."""
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'run_np_demos.sh'), STAGE, 'gpu'], capture_output=True, text=True,
+                       cwd=ROOT, timeout=1800)
+    assert r.returncode == 0 and 'DIFF' not in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count('SAME') >= 6, r.stdout
+
+
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_reference_np_demos_under_install_host_logic():
+    env = dict(os.environ, DEMOS='np_id3gini.py\nnp_lpsolver.py\nnp_aes.py -1\nnp_onewayhashchains.py -k2 --no-random-seed\nsha3.py')
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'run_np_demos.sh'), '/root/reference', 'cpuctx'], capture_output=True,
+                       text=True, cwd=ROOT, timeout=1800, env=env)
+    assert r.returncode == 0 and 'DIFF' not in r.stdout and r.stdout.count('SAME') == 5, (r.stdout + r.stderr)[-3000:]

@@ -104,3 +104,16 @@ def test_device_rows_marshal_to_reference_bytes(wire_golden):
             q = F.order
             raw = b''.join(int(v).to_bytes(F.byte_length, 'little') for v in (q, q + 1))
             assert [int(v) for v in F.array.from_wire(raw)._dev.to_ints()] == [0, 1], name     # reduced, like field.array()
+
+
+def test_find_prime_root_matches_reference():
+    """finfields.find_prime_root incl. n-th roots of unity for n > 2 (finfields.py:311-344) against the reference's
+    outputs (tests/golden/roots.json)."""
+    from mpyc_amd import finfields as gff
+    with open(os.path.join(GOLDEN, 'roots.json')) as fh:
+        cases = json.load(fh)
+    for c in cases:
+        p, n, w = gff.find_prime_root(c['l'], c['blum'], c['n'])
+        assert (p, n, w) == (int(c['p'], 16), c['n_out'], int(c['w'], 16)), c
+        if c['n'] > 2:
+            assert pow(w, n, p) == 1 and w != 1 and p % 4 == 3 and (p - 1) % (2 * n) == 0

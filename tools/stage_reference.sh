@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 rm -rf _refstage && mkdir -p _refstage/demos
 cp -r /root/reference/mpyc _refstage/mpyc
 cp -r /root/reference/tests _refstage/tests
-cp /root/reference/demos/np_aes.py /root/reference/demos/np_lpsolver.py /root/reference/demos/np_id3gini.py _refstage/demos/
+cp /root/reference/demos/np_*.py /root/reference/demos/pseudoinverse.py /root/reference/demos/sha3.py _refstage/demos/
 cp -r /root/reference/demos/data _refstage/demos/data 2>/dev/null || true
 find _refstage -name __pycache__ -prune -exec rm -rf {} +
 du -sh _refstage
