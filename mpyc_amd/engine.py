@@ -27,6 +27,9 @@ def _torch_dtype(eb: int):
     return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 12: torch.int32, 16: torch.int64}[eb]
 
 
+_MASK64_OBJ = (1 << 64) - 1
+
+
 def limbs_of(eb: int) -> int:
     """Trailing limb dimension of a device tensor: 0 (scalar dtype), 2 (16 bytes = 2 x int64), 3 (12 bytes = 3 x int32)."""
     return {16: 2, 12: 3}.get(eb, 0)
@@ -49,27 +52,51 @@ def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
         return vals.astype(_np_dtype(eb))
     vals = list(vals) if not isinstance(vals, (list, np.ndarray)) else vals
     n = len(vals)
-    if eb == 16:
-        buf = b''.join(int(v).to_bytes(16, 'little') for v in vals)
-        return np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).copy()
-    if eb == 12:
-        buf = b''.join(int(v).to_bytes(12, 'little') for v in vals)
-        return np.frombuffer(buf, dtype=np.uint32).reshape(n, 3).copy()
     if n == 0:
-        return np.zeros(0, dtype=_np_dtype(eb))
-    return np.array(vals, dtype=object).astype(np.uint64).astype(_np_dtype(eb))
+        return np.zeros((0, limbs_of(eb)) if limbs_of(eb) else 0, dtype=_np_dtype(eb))
+    obj = vals if isinstance(vals, np.ndarray) else np.array(vals, dtype=object)
+    if eb <= 8:
+        return obj.astype(np.uint64).astype(_np_dtype(eb))
+    # two / three limbs: split inside NumPy's object loops (3 big-int operations per element instead of a Python-level
+    # to_bytes + join per element)
+    try:
+        lo64 = (obj & _MASK64_OBJ).astype(np.uint64)
+        hi64 = (obj >> 64).astype(np.uint64)
+    except (TypeError, OverflowError):       # elements that are not plain ints (numpy integers in an object array, ...)
+        ints = [int(v) for v in obj]
+        buf = b''.join(v.to_bytes(16, 'little') for v in ints)
+        both = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2)
+        lo64, hi64 = both[:, 0], both[:, 1]
+    if eb == 16:
+        out = np.empty((n, 2), dtype=np.uint64)
+        out[:, 0], out[:, 1] = lo64, hi64
+        return out
+    out = np.empty((n, 3), dtype=np.uint32)
+    out[:, 0] = (lo64 & np.uint64(0xffffffff)).astype(np.uint32)
+    out[:, 1] = (lo64 >> np.uint64(32)).astype(np.uint32)
+    out[:, 2] = hi64.astype(np.uint32)
+    return out
+
+
+def np_to_objects(arr: np.ndarray, eb: int) -> np.ndarray:
+    """Limb array -> 1-D object ndarray of Python ints, converted inside NumPy's C loops (this is the price of the
+    reference's representation: ~30 ns per element for one limb, three object operations per element for two)."""
+    if eb == 16:
+        a = arr.reshape(-1, 2)
+        if not len(a):
+            return np.empty(0, dtype=object)
+        return (a[:, 1].astype(object) << 64) | a[:, 0].astype(object)
+    if eb == 12:
+        a = arr.view(np.uint32).reshape(-1, 3)
+        if not len(a):
+            return np.empty(0, dtype=object)
+        lo = a[:, 0].astype(np.uint64) | (a[:, 1].astype(np.uint64) << np.uint64(32))
+        return (a[:, 2].astype(object) << 64) | lo.astype(object)
+    return arr.reshape(-1).astype(object)
 
 
 def np_to_ints(arr: np.ndarray, eb: int) -> List[int]:
-    if eb == 16:
-        a = arr.reshape(-1, 2)
-        lo = a[:, 0].astype(object)
-        hi = a[:, 1].astype(object)
-        return list((hi << 64) | lo) if len(a) else []
-    if eb == 12:
-        a = arr.view(np.uint32).reshape(-1, 3).astype(object)
-        return list((a[:, 2] << 64) | (a[:, 1] << 32) | a[:, 0]) if len(a) else []
-    return [int(v) for v in arr.reshape(-1).astype(object)] if arr.size else []
+    return np_to_objects(arr, eb).tolist()
 
 
 class DevArray:

@@ -25,7 +25,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .engine import DevArray, DevMatrix, FieldContext, ints_to_np
+from .engine import np_to_objects, DevArray, DevMatrix, FieldContext, ints_to_np
 from .gfpx import BinaryPolynomial, _clinvert, _clmod, _clmul
 
 __all__ = ['GF', 'find_prime_root', 'find_irreducible', 'FieldArray', 'PrimeFieldElement', 'BinaryFieldElement']
@@ -670,13 +670,22 @@ class FieldArray:
             raise TypeError('float values are not field elements')            # tests/test_finfields.py:372-382
         shape = a.shape
         flat = a.reshape(-1)
-        if flat.dtype == object:
-            if any(isinstance(v, (float, complex, np.floating)) for v in flat):
+        fast = None
+        if flat.dtype == object and flat.size:
+            # one C-level pass over the element TYPES instead of per-element isinstance tests (10^5..10^7 elements
+            # per call on the runtime's hot path)
+            kinds = set(map(type, flat.tolist()))
+            if any(issubclass(k, (float, complex, np.floating, np.complexfloating)) for k in kinds):
                 raise TypeError('float values are not field elements')
-            flat = np.array([int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v))
-                             for v in flat], dtype=object) if flat.size else flat
+            if not all(issubclass(k, int) for k in kinds):       # field elements, numpy integers, polynomials, ...
+                flat = np.array([int(v) if isinstance(v, (int, np.integer)) else int(getattr(v, 'value', v))
+                                 for v in flat], dtype=object)
+            if check and ctx.elem_bytes <= 8 and not _fops(F).binary:
+                fast = self._limbs_one_word(flat, ctx.elem_bytes, _fops(F).modulus)
         if not flat.size:
             self._dev = ctx.empty(0)
+        elif fast is not None:
+            self._dev = ctx.reduce(ctx.from_numpy(fast))
         elif not check:
             self._dev = ctx.from_numpy(ints_to_np(flat, ctx.elem_bytes))
         elif self._fits_limbs(flat, ctx.elem_bytes, F):
@@ -688,6 +697,32 @@ class FieldArray:
             # the host while marshalling (the reference does the same `%` on the host for every input)
             self._dev = ctx.from_numpy(ints_to_np(self._canonical_host(flat, F), ctx.elem_bytes))
         self._shape = tuple(shape)
+
+    @staticmethod
+    def _limbs_one_word(flat, eb, p):
+        """Object array of Python ints -> one-limb array congruent mod p, or None if some value needs the general
+        path.  Signed 64-bit conversion inside NumPy (raises on overflow), negatives folded with a vectorised `%`
+        (Python semantics: result in [0, p), finfields.py:724) -- the device reduces afterwards."""
+        try:
+            a64 = flat.astype(np.int64)
+        except (OverflowError, TypeError):
+            try:
+                u64 = flat.astype(np.uint64)              # values in [2^63, 2^64)
+            except (OverflowError, TypeError):
+                return None
+            return u64 if eb == 8 else None
+        if p < (1 << 63):
+            if eb == 4:
+                return (a64 % np.int64(p)).astype(np.uint32)
+            neg = a64 < 0
+            if neg.any():
+                a64 = np.where(neg, a64 % np.int64(p), a64)
+            return a64.view(np.uint64)
+        neg = a64 < 0                                      # 64-bit moduli: v in (-2^63, 0) -> p - |v|
+        u = a64.view(np.uint64).copy()
+        if neg.any():
+            u[neg] = np.uint64(p) - (-a64[neg]).view(np.uint64)
+        return u
 
     @staticmethod
     def _fits_limbs(flat, eb, F):
@@ -789,12 +824,13 @@ class FieldArray:
 
     def _host_value(self) -> np.ndarray:
         if self._cache is None:
-            ints = self._dev.to_ints()
             ops = _fops(type(self).field)
+            dev = self._dev
+            v = np_to_objects(dev.to_numpy(), dev.ctx.elem_bytes)
             if ops.binary:
-                ints = [ops.box(v) for v in ints]
-            v = np.empty(len(ints), dtype=object)
-            v[:] = ints
+                boxed = np.empty(len(v), dtype=object)
+                boxed[:] = [ops.box(x) for x in v.tolist()]
+                v = boxed
             v = v.reshape(self._shape)
             v.flags.writeable = False
             self._cache = v
