@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::el
     }
 }
 
-// The same product with R rows of A per workgroup: the values of B a thread needs (B is re-read by every workgroup:
+// The same product with R rows of A per workgroup (R = 2 in use): the values of B a thread needs (B is re-read by every workgroup:
 // with one row per workgroup the L2 -> CU traffic for B equals the HBM traffic for A) are loaded ONCE per R rows and
 // the R row packs are all in flight before the first multiply.  `bpack`: N == 1 with unit-stride, aligned B -- the
 // vector is read as 16-byte packs with the same index as A's.
@@ -2622,8 +2622,9 @@ struct Launchers {
         const int vec = al(A) && stride_ok(lda);
         const int bvec = al(B) && stride_ok(ldb) && (N % (int)(16 / sizeof(W)) == 0) && sizeof(E) != 12;
         if constexpr (NN <= 2 && sizeof(E) != 12) {
-            // long rows, one or two columns: R rows per workgroup share every load of B (still >= 4 workgroups per CU)
-            constexpr int R = NN == 1 ? 4 : 2;
+            // long rows, one or two columns: R = 2 rows per workgroup share every load of B (measured at 4096^2 / 8192^2:
+            // R = 1 32.5 / 117 us, R = 2 27.4 / 85 us, R = 4 28.3 / 99 us, R = 8 35.8 / 112 us)
+            constexpr int R = 2;
             if (skinny_v2() && vec && K >= 1024 && M >= 1024 * R) {
                 const int bpack = (N == 1 && ldb == 1 && al(B)) ? 1 : 0;
                 hipLaunchKernelGGL((k_matvec_rows_r<F, NN, R>), dim3((unsigned)((M + R - 1) / R)), dim3(BLOCK), 0, st, f, A, lda, B,
