@@ -76,7 +76,9 @@ const char* ffgpu_last_hip_error(void);          /* text of the last failing HIP
 int         ffgpu_device_count(int* count);
 
 /* ---- field context ---------------------------------------------------- */
-/* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p (nlimbs 1..2).
+/* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p (nlimbs 1..2; 3 for the primes p = 2^k - c,
+ * 129 <= k <= 192, c < 2^31 -- the l+32-bit default fields of SecInt(97..160), sectypes.py:673-676 --, which are
+ * stored as three 64-bit limbs = 24 bytes per element; other primes above 128 bits: FFGPU_ENOTSUP).
  * FFGPU_BINARY: bit pattern of the irreducible polynomial including its leading
  * term (degree n <= 128 needs up to 3 limbs).  Primality / irreducibility is the
  * caller's job (the reference checks it in pGF/xGF before any array exists).
@@ -89,7 +91,11 @@ int ffgpu_ctx_destroy(ffgpu_ctx* ctx);
  * (FFGPU_EINVAL if timing is off or nothing has been launched).  Off by default: no events, no cost.   */
 int ffgpu_ctx_set_timing(ffgpu_ctx* ctx, int enable);
 int ffgpu_last_kernel_ms(ffgpu_ctx* ctx, float* ms);
-int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8, 12 or 16           */
+int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8, 12, 16 or 24       */
+/* Host SCALARS (constants, Lagrange coefficients, matrix entries, PRSS weights: every `const uint64_t* host_...`
+ * argument that is documented as "canonical 2-limb scalars") occupy ffgpu_ctx_scalar_limbs(ctx) little-endian
+ * limbs each: 2, or 3 for the 24-byte prime fields.  Exponents (ffgpu_pow) may have up to 3 limbs.            */
+int ffgpu_ctx_scalar_limbs(const ffgpu_ctx* ctx);
 int ffgpu_ctx_reduction(const ffgpu_ctx* ctx);    /* one of FFGPU_RED_*          */
 int ffgpu_ctx_device(const ffgpu_ctx* ctx);
 

@@ -22,11 +22,11 @@ def install():
     (INTEGRATION.md section 2).  Must run before any field is created: mpyc caches array types
     per field (finfields.py:45,347).  Returns the list of substituted names.
 
-    * `finfields.arrayGF` (finfields.py:45-60) is wrapped: for every prime field of up to 128 bits and every
+    * `finfields.arrayGF` (finfields.py:45-60) is wrapped: for every prime field of up to 128 bits, the 129..192-bit primes 2^k - c (c < 2^31), and every
       GF(2^n), n <= 128, the array type derives from BOTH mpyc_amd.finfields.FieldArray (behaviour, device
       storage) and mpyc's own finfields.FiniteFieldArray (so `isinstance(x, finfields.FiniteFieldArray)`,
       sectypes.py:1372, holds); its inherited `value` slot is shadowed by the lazy device-backed property.
-      Fields the device path does not cover (wider primes, odd-characteristic extension fields) keep the
+      Fields the device path does not cover (other wide primes, odd-characteristic extension fields) keep the
       reference's own array classes.
     * `thresha.np_random_split / np_recombine / np_pseudorandom_share(_0)` are replaced for those fields; the
       list-path functions from `list_path_min` secrets on.
@@ -50,7 +50,7 @@ def install():
             ops = gff._fops(field)
         except NotImplementedError:
             return False
-        return ops.modulus.bit_length() <= (129 if ops.binary else 128)
+        return ops.modulus.bit_length() <= 129 if ops.binary else gff.device_supports_prime(ops.modulus)
 
     @functools.cache
     def arrayGF(field, modulus):

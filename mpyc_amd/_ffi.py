@@ -39,6 +39,7 @@ _SIGS = {
     'ffgpu_last_kernel_ms': [_vp, ctypes.POINTER(ctypes.c_float)],
     'ffgpu_ctx_elem_bytes': [_vp],
     'ffgpu_ctx_reduction': [_vp],
+    'ffgpu_ctx_scalar_limbs': [_vp],
     'ffgpu_ctx_device': [_vp],
     'ffgpu_malloc': [_vp, _sz, ctypes.POINTER(_vp)],
     'ffgpu_free': [_vp, _vp],

@@ -24,6 +24,7 @@ const FieldOps* ffgpu_ops_rc32();
 const FieldOps* ffgpu_ops_pm128_k128();      // PM128<true>
 const FieldOps* ffgpu_ops_pm128_gen();       // PM128<false>
 const FieldOps* ffgpu_ops_pm96();            // PM96
+const FieldOps* ffgpu_ops_pm192();           // PM192
 const FieldOps* ffgpu_ops_mont128();
 const FieldOps* ffgpu_ops_gf2p8();
 const FieldOps* ffgpu_ops_gf2w64();
@@ -162,6 +163,7 @@ static const FieldOps* ops_for(int kind) {
         case POL_PM128_K128: return ffgpu_ops_pm128_k128();
         case POL_PM128_GEN: return ffgpu_ops_pm128_gen();
         case POL_PM96: return ffgpu_ops_pm96();
+        case POL_PM192: return ffgpu_ops_pm192();
         case POL_MONT128: return ffgpu_ops_mont128();
         case POL_GF2P8: return ffgpu_ops_gf2p8();
         case POL_GF2W64: return ffgpu_ops_gf2w64();
@@ -212,8 +214,7 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     memset(&pb, 0, sizeof(pb));
     int rc;
     if (kind == FFGPU_PRIME) {
-        if (nlimbs > 2 && modulus[2]) rc = FFGPU_ENOTSUP;
-        else rc = build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+        rc = build_prime_policy3(&pb, modulus, nlimbs);
     } else if (kind == FFGPU_BINARY) {
         rc = build_binary_policy(&pb, modulus, nlimbs);
     } else {
@@ -427,11 +428,12 @@ int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, vo
 }
 
 static int make_exp(const uint64_t* e, int limbs, ExpArgs* ex) {
-    if (!e || limbs < 1 || limbs > 2) return FFGPU_EINVAL;
+    if (!e || limbs < 1 || limbs > 3) return FFGPU_EINVAL;
     ex->e[0] = e[0];
     ex->e[1] = limbs > 1 ? e[1] : 0;
+    ex->e[2] = limbs > 2 ? e[2] : 0;
     int nb = 0;
-    for (int i = 127; i >= 0; --i)
+    for (int i = 191; i >= 0; --i)
         if ((ex->e[i >> 6] >> (i & 63)) & 1) {
             nb = i + 1;
             break;
@@ -452,7 +454,7 @@ int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_l
     LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ex.nbits == 0) {
         // a^0 = 1 (also for a = 0, as pow(0, 0, p) = 1): 0*a + 1
-        uint64_t zero[2] = {0, 0}, one[2] = {1, 0};
+        uint64_t zero[3] = {0, 0, 0}, one[3] = {1, 0, 0};
         rc = launch_status(ctx->ops->ew1(ctx->policy, ctx->device, OP_MUL, a, zero, out, n, (hipStream_t)stream));
         if (rc != FFGPU_OK) return rc;
         return launch_status(ctx->ops->ew1(ctx->policy, ctx->device, OP_ADD, out, one, out, n, (hipStream_t)stream));
@@ -460,8 +462,28 @@ int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_l
     return launch_status(ctx->ops->pow(ctx->policy, ctx->device, a, &ex, out, n, (hipStream_t)stream));
 }
 
+// three-limb primes: exponents derived from p by limb arithmetic
+static void sub_small3(const uint64_t p[3], uint64_t d, uint64_t out[3]) {     // p - d, d small, p >= d
+    out[0] = p[0] - d;
+    const uint64_t b = p[0] < d;
+    out[1] = p[1] - b;
+    out[2] = p[2] - ((p[1] < b) ? 1 : 0);
+}
+static void shr1_3(uint64_t x[3]) {
+    x[0] = (x[0] >> 1) | (x[1] << 63);
+    x[1] = (x[1] >> 1) | (x[2] << 63);
+    x[2] >>= 1;
+}
+static bool three_limb_prime(const ffgpu_ctx* ctx) { return ctx->kind == FFGPU_PRIME && ctx->modulus[2] != 0; }
+
 // exponent q - 2 for x^-1 = x^(q-2); false for the two-element fields, where x^-1 = x
 static bool inverse_exponent(const ffgpu_ctx* ctx, ExpArgs* ex) {
+    if (three_limb_prime(ctx)) {
+        uint64_t e3[3];
+        sub_small3(ctx->modulus, 2, e3);
+        make_exp(e3, 3, ex);
+        return true;
+    }
     ff_u128 q;
     if (ctx->kind == FFGPU_PRIME) {
         q = ff_make128(ctx->modulus[1], ctx->modulus[0]);
@@ -486,12 +508,24 @@ int ffgpu_sqrt_cl(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* stre
     if (ctx->kind != FFGPU_PRIME || (ctx->modulus[0] & 3) != 1) return FFGPU_ENOTSUP;
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && out);
-    ff_u128 p = ff_make128(ctx->modulus[1], ctx->modulus[0]);
-    ff_u128 e1 = (p - 1) >> 1, e2 = (p >> 1) + 1;          // (p-1)/2 and (p+1)/2 (p odd; no overflow at 128 bits)
-    uint64_t l1[2] = {ff_lo(e1), ff_hi(e1)}, l2[2] = {ff_lo(e2), ff_hi(e2)};
     ExpArgs eleg, elad;
-    make_exp(l1, 2, &eleg);
-    make_exp(l2, 2, &elad);
+    if (three_limb_prime(ctx)) {
+        uint64_t l1[3], l2[3];
+        sub_small3(ctx->modulus, 1, l1);                   // (p-1)/2
+        shr1_3(l1);
+        sub_small3(ctx->modulus, 1, l2);                   // (p+1)/2 = (p-1)/2 + 1 (p odd: the low limb cannot wrap)
+        shr1_3(l2);
+        l2[0] += 1;
+        if (l2[0] == 0 && ++l2[1] == 0) ++l2[2];
+        make_exp(l1, 3, &eleg);
+        make_exp(l2, 3, &elad);
+    } else {
+        ff_u128 p = ff_make128(ctx->modulus[1], ctx->modulus[0]);
+        ff_u128 e1 = (p - 1) >> 1, e2 = (p >> 1) + 1;      // (p-1)/2 and (p+1)/2 (p odd; no overflow at 128 bits)
+        uint64_t l1[2] = {ff_lo(e1), ff_hi(e1)}, l2[2] = {ff_lo(e2), ff_hi(e2)};
+        make_exp(l1, 2, &eleg);
+        make_exp(l2, 2, &elad);
+    }
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ctx->ops->sqrt_cl(ctx->policy, ctx->device, a, &eleg, &elad, out, n, (hipStream_t)stream));
@@ -517,6 +551,14 @@ int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero
     ARGCHK(ctx);
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && out);
+    if (three_limb_prime(ctx)) {
+        ExpArgs ex3;
+        inverse_exponent(ctx, &ex3);
+        DeviceGuard g3(ctx->device);
+        LaunchTimer lt3(ctx, (hipStream_t)stream);
+        return launch_status(ctx->ops->inv(ctx->policy, ctx->device, a, &ex3, out, n, (int*)dev_zero_flag,
+                                           (hipStream_t)stream));
+    }
     // exponent q - 2 (order of the multiplicative group minus one)
     ff_u128 q;
     if (ctx->kind == FFGPU_PRIME) {
@@ -532,7 +574,7 @@ int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero
     LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ctx->kind == FFGPU_PRIME && q == 2) {   // GF(2): 1^-1 = 1
         ExpArgs one;
-        one.e[0] = 1; one.e[1] = 0; one.nbits = 1;
+        one.e[0] = 1; one.e[1] = one.e[2] = 0; one.nbits = 1;
         return launch_status(ctx->ops->inv(ctx->policy, ctx->device, a, &one, out, n, (int*)dev_zero_flag,
                                            (hipStream_t)stream));
     }
@@ -601,6 +643,8 @@ static int do_split_rng(ffgpu_ctx* ctx, const void* a, const void* b, bool fused
     return launch_status(ctx->ops->split(ctx->policy, ctx->device, a, fused ? b : nullptr, nullptr, 0, t, m,
                                          shares, share_stride, n, (hipStream_t)stream, t > 0 ? &ra : nullptr));
 }
+int ffgpu_ctx_scalar_limbs(const ffgpu_ctx* ctx) { return (ctx && ctx->elem_bytes == 24) ? 3 : 2; }
+
 size_t ffgpu_rng_state_bytes(void) { return sizeof(RngKey); }
 
 int ffgpu_rng_state_init(ffgpu_ctx* ctx, void* dev_state, const uint8_t* host_key32, uint64_t nonce, int rounds,
@@ -758,7 +802,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int mod_bits = 128;
-    if (ctx->kind == FFGPU_PRIME) mod_bits = ctx->modulus[1] ? 128 : 64 - __builtin_clzll(ctx->modulus[0] | 1);
+    if (ctx->kind == FFGPU_PRIME) mod_bits = ctx->modulus[2] ? 192 : ctx->modulus[1] ? 128 : 64 - __builtin_clzll(ctx->modulus[0] | 1);
     {
         // scratch: int8 limb planes for the matrix-core product (10 x (M + N) x K bytes, up to 8 GiB), else 64 MiB of
         // split-K partial sums

@@ -654,6 +654,226 @@ struct PM96 : PM128<false> {
 };
 
 // ---------------------------------------------------------------------------
+// PM192: prime p = 2^k - c, 129 <= k <= 192, c < 2^31, three 64-bit limbs, 24-byte storage
+// (SecInt(97..160): the l + 32-bit default fields, e.g. the 136-bit field of the largest
+// demos/np_lpsolver.py dataset).  Same fold-with-2^k == c reduction as PM128, one limb wider:
+// a product is 9 limb products + a 3-limb fold; every kernel stays HBM-bound at 24 bytes per
+// element.  Share generation uses the Horner step (no lazy accumulator).
+// ---------------------------------------------------------------------------
+struct u192e {
+    uint64_t lo, mid, hi;
+};
+
+struct PM192 {
+    typedef u192e elem;
+    typedef u192e word;
+    enum { EPW = 1 };
+    enum { BINARY = 0 };
+    uint64_t p0, p1, p2;   // modulus
+    uint64_t mask_hi;      // top limb of 2^k - 1 (the two low limbs are all ones)
+    uint32_t c;            // 2^k - p
+    uint32_t k;
+
+    struct acc {
+        uint64_t a[7];     // unreduced dot product: < 2^(2k + 8)
+    };
+    FF_HD u192e prep(u192e cst) const { return cst; }
+
+    static FF_HD bool ge(const u192e& a, const u192e& b) {
+        if (a.hi != b.hi) return a.hi > b.hi;
+        if (a.mid != b.mid) return a.mid > b.mid;
+        return a.lo >= b.lo;
+    }
+    static FF_HD u192e add3(const u192e& a, const u192e& b, uint64_t& carry) {
+        u192e r;
+        ff_u128 t = (ff_u128)a.lo + b.lo;
+        r.lo = ff_lo(t);
+        t = (ff_u128)a.mid + b.mid + ff_hi(t);
+        r.mid = ff_lo(t);
+        t = (ff_u128)a.hi + b.hi + ff_hi(t);
+        r.hi = ff_lo(t);
+        carry = ff_hi(t);
+        return r;
+    }
+    static FF_HD u192e sub3(const u192e& a, const u192e& b) {   // a - b mod 2^192
+        u192e r;
+        r.lo = a.lo - b.lo;
+        uint64_t br = a.lo < b.lo;
+        uint64_t m = a.mid - b.mid;
+        uint64_t br2 = (a.mid < b.mid) | ((m < br) ? 1u : 0u);
+        r.mid = m - br;
+        r.hi = a.hi - b.hi - br2;
+        return r;
+    }
+    FF_HD u192e P() const {
+        u192e r;
+        r.lo = p0;
+        r.mid = p1;
+        r.hi = p2;
+        return r;
+    }
+    FF_HD u192e csub(const u192e& x) const { return ge(x, P()) ? sub3(x, P()) : x; }
+    FF_HD u192e add(const u192e& a, const u192e& b) const {
+        uint64_t carry;
+        u192e t = add3(a, b, carry);
+        return (carry || ge(t, P())) ? sub3(t, P()) : t;      // carry only when k = 192
+    }
+    FF_HD u192e sub(const u192e& a, const u192e& b) const {
+        u192e t = sub3(a, b);
+        if (!ge(a, b)) {
+            uint64_t carry;
+            t = add3(t, P(), carry);
+        }
+        return t;
+    }
+    FF_HD u192e neg(const u192e& a) const {
+        if ((a.lo | a.mid | a.hi) == 0) return a;
+        return sub3(P(), a);
+    }
+    // 64-bit word j of (X >> k) for a little-endian limb array X of n limbs (zero beyond)
+    FF_HD uint64_t word_above_k(const uint64_t* x, int n, int j) const {
+        const int q = (int)(k >> 6) + j, s = (int)(k & 63);
+        const uint64_t w0 = q < n ? x[q] : 0, w1 = q + 1 < n ? x[q + 1] : 0;
+        return s ? (w0 >> s) | (w1 << (64 - s)) : w0;
+    }
+    // T = (t3 : t2 : t1 : t0) < 2^(k + 63)  ->  canonical.  One fold leaves < 2^k + 2^94; TWO_FOLDS handles what
+    // sticks out after the first (needed when T >= 2^(k + 32)).
+    template <bool TWO_FOLDS>
+    FF_HD u192e fold(const uint64_t t[4]) const {
+        uint64_t wh = word_above_k(t, 4, 0);
+        u192e u;
+        u.lo = t[0];
+        u.mid = t[1];
+        u.hi = t[2] & mask_hi;
+        uint64_t over = 0;                                 // bit 192 of the running sum (k = 192 only)
+#pragma unroll
+        for (int pass = 0; pass < (TWO_FOLDS ? 2 : 1); ++pass) {
+            const ff_u128 add_ = (ff_u128)wh * c;
+            ff_u128 s = (ff_u128)u.lo + ff_lo(add_);
+            u.lo = ff_lo(s);
+            s = (ff_u128)u.mid + ff_hi(add_) + ff_hi(s);
+            u.mid = ff_lo(s);
+            s = (ff_u128)u.hi + ff_hi(s);
+            u.hi = ff_lo(s);
+            over += ff_hi(s);
+            if (TWO_FOLDS && pass == 0) {
+                const uint64_t lim[4] = {u.lo, u.mid, u.hi, over};
+                wh = word_above_k(lim, 4, 0);
+                u.hi &= mask_hi;
+                over = 0;
+            }
+        }
+        if (over) {                                        // k = 192: 2^192 == c
+            uint64_t carry;
+            u192e cc;
+            cc.lo = c;
+            cc.mid = cc.hi = 0;
+            u = add3(u, cc, carry);
+        }
+        return csub(csub(u));
+    }
+    static FF_HD void mul384(const u192e& a, const u192e& b, uint64_t x[6]) {
+        const uint64_t al[3] = {a.lo, a.mid, a.hi}, bl[3] = {b.lo, b.mid, b.hi};
+        ff_u128 col = 0;        // running column sum (low 128 bits) ...
+        uint64_t top = 0;       // ... and its overflow into bit 128+
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int j = kk - i;
+                if (j < 0 || j > 2) continue;
+                const ff_u128 pr = (ff_u128)al[i] * bl[j];
+                col += pr;
+                top += col < pr ? 1 : 0;
+            }
+            x[kk] = ff_lo(col);
+            col = (col >> 64) | ((ff_u128)top << 64);
+            top = 0;
+        }
+        x[5] = ff_lo(col);
+    }
+    // (x5..x0) < 2^(2k) -> canonical:  T = (X >> k) * c + (X & mask)  < 2^(k + 32)
+    FF_HD u192e red384(const uint64_t x[6]) const {
+        uint64_t h[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h[j] = word_above_k(x, 6, j);
+        uint64_t t[4];
+        ff_u128 s = (ff_u128)h[0] * c + x[0];
+        t[0] = ff_lo(s);
+        s = (ff_u128)h[1] * c + x[1] + ff_hi(s);
+        t[1] = ff_lo(s);
+        s = (ff_u128)h[2] * c + (x[2] & mask_hi) + ff_hi(s);
+        t[2] = ff_lo(s);
+        t[3] = ff_hi(s);
+        return fold<false>(t);
+    }
+    FF_HD u192e mul(const u192e& a, const u192e& b) const {
+        uint64_t x[6];
+        mul384(a, b, x);
+        return red384(x);
+    }
+    FF_HD u192e reduce_raw(const u192e& a) const {
+        const uint64_t t[4] = {a.lo, a.mid, a.hi, 0};
+        return fold<false>(t);
+    }
+    FF_HD u192e muladd_small(const u192e& y, uint32_t x, const u192e& cadd) const {
+        uint64_t t[4];
+        ff_u128 s = (ff_u128)y.lo * x + cadd.lo;
+        t[0] = ff_lo(s);
+        s = (ff_u128)y.mid * x + cadd.mid + ff_hi(s);
+        t[1] = ff_lo(s);
+        s = (ff_u128)y.hi * x + cadd.hi + ff_hi(s);
+        t[2] = ff_lo(s);
+        t[3] = ff_hi(s);                                   // V < 2^(k + 33)
+        return fold<true>(t);
+    }
+    FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
+
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        u192e v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, const u192e& sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, const u192e&, uint32_t) const {}
+    FF_HD u192e sacc_reduce(const sacc& a) const { return a.v; }
+
+    FF_HD void acc_zero(acc& s) const {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) s.a[i] = 0;
+    }
+    FF_HD void acc_mac(acc& s, const u192e& lam, const u192e& xe) const {
+        uint64_t x[6];
+        mul384(lam, xe, x);
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const ff_u128 t = (ff_u128)s.a[i] + x[i] + carry;
+            s.a[i] = ff_lo(t);
+            carry = ff_hi(t);
+        }
+        s.a[6] += carry;
+    }
+    // V < 2^(2k + 8): xh = V >> k (< 2^(k+8): four limbs), T = xh * c + (V & mask) < 2^(k + 40)
+    FF_HD u192e acc_reduce(const acc& s) const {
+        uint64_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = word_above_k(s.a, 7, j);
+        uint64_t t[4];
+        ff_u128 v = (ff_u128)h[0] * c + s.a[0];
+        t[0] = ff_lo(v);
+        v = (ff_u128)h[1] * c + s.a[1] + ff_hi(v);
+        t[1] = ff_lo(v);
+        v = (ff_u128)h[2] * c + (s.a[2] & mask_hi) + ff_hi(v);
+        t[2] = ff_lo(v);
+        // h[3] < 2^8 contributes h[3] * c * 2^192 = h[3] * c * (2^(192-k) mod-free shift): fold it as limb 3
+        v = (ff_u128)h[3] * c + ff_hi(v);
+        t[3] = ff_lo(v);                                   // < 2^40
+        return fold<true>(t);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // MONT128: arbitrary odd modulus 2^64 < p < 2^128 (two limbs).  Canonical
 // in/out: mul(a,b) = REDC(REDC(a*b) * R^2) with R = 2^128, i.e. two word-serial
 // Montgomery reductions; chains (Horner, dot products) stay cheap because the

@@ -38,6 +38,11 @@ struct alignas(16) Pack {
     enum { N = 16 / sizeof(W) };
     W w[N];
 };
+template <>
+struct Pack<u192e> {          // three-limb elements: one per lane (24 bytes: dwordx4 + dwordx2)
+    enum { N = 1 };
+    u192e w[1];
+};
 
 // 16-byte global accesses with an optional non-temporal hint.  Every array here is
 // streamed exactly once per launch, so by default loads and stores carry `nt`
@@ -79,6 +84,47 @@ template <>
 struct MemPack<PM96> {
     typedef e96 type;
 };
+template <>
+struct MemPack<PM192> {
+    typedef u192e type;
+};
+typedef uint32_t ff_u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ Pack<u192e> ldg(const u192e* p) {
+    const ff_u32x2* q = reinterpret_cast<const ff_u32x2*>(p);     // 8-byte aligned elements: dwordx2 x 3
+    ff_u32x2 a0, a1, b;
+    if constexpr (NT) {
+        a0 = __builtin_nontemporal_load(q);
+        a1 = __builtin_nontemporal_load(q + 1);
+        b = __builtin_nontemporal_load(q + 2);
+    } else {
+        a0 = q[0];
+        a1 = q[1];
+        b = q[2];
+    }
+    Pack<u192e> r;
+    r.w[0].lo = (uint64_t)a0.x | ((uint64_t)a0.y << 32);
+    r.w[0].mid = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+    r.w[0].hi = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    return r;
+}
+template <bool NT>
+__device__ __forceinline__ void stg(u192e* p, const Pack<u192e>& x) {
+    ff_u32x2* q = reinterpret_cast<ff_u32x2*>(p);
+    ff_u32x2 a0, a1, b;
+    a0.x = (uint32_t)x.w[0].lo;  a0.y = (uint32_t)(x.w[0].lo >> 32);
+    a1.x = (uint32_t)x.w[0].mid; a1.y = (uint32_t)(x.w[0].mid >> 32);
+    b.x = (uint32_t)x.w[0].hi;   b.y = (uint32_t)(x.w[0].hi >> 32);
+    if constexpr (NT) {
+        __builtin_nontemporal_store(a0, q);
+        __builtin_nontemporal_store(a1, q + 1);
+        __builtin_nontemporal_store(b, q + 2);
+    } else {
+        q[0] = a0;
+        q[1] = a1;
+        q[2] = b;
+    }
+}
 typedef uint32_t ff_u32x3 __attribute__((ext_vector_type(3)));
 template <bool NT>
 __device__ __forceinline__ Pack<u128e> ldg(const e96* p) {
@@ -735,7 +781,12 @@ __global__ __launch_bounds__(BLOCK) void k_recombine_any(F f, RecArgsAny<F> ra, 
 // ---- helpers for the exponentiation / inversion kernels ---------------------------------------
 template <class F>
 FF_HD typename F::word ff_one(const F&) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        typename F::word w;
+        w.lo = 1;
+        w.mid = w.hi = 0;
+        return w;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = 1;
         w.hi = 0;
@@ -754,7 +805,11 @@ FF_HD typename F::word ff_one_elem(const F& f) {       // one in element 0 only 
 // zero elements are replaced by one (so that products stay invertible); zm remembers where
 template <class F>
 FF_HD typename F::word ff_zero_fix(const F&, typename F::word v, uint32_t& zm) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        zm = (v.lo | v.mid | v.hi) == 0;
+        if (zm) v.lo = 1;
+        return v;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         zm = (v.lo | v.hi) == 0;
         if (zm) v.lo = 1;
         return v;
@@ -770,7 +825,10 @@ FF_HD typename F::word ff_zero_fix(const F&, typename F::word v, uint32_t& zm) {
 }
 template <class F>
 FF_HD typename F::word ff_zero_apply(const F&, typename F::word r, uint32_t zm) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        if (zm) r.lo = r.mid = r.hi = 0;
+        return r;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         if (zm) r.lo = r.hi = 0;
         return r;
     } else if constexpr (F::EPW == 4) {
@@ -781,7 +839,7 @@ FF_HD typename F::word ff_zero_apply(const F&, typename F::word r, uint32_t zm) 
 }
 
 struct ExpArgs {
-    uint64_t e[2];   // public exponent, little-endian limbs
+    uint64_t e[3];   // public exponent, little-endian limbs (three for the three-limb prime fields)
     int nbits;       // bit length of the exponent (>= 1)
 };
 
@@ -900,7 +958,15 @@ __device__ __forceinline__ typename F::word prss_draw(const F& f, const PrssArgs
     constexpr int LB = F::EPW > 1 ? 1 : (int)sizeof(W);   // limb bytes of one element
     const int l = pa.l;
     auto limb = [&](int off, int nbytes) -> W {           // little-endian bytes [off, off+nbytes) as a word
-        if constexpr (LB == 16) {
+        if constexpr (LB == 24) {
+            uint64_t v3[3] = {0, 0, 0};
+            for (int b = 0; b < nbytes; ++b) v3[b >> 3] |= (uint64_t)p[off + b] << (8 * (b & 7));
+            W w;
+            w.lo = v3[0];
+            w.mid = v3[1];
+            w.hi = v3[2];
+            return w;
+        } else if constexpr (LB == 16) {
             uint64_t lo = 0, hi = 0;
             for (int b = 0; b < nbytes && b < 8; ++b) lo |= (uint64_t)p[off + b] << (8 * b);
             for (int b = 8; b < nbytes; ++b) hi |= (uint64_t)p[off + b] << (8 * (b - 8));
@@ -918,7 +984,12 @@ __device__ __forceinline__ typename F::word prss_draw(const F& f, const PrssArgs
         // power-of-two bound (or a draw no wider than an element): mask / plain reduction
         W v = limb(0, l < LB ? l : LB);
         if (pa.mask_bits > 0) {
-            if constexpr (LB == 16) {
+            if constexpr (LB == 24) {
+                int mb = pa.mask_bits;
+                if (mb < 64) { v.lo &= (1ull << mb) - 1; v.mid = v.hi = 0; }
+                else if (mb < 128) { v.mid &= (1ull << (mb - 64)) - 1; v.hi = 0; }
+                else if (mb < 192) v.hi &= (1ull << (mb - 128)) - 1;
+            } else if constexpr (LB == 16) {
                 int mb = pa.mask_bits;
                 if (mb < 64) { v.lo &= (1ull << mb) - 1; v.hi = 0; }
                 else if (mb < 128) v.hi &= (1ull << (mb - 64)) - 1;
@@ -931,7 +1002,8 @@ __device__ __forceinline__ typename F::word prss_draw(const F& f, const PrssArgs
     }
     // wide value mod order, limb by limb from the top: r = r * 2^(8 LB) + limb
     W R;
-    if constexpr (LB == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
+    if constexpr (LB == 24) { R.lo = pa.r0; R.mid = pa.r1; R.hi = 0; }
+    else if constexpr (LB == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
     int top = (l - 1) / LB * LB;
     W r = f.reduce_raw(limb(top, l - top));
     for (int off = top - LB; off >= 0; off -= LB) r = f.add(f.mul(r, R), f.reduce_raw(limb(off, LB)));
@@ -980,7 +1052,12 @@ __global__ __launch_bounds__(BLOCK) void k_prss(F f, PrssArgs<F> pa, typename F:
 // reads are row-contiguous.  Ragged edges are zero-filled on load and masked on store.
 template <class W>
 __device__ __forceinline__ W ff_keep_if(W v, bool ok) {
-    if constexpr (sizeof(W) == 16) {
+    if constexpr (sizeof(W) == 24) {
+        v.lo = ok ? v.lo : 0;
+        v.mid = ok ? v.mid : 0;
+        v.hi = ok ? v.hi : 0;
+        return v;
+    } else if constexpr (sizeof(W) == 16) {
         v.lo = ok ? v.lo : 0;
         v.hi = ok ? v.hi : 0;
         return v;
@@ -1240,7 +1317,12 @@ __global__ __launch_bounds__(BLOCK) void k_dot_final(F f, const typename F::word
 // Non-residues give the same (meaningless) value as the reference, which does not test either.
 template <class F>
 FF_HD typename F::word ff_small(const F&, uint32_t b) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        typename F::word w;
+        w.lo = b;
+        w.mid = w.hi = 0;
+        return w;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = b;
         w.hi = 0;
@@ -2235,10 +2317,24 @@ struct FieldOps {
                 const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
 };
 
-// canonical 2-limb host scalar -> policy word (broadcast for packed fields)
+// Host scalars (Lagrange coefficients, constants, matrix entries) cross the C ABI as little-endian 64-bit limbs:
+// 2 per scalar, 3 for the three-limb prime fields (ffgpu_ctx_scalar_limbs).
+template <class F>
+constexpr int scalar_limbs() {
+    return sizeof(typename F::word) == 24 ? 3 : 2;
+}
+// scalar number idx of a host array -> policy word (broadcast for packed fields)
+template <class F>
+inline typename F::word word_at(const F& f, const uint64_t* base, size_t idx);
 template <class F>
 inline typename F::word word_from_limbs(const F& f, uint64_t lo, uint64_t hi) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        typename F::word w;
+        w.lo = lo;
+        w.mid = hi;
+        w.hi = 0;
+        return w;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = lo;
         w.hi = hi;
@@ -2248,6 +2344,20 @@ inline typename F::word word_from_limbs(const F& f, uint64_t lo, uint64_t hi) {
         return b * 0x01010101u;
     } else {
         return (typename F::word)lo;
+    }
+}
+template <class F>
+inline typename F::word word_at(const F& f, const uint64_t* base, size_t idx) {
+    constexpr int SL = scalar_limbs<F>();
+    const uint64_t* l = base + idx * SL;
+    if constexpr (SL == 3) {
+        typename F::word w;
+        w.lo = l[0];
+        w.mid = l[1];
+        w.hi = l[2];
+        return w;
+    } else {
+        return word_from_limbs<F>(f, l[0], l[1]);
     }
 }
 
@@ -2266,8 +2376,9 @@ template <class F>
 struct Launchers {
     typedef typename F::elem E;
     typedef typename F::word W;
-    enum { EPV = (16 / sizeof(W)) * F::EPW };  // elements per pack (one lane's access)
-    enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : 16 };   // dwordx3 needs dword alignment only
+    enum { EPV = Pack<W>::N * F::EPW };  // elements per pack (one lane's access)
+    // dwordx3 needs dword alignment only; three-limb elements go as three dwordx2
+    enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : sizeof(E) == 24 ? 8 : 16 };
     static bool al(const void* p) { return ((uintptr_t)p & (PACK_ALIGN - 1)) == 0; }
     static bool stride_ok(size_t stride) { return (stride * sizeof(E)) % PACK_ALIGN == 0; }
 
@@ -2312,7 +2423,7 @@ struct Launchers {
                    size_t n, hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
-        W s = word_from_limbs<F>(f, scalar2 ? scalar2[0] : 0, scalar2 ? scalar2[1] : 0);
+        W s = scalar2 ? word_at<F>(f, scalar2, 0) : word_from_limbs<F>(f, 0, 0);
         const E* A = (const E*)a;
         E* O = (E*)o;
         switch (op) {
@@ -2427,19 +2538,20 @@ struct Launchers {
         }
         for (int j = 0; j < kA; ++j) {
             gs.rowsA[j] = (const E*)rowsA[j];
-            gs.lamA[j] = f.prep(word_from_limbs<F>(f, lamA2[2 * j], lamA2[2 * j + 1]));
+            gs.lamA[j] = f.prep(word_at<F>(f, lamA2, j));
             vec = vec && al(rowsA[j]);
         }
         for (int j = 0; j < kB; ++j) {
             gs.rowsB[j] = (const E*)rowsB[j];
-            gs.lamB[j] = f.prep(word_from_limbs<F>(f, lamB2[2 * j], lamB2[2 * j + 1]));
+            gs.lamB[j] = f.prep(word_at<F>(f, lamB2, j));
             vec = vec && al(rowsB[j]);
         }
         gs.kA = kA;
         gs.kB = kB;
         gs.square = kB == 0;
-        gs.plainA = kA == 1 && lamA2[0] == 1 && lamA2[1] == 0;
-        gs.plainB = kB == 1 && lamB2[0] == 1 && lamB2[1] == 0;
+        constexpr int SLG = scalar_limbs<F>();
+        gs.plainA = kA == 1 && lamA2[0] == 1 && lamA2[1] == 0 && (SLG < 3 || lamA2[SLG - 1] == 0);
+        gs.plainB = kB == 1 && lamB2[0] == 1 && lamB2[1] == 0 && (SLG < 3 || lamB2[SLG - 1] == 0);
         size_t nvec = vec ? n / EPV : 0;
         RngArgs ra = *rng;
         const bool spread = nvec > 0 && nvec < 262144;
@@ -2516,8 +2628,7 @@ struct Launchers {
         }
         for (int r = 0; r < w; ++r)
             for (int j = 0; j < K; ++j) {
-                const uint64_t* l = lam2 + 2 * ((size_t)r * K + j);
-                ra.lam[r * K + j] = f.prep(word_from_limbs<F>(f, l[0], l[1]));
+                ra.lam[r * K + j] = f.prep(word_at<F>(f, lam2, (size_t)r * K + j));
             }
         for (int i = w * K; i < MAXW * K; ++i) ra.lam[i] = ra.lam[0];
         size_t nvec = vec ? n / EPV : 0;
@@ -2540,8 +2651,7 @@ struct Launchers {
                 RecArgsAny<F> ra;
                 for (int j = 0; j < k; ++j) {
                     ra.rows[j] = (const E*)rows[j];
-                    const uint64_t* l = lam2 + 2 * ((size_t)r * k + j);
-                    ra.lam[j] = f.prep(word_from_limbs<F>(f, l[0], l[1]));
+                    ra.lam[j] = f.prep(word_at<F>(f, lam2, (size_t)r * k + j));
                 }
                 for (int j = k; j < MAXK_ANY; ++j) {
                     ra.rows[j] = ra.rows[0];
@@ -2556,7 +2666,7 @@ struct Launchers {
         }
         for (int r0 = 0; r0 < w; r0 += MAXW) {
             int wc = (w - r0) < MAXW ? (w - r0) : MAXW;
-            const uint64_t* l = lam2 + 2 * (size_t)r0 * k;
+            const uint64_t* l = lam2 + scalar_limbs<F>() * (size_t)r0 * k;
             E* o = O + (size_t)r0 * ostride;
             switch (k) {
                 case 1: go_rec<1>(f, lc, rows, l, wc, o, ostride, n, st); break;
@@ -2620,7 +2730,7 @@ struct Launchers {
             return;
         }
         const int vec = al(A) && stride_ok(lda);
-        const int bvec = al(B) && stride_ok(ldb) && (N % (int)(16 / sizeof(W)) == 0) && sizeof(E) != 12;
+        const int bvec = al(B) && stride_ok(ldb) && (N % (int)Pack<W>::N == 0) && sizeof(E) != 12;
         if constexpr (NN <= 2 && sizeof(E) != 12) {
             // long rows, one or two columns: R = 2 rows per workgroup share every load of B (measured at 4096^2 / 8192^2:
             // R = 1 32.5 / 117 us, R = 2 27.4 / 85 us, R = 4 28.3 / 99 us, R = 8 35.8 / 112 us)
@@ -2638,7 +2748,7 @@ struct Launchers {
     template <int MM>
     static void go_vecmat(const F& f, const E* A, size_t lda, const E* B, size_t ldb, W* part, int M, int K, int N,
                           int ks, int kchunk, hipStream_t st) {
-        constexpr int CW = 16 / sizeof(W);
+        constexpr int CW = Pack<W>::N;
         const bool vec = sizeof(E) != 12 && CW > 1 && al(B) && stride_ok(ldb) && N % CW == 0;
         if (vec) {
             dim3 grid((N / CW + BLOCK - 1) / BLOCK, ks);
@@ -2664,7 +2774,7 @@ struct Launchers {
             }
             if (M <= SKINNY_MAX && N >= 64 && K >= 1 && workspace) {
                 // split K so that about 2^18 threads are in flight; each chunk at least 8 rows
-                const int cols_blocks = (N / (int)(16 / sizeof(W)) + BLOCK - 1) / BLOCK;
+                const int cols_blocks = (N / (int)Pack<W>::N + BLOCK - 1) / BLOCK;
                 int ks = (1024 + cols_blocks - 1) / cols_blocks;
                 if (ks > (K + 7) / 8) ks = (K + 7) / 8;
                 if (ks < 1) ks = 1;
@@ -2910,9 +3020,9 @@ struct Launchers {
         LaunchCfg lc = launch_cfg(device);
         GroupMatArgs<F> ga;
         memset(&ga, 0, sizeof(ga));
-        for (int i = 0; i < r * g; ++i) ga.m[i] = f.prep(word_from_limbs<F>(f, m2[2 * i], m2[2 * i + 1]));
+        for (int i = 0; i < r * g; ++i) ga.m[i] = f.prep(word_at<F>(f, m2, i));
         for (int a = 0; a < r; ++a) {
-            W b = word_from_limbs<F>(f, bias2 ? bias2[2 * a] : 0, bias2 ? bias2[2 * a + 1] : 0);
+            W b = bias2 ? word_at<F>(f, bias2, a) : word_from_limbs<F>(f, 0, 0);
             if constexpr (F::EPW > 1) b &= 0xffu;     // one element per word on this (element-wise) path
             ga.bias[a] = b;
         }
@@ -2960,7 +3070,7 @@ struct Launchers {
         memset(&pa, 0, sizeof(pa));
         for (int s = 0; s < ks; ++s) pa.streams[s] = (const uint8_t*)streams[s];
         for (int i = 0; i < ks * d; ++i)
-            pa.w[i] = f.prep(word_from_limbs<F>(f, weights2[2 * i], weights2[2 * i + 1]));
+            pa.w[i] = f.prep(word_at<F>(f, weights2, i));
         pa.r0 = r2[0];
         pa.r1 = r2[1];
         pa.ks = ks; pa.d = d; pa.l = l; pa.mask_bits = mask_bits; pa.accumulate = accumulate;

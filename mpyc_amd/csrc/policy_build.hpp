@@ -22,7 +22,8 @@ enum PolicyKind {
     POL_MONT128,
     POL_GF2P8,
     POL_GF2W64,
-    POL_GF2W128
+    POL_GF2W128,
+    POL_PM192           // three-limb pseudo-Mersenne primes (24-byte storage)
 };
 
 // status values mirror include/ffgpu.h
@@ -139,6 +140,27 @@ inline int build_prime_policy(PolicyBlob* c, ff_u128 p) {
     return PB_OK;
 }
 
+// primes given as up to three limbs: 129..192-bit primes of the shape 2^k - c, c < 2^31, get the PM192 policy
+inline int build_prime_policy3(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
+    const uint64_t m2 = nlimbs > 2 ? mod[2] : 0;
+    if (!m2) return build_prime_policy(c, ff_make128(nlimbs > 1 ? mod[1] : 0, mod[0]));
+    const int k = 128 + (64 - __builtin_clzll(m2));
+    // 2^k - p must be < 2^31: all bits of p above bit 31 and below bit k are ones
+    const uint64_t top_mask = k == 192 ? ~0ull : ((1ull << (k - 128)) - 1);
+    if (m2 != top_mask || mod[1] != ~0ull || (mod[0] >> 31) != (~0ull >> 31)) return PB_ENOTSUP;
+    const uint64_t cc = (0 - mod[0]) & 0xffffffffull;            // 2^k - p = 2^64 - mod[0] (the upper limbs are all ones)
+    if (cc == 0 || cc >= (1ull << 31) || !(mod[0] & 1)) return PB_ENOTSUP;
+    PM192 f;
+    f.p0 = mod[0];
+    f.p1 = mod[1];
+    f.p2 = m2;
+    f.mask_hi = top_mask;
+    f.c = (uint32_t)cc;
+    f.k = (uint32_t)k;
+    store_policy(c, f, POL_PM192, PB_RED_PM);
+    return PB_OK;
+}
+
 inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
     uint64_t m0 = mod[0], m1 = nlimbs > 1 ? mod[1] : 0, m2 = nlimbs > 2 ? mod[2] : 0;
     int deg;
@@ -221,6 +243,7 @@ inline void rng_const(const PolicyBlob& pb, uint64_t out[2]) {
         case POL_PM128_GEN: rng_const_prime<PM128<false> >(pb, 128, out); break;
         case POL_PM96: rng_const_prime<PM96>(pb, 128, out); break;
         case POL_MONT128: rng_const_prime<MONT128>(pb, 128, out); break;
+        case POL_PM192: rng_const_prime<PM192>(pb, 192, out); break;      // c * 2^(192-k) < 2^94: two limbs
         default: break;  // binary fields: masks only
     }
 }

@@ -160,6 +160,25 @@ struct Sampler<PM96> {
 };
 
 template <>
+struct Sampler<PM192> {
+    enum { S = 24, REJECT = 1 };   // six keystream words per sample; two further candidates in a re-draw block
+    typedef PM192 F;
+    static FF_HD u192e get(const F& f, const uint32_t* w) {
+        u192e v;
+        v.lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        v.mid = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        v.hi = ((uint64_t)w[4] | ((uint64_t)w[5] << 32)) & f.mask_hi;
+        return v;
+    }
+    static FF_HD u192e sample(const F& f, uint64_t, uint64_t, const uint32_t* w, int* ok) {
+        const u192e v = get(f, w);
+        *ok = !F::ge(v, f.P());
+        return v;
+    }
+    static FF_HD u192e last_resort(const F& f, const uint32_t* w) { return f.csub(get(f, w)); }
+};
+
+template <>
 struct Sampler<MONT128> {
     enum { S = 32, REJECT = 0 };
     static FF_HD u128e sample(const MONT128& f, uint64_t Rlo, uint64_t Rhi, const uint32_t* w, int*) {

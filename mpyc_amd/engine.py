@@ -20,27 +20,28 @@ _MASK64 = (1 << 64) - 1
 
 
 def _np_dtype(eb: int):
-    return {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb]
+    return {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64, 24: np.uint64}[eb]
 
 
 def _torch_dtype(eb: int):
-    return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 12: torch.int32, 16: torch.int64}[eb]
+    return {1: torch.uint8, 4: torch.int32, 8: torch.int64, 12: torch.int32, 16: torch.int64, 24: torch.int64}[eb]
 
 
 _MASK64_OBJ = (1 << 64) - 1
 
 
 def limbs_of(eb: int) -> int:
-    """Trailing limb dimension of a device tensor: 0 (scalar dtype), 2 (16 bytes = 2 x int64), 3 (12 bytes = 3 x int32)."""
-    return {16: 2, 12: 3}.get(eb, 0)
+    """Trailing limb dimension of a device tensor: 0 (scalar dtype), 2 (16 bytes = 2 x int64), 3 (12 bytes = 3 x int32,
+    24 bytes = 3 x int64)."""
+    return {16: 2, 12: 3, 24: 3}.get(eb, 0)
 
 
 def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
     """Canonical Python ints -> limb array ((n,) for eb<=8, (n,2) uint64 for eb=16, (n,3) uint32 for eb=12)."""
     if isinstance(vals, np.ndarray) and vals.dtype != object:
         vals = vals.reshape(-1)
-        if eb == 16:
-            out = np.zeros((vals.size, 2), dtype=np.uint64)
+        if eb in (16, 24):
+            out = np.zeros((vals.size, eb // 8), dtype=np.uint64)
             out[:, 0] = vals.astype(np.uint64)
             return out
         if eb == 12:
@@ -59,6 +60,16 @@ def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
         return obj.astype(np.uint64).astype(_np_dtype(eb))
     # two / three limbs: split inside NumPy's object loops (3 big-int operations per element instead of a Python-level
     # to_bytes + join per element)
+    if eb == 24:
+        try:
+            out = np.empty((n, 3), dtype=np.uint64)
+            out[:, 0] = (obj & _MASK64_OBJ).astype(np.uint64)
+            out[:, 1] = ((obj >> 64) & _MASK64_OBJ).astype(np.uint64)
+            out[:, 2] = (obj >> 128).astype(np.uint64)
+            return out
+        except (TypeError, OverflowError):
+            buf = b''.join(int(v).to_bytes(24, 'little') for v in obj)
+            return np.frombuffer(buf, dtype=np.uint64).reshape(n, 3).copy()
     try:
         lo64 = (obj & _MASK64_OBJ).astype(np.uint64)
         hi64 = (obj >> 64).astype(np.uint64)
@@ -81,6 +92,11 @@ def ints_to_np(vals: Iterable[int], eb: int) -> np.ndarray:
 def np_to_objects(arr: np.ndarray, eb: int) -> np.ndarray:
     """Limb array -> 1-D object ndarray of Python ints, converted inside NumPy's C loops (this is the price of the
     reference's representation: ~30 ns per element for one limb, three object operations per element for two)."""
+    if eb == 24:
+        a = arr.reshape(-1, 3)
+        if not len(a):
+            return np.empty(0, dtype=object)
+        return (a[:, 2].astype(object) << 128) | (a[:, 1].astype(object) << 64) | a[:, 0].astype(object)
     if eb == 16:
         a = arr.reshape(-1, 2)
         if not len(a):
@@ -236,6 +252,7 @@ class FieldContext:
         self._h = h
         self.elem_bytes = L.ffgpu_ctx_elem_bytes(h)
         self.limbs = limbs_of(self.elem_bytes)        # trailing limb dimension of device tensors (0, 2 or 3)
+        self.scalar_limbs = int(L.ffgpu_ctx_scalar_limbs(h))   # limbs per host scalar in the C ABI (2; 3 for 24-byte fields)
         self.reduction = _ffi.RED_NAMES.get(L.ffgpu_ctx_reduction(h), '?')
         if binary:
             self.order = 1 << (self.modulus.bit_length() - 1)
@@ -355,7 +372,7 @@ class FieldContext:
     def _ews(self, fn, a, scalar: int, out):
         self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
-        _ffi.check(fn(self._h, a.ptr, _ffi.limbs(scalar, 2), out.ptr, a.n, self._stream()), fn.__name__)
+        _ffi.check(fn(self._h, a.ptr, _ffi.limbs(scalar, self.scalar_limbs), out.ptr, a.n, self._stream()), fn.__name__)
         return out
 
     def add_scalar(self, a, s: int, out=None):
@@ -375,11 +392,11 @@ class FieldContext:
 
     def pow(self, a, e: int, out=None):
         """a ** e for a public exponent 0 <= e < 2^128, one kernel (finfields.py:1159-1187)."""
-        if e < 0 or e >> 128:
+        if e < 0 or e >> 192:
             raise ValueError('exponent out of range')
         self._same(a.n, out, what='output')
         out = out or self.empty(a.n)
-        _ffi.check(self._L.ffgpu_pow(self._h, a.ptr, _ffi.limbs(e, 2), 2, out.ptr, a.n, self._stream()), 'pow')
+        _ffi.check(self._L.ffgpu_pow(self._h, a.ptr, _ffi.limbs(e, 3), 3, out.ptr, a.n, self._stream()), 'pow')
         return out
 
     def inv(self, a, out=None, check_zero: bool = True):
@@ -539,11 +556,7 @@ class FieldContext:
             raise ValueError('need w*k lambda values')
         self._same(rows[0].n, *rows, what='share row')
         ptrs = (ctypes.c_void_p * k)(*[r.ptr for r in rows])
-        lam = (ctypes.c_uint64 * (2 * w * k))()
-        for i, v in enumerate(lambdas):
-            v = int(v)
-            lam[2 * i] = v & _MASK64
-            lam[2 * i + 1] = v >> 64
+        lam = self._scalars(lambdas)
         return k, ptrs, lam
 
     def recombine(self, rows: Sequence[DevArray], lambdas: Sequence[int], w: int = 1, out=None):
@@ -614,14 +627,8 @@ class FieldContext:
             raise ValueError('array length is not a multiple of the group size')
         ng = x.n // g
         out = out or self.empty(ng * r)
-        m = (ctypes.c_uint64 * (2 * r * g))()
-        for i, v in enumerate(v for row in matrix for v in row):
-            m[2 * i], m[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
-        b = None
-        if bias is not None:
-            b = (ctypes.c_uint64 * (2 * r))()
-            for i, v in enumerate(bias):
-                b[2 * i], b[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        m = self._scalars([v for row in matrix for v in row])
+        b = self._scalars(bias) if bias is not None else None
         _ffi.check(self._L.ffgpu_group_matvec(self._h, m, b, r, g, x.ptr, out.ptr, ng, self._stream()), 'group_matvec')
         return out
 
@@ -709,9 +716,7 @@ class FieldContext:
             a = np.frombuffer(sbytes, dtype=np.uint8, count=n * d * l)
             devs.append(torch.from_numpy(a.copy()).to(self.torch_device))
         ptrs = (ctypes.c_void_p * ks)(*[t.data_ptr() for t in devs])
-        w = (ctypes.c_uint64 * (2 * ks * d))()
-        for i, v in enumerate(weights):
-            w[2 * i], w[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+        w = self._scalars(weights)
         _ffi.check(self._L.ffgpu_prss_combine(self._h, ptrs, ks, d, l, mask_bits, w, int(accumulate), out.ptr, n,
                                               self._stream()), 'prss_combine')
         return out
@@ -736,11 +741,14 @@ class FieldContext:
                                                   self._stream()), 'bit_affine')
         return out
 
-    @staticmethod
-    def _scalars(vals: Sequence[int]):
-        w = (ctypes.c_uint64 * (2 * max(1, len(vals))))()
+    def _scalars(self, vals: Sequence[int]):
+        """Host scalars in the C ABI's layout: scalar_limbs little-endian 64-bit limbs each (ffgpu_ctx_scalar_limbs)."""
+        sl = self.scalar_limbs
+        w = (ctypes.c_uint64 * (sl * max(1, len(vals))))()
         for i, v in enumerate(vals):
-            w[2 * i], w[2 * i + 1] = int(v) & _MASK64, int(v) >> 64
+            v = int(v)
+            for q in range(sl):
+                w[sl * i + q] = (v >> (64 * q)) & _MASK64
         return w
 
     def gf256_mask_open(self, rows: Sequence[DevArray], coefs: Sequence[int], rbits: Sequence[DevArray],

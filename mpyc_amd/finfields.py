@@ -322,12 +322,20 @@ def _make_array(field):
     return arr
 
 
+def device_supports_prime(p: int) -> bool:
+    """Primes the engine has a storage format / reduction for: everything up to 128 bits, and 129..192-bit primes
+    2^k - c with c < 2^31 (three 64-bit limbs; include/ffgpu.h ffgpu_ctx_create)."""
+    k = p.bit_length()
+    return k <= 128 or (k <= 192 and (1 << k) - p < (1 << 31))
+
+
 @functools.lru_cache(maxsize=None)
 def _pGF(p):
     if not is_prime(p):
         raise ValueError('modulus is not a prime')                            # finfields.py:351
-    if p.bit_length() > 128:
-        raise NotImplementedError('primes above 128 bits are not supported by the device path')
+    if not device_supports_prime(p):
+        raise NotImplementedError('primes above 128 bits are supported by the device path only in the shape '
+                                  '2^k - c, k <= 192, c < 2^31 (the defaults of find_prime_root)')
     F = type(f'GF({p})', (PrimeFieldElement,), {'__slots__': ()})
     F.modulus, F.order, F.characteristic, F.ext_deg = p, p, p, 1
     F.byte_length = (p.bit_length() + 7) >> 3
@@ -1105,7 +1113,7 @@ class FieldArray:
         if e < 0:
             return self.reciprocal() ** (-e)
         order1 = _fops(type(self).field).order - 1
-        if e >> 128:
+        if e >> 192:
             e = e % order1 if e % order1 or not e else order1      # a^(q-1) = 1 for a != 0, keep 0^e = 0
         return self._wrap(self.ctx.pow(self._dev, e), self._shape)    # one kernel: finfields.py:1159-1187
 
@@ -1699,7 +1707,7 @@ class FieldArray:
             if check and n and b[:, eb:].any():
                 raise ValueError('field element on the wire exceeds the element width')
             b = b[:, :eb]
-        raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb])
+        raw = np.ascontiguousarray(b).view({1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64, 24: np.uint64}[eb])
         raw = raw.reshape(n, ctx.limbs) if ctx.limbs else raw.reshape(n)
         dev = ctx.from_numpy(raw)
         if check and n:

@@ -42,7 +42,7 @@ def elem_bytes(modulus: int, binary: bool) -> int:
     b = modulus.bit_length()
     if 64 < b <= 96 and (1 << b) - modulus < (1 << 31):
         return 12                      # p = 2^k - c, k <= 96: three 32-bit limbs (include/ffgpu.h)
-    return 4 if b <= 32 else 8 if b <= 64 else 16
+    return 4 if b <= 32 else 8 if b <= 64 else 16 if b <= 128 else 24     # 24: three 64-bit limbs (2^k - c, k <= 192)
 
 
 class CField:

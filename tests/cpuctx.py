@@ -27,6 +27,7 @@ class CpuFieldContext(engine.FieldContext):
         self.F = po.Field(self.modulus, self.binary)
         self.elem_bytes = elem_bytes(self.modulus, self.binary)
         self.limbs = limbs_of(self.elem_bytes)
+        self.scalar_limbs = 3 if self.elem_bytes == 24 else 2
         self.reduction = 'cpu-emulation'
         self.order = self.F.order
         self._h = None

@@ -17,6 +17,9 @@ def field_of(case):
 
 def pack(vals, eb):
     """ints -> raw little-endian numpy array ((n,), (n,2) uint64 for 16 bytes, (n,3) uint32 for 12 bytes)."""
+    if eb == 24:
+        buf = b''.join(int(v).to_bytes(24, 'little') for v in vals)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(len(vals), 3).copy()
     if eb == 16:
         buf = b''.join(int(v).to_bytes(16, 'little') for v in vals)
         return np.frombuffer(buf, dtype=np.uint64).reshape(len(vals), 2).copy()
@@ -29,10 +32,13 @@ def pack(vals, eb):
 
 def lshape(eb, *dims):
     """numpy shape of a raw limb array with the given leading dims"""
-    return tuple(dims) + ({16: (2,), 12: (3,)}.get(eb, ()))
+    return tuple(dims) + ({16: (2,), 12: (3,), 24: (3,)}.get(eb, ()))
 
 
 def unpack(arr, eb):
+    if eb == 24:
+        a = np.ascontiguousarray(arr).reshape(-1, 3)
+        return [int(a[i, 0]) | (int(a[i, 1]) << 64) | (int(a[i, 2]) << 128) for i in range(a.shape[0])]
     if eb == 16:
         a = np.ascontiguousarray(arr).reshape(-1, 2)
         return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in range(a.shape[0])]

@@ -44,7 +44,13 @@ static void stw(unsigned char* p, size_t i, typename F::word w) {
 
 template <class F>
 static typename F::word cst(const F& f, const uint64_t* l) {
-    if constexpr (sizeof(typename F::word) == 16) {
+    if constexpr (sizeof(typename F::word) == 24) {
+        typename F::word w;
+        w.lo = l[0];
+        w.mid = l[1];
+        w.hi = l[2];
+        return w;
+    } else if constexpr (sizeof(typename F::word) == 16) {
         typename F::word w;
         w.lo = l[0];
         w.hi = l[1];
@@ -78,7 +84,7 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 typename F::acc s;
                 f.acc_zero(s);
                 for (int j = 0; j < k; ++j)
-                    f.acc_mac(s, f.prep(cst<F>(f, lam + 2 * j)), ldw<F>(a, (size_t)j * n + i));
+                    f.acc_mac(s, f.prep(cst<F>(f, lam + (sizeof(typename F::word) == 24 ? 3 : 2) * j)), ldw<F>(a, (size_t)j * n + i));
                 r = f.acc_reduce(s);
                 break;
             }
@@ -113,8 +119,7 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
                       uint32_t x, const uint64_t* lam, int k, int* policy_kind, int* elem_bytes) {
     PolicyBlob pb;
     memset(&pb, 0, sizeof(pb));
-    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs)
-                    : build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs) : build_prime_policy3(&pb, modulus, nlimbs);
     if (rc) return 100 + rc;
     if (policy_kind) *policy_kind = pb.kind;
     if (elem_bytes) *elem_bytes = pb.elem_bytes;
@@ -132,6 +137,7 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
         case POL_GF2P8: return run<GF2P8>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W128: return run<GF2W128>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_PM192: return run<PM192>(pb, op, a, b, c, out, n, x, lam, k);
         default: return 2;
     }
 }
@@ -147,7 +153,7 @@ static void draw_rows(const PolicyBlob& pb, const RngKey& rk, unsigned char* out
     memcpy(&f, pb.bytes, sizeof(F));
     uint64_t R[2];
     rng_const(pb, R);
-    constexpr int WPP = 16 / sizeof(typename F::word);
+    constexpr int WPP = sizeof(typename F::word) >= 16 ? 1 : 16 / sizeof(typename F::word);     // words per pack (kernels.hpp Pack<W>::N)
     constexpr int EPV = WPP * F::EPW;
     size_t npacks = (n + EPV - 1) / EPV;
     for (size_t i = 0; i < npacks; ++i) {
@@ -186,8 +192,7 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
                              uint64_t nonce, int rounds, int t, unsigned char* out, size_t cstride, size_t n) {
     PolicyBlob pb;
     memset(&pb, 0, sizeof(pb));
-    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs)
-                    : build_prime_policy(&pb, ff_make128(nlimbs > 1 ? modulus[1] : 0, modulus[0]));
+    int rc = binary ? build_binary_policy(&pb, modulus, nlimbs) : build_prime_policy3(&pb, modulus, nlimbs);
     if (rc) return 100 + rc;
     RngKey rk;
     memset(&rk, 0, sizeof(rk));
@@ -208,6 +213,7 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
         case POL_GF2P8: return rng_rows<GF2P8>(pb, rk, t, out, cstride, n);
         case POL_GF2W64: return rng_rows<GF2W64>(pb, rk, t, out, cstride, n);
         case POL_GF2W128: return rng_rows<GF2W128>(pb, rk, t, out, cstride, n);
+        case POL_PM192: return rng_rows<PM192>(pb, rk, t, out, cstride, n);
         default: return 2;
     }
 }

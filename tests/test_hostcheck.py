@@ -27,9 +27,11 @@ def run(hc, F, op, a, b=None, c=None, x=0, lam=None, k=0, n=None):
     out = np.zeros_like(A[:n] if eb != 16 else A[:n])
     lam_arr = None
     if lam is not None:
-        lam_arr = (ctypes.c_uint64 * (2 * len(lam)))()
+        sl = 3 if eb == 24 else 2                        # limbs per host scalar (ffgpu_ctx_scalar_limbs)
+        lam_arr = (ctypes.c_uint64 * (sl * len(lam)))()
         for i, v in enumerate(lam):
-            lam_arr[2 * i], lam_arr[2 * i + 1] = v & (2**64 - 1), v >> 64
+            for q in range(sl):
+                lam_arr[sl * i + q] = (v >> (64 * q)) & (2**64 - 1)
     pk, ebo = ctypes.c_int(), ctypes.c_int()
     p = lambda z: z.ctypes.data_as(ctypes.c_void_p) if z is not None else None
     rc = hc.hc_run(int(F.binary), limbs3(F.modulus), 3, op, p(A), p(B), p(C), p(out), ctypes.c_size_t(n),
@@ -281,3 +283,56 @@ def test_matrix_core_operand_digits_two_limbs(hostcheck):
                 d = list(buf)
                 val = sum(v << (8 * i) for i, v in enumerate(d))
                 assert val == (x if x <= T else x - p), (L, hex(p), hex(x), d)
+
+
+
+# ---- three-limb pseudo-Mersenne primes (PM192: SecInt(97..160) default fields) -----------------------------------
+def _pm192_primes():
+    from mpyc_amd.finfields import find_prime_root, is_prime
+    ps = [find_prime_root(l)[0] for l in (129, 136, 160, 191, 192)]          # the primes MPyC picks by default
+    c = 2**31 - 1                                                            # the largest admissible fold constant
+    while not is_prime(2**150 - c):
+        c -= 2
+    return ps + [2**150 - c]
+
+
+def test_pm192_policy_and_arithmetic(hostcheck):
+    """Every operation of the three-limb policy against Python integers: edge values crossed, random values,
+    all raw 192-bit patterns for the reduction, Horner steps with 32-bit multipliers, dot products at the
+    accumulator's declared bound (192 terms of (p-1)^2)."""
+    PM192 = 13
+    rng = random.Random(192)
+    for p in _pm192_primes():
+        F = po.Field(p, False)
+        assert elem_bytes(p, False) == 24
+        k = p.bit_length()
+        ev = sorted(v for v in {0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2**64 - 1, 2**64, 2**128 - 1, 2**128,
+                                2**(k - 1), 2**(k - 1) - 1, 2**127, 2**63, p - 2**64, p - 2**128} if 0 <= v < p)
+        a, b = cross(ev)
+        a += [rng.randrange(p) for _ in range(300)]
+        b += [rng.randrange(p) for _ in range(300)]
+        cc = [rng.randrange(p) for _ in range(len(a))]
+        got, pk = run(hostcheck, F, HC_ADD, a, b)
+        assert pk == PM192 and got == [(x + y) % p for x, y in zip(a, b)], hex(p)
+        assert run(hostcheck, F, HC_SUB, a, b)[0] == [(x - y) % p for x, y in zip(a, b)], hex(p)
+        assert run(hostcheck, F, HC_MUL, a, b)[0] == [(x * y) % p for x, y in zip(a, b)], hex(p)
+        assert run(hostcheck, F, HC_NEG, a)[0] == [(-x) % p for x in a], hex(p)
+        assert run(hostcheck, F, HC_MULADD, a, b, cc)[0] == [(x * y + z) % p for x, y, z in zip(a, b, cc)], hex(p)
+        raw = [2**192 - 1, 2**192 - 2, p, p + 1, 2 * p % 2**192, 2**191, 2**k % 2**192] + [rng.randrange(2**192) for _ in range(200)]
+        assert run(hostcheck, F, HC_REDUCE, raw)[0] == [x % p for x in raw], hex(p)
+        for x in (0, 1, 2, 7, 255, 65536, 2**31, 2**32 - 1):
+            assert run(hostcheck, F, HC_MULADD_SMALL, a, c=cc, x=x)[0] == [(y * x + z) % p for y, z in zip(a, cc)], (hex(p), x)
+        for kk in (1, 2, 7, 64, 192):
+            n = 40
+            rows = [[p - 1] * 3 + [rng.randrange(p) for _ in range(n - 3)] for _ in range(kk)]
+            lam = [p - 1] * kk if kk != 7 else [rng.randrange(p) for _ in range(kk)]
+            flat = [v for r in rows for v in r]
+            got, _ = run(hostcheck, F, HC_DOT, flat, lam=lam, k=kk, n=n)
+            assert got == [sum(lam[j] * rows[j][i] for j in range(kk)) % p for i in range(n)], (hex(p), kk)
+    # what the policy does not cover: three-limb primes that are not 2^k - c with c < 2^31
+    from mpyc_amd.finfields import is_prime
+    q = 2**140 + 1
+    while not is_prime(q):
+        q += 2
+    rc = hostcheck.hc_run(0, limbs3(q), 3, HC_ADD, None, None, None, None, ctypes.c_size_t(0), ctypes.c_uint32(0), None, 0, None, None)
+    assert rc == 102                                                         # 100 + PB_ENOTSUP
