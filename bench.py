@@ -762,9 +762,37 @@ def main():
                                       'achieved': round(352 * n / (gate_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
                                       'frac': round(352 * n / (gate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       'ms_per_launch': round(gate_ms, 5)}
-            # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
             del sets128[:]
             torch.cuda.empty_cache()
+            # three-limb primes (SecInt(97..160) defaults; np_lpsolver's largest dataset runs over the 136-bit one):
+            # 24-byte elements, one per lane, the same kernels instantiated on the PM192 policy
+            from mpyc_amd.finfields import find_prime_root
+            from mpyc_amd.engine import DevArray
+            P136 = find_prime_root(136)[0]
+            ctx136 = FieldContext(P136, device=local_rank)
+            eb3 = 24
+
+            def rows136():
+                a_ = DevArray(ctx136, torch.randint(0, 2**62, (n, 3), dtype=torch.int64, device=ctx.torch_device, generator=gen), n)
+                return ctx136.reduce(a_, out=a_)
+            a3, b3, c3 = rows136(), rows136(), ctx136.empty(n)
+            sh3 = ctx136.empty_matrix(m, n)
+            ms = time_launches(lambda s_: ctx136.mul(a3, b3, out=c3), [0], reps)
+            kern['mul_p136'] = dict(roof(3 * eb3 * n, ms), algorithmic_bytes_per_unit=3 * eb3, units_per_s=round(n / (ms * 1e-3), 1))
+            ms = time_launches(lambda s_: ctx136.split_rng(c3, t, m, key=bytes(range(32)), nonce=5, out=sh3), [0], reps)
+            bpu = (1 + m) * eb3
+            kern['split_rng_p136_m3t1_chacha20'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                        units_per_s=round(n / (ms * 1e-3), 1))
+            y3 = ctx136.empty(n)
+            rec3 = ctx136.recombine_plan([sh3.row(j) for j in range(k)], lagrange(P136, range(1, k + 1)), y3)
+            ms = time_launches(lambda s_: rec3(), [0], reps)
+            bpu = (k + 1) * eb3
+            kern['recombine_p136_k3'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+            if not torch.equal(y3.t, c3.t):
+                raise SystemExit('bench parity check failed for the 136-bit field')
+            del a3, b3, c3, sh3, y3, rec3
+            torch.cuda.empty_cache()
+            # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
             ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
             # demos/np_aes.py:23-33: A = circulant([1,0,0,0,1,1,1,1]) (row j = first row rolled by j), B = 0x63
             r_ = [1, 0, 0, 0, 1, 1, 1, 1]

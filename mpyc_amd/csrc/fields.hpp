@@ -664,6 +664,20 @@ struct u192e {
     uint64_t lo, mid, hi;
 };
 
+// cond ? a : b on words.  For the three-limb struct the choice is made limb by limb: `cond ? x : y` on two
+// struct lvalues becomes a choice between their ADDRESSES, which keeps local arrays of them in scratch memory.
+template <class W>
+FF_HD W ff_pick(bool cond, const W& a, const W& b) {
+    return cond ? a : b;
+}
+FF_HD u192e ff_pick(bool cond, const u192e& a, const u192e& b) {
+    u192e r;
+    r.lo = cond ? a.lo : b.lo;
+    r.mid = cond ? a.mid : b.mid;
+    r.hi = cond ? a.hi : b.hi;
+    return r;
+}
+
 struct PM192 {
     typedef u192e elem;
     typedef u192e word;
@@ -730,11 +744,13 @@ struct PM192 {
         if ((a.lo | a.mid | a.hi) == 0) return a;
         return sub3(P(), a);
     }
-    // 64-bit word j of (X >> k) for a little-endian limb array X of n limbs (zero beyond)
+    // 64-bit word j of (X >> k) for a little-endian limb array X of n limbs (zero beyond).  129 <= k <= 192, so the
+    // word sits at limb 2 + j (shifted by k - 128) or, for k = 192, at limb 3 + j: constant indices once j is
+    // unrolled -- a runtime limb index would put the array in scratch memory.
     FF_HD uint64_t word_above_k(const uint64_t* x, int n, int j) const {
-        const int q = (int)(k >> 6) + j, s = (int)(k & 63);
-        const uint64_t w0 = q < n ? x[q] : 0, w1 = q + 1 < n ? x[q + 1] : 0;
-        return s ? (w0 >> s) | (w1 << (64 - s)) : w0;
+        const int s = (int)(k & 63);
+        const uint64_t w0 = 2 + j < n ? x[2 + j] : 0, w1 = 3 + j < n ? x[3 + j] : 0;
+        return k == 192 ? w1 : (w0 >> s) | (w1 << ((64 - s) & 63));
     }
     // T = (t3 : t2 : t1 : t0) < 2^(k + 63)  ->  canonical.  One fold leaves < 2^k + 2^94; TWO_FOLDS handles what
     // sticks out after the first (needed when T >= 2^(k + 32)).

@@ -2763,7 +2763,8 @@ struct Launchers {
                       hipStream_t st) {
         const F& f = *reinterpret_cast<const F*>(Fp);
         if constexpr (F::EPW == 1) {
-            if (N <= SKINNY_MAX && M >= 64 && K >= 1) {
+            // (three-limb words: the eight-column kernel would spill, N in 5..8 takes the tiled product)
+            if (N <= (sizeof(W) > 16 ? 4 : SKINNY_MAX) && M >= 64 && K >= 1) {
                 const E* a = (const E*)A; const E* b = (const E*)B; E* c = (E*)C;
                 if (N == 1) go_matvec<1>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
                 else if (N == 2) go_matvec<2>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
@@ -2915,7 +2916,7 @@ struct Launchers {
             }
             // small outputs (a 64 x 64 product is two 64 x 32 tiles): 32 x 32 tiles give four times as many workgroups
             const bool small_out = ((M + 63) / 64) * ((N + 31) / 32) < 64;
-            const int tcode = (sizeof(W) == 16 || small_out) ? 22 : tile;
+            const int tcode = (sizeof(W) >= 16 || small_out) ? 22 : tile;   // two- and three-limb words: 2x2 keeps two waves per SIMD
             const int bm = tcode == 42 ? 64 : tcode == 22 ? 32 : tcode == 84 ? 128 : 64;
             const int bn = tcode == 42 ? 32 : tcode == 22 ? 32 : tcode == 84 ? 64 : 64;
             dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm);

@@ -304,7 +304,7 @@ FF_HD void rng_draw_pack(const F& f, const RngKey& rk, uint64_t R0, uint64_t R1,
         for (int q = 0; q < WPP; ++q) {
             typename F::word v = g[0][j][q];
 #pragma unroll
-            for (int uu = 1; uu < L::G; ++uu) v = (uu == u) ? g[uu][j][q] : v;
+            for (int uu = 1; uu < L::G; ++uu) v = ff_pick(uu == u, g[uu][j][q], v);
             c[j][q] = v;
         }
 }
