@@ -459,16 +459,6 @@ def main():
                       'ms_per_step': round(elapsed_unfused / args.steps * 1e3, 5),
                       'note': 'same step as three kernels (mul, split, recombine) with c written to HBM'}
 
-    # configs[3] on all N ranks: element-sharded P128 gate and the party-major exchange (the one collective)
-    if not args.no_multi_gpu_leg:
-        full = args.layout == 'party-major'
-        try:
-            leg = multi_gpu_leg(dist, rank, world, local_rank, backend, n,
-                                args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else 2, lagrange)
-        except torch.OutOfMemoryError as exc:
-            leg = {'error': f'OutOfMemoryError: {exc}'}
-        out['multi_gpu'] = leg
-        torch.cuda.empty_cache()
     if args.layout == 'party-major':
         args.no_extras = True
         args.no_cpu_baseline = True
@@ -933,11 +923,44 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
 
+    # configs[3] on all N ranks: element-sharded P128 gate and the party-major exchange (the one collective).
+    # It runs LAST and under a watchdog: whatever happens in the collectives (a rank failing, a transport that
+    # hangs), rank 0 still prints the line with everything measured above.
+    def finish(code=None):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if code is not None:
+            sys.stdout.flush()
+            os._exit(code)
+
+    if not args.no_multi_gpu_leg:
+        import threading
+        full = args.layout == 'party-major'
+        leg_done = threading.Event()
+        limit = float(os.environ.get('FFGPU_BENCH_LEG_TIMEOUT', '300'))
+
+        def watchdog():
+            if not leg_done.wait(limit):
+                out['multi_gpu'] = {'error': f'multi-GPU leg did not finish within {limit:.0f} s (rank {rank})'}
+                finish(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            leg = multi_gpu_leg(dist, rank, world, local_rank, backend, n,
+                                args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else 2, lagrange)
+        except torch.OutOfMemoryError as exc:
+            leg = {'error': f'OutOfMemoryError: {exc}'}
+        except Exception as exc:          # noqa: BLE001 -- the other ranks may now be waiting in a collective: end here
+            out['multi_gpu'] = {'error': f'{type(exc).__name__}: {exc}'}
+            leg_done.set()
+            finish(0)
+        leg_done.set()
+        out['multi_gpu'] = leg
+        torch.cuda.empty_cache()
+
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    finish()
 
 
 if __name__ == '__main__':
