@@ -352,10 +352,19 @@ __device__ __forceinline__ Pack<typename F::word> gate_load(const F& f, const ty
     typename F::acc acc[P::N];
 #pragma unroll
     for (int q = 0; q < P::N; ++q) f.acc_zero(acc[q]);
-    for (int j = 0; j < k; ++j) {
-        const P x = ldg<NT>(reinterpret_cast<const MP*>(rows[j]) + i);
+    // rows in chunks of four: the loads of a chunk are issued together and waited for once (k is wave-uniform, the
+    // guards are scalar branches) -- one load, one wait, one multiply-add per row would expose k memory latencies
+    for (int j0 = 0; j0 < k; j0 += 4) {
+        P x[4];
 #pragma unroll
-        for (int q = 0; q < P::N; ++q) f.acc_mac(acc[q], lam[j], x.w[q]);
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u < k) x[u] = ldg<NT>(reinterpret_cast<const MP*>(rows[j0 + u]) + i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u < k) {
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) f.acc_mac(acc[q], lam[j0 + u], x[u].w[q]);
+            }
     }
     P r;
 #pragma unroll
@@ -452,8 +461,8 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             __syncthreads();
         }
     }
-    // one pack: loads, optional local product, m share evaluations, m stores
-    auto do_pack = [&](size_t i, W (&c)[TT][P::N]) {
+    // one pack: loads and the optional local product ...
+    auto load_s = [&](size_t i) -> P {
         P s, s2;
         if constexpr (REC) {
             const size_t iA = i + yoffA / EPV_, iB = i + yoffB / EPV_;      // batch offsets are whole packs on this path
@@ -465,14 +474,6 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
         } else {
             s = ldg<NT>(av + i);
             if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
-        }
-        if constexpr (!(RNG && T > 0)) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
-            }
         }
         if constexpr (TABMUL) {
             if (ra.aux) {
@@ -496,6 +497,57 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
 #pragma unroll
             for (int q = 0; q < P::N; ++q) s.w[q] = f.mul(s.w[q], s2.w[q]);
         }
+        return s;
+    };
+    // ... then m share evaluations and m stores
+    auto eval_store = [&](size_t i, const P& s, W (&c)[TT][P::N]) {
+        if constexpr (!(RNG && T > 0)) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+            }
+        }
+        if constexpr (!F::BINARY && T >= 1) {
+            // The parties' points are the consecutive integers 1..m (thresha.py:55-61), so the polynomial is
+            // evaluated by FORWARD DIFFERENCES: f(x) = f(x-1) + D1, D1 += D2, ... -- T modular additions per
+            // share and no multiplication (Horner: T multiply-adds by the point, ~4x the instructions; this is
+            // what the kernels with the in-register ChaCha draw are bound by).  D_j = j! sum_i S(i, j) c_i with
+            // the Stirling numbers of the second kind: the same residues as Horner's, in any commutative ring.
+            W dd[TT][P::N];
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) {
+                if constexpr (T == 1) {
+                    dd[0][q] = c[0][q];
+                } else if constexpr (T == 2) {
+                    dd[1][q] = f.add(c[1][q], c[1][q]);
+                    dd[0][q] = f.add(c[0][q], c[1][q]);
+                } else if constexpr (T == 3) {
+                    const W c3x6 = f.muladd_small(c[2][q], 5u, c[2][q]);
+                    dd[2][q] = c3x6;
+                    dd[1][q] = f.add(f.add(c[1][q], c[1][q]), c3x6);
+                    dd[0][q] = f.add(f.add(c[0][q], c[1][q]), c[2][q]);
+                } else {
+                    static_assert(T <= 4, "difference table written out for T <= 4");
+                    const W c3x6 = f.muladd_small(c[2][q], 5u, c[2][q]);
+                    dd[3][q] = f.muladd_small(c[3][q], 23u, c[3][q]);
+                    dd[2][q] = f.muladd_small(c[3][q], 36u, c3x6);
+                    dd[1][q] = f.muladd_small(c[3][q], 14u, f.add(f.add(c[1][q], c[1][q]), c3x6));
+                    dd[0][q] = f.add(f.add(c[0][q], c[1][q]), f.add(c[2][q], c[3][q]));
+                }
+            }
+            P y = s;
+            for (int party = 1; party <= m; ++party) {
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    y.w[q] = f.add(y.w[q], dd[0][q]);
+#pragma unroll
+                    for (int j = 0; j + 1 < T; ++j) dd[j][q] = f.add(dd[j][q], dd[j + 1][q]);
+                }
+                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+            }
+        } else
         for (int party = 1; party <= m; ++party) {
             P y;
             if constexpr (T == 0) {
@@ -531,18 +583,42 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
         // (G x the ChaCha work, G x the parallelism -- the grouped loop leaves most CUs idle below ~10^5 packs)
         for (size_t i = gid; i < nvec; i += gsz) {
             W c[TT][P::N];
+            const P s = load_s(i);
             rng_draw_pack<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)i, (uint64_t)npacks_all, c);
-            do_pack(i, c);
+            eval_store(i, s, c);
         }
     } else {
         for (size_t ig = gid; ig < ngroups; ig += gsz) {
             W cg[G][TT][P::N];
-            if constexpr (RNG && T > 0) rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
+            // the group's G packs are fetched (all loads in flight together) BEFORE the keystream is computed, so
+            // the ChaCha rounds run in the shadow of the loads instead of each pack waiting for its own after them
+            // (split_rng over GF(2^61-1), m=3, t=1: 54.5 vs 59.5 us)
+            P sv[G];
+            if constexpr (REC) {
+                // chain gate: the operand fetch is itself a recombination (k loads and multiply-adds per pack); here
+                // the keystream first and the packs one after the other measured faster (105-115 vs 118-121 us for
+                // 10^7 elements of GF(2^61-1), m=3, t=1, ChaCha20)
+                rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const size_t i = (size_t)u * ngroups + ig;
+                    if (i < nvec) {
+                        sv[0] = load_s(i);
+                        eval_store(i, sv[0], cg[u]);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const size_t i = (size_t)u * ngroups + ig;             // stride NG: lanes stay on adjacent packs
-                if (i >= nvec) continue;
-                do_pack(i, cg[u]);
+                if (i < nvec) sv[u] = load_s(i);
+            }
+            if constexpr (RNG && T > 0) rng_draw_group<F, TT, P::N>(f, ra.rk, ra.r0, ra.r1, (uint64_t)ig, cg);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const size_t i = (size_t)u * ngroups + ig;
+                if (i < nvec) eval_store(i, sv[u], cg[u]);
             }
         }
     }
