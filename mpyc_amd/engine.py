@@ -596,6 +596,12 @@ class FieldContext:
         """C (M, N) = A (M, K) @ B (K, N): contiguous row-major operands (finfields.py:1126-1135)."""
         if A.n != M * K or B.n != K * N:
             raise ValueError('matmul: operand sizes do not match the shapes')
+        if out is not None:
+            self._same(M * N, out, what='matmul output')
+            eb = self.elem_bytes
+            for x in (A, B):                       # C is written while other tiles still read A and B
+                if out.ptr < x.ptr + x.n * eb and x.ptr < out.ptr + out.n * eb:
+                    raise ValueError('matmul: the output overlaps an operand')
         out = out or self.empty(M * N)
         _ffi.check(self._L.ffgpu_matmul(self._h, A.ptr, K, B.ptr, N, out.ptr, N, M, K, N, self._stream()), 'matmul')
         return out
