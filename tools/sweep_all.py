@@ -7,7 +7,7 @@ from mpyc_amd import finfields as gff, gfpx, thresha as gth
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
 FAM = [('PM64 2^61-1', 2**61 - 1, False), ('PM64 2^64-189', 2**64 - 189, False), ('RC64 generic', 6616326157076047771, False),
        ('RC32 2^31-1', 2**31 - 1, False), ('PM128 2^128-173', 2**128 - 173, False), ('PM128 2^127-1', 2**127 - 1, False), ('PM96 2^96-17', 2**96 - 17, False),
-       ('MONT128 generic', 258797994007609146293811961253269568351, False), ('GF2P8 0x11b', 0x11b, True),
+       ('MONT128 generic', 258797994007609146293811961253269568351, False), ('PM192 2^136-c', gff.find_prime_root(136)[0], False), ('GF2P8 0x11b', 0x11b, True),
        ('GF2W64 2^64', (1 << 64) | 0x1b, True), ('GF2W128 2^128', (1 << 128) | 0x87, True)]
 only = sys.argv[1:] 
 for name, mod, binary in FAM:
@@ -18,7 +18,10 @@ for name, mod, binary in FAM:
     n = 40_000_000 if eb == 1 else 10_000_000
     F = gff.GF(gfpx.BinaryPolynomial(mod)) if binary else gff.GF(mod)
     def rnd(rows):
-        if eb == 16:
+        if eb == 24:
+            x = torch.randint(0, 2**62, (rows, n, 3), dtype=torch.int64, device='cuda:0', generator=gen)
+            x[..., 2] &= 0x7f                      # below 2^135: canonical
+        elif eb == 16:
             x = torch.randint(0, 2**62, (rows, n, 2), dtype=torch.int64, device='cuda:0', generator=gen)
         elif eb == 12:
             x = torch.randint(0, 2**31 - 1, (rows, n, 3), dtype=torch.int32, device='cuda:0', generator=gen)
