@@ -44,6 +44,13 @@ def golden_fields():
 
 
 @pytest.fixture(scope='session')
+def golden_wide():
+    """three-limb primes (129..192 bits), same case format as fields.json"""
+    with open(os.path.join(GOLDEN, 'wide.json')) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope='session')
 def golden_sbox():
     with open(os.path.join(GOLDEN, 'sbox.json')) as fh:
         return json.load(fh)

@@ -103,7 +103,7 @@ class Replay:
         return v
 
 
-def field_case(name, F, is_binary):
+def field_case(name, F, is_binary, raw_width=None):
     q = F.order
     bits = (q - 1).bit_length() if q > 2 else 1
     ev = edge_values(q, max(bits, 1))
@@ -130,6 +130,7 @@ def field_case(name, F, is_binary):
     if not is_binary:
         width = 8 * ((bits + 7) // 8)
         width = 32 if width <= 32 else 64 if width <= 64 else 128
+        width = raw_width or width
         raw = [2**width - 1, 2**width - 2, q, q + 1, 2 * q % 2**width] + [rng.randrange(2**width) for _ in range(11)]
         case['raw_width'] = width
         case['raw'] = hxl(raw)
@@ -512,8 +513,30 @@ def roots_cases():
 
 ALL = ('main', 'prss', 'matmul', 'linalg', 'npfuncs', 'sqrt', 'wire', 'roots')
 
+def wide_cases():
+    """Three-limb primes (129..192 bits: the default fields of SecInt(97..160), finfields.py:311-344): the same
+    case as fields.json holds for every other field, in a file of its own with its own random stream (the streams
+    of the older fixtures do not move)."""
+    global rng
+    saved, rng = rng, random.Random(20260925 + 192)
+    try:
+        cases = {}
+        for bits in (129, 136, 160, 192):
+            p = int(finfields.find_prime_root(bits)[0])
+            assert p.bit_length() == bits
+            cases[f'P{bits}'] = field_case(f'P{bits}', finfields.GF(p), False, raw_width=192)
+    finally:
+        rng = saved
+    with open(os.path.join(OUT, 'wide.json'), 'w') as fh:
+        json.dump(cases, fh, separators=(',', ':'))
+    print('wrote wide.json:', {k: v['modulus'] for k, v in cases.items()})
+
+
 if __name__ == '__main__':
     args = sys.argv[1:]
+    if 'wide' in args:
+        wide_cases()
+        sys.exit(0)
     if 'wire' in args:
         wire_cases()
         sys.exit(0)
@@ -540,3 +563,4 @@ if __name__ == '__main__':
     sqrt_cases()
     wire_cases()
     roots_cases()
+    wide_cases()

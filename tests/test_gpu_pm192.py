@@ -137,3 +137,11 @@ def test_pm192_mirror_api_wire_and_full_size_round_trip():
     r2 = thresha.np_recombine(F, [(x, sh[x - 1]) for x in (7, 5, 2, 6)])
     r3 = thresha.np_recombine(F, [(x, sh[x - 1]) for x in range(1, 8)])
     assert bool((r1 == S).all()) and bool((r2 == S).all()) and bool((r3 == S).all())
+
+
+def test_pm192_golden_vectors_from_the_reference(eng, golden_wide):
+    """element-wise results, both sharing conventions, recombination from several point sets and at several targets:
+    the reference's own outputs for the 129 / 136 / 160 / 192-bit default primes (tests/golden/wide.json)"""
+    import test_gpu_parity as tp
+    tp.test_golden_elementwise(eng, golden_wide)
+    tp.test_golden_sharing(eng, golden_wide)

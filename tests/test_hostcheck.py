@@ -336,3 +336,13 @@ def test_pm192_policy_and_arithmetic(hostcheck):
         q += 2
     rc = hostcheck.hc_run(0, limbs3(q), 3, HC_ADD, None, None, None, None, ctypes.c_size_t(0), ctypes.c_uint32(0), None, 0, None, None)
     assert rc == 102                                                         # 100 + PB_ENOTSUP
+
+
+def test_wide_primes_device_header_against_reference_vectors(hostcheck, golden_wide):
+    """PM192 (fields.hpp, compiled for the host) against the reference's outputs for its 129..192-bit default primes, then
+    the same cross-product / random / multiply-add / dot checks as every other policy"""
+    test_golden_elementwise(hostcheck, golden_wide)
+    test_edges_cross_product(hostcheck, golden_wide)
+    test_random_mul(hostcheck, golden_wide)
+    test_muladd_small(hostcheck, golden_wide)
+    test_dot(hostcheck, golden_wide)

@@ -179,3 +179,11 @@ def test_py_aes128_fips197():
     key = list(bytes.fromhex('2b7e151628aed2a6abf7158809cf4f3c'))
     pt = list(bytes.fromhex('3243f6a8885a308d313198a2e0370734'))
     assert bytes(po.aes128_encrypt(key, pt)).hex() == '3925841d02dc09fbdc118597196a0b32'
+
+
+def test_py_wide_primes(golden_wide):
+    """the three-limb primes (129..192 bits; reference outputs in wide.json): the Python-integer oracle is the checker
+    for them on the GPU (tests/test_gpu_pm192.py) -- the C oracle stops at 128 bits"""
+    assert sorted(golden_wide) == ['P129', 'P136', 'P160', 'P192']
+    test_py_elementwise(golden_wide)
+    test_py_sharing(golden_wide)
