@@ -25,6 +25,7 @@ const FieldOps* ffgpu_ops_pm128_k128();      // PM128<true>
 const FieldOps* ffgpu_ops_pm128_gen();       // PM128<false>
 const FieldOps* ffgpu_ops_pm96();            // PM96
 const FieldOps* ffgpu_ops_pm192();           // PM192
+const FieldOps* ffgpu_ops_mont192();         // MONT192
 const FieldOps* ffgpu_ops_mont128();
 const FieldOps* ffgpu_ops_gf2p8();
 const FieldOps* ffgpu_ops_gf2w64();
@@ -164,6 +165,7 @@ static const FieldOps* ops_for(int kind) {
         case POL_PM128_GEN: return ffgpu_ops_pm128_gen();
         case POL_PM96: return ffgpu_ops_pm96();
         case POL_PM192: return ffgpu_ops_pm192();
+        case POL_MONT192: return ffgpu_ops_mont192();
         case POL_MONT128: return ffgpu_ops_mont128();
         case POL_GF2P8: return ffgpu_ops_gf2p8();
         case POL_GF2W64: return ffgpu_ops_gf2w64();

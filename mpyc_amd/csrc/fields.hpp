@@ -1030,6 +1030,127 @@ FF_HD u128e MONT128::sacc_reduce(const sacc& a) const {
     return E(montmul(redc(x), ff_make128(r2_hi, r2_lo)));
 }
 
+// ---------------------------------------------------------------------------
+// MONT192: arbitrary odd primes of 129..192 bits (e.g. the "root of unity" primes 1 + 2n(3 + 2j) that
+// sectypes.SecInt(l, n=N) asks find_prime_root for, finfields.py:332-343), three 64-bit limbs, 24-byte storage.
+// Montgomery arithmetic with R = 2^192 INSIDE a product only: values in memory are canonical residues
+// (finfields.py:66,708), as for MONT128.
+// ---------------------------------------------------------------------------
+struct MONT192 {
+    typedef u192e elem;
+    typedef u192e word;
+    enum { EPW = 1 };
+    enum { BINARY = 0 };
+    uint64_t p0, p1, p2;        // modulus
+    uint64_t r2_0, r2_1, r2_2;  // R^2 mod p
+    uint64_t pinv;              // -p^{-1} mod 2^64
+    uint64_t pad_;
+
+    struct acc {
+        u192e v;                // running canonical sum
+    };
+    FF_HD u192e P() const {
+        u192e r;
+        r.lo = p0;
+        r.mid = p1;
+        r.hi = p2;
+        return r;
+    }
+    FF_HD u192e R2() const {
+        u192e r;
+        r.lo = r2_0;
+        r.mid = r2_1;
+        r.hi = r2_2;
+        return r;
+    }
+    FF_HD u192e csub(const u192e& x) const { return PM192::ge(x, P()) ? PM192::sub3(x, P()) : x; }
+    FF_HD u192e add(const u192e& a, const u192e& b) const {
+        uint64_t carry;
+        const u192e t = PM192::add3(a, b, carry);
+        return (carry || PM192::ge(t, P())) ? PM192::sub3(t, P()) : t;
+    }
+    FF_HD u192e sub(const u192e& a, const u192e& b) const {
+        u192e t = PM192::sub3(a, b);
+        if (!PM192::ge(a, b)) {
+            uint64_t carry;
+            t = PM192::add3(t, P(), carry);
+        }
+        return t;
+    }
+    FF_HD u192e neg(const u192e& a) const {
+        if ((a.lo | a.mid | a.hi) == 0) return a;
+        return PM192::sub3(P(), a);
+    }
+    // REDC of T = (x5..x0) < p * 2^192  ->  T * 2^-192 mod p, canonical (word-serial, three rounds)
+    FF_HD u192e redc(const uint64_t x[6]) const {
+        uint64_t t0 = x[0], t1 = x[1], t2 = x[2], t3 = x[3], t4 = x[4], t5 = x[5], t6 = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint64_t m = t0 * pinv;
+            ff_u128 c = (ff_u128)m * p0 + t0;              // low limb becomes 0
+            c = (ff_u128)m * p1 + t1 + ff_hi(c);
+            const uint64_t n0 = ff_lo(c);
+            c = (ff_u128)m * p2 + t2 + ff_hi(c);
+            const uint64_t n1 = ff_lo(c);
+            c = (ff_u128)t3 + ff_hi(c);
+            const uint64_t n2 = ff_lo(c);
+            c = (ff_u128)t4 + ff_hi(c);
+            const uint64_t n3 = ff_lo(c);
+            c = (ff_u128)t5 + ff_hi(c);
+            const uint64_t n4 = ff_lo(c);
+            const uint64_t n5 = t6 + ff_hi(c);
+            t0 = n0; t1 = n1; t2 = n2; t3 = n3; t4 = n4; t5 = n5; t6 = 0;
+        }
+        // result = (t3 : t2 : t1 : t0) < 2p, t3 in {0, 1}
+        u192e r;
+        r.lo = t0;
+        r.mid = t1;
+        r.hi = t2;
+        return (t3 || PM192::ge(r, P())) ? PM192::sub3(r, P()) : r;
+    }
+    FF_HD u192e montmul(const u192e& a, const u192e& b) const {
+        uint64_t x[6];
+        PM192::mul384(a, b, x);
+        return redc(x);
+    }
+    // constants of dot products / gates are pre-scaled by R: one REDC per term (acc_mac)
+    FF_HD u192e prep(const u192e& cst) const { return montmul(cst, R2()); }
+    FF_HD u192e mul(const u192e& a, const u192e& b) const { return montmul(montmul(a, b), R2()); }
+    // a < 2^192: a * R^2 / R = a R mod p, then / R
+    FF_HD u192e reduce_raw(const u192e& a) const {
+        const u192e t = montmul(a, R2());
+        const uint64_t x[6] = {t.lo, t.mid, t.hi, 0, 0, 0};
+        return redc(x);
+    }
+    // T = y * x + cadd < 2^32 p + p as four limbs: REDC (T / R), then one Montgomery product by R^2
+    FF_HD u192e muladd_small(const u192e& y, uint32_t x, const u192e& cadd) const {
+        uint64_t t[6];
+        ff_u128 v = (ff_u128)y.lo * x + cadd.lo;
+        t[0] = ff_lo(v);
+        v = (ff_u128)y.mid * x + cadd.mid + ff_hi(v);
+        t[1] = ff_lo(v);
+        v = (ff_u128)y.hi * x + cadd.hi + ff_hi(v);
+        t[2] = ff_lo(v);
+        t[3] = ff_hi(v);
+        t[4] = t[5] = 0;
+        return montmul(redc(t), R2());
+    }
+    FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
+
+    enum { HAS_SACC = 0 };
+    struct sacc {
+        u192e v;
+    };
+    FF_HD bool sacc_ok(int, int) const { return false; }
+    FF_HD void sacc_init(sacc& a, const u192e& sv) const { a.v = sv; }
+    FF_HD void sacc_mac(sacc&, const u192e&, uint32_t) const {}
+    FF_HD u192e sacc_reduce(const sacc& a) const { return a.v; }
+
+    FF_HD void acc_zero(acc& s) const { s.v.lo = s.v.mid = s.v.hi = 0; }
+    FF_HD void acc_mac(acc& s, const u192e& lamR, const u192e& xe) const { s.v = add(s.v, montmul(lamR, xe)); }
+    FF_HD u192e acc_reduce(const acc& s) const { return s.v; }
+};
+
 
 // ---------------------------------------------------------------------------
 // GF2P8: GF(2^n), 1 <= n <= 8, one element per byte, arithmetic on four

@@ -88,6 +88,10 @@ template <>
 struct MemPack<PM192> {
     typedef u192e type;
 };
+template <>
+struct MemPack<MONT192> {
+    typedef u192e type;
+};
 typedef uint32_t ff_u32x2 __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ Pack<u192e> ldg(const u192e* p) {

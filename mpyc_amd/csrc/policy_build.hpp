@@ -23,7 +23,8 @@ enum PolicyKind {
     POL_GF2P8,
     POL_GF2W64,
     POL_GF2W128,
-    POL_PM192           // three-limb pseudo-Mersenne primes (24-byte storage)
+    POL_PM192,          // three-limb pseudo-Mersenne primes (24-byte storage)
+    POL_MONT192         // any other odd prime of 129..192 bits (24-byte storage)
 };
 
 // status values mirror include/ffgpu.h
@@ -140,16 +141,36 @@ inline int build_prime_policy(PolicyBlob* c, ff_u128 p) {
     return PB_OK;
 }
 
-// primes given as up to three limbs: 129..192-bit primes of the shape 2^k - c, c < 2^31, get the PM192 policy
+// primes given as up to three limbs: 129..192-bit primes of the shape 2^k - c, c < 2^31, get the PM192 policy, all
+// other odd ones the three-limb Montgomery policy
 inline int build_prime_policy3(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
     const uint64_t m2 = nlimbs > 2 ? mod[2] : 0;
     if (!m2) return build_prime_policy(c, ff_make128(nlimbs > 1 ? mod[1] : 0, mod[0]));
     const int k = 128 + (64 - __builtin_clzll(m2));
     // 2^k - p must be < 2^31: all bits of p above bit 31 and below bit k are ones
     const uint64_t top_mask = k == 192 ? ~0ull : ((1ull << (k - 128)) - 1);
-    if (m2 != top_mask || mod[1] != ~0ull || (mod[0] >> 31) != (~0ull >> 31)) return PB_ENOTSUP;
     const uint64_t cc = (0 - mod[0]) & 0xffffffffull;            // 2^k - p = 2^64 - mod[0] (the upper limbs are all ones)
-    if (cc == 0 || cc >= (1ull << 31) || !(mod[0] & 1)) return PB_ENOTSUP;
+    if (m2 != top_mask || mod[1] != ~0ull || (mod[0] >> 31) != (~0ull >> 31) || cc == 0 || cc >= (1ull << 31)) {
+        if (!(mod[0] & 1)) return PB_EMODULUS;
+        MONT192 g;
+        g.p0 = mod[0];
+        g.p1 = mod[1];
+        g.p2 = m2;
+        uint64_t inv = g.p0;                                     // -p^{-1} mod 2^64 by Newton iteration
+        for (int i = 0; i < 6; ++i) inv *= 2 - g.p0 * inv;
+        g.pinv = 0 - inv;
+        g.pad_ = 0;
+        u192e r;                                                 // R^2 = 2^384 mod p by 384 modular doublings of 1
+        r.lo = 1;
+        r.mid = r.hi = 0;
+        for (int i = 0; i < 384; ++i) r = g.add(r, r);
+        g.r2_0 = r.lo;
+        g.r2_1 = r.mid;
+        g.r2_2 = r.hi;
+        store_policy(c, g, POL_MONT192, PB_RED_MONT);
+        return PB_OK;
+    }
+    if (!(mod[0] & 1)) return PB_EMODULUS;
     PM192 f;
     f.p0 = mod[0];
     f.p1 = mod[1];

@@ -194,6 +194,22 @@ struct Sampler<MONT128> {
 };
 
 template <>
+struct Sampler<MONT192> {
+    // 256 keystream bits per sample, reduced: (lo + 2^192 hi) mod p, lo of 192 bits, hi of 64 (bias < 2^-64 for
+    // every 129..192-bit p).  2^192 hi mod p is ONE Montgomery product: montmul(hi, R^2) = hi R mod p, R = 2^192.
+    enum { S = 32, REJECT = 0 };
+    static FF_HD u192e sample(const MONT192& f, uint64_t, uint64_t, const uint32_t* w, int*) {
+        u192e lo, hi;
+        lo.lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        lo.mid = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        lo.hi = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
+        hi.lo = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+        hi.mid = hi.hi = 0;
+        return f.add(f.reduce_raw(lo), f.montmul(hi, f.R2()));
+    }
+};
+
+template <>
 struct Sampler<GF2P8> {
     enum { S = 4, REJECT = 0 };  // one 32-bit word = 4 packed elements, masked to n bits each
     static FF_HD uint32_t sample(const GF2P8& f, uint64_t, uint64_t, const uint32_t* w, int*) {

@@ -323,10 +323,10 @@ def _make_array(field):
 
 
 def device_supports_prime(p: int) -> bool:
-    """Primes the engine has a storage format / reduction for: everything up to 128 bits, and 129..192-bit primes
-    2^k - c with c < 2^31 (three 64-bit limbs; include/ffgpu.h ffgpu_ctx_create)."""
-    k = p.bit_length()
-    return k <= 128 or (k <= 192 and (1 << k) - p < (1 << 31))
+    """Primes the engine has a storage format / reduction for: every prime of up to 192 bits (three 64-bit limbs above
+    128 bits: 2^k - c with c < 2^31 by folding, any other odd prime by Montgomery products; include/ffgpu.h
+    ffgpu_ctx_create)."""
+    return p.bit_length() <= 192
 
 
 @functools.lru_cache(maxsize=None)
@@ -334,8 +334,7 @@ def _pGF(p):
     if not is_prime(p):
         raise ValueError('modulus is not a prime')                            # finfields.py:351
     if not device_supports_prime(p):
-        raise NotImplementedError('primes above 128 bits are supported by the device path only in the shape '
-                                  '2^k - c, k <= 192, c < 2^31 (the defaults of find_prime_root)')
+        raise NotImplementedError('primes above 192 bits are not supported by the device path')
     F = type(f'GF({p})', (PrimeFieldElement,), {'__slots__': ()})
     F.modulus, F.order, F.characteristic, F.ext_deg = p, p, p, 1
     F.byte_length = (p.bit_length() + 7) >> 3

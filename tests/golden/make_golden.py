@@ -525,6 +525,11 @@ def wide_cases():
             p = int(finfields.find_prime_root(bits)[0])
             assert p.bit_length() == bits
             cases[f'P{bits}'] = field_case(f'P{bits}', finfields.GF(p), False, raw_width=192)
+        # primes of no special shape: the root-of-unity prime SecInt(104, n=118) asks for (demos/np_lpsolver.py:74 with
+        # its largest dataset; finfields.py:332-343), and the first prime above 2^128
+        from mpyc import gmpy as g
+        for name, p in (('P136R', int(finfields.find_prime_root(136, n=118)[0])), ('P129G', int(g.next_prime(2**128)))):
+            cases[name] = field_case(name, finfields.GF(p), False, raw_width=192)
     finally:
         rng = saved
     with open(os.path.join(OUT, 'wide.json'), 'w') as fh:

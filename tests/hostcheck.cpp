@@ -138,6 +138,7 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
         case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W128: return run<GF2W128>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_PM192: return run<PM192>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_MONT192: return run<MONT192>(pb, op, a, b, c, out, n, x, lam, k);
         default: return 2;
     }
 }
@@ -214,6 +215,7 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
         case POL_GF2W64: return rng_rows<GF2W64>(pb, rk, t, out, cstride, n);
         case POL_GF2W128: return rng_rows<GF2W128>(pb, rk, t, out, cstride, n);
         case POL_PM192: return rng_rows<PM192>(pb, rk, t, out, cstride, n);
+        case POL_MONT192: return rng_rows<MONT192>(pb, rk, t, out, cstride, n);
         default: return 2;
     }
 }

@@ -1,6 +1,7 @@
-"""Three-limb prime fields (PM192: p = 2^k - c, 129 <= k <= 192 -- the default fields of SecInt(97..160), e.g. the
-136-bit field of demos/np_lpsolver.py's largest dataset) through the C ABI and the mirror API, against Python
-integers (oracle/pyoracle.py; the C oracle stops at 128 bits).  Bit-exact."""
+"""Three-limb prime fields (129..192 bits: PM192 for p = 2^k - c -- the default fields of SecInt(97..160) --, MONT192
+for every other odd prime, e.g. the root-of-unity field of demos/np_lpsolver.py's largest dataset) through the C ABI
+and the mirror API, against Python integers (oracle/pyoracle.py; the C oracle stops at 128 bits) and the reference's
+vectors (tests/golden/wide.json).  Bit-exact."""
 import random
 
 import numpy as np
@@ -14,8 +15,11 @@ torch = pytest.importorskip('torch')
 
 
 def primes():
-    from mpyc_amd.finfields import find_prime_root
-    return [find_prime_root(l)[0] for l in (129, 136, 160, 192)]
+    """2^k - c primes (PM192: MPyC's defaults) and primes of no special shape (MONT192): the root-of-unity prime of
+    SecInt(104, n=118) -- the field of demos/np_lpsolver.py -i5 --, the first prime above 2^128, one close to 2^192"""
+    from mpyc_amd.finfields import find_prime_root, next_prime
+    return [find_prime_root(l)[0] for l in (129, 136, 160, 192)] + [find_prime_root(136, n=118)[0], next_prime(2**128),
+                                                                    next_prime(2**192 - 2**40)]
 
 
 @pytest.fixture(scope='module')
@@ -107,10 +111,11 @@ def test_pm192_elementwise_sharing_and_linear_algebra(eng):
             assert got == want, (hex(p), M, K, N)
 
 
-def test_pm192_mirror_api_wire_and_full_size_round_trip():
+@pytest.mark.parametrize('root_n', [1, 118])
+def test_pm192_mirror_api_wire_and_full_size_round_trip(root_n):
     from mpyc_amd import finfields, thresha
     rng = random.Random(7)
-    p = finfields.find_prime_root(136)[0]
+    p = finfields.find_prime_root(136, n=root_n)[0]        # n = 1: 2^136 - c; n = 118: 1 + 2n(3 + 2j), no special shape
     F = finfields.GF(p)
     assert F.byte_length == 17
     a = [rng.randrange(p) for _ in range(200)]

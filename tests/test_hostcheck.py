@@ -300,9 +300,16 @@ def test_pm192_policy_and_arithmetic(hostcheck):
     """Every operation of the three-limb policy against Python integers: edge values crossed, random values,
     all raw 192-bit patterns for the reduction, Horner steps with 32-bit multipliers, dot products at the
     accumulator's declared bound (192 terms of (p-1)^2)."""
-    PM192 = 13
+    PM192, MONT192 = 13, 14
     rng = random.Random(192)
-    for p in _pm192_primes():
+    from mpyc_amd.finfields import find_prime_root, next_prime
+    # three-limb Montgomery policy: the "root of unity" primes of SecInt(l, n=N) (finfields.py:332-343; the 136-bit one
+    # is the field of demos/np_lpsolver.py -i5), a prime just above 2^128, one just below 2^192 that is not 2^192 - c
+    generic = [find_prime_root(136, n=118)[0], find_prime_root(160, n=5)[0], next_prime(2**128), next_prime(2**191 + 2**100),
+               next_prime(2**192 - 2**40)]
+    assert all(129 <= q.bit_length() <= 192 for q in generic)
+    for p in _pm192_primes() + generic:
+        want_kind = MONT192 if p in generic else PM192
         F = po.Field(p, False)
         assert elem_bytes(p, False) == 24
         k = p.bit_length()
@@ -313,7 +320,7 @@ def test_pm192_policy_and_arithmetic(hostcheck):
         b += [rng.randrange(p) for _ in range(300)]
         cc = [rng.randrange(p) for _ in range(len(a))]
         got, pk = run(hostcheck, F, HC_ADD, a, b)
-        assert pk == PM192 and got == [(x + y) % p for x, y in zip(a, b)], hex(p)
+        assert pk == want_kind and got == [(x + y) % p for x, y in zip(a, b)], hex(p)
         assert run(hostcheck, F, HC_SUB, a, b)[0] == [(x - y) % p for x, y in zip(a, b)], hex(p)
         assert run(hostcheck, F, HC_MUL, a, b)[0] == [(x * y) % p for x, y in zip(a, b)], hex(p)
         assert run(hostcheck, F, HC_NEG, a)[0] == [(-x) % p for x in a], hex(p)
@@ -329,13 +336,9 @@ def test_pm192_policy_and_arithmetic(hostcheck):
             flat = [v for r in rows for v in r]
             got, _ = run(hostcheck, F, HC_DOT, flat, lam=lam, k=kk, n=n)
             assert got == [sum(lam[j] * rows[j][i] for j in range(kk)) % p for i in range(n)], (hex(p), kk)
-    # what the policy does not cover: three-limb primes that are not 2^k - c with c < 2^31
-    from mpyc_amd.finfields import is_prime
-    q = 2**140 + 1
-    while not is_prime(q):
-        q += 2
-    rc = hostcheck.hc_run(0, limbs3(q), 3, HC_ADD, None, None, None, None, ctypes.c_size_t(0), ctypes.c_uint32(0), None, 0, None, None)
-    assert rc == 102                                                         # 100 + PB_ENOTSUP
+    # even moduli of three limbs are refused
+    rc = hostcheck.hc_run(0, limbs3(2**140 + 2), 3, HC_ADD, None, None, None, None, ctypes.c_size_t(0), ctypes.c_uint32(0), None, 0, None, None)
+    assert rc == 104                                                         # 100 + PB_EMODULUS
 
 
 def test_wide_primes_device_header_against_reference_vectors(hostcheck, golden_wide):

@@ -184,6 +184,6 @@ def test_py_aes128_fips197():
 def test_py_wide_primes(golden_wide):
     """the three-limb primes (129..192 bits; reference outputs in wide.json): the Python-integer oracle is the checker
     for them on the GPU (tests/test_gpu_pm192.py) -- the C oracle stops at 128 bits"""
-    assert sorted(golden_wide) == ['P129', 'P136', 'P160', 'P192']
+    assert sorted(golden_wide) == ['P129', 'P129G', 'P136', 'P136R', 'P160', 'P192']
     test_py_elementwise(golden_wide)
     test_py_sharing(golden_wide)
