@@ -65,7 +65,7 @@ extern "C" {
 #define FFGPU_RED_RECIPROCAL      2  /* arbitrary modulus: Barrett-type reciprocal    */
 #define FFGPU_RED_GF2_SWAR        3  /* GF(2^n), n<=8: packed shift-xor               */
 #define FFGPU_RED_GF2_WIDE        4  /* GF(2^n), n<=128: limb shift-xor               */
-#define FFGPU_RED_MONTGOMERY      5  /* arbitrary odd 65..128-bit p: two-limb REDC    */
+#define FFGPU_RED_MONTGOMERY      5  /* arbitrary odd 65..192-bit p: word-serial REDC */
 
 typedef struct ffgpu_ctx ffgpu_ctx;
 
@@ -76,9 +76,11 @@ const char* ffgpu_last_hip_error(void);          /* text of the last failing HIP
 int         ffgpu_device_count(int* count);
 
 /* ---- field context ---------------------------------------------------- */
-/* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p (nlimbs 1..2; 3 for the primes p = 2^k - c,
- * 129 <= k <= 192, c < 2^31 -- the l+32-bit default fields of SecInt(97..160), sectypes.py:673-676 --, which are
- * stored as three 64-bit limbs = 24 bytes per element; other primes above 128 bits: FFGPU_ENOTSUP).
+/* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p, nlimbs 1..3: primes of 129..192 bits are stored
+ * as three 64-bit limbs = 24 bytes per element (p = 2^k - c with c < 2^31 -- the l+32-bit default fields of
+ * SecInt(97..160), sectypes.py:673-676 -- reduce by folding, any other odd prime of that size -- e.g. the
+ * root-of-unity primes of SecInt(l, n=N), finfields.py:332-343 -- by Montgomery products); above 192 bits:
+ * FFGPU_ENOTSUP.
  * FFGPU_BINARY: bit pattern of the irreducible polynomial including its leading
  * term (degree n <= 128 needs up to 3 limbs).  Primality / irreducibility is the
  * caller's job (the reference checks it in pGF/xGF before any array exists).
