@@ -1543,15 +1543,20 @@ struct GF2W128 {
 // representative is x itself up to 127 S = 0x7f7f..7f and x - p above (not the balanced residue: for p close to
 // 2^64 the value p/2 is NOT representable, the carries would run out of the top digit).
 template <int L>
-FF_HD void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
+FF_HD uint64_t limb_digits_packed(uint64_t x, uint64_t p) {
+    // All L digits at once: with C = 0x80...80, u = v + C adds 128 to every byte and lets the carries run, so byte l
+    // of u is d_l + 128 and u ^ C holds the signed digits (sum_l (u_l - 128) 256^l = u - C = v; -C <= v <= top keeps
+    // u inside 64 bits).  Digit l = byte l of the result; for L = 4 the upper bytes are the sign extension.
     const uint64_t top = 0x7f7f7f7f7f7f7f7full >> (8 * (8 - L));
-    __int128 v = (x > top) ? (__int128)x - (__int128)p : (__int128)x;
+    const uint64_t c = 0x8080808080808080ull >> (8 * (8 - L));
+    const uint64_t v = (x > top) ? x - p : x;          // two's complement when negative
+    return (v + c) ^ c;
+}
+template <int L>
+FF_HD void limb_digits(uint64_t x, uint64_t p, int8_t (&d)[L]) {
+    const uint64_t u = limb_digits_packed<L>(x, p);
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int8_t dl = (int8_t)((int)(v & 0xff));
-        d[l] = dl;
-        v = (v >> 8) + (dl < 0 ? 1 : 0);
-    }
+    for (int l = 0; l < L; ++l) d[l] = (int8_t)(uint8_t)(u >> (8 * l));
 }
 
 // The same for two-limb values (primes of 65..128 bits): L = 12 (96-bit storage) or 16 digits.  x - p can be as

@@ -1728,11 +1728,28 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm(F f, const int8_t* __restri
 // the 16 lanes a ds_read_b128 phase serves read 256 contiguous bytes (conflict-free).  (A variant that also
 // double-buffers the FRAGMENT registers -- LDS reads of step s+1 issued before the MFMAs of step s -- measured the
 // same: the LDS latency is not what the loop waits for; profiles/r02_limb_gemm.md.)
-template <class F, int L>
+// BRAW: the right operand is the field matrix itself (row-major K x N, leading dimension ldb) instead of digit
+// planes: a thread fetches eight consecutive k of one column (the loads of a wave cover 512 contiguous bytes per
+// k), converts them to signed digits in registers (limb_digits_packed: three instructions per element), transposes
+// the 8 x 8 digit bytes with v_perm_b32 and writes eight 8-byte runs into the same LDS image.  For a few rows
+// against a big matrix (a batch of activations times a weight matrix: M <= 128) this removes the pass that writes and
+// re-reads the planes of B, which cost more than a third of the product (64 x 4096 x 4096: split 54-67 us, product 94).
+__device__ __forceinline__ void transpose4x4_bytes(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t (&o)[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+template <class F, int L, bool BRAW = false>
 __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Mp,
                                                           int Np, int Kp, int kb, int ke, int accumulate, int kslice,
-                                                          size_t zstride) {
+                                                          size_t zstride, const typename F::elem* __restrict__ Braw = nullptr,
+                                                          size_t ldb = 0, int K = 0, uint64_t pmod = 0) {
+    static_assert(!BRAW || (L == 8 && sizeof(typename F::elem) == 8), "raw right operand: 64-bit storage, eight digits");
     typedef typename F::word W;
     constexpr int ND = 2 * L - 1;
     constexpr int CHUNKS = L * 2 * 64;                 // 16-byte chunks of one operand tile per k-step
@@ -1754,21 +1771,54 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
 #pragma unroll
     for (int d = 0; d < ND; ++d) acc[d] = (ff_v16i){0};
     // chunk c of a tile: plane l = c / 128, k-half hh = (c / 64) % 2, row = c % 64  (== its LDS index)
-    ff_v4i ga[PER_THREAD], gb[PER_THREAD];
+    ff_v4i ga[PER_THREAD], gb[BRAW ? 1 : PER_THREAD];
+    uint64_t braw[BRAW ? 8 : 1];
+    const int bcol = threadIdx.x & 63, bkg = threadIdx.x >> 6;      // BRAW: this thread's column and group of eight k
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < PER_THREAD; ++u) {
             const int c = threadIdx.x + u * BLOCK;
             const int l = c >> 7, hh = (c >> 6) & 1, row = c & 63;
             ga[u] = *reinterpret_cast<const ff_v4i*>(Ap + limb_off<L>(l, bm0 + row, k0 + 16 * hh, Kp));
-            gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + limb_off<L>(l, bn0 + row, k0 + 16 * hh, Kp));
+            if constexpr (!BRAW) gb[u] = *reinterpret_cast<const ff_v4i*>(Bp + limb_off<L>(l, bn0 + row, k0 + 16 * hh, Kp));
+        }
+        if constexpr (BRAW) {
+            const int col = bn0 + bcol;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = k0 + bkg * 8 + i;
+                braw[i] = (kk < K && col < N) ? (uint64_t)Braw[(size_t)kk * ldb + col] : 0;
+            }
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < PER_THREAD; ++u) {
             sA[buf][threadIdx.x + u * BLOCK] = ga[u];
-            sB[buf][threadIdx.x + u * BLOCK] = gb[u];
+            if constexpr (!BRAW) sB[buf][threadIdx.x + u * BLOCK] = gb[u];
+        }
+        if constexpr (BRAW) {
+            uint32_t lo[8], hi[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint64_t d = limb_digits_packed<8>(braw[i], pmod);      // byte l = digit l of element k
+                lo[i] = (uint32_t)d;
+                hi[i] = (uint32_t)(d >> 32);
+            }
+            uint32_t w[4][4];                      // [digit quad: lo/k0-3, lo/k4-7, hi/k0-3, hi/k4-7][digit in the quad]
+            transpose4x4_bytes(lo[0], lo[1], lo[2], lo[3], w[0]);
+            transpose4x4_bytes(lo[4], lo[5], lo[6], lo[7], w[1]);
+            transpose4x4_bytes(hi[0], hi[1], hi[2], hi[3], w[2]);
+            transpose4x4_bytes(hi[4], hi[5], hi[6], hi[7], w[3]);
+            // digit plane l, k-half hh, column: 16-byte chunk ((l * 2 + hh) * 64 + col); this thread's eight k are its
+            // lower or upper eight bytes
+            uint64_t* sb8 = reinterpret_cast<uint64_t*>(&sB[buf][0]);
+            const int hh = bkg >> 1, half = bkg & 1;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const uint64_t run = (uint64_t)w[(l >> 2) * 2][l & 3] | ((uint64_t)w[(l >> 2) * 2 + 1][l & 3] << 32);
+                sb8[(((l * 2 + hh) * 64 + bcol) << 1) + half] = run;
+            }
         }
     };
     if (kb < ke) {
@@ -2460,6 +2510,14 @@ struct Launchers {
     // dwordx3 needs dword alignment only; three-limb elements go as three dwordx2
     enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : sizeof(E) == 24 ? 8 : 16 };
     static bool al(const void* p) { return ((uintptr_t)p & (PACK_ALIGN - 1)) == 0; }
+    static bool limb_braw() {                       // FFGPU_MM_BRAW=0: always go through digit planes of B (A/B measurements)
+        static int v = -1;
+        if (v < 0) {
+            const char* e = getenv("FFGPU_MM_BRAW");
+            v = e ? atoi(e) : 1;
+        }
+        return v != 0;
+    }
     static bool stride_ok(size_t stride) { return (stride * sizeof(E)) % PACK_ALIGN == 0; }
 
     template <int OP>
@@ -2897,7 +2955,24 @@ struct Launchers {
                 auto go = [&](auto lc_) {
                     constexpr int LL = decltype(lc_)::value;
                     hipLaunchKernelGGL((k_limb_split_a<F, LL>), dim3(ga), dim3(BLOCK), 0, st, (const E*)A, lda, pmod, Ap, M, K, Mp, Kp);
-                    hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
+                    // up to 128 rows: the product kernel converts B itself (BRAW), no digit planes of B
+                    constexpr bool CAN_RAW = LL == 8 && sizeof(E) == 8;
+                    const bool braw = CAN_RAW && gg.y <= 2 && use_mfma == 1 && limb_braw();
+                    if (!braw)
+                        hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
+                    auto product = [&](dim3 grid, E* out, size_t out_ld, int kb, int ke, int acc_, int kslice, size_t zs) {
+                        if constexpr (CAN_RAW) {
+                            if (braw) {
+                                hipLaunchKernelGGL((k_limb_gemm_lds<F, LL, true>), grid, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
+                                                   (const int8_t*)nullptr, out, out_ld, M, N, Mp, Np, Kp, kb, ke, acc_, kslice, zs,
+                                                   (const E*)B, ldb, K, pmod);
+                                return;
+                            }
+                        }
+                        hipLaunchKernelGGL((k_limb_gemm_lds<F, LL, false>), grid, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
+                                           (const int8_t*)Bp, out, out_ld, M, N, Mp, Np, Kp, kb, ke, acc_, kslice, zs,
+                                           (const E*)nullptr, (size_t)0, 0, (uint64_t)0);
+                    };
                     // few output tiles (a batch of 64..256 rows against a big matrix): split K over blockIdx.z into
                     // slabs behind the planes, summed by k_splitk_sum
                     const size_t tiles = (size_t)gg.x * gg.y;
@@ -2912,8 +2987,7 @@ struct Launchers {
                         ks = (Kp + kslice - 1) / kslice;
                         E* slabs = (E*)((char*)workspace + ((need + 255) / 256) * 256);
                         dim3 g3(gg.x, gg.y, ks);
-                        hipLaunchKernelGGL((k_limb_gemm_lds<F, LL>), g3, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
-                                           slabs, (size_t)N, M, N, Mp, Np, Kp, 0, Kp, 0, kslice, (size_t)M * N);
+                        product(g3, slabs, (size_t)N, 0, Kp, 0, kslice, (size_t)M * N);
                         hipLaunchKernelGGL((k_splitk_sum<F>), dim3((unsigned)(((size_t)M * N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, f,
                                            (const E*)slabs, ks, M, N, (E*)C, ldc);
                         return;
@@ -2924,8 +2998,7 @@ struct Launchers {
                             hipLaunchKernelGGL((k_limb_gemm<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap, (const int8_t*)Bp,
                                                (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0);
                         else
-                            hipLaunchKernelGGL((k_limb_gemm_lds<F, LL>), gg, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
-                                               (const int8_t*)Bp, (E*)C, ldc, M, N, Mp, Np, Kp, kb, ke, kb > 0 ? 1 : 0, 0, (size_t)0);
+                            product(gg, (E*)C, ldc, kb, ke, kb > 0 ? 1 : 0, 0, (size_t)0);
                     }
                 };
                 if (L == 4) go(std::integral_constant<int, 4>());

@@ -644,16 +644,17 @@ def test_matrix_core_product(eng, coracle):
         edge = sorted({v % modulus for v in (0, 1, 127, 128, 255, 256, T8 - 1, T8, T8 + 1, T8 + 2, modulus // 2, modulus // 2 + 1,
                                               modulus - 1, modulus - 2, modulus - 128, modulus - 129, 2**31, 2**63 % modulus,
                                               0x8080808080808080 % modulus, 0x80 << 24)})
-        M = K = N = 256
-        rng = random.Random(modulus % 1000)
-        a = [edge[(i * 7 + k_ * 3) % len(edge)] if (i + k_) % 3 else rng.randrange(modulus) for i in range(M) for k_ in range(K)]
-        b = [edge[(k_ * 5 + j) % len(edge)] if (j + k_) % 4 else rng.randrange(modulus) for k_ in range(K) for j in range(N)]
-        A, B = pack(a, eb), pack(b, eb)
-        got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
-        coracle.set_threads(coracle.max_threads())
-        want = coracle.matmul(cf, A, B, M, K, N)
-        coracle.set_threads(1)
-        assert (got == want).all(), hex(modulus)
+        # 256 rows: digit planes of both operands; 64 rows: the product kernel converts B itself (k_limb_gemm_lds BRAW)
+        for (M, K, N) in ((256, 256, 256), (64, 1024, 256)):
+            rng = random.Random(modulus % 1000)
+            a = [edge[(i * 7 + k_ * 3) % len(edge)] if (i + k_) % 3 else rng.randrange(modulus) for i in range(M) for k_ in range(K)]
+            b = [edge[(k_ * 5 + j) % len(edge)] if (j + k_) % 4 else rng.randrange(modulus) for k_ in range(K) for j in range(N)]
+            A, B = pack(a, eb), pack(b, eb)
+            got = ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy()
+            coracle.set_threads(coracle.max_threads())
+            want = coracle.matmul(cf, A, B, M, K, N)
+            coracle.set_threads(1)
+            assert (got == want).all(), (hex(modulus), M, K, N)
     # all-(p-1) operands: every limb product at its maximum
     ctx = ctx_for(eng, P64, False)
     M = K = N = 256
