@@ -60,6 +60,7 @@ def test_ctx_classification(L):
         (_ffi.PRIME, 2**97 - 141, 16, 1), (_ffi.PRIME, 19, 4, 2),
         (_ffi.PRIME, 2**31 - 1, 4, 2), (_ffi.PRIME, 6616326157076047771, 8, 2),
         (_ffi.PRIME, 258797994007609146293811961253269568351, 16, 5),
+        (_ffi.PRIME, 2**136 - 113, 24, 1), (_ffi.PRIME, 2**135 + 4823, 24, 5), (_ffi.PRIME, 2**192 - 237, 24, 1),
         (_ffi.BINARY, 0x11b, 1, 3), (_ffi.BINARY, 0b111, 1, 3), (_ffi.BINARY, (1 << 64) | 0x1b, 8, 4),
         (_ffi.BINARY, (1 << 128) | 0x87, 16, 4),
     ]
@@ -76,7 +77,8 @@ def test_bad_arguments(L):
     from mpyc_amd import _ffi
     assert mk(L, _ffi.PRIME, 0)[0] == _ffi.EMODULUS
     assert mk(L, _ffi.PRIME, 1)[0] == _ffi.EMODULUS
-    assert mk(L, _ffi.PRIME, 1 << 128)[0] == _ffi.ENOTSUP          # 129-bit "prime"
+    assert mk(L, _ffi.PRIME, 1 << 128)[0] == _ffi.EMODULUS         # even three-limb modulus
+    assert mk(L, _ffi.PRIME, (1 << 192) + 7, nl=4)[0] != 0          # above 192 bits
     assert mk(L, _ffi.PRIME, (1 << 127) + 2**40)[0] == _ffi.EMODULUS  # even two-limb modulus
     assert mk(L, 7, 19)[0] == _ffi.EINVAL
     assert mk(L, _ffi.BINARY, 1)[0] == _ffi.EMODULUS
