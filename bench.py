@@ -487,7 +487,7 @@ def main():
         # fused local product + share generation (c never written)
         ms = time_launches(f_fused, sets, reps)
         bpu = (2 + t + m) * eb
-        kern['mul_split_fused_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,T=1,fused mul,nt,lazy>',
+        kern['mul_split_fused_p61_m3t1'] = dict(roof(bpu * n, ms), kernel='k_split<PM64<false,true>,T=1,fused mul,nt>',
                                                 algorithmic_bytes_per_unit=bpu,
                                                 units_per_s=round(n / (ms * 1e-3), 1))
         # achievable-bandwidth yardstick: the library's streaming copy, 80 MB blocks rotating
@@ -895,15 +895,15 @@ def main():
                             if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
             with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                 pmc = json.load(fh)
-            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, true, false, false>',
+            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, false, false>',
                      'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
-                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, true, false, false>',
+                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, false, false>',
                      'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
                      'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
-                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, true, false, false>',
+                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, false, false>',
                      'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
                      'mul_p128': 'k_ew2<PM128<true>, 2, true>',
-                     'split_p128_m7t3': 'k_split<PM128<true>, 3, false, true, true, false, false>',
+                     'split_p128_m7t3': 'k_split<PM128<true>, 3, false, true, false, false>',
                      'recombine_p128_k7': 'k_recombine<PM128<true>, 7, true>',
                      'device_copy': 'k_copy16'}
             for q, kn in names.items():

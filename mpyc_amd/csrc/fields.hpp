@@ -135,56 +135,6 @@ struct PM64 {
         uint64_t wh = (uint64_t)(w >> k);
         return csub((ff_lo(w) & mask) + wh * (uint64_t)c);
     }
-    // Share generation as ONE lazily reduced dot product per share:
-    //   share = s + sum_j C_j * xp_j,   xp_j = x^(j+1) a public 32-bit integer.
-    // Terms are accumulated as a 64-bit low part + a high part and folded once.
-    // Valid when x^t < 2^32 and (t+1)*c < 2^32 (sacc_ok); otherwise the kernel
-    // uses the Horner form (muladd_small).
-    enum { HAS_SACC = 1 };
-    struct sacc {
-        uint64_t lo, hi;
-    };
-    FF_HD bool sacc_ok(int t, int m) const {
-        double pw = 1.0;
-        for (int j = 0; j < t; ++j) pw *= (double)m;
-        if (!(pw < 4294967296.0) || t > 65535) return false;
-        double tc = (double)(t + 1) * (double)c;
-        if (K64) return tc < 2147483648.0;          // hi*c < 2^63: one wrap, one csub
-        if (C1) return true;
-        // second fold must land below 2p: (t+1) c^2 2^32 < 2^(2k-1)
-        double lim = 1.0;
-        for (uint32_t i = 0; i < 2 * k - 33; ++i) lim *= 2.0;
-        return tc < 4294967296.0 && tc * (double)c < lim;
-    }
-    FF_HD void sacc_init(sacc& a, uint64_t sv) const {
-        a.lo = sv;
-        a.hi = 0;
-    }
-    FF_HD void sacc_mac(sacc& a, uint64_t cj, uint32_t xp) const {
-        uint64_t p0 = (uint64_t)(uint32_t)cj * xp;
-        uint64_t p1 = (uint64_t)(uint32_t)(cj >> 32) * xp + (p0 >> 32);
-        uint64_t tl = (p1 << 32) | (uint32_t)p0;
-        a.lo += tl;
-        a.hi += (p1 >> 32) + (a.lo < tl);
-    }
-    FF_HD uint64_t sacc_reduce(const sacc& a) const {
-        // T = hi*2^64 + lo, hi < (t+1)*2^32
-        if (K64) {
-            uint64_t u = a.hi * (uint64_t)c + a.lo;  // hi*c < 2^64 by sacc_ok
-            if (u < a.lo) u += c;
-            return csub(u);
-        }
-        uint64_t xh = (a.hi << (64 - k)) | (a.lo >> k);  // T >> k < (t+1)*2^32 + 1
-        uint64_t xl = a.lo & mask;
-        if (C1) {
-            uint64_t w = xl + xh;
-            return csub((w & mask) + (w >> k));
-        }
-        uint64_t w = xh * (uint64_t)c;  // < 2^64 by sacc_ok (+ slack from k >= 33)
-        ff_u128 ww = (ff_u128)w + xl;
-        uint64_t wh = (uint64_t)(ww >> k);
-        return csub((ff_lo(ww) & mask) + wh * (uint64_t)c);
-    }
     FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
         // a*b + c < p^2 + p < 2^(2k) for k<64; may wrap 128 bits only if k==64
         if (K64) return add(mul(a, b), cadd);
@@ -241,28 +191,6 @@ struct RC64 {
 
 
     // (u1:u0) mod d, requires u1 < d
-    // lazily reduced share generation (see PM64): T = hi*2^64 + lo < (t+1) * 2^32 * p
-    enum { HAS_SACC = 1 };
-    struct sacc {
-        uint64_t lo, hi;
-    };
-    FF_HD bool sacc_ok(int t, int m) const {
-        double pw = 1.0;
-        for (int j = 0; j < t; ++j) pw *= (double)m;
-        return t >= 2 && pw < 4294967296.0 && t < 65536;   // t = 1: one Horner step is cheaper (measured)
-    }
-    FF_HD void sacc_init(sacc& a, uint64_t sv) const {
-        a.lo = sv;
-        a.hi = 0;
-    }
-    FF_HD void sacc_mac(sacc& a, uint64_t cj, uint32_t xp) const {
-        uint64_t p0 = (uint64_t)(uint32_t)cj * xp;
-        uint64_t p1 = (uint64_t)(uint32_t)(cj >> 32) * xp + (p0 >> 32);
-        uint64_t tl = (p1 << 32) | (uint32_t)p0;
-        a.lo += tl;
-        a.hi += (p1 >> 32) + (a.lo < tl);
-    }
-    FF_HD uint64_t sacc_reduce(const sacc& a) const;   // defined after acc_reduce
     FF_HD uint64_t rem21(uint64_t u1, uint64_t u0) const {
         ff_u128 q = (ff_u128)v * u1 + ff_make128(u1, u0);
         uint64_t q1 = ff_hi(q) + 1;
@@ -315,13 +243,6 @@ struct RC64 {
         return rem21(r1, w0) >> s;
     }
 };
-FF_HD uint64_t RC64::sacc_reduce(const sacc& a) const {
-    acc t;
-    t.a0 = a.lo;
-    t.a1 = a.hi;
-    t.a2 = 0;
-    return acc_reduce(t);   // (T << s) has its top limb below d: T < (t+1) 2^32 p
-}
 
 // ---------------------------------------------------------------------------
 // RC32: arbitrary modulus 2 <= p < 2^32 stored as uint32 (half the HBM bytes of
@@ -342,28 +263,6 @@ struct RC32 {
     FF_HD uint32_t prep(uint32_t cst) const { return cst; }
 
 
-    // lazily reduced share generation: 64-bit terms C_j * x^(j+1) summed in the 96-bit accumulator
-    enum { HAS_SACC = 1 };
-    struct sacc {
-        uint64_t lo;
-        uint32_t hi;
-    };
-    FF_HD bool sacc_ok(int t, int m) const {
-        double pw = 1.0;
-        for (int j = 0; j < t; ++j) pw *= (double)m;
-        return t >= 2 && pw < 4294967296.0 && t < 200;     // carries stay below the accumulator's 2^8 headroom
-    }
-    FF_HD void sacc_init(sacc& a, uint32_t sv) const {
-        a.lo = sv;
-        a.hi = 0;
-    }
-    FF_HD void sacc_mac(sacc& a, uint32_t cj, uint32_t xp) const {
-        uint64_t pr = (uint64_t)cj * xp;
-        uint64_t nn = a.lo + pr;
-        a.hi += nn < pr;
-        a.lo = nn;
-    }
-    FF_HD uint32_t sacc_reduce(const sacc& a) const;   // defined after acc_reduce
     FF_HD uint32_t rem21(uint32_t u1, uint32_t u0) const {
         uint64_t q = (uint64_t)v * u1 + (((uint64_t)u1 << 32) | u0);
         uint32_t q1 = (uint32_t)(q >> 32) + 1;
@@ -418,12 +317,6 @@ struct RC32 {
         return rem21(r1, w0) >> s;
     }
 };
-FF_HD uint32_t RC32::sacc_reduce(const sacc& a) const {
-    acc t;
-    t.lo = a.lo;
-    t.hi = a.hi;
-    return acc_reduce(t);
-}
 
 // ---------------------------------------------------------------------------
 // PM128: prime p = 2^k - c, 65 <= k <= 128, c < 2^31, two 64-bit limbs
@@ -563,34 +456,6 @@ struct PM128 {
         return add(mul(a, b), cadd);
     }
 
-    // lazily reduced share generation (see PM64): T = a2*2^128 + (a1:a0)
-    enum { HAS_SACC = 1 };
-    struct sacc {
-        uint64_t a0, a1, a2;
-    };
-    FF_HD bool sacc_ok(int t, int m) const {
-        double pw = 1.0;
-        for (int j = 0; j < t; ++j) pw *= (double)m;
-        return pw < 4294967296.0 && t < 65536;
-    }
-    FF_HD void sacc_init(sacc& a, const u128e& sv) const {
-        a.a0 = sv.lo;
-        a.a1 = sv.hi;
-        a.a2 = 0;
-    }
-    FF_HD void sacc_mac(sacc& a, const u128e& cj, uint32_t xp) const {
-        ff_u128 l = (ff_u128)cj.lo * xp;                 // 96 bits
-        ff_u128 h = (ff_u128)cj.hi * xp + ff_hi(l);      // 96 bits
-        ff_u128 t0 = (ff_u128)a.a0 + ff_lo(l);
-        a.a0 = ff_lo(t0);
-        ff_u128 t1 = (ff_u128)a.a1 + ff_lo(h) + ff_hi(t0);
-        a.a1 = ff_lo(t1);
-        a.a2 += ff_hi(h) + ff_hi(t1);
-    }
-    FF_HD u128e sacc_reduce(const sacc& a) const {
-        // T < (t+1) * 2^(k+32) < 2^(k+64)
-        return E(fold3<true>(a.a2, ff_make128(a.a1, a.a0)));
-    }
 
     FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = 0; }
     FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& xe) const {
@@ -845,14 +710,6 @@ struct PM192 {
     }
     FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
 
-    enum { HAS_SACC = 0 };
-    struct sacc {
-        u192e v;
-    };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, const u192e& sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, const u192e&, uint32_t) const {}
-    FF_HD u192e sacc_reduce(const sacc& a) const { return a.v; }
 
     FF_HD void acc_zero(acc& s) const {
 #pragma unroll
@@ -961,33 +818,6 @@ struct MONT128 {
         return redc(x);
     }
     FF_HD u128e prep(const u128e& cst) const { return E(montmul(U(cst), ff_make128(r2_hi, r2_lo))); }
-    // lazily reduced share generation: T = s + sum_j C_j * x^(j+1) < (t+1) 2^32 p as three limbs; one REDC
-    // (T / R) and one Montgomery product by R^2 bring it back: 1.5 Montgomery products per SHARE instead
-    // of two per Horner STEP.
-    enum { HAS_SACC = 1 };
-    struct sacc {
-        uint64_t a0, a1, a2;
-    };
-    FF_HD bool sacc_ok(int t, int m) const {
-        double pw = 1.0;
-        for (int j = 0; j < t; ++j) pw *= (double)m;
-        return pw < 4294967296.0 && t < 65536;
-    }
-    FF_HD void sacc_init(sacc& a, const u128e& sv) const {
-        a.a0 = sv.lo;
-        a.a1 = sv.hi;
-        a.a2 = 0;
-    }
-    FF_HD void sacc_mac(sacc& a, const u128e& cj, uint32_t xp) const {
-        ff_u128 l = (ff_u128)cj.lo * xp;
-        ff_u128 h = (ff_u128)cj.hi * xp + ff_hi(l);
-        ff_u128 t0 = (ff_u128)a.a0 + ff_lo(l);
-        a.a0 = ff_lo(t0);
-        ff_u128 t1 = (ff_u128)a.a1 + ff_lo(h) + ff_hi(t0);
-        a.a1 = ff_lo(t1);
-        a.a2 += ff_hi(h) + ff_hi(t1);
-    }
-    FF_HD u128e sacc_reduce(const sacc& a) const;   // defined after montmul
     FF_HD u128e mul(const u128e& a, const u128e& b) const {
         ff_u128 t = montmul(U(a), U(b));                   // a*b/R
         return E(montmul(t, ff_make128(r2_hi, r2_lo)));     // * R^2 / R = a*b
@@ -1025,10 +855,6 @@ struct MONT128 {
         return r;
     }
 };
-FF_HD u128e MONT128::sacc_reduce(const sacc& a) const {
-    const uint64_t x[4] = {a.a0, a.a1, a.a2, 0};
-    return E(montmul(redc(x), ff_make128(r2_hi, r2_lo)));
-}
 
 // ---------------------------------------------------------------------------
 // MONT192: arbitrary odd primes of 129..192 bits (e.g. the "root of unity" primes 1 + 2n(3 + 2j) that
@@ -1137,14 +963,6 @@ struct MONT192 {
     }
     FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
 
-    enum { HAS_SACC = 0 };
-    struct sacc {
-        u192e v;
-    };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, const u192e& sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, const u192e&, uint32_t) const {}
-    FF_HD u192e sacc_reduce(const sacc& a) const { return a.v; }
 
     FF_HD void acc_zero(acc& s) const { s.v.lo = s.v.mid = s.v.hi = 0; }
     FF_HD void acc_mac(acc& s, const u192e& lamR, const u192e& xe) const { s.v = add(s.v, montmul(lamR, xe)); }
@@ -1174,14 +992,6 @@ struct GF2P8 {
     FF_HD uint32_t prep(uint32_t cst) const { return cst; }
 
 
-    enum { HAS_SACC = 0 };
-    struct sacc {
-        uint32_t v;
-    };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, uint32_t sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, uint32_t, uint32_t) const {}
-    FF_HD uint32_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint32_t add(uint32_t a, uint32_t b) const { return a ^ b; }
     FF_HD uint32_t sub(uint32_t a, uint32_t b) const { return a ^ b; }
     FF_HD uint32_t neg(uint32_t a) const { return a; }
@@ -1323,14 +1133,6 @@ struct GF2W64 {
     // constants are used as-is (no domain conversion)
     FF_HD uint64_t prep(uint64_t cst) const { return cst; }
 
-    enum { HAS_SACC = 0 };
-    struct sacc {
-        uint64_t v;
-    };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, uint64_t sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, uint64_t, uint32_t) const {}
-    FF_HD uint64_t sacc_reduce(const sacc& a) const { return a.v; }
     FF_HD uint64_t add(uint64_t a, uint64_t b) const { return a ^ b; }
     FF_HD uint64_t sub(uint64_t a, uint64_t b) const { return a ^ b; }
     FF_HD uint64_t neg(uint64_t a) const { return a; }
@@ -1402,14 +1204,6 @@ struct GF2W128 {
     // constants are used as-is (no domain conversion)
     FF_HD u128e prep(u128e cst) const { return cst; }
 
-    enum { HAS_SACC = 0 };
-    struct sacc {
-        u128e v;
-    };
-    FF_HD bool sacc_ok(int, int) const { return false; }
-    FF_HD void sacc_init(sacc& a, u128e sv) const { a.v = sv; }
-    FF_HD void sacc_mac(sacc&, u128e, uint32_t) const {}
-    FF_HD u128e sacc_reduce(const sacc& a) const { return a.v; }
     static FF_HD ff_u128 U(const u128e& a) { return ff_make128(a.hi, a.lo); }
     static FF_HD u128e E(ff_u128 x) {
         u128e r;
@@ -1536,6 +1330,44 @@ struct GF2W128 {
         return r;
     }
 };
+
+// ---- share generation by forward differences (prime fields) -------------------------------------------------
+// The parties' points are the consecutive integers 1..m (thresha.py:55-61), so f(x) = s + c_1 x + ... + c_T x^T is
+// evaluated as f(x) = f(x-1) + D_1, D_1 += D_2, ..., D_{T-1} += D_T: T modular additions per share and no
+// multiplication.  D_j = j! sum_i S(i, j) c_i at x = 0 with the Stirling numbers of the second kind (an identity
+// in any commutative ring, so the residues are Horner's):
+//   T = 1: D1 = c1             T = 2: D1 = c1 + c2, D2 = 2 c2          T = 3: D1 = c1 + c2 + c3, D2 = 2 c2 + 6 c3, D3 = 6 c3
+//   T = 4: D1 = c1 + c2 + c3 + c4, D2 = 2 c2 + 6 c3 + 14 c4, D3 = 6 c3 + 36 c4, D4 = 24 c4
+template <class F, int T>
+FF_HD void share_diff_init(const F& f, const typename F::word (&c)[T], typename F::word (&dd)[T]) {
+    typedef typename F::word W;
+    static_assert(T >= 1 && T <= 4, "difference table written out for 1 <= T <= 4");
+    if constexpr (T == 1) {
+        dd[0] = c[0];
+    } else if constexpr (T == 2) {
+        dd[1] = f.add(c[1], c[1]);
+        dd[0] = f.add(c[0], c[1]);
+    } else if constexpr (T == 3) {
+        const W c3x6 = f.muladd_small(c[2], 5u, c[2]);
+        dd[2] = c3x6;
+        dd[1] = f.add(f.add(c[1], c[1]), c3x6);
+        dd[0] = f.add(f.add(c[0], c[1]), c[2]);
+    } else {
+        const W c3x6 = f.muladd_small(c[2], 5u, c[2]);
+        dd[3] = f.muladd_small(c[3], 23u, c[3]);
+        dd[2] = f.muladd_small(c[3], 36u, c3x6);
+        dd[1] = f.muladd_small(c[3], 14u, f.add(f.add(c[1], c[1]), c3x6));
+        dd[0] = f.add(f.add(c[0], c[1]), f.add(c[2], c[3]));
+    }
+}
+// y = f(x - 1)  ->  f(x); the table moves on to x
+template <class F, int T>
+FF_HD typename F::word share_diff_next(const F& f, const typename F::word& y, typename F::word (&dd)[T]) {
+    const typename F::word r = f.add(y, dd[0]);
+#pragma unroll
+    for (int j = 0; j + 1 < T; ++j) dd[j] = f.add(dd[j], dd[j + 1]);
+    return r;
+}
 
 // ---- operand digits for the matrix-core dense product (kernels.hpp k_limb_gemm) ------------------------------
 // L signed base-256 digits d_l in [-128, 127] of a representative of x modulo p.  L such digits represent exactly

@@ -423,7 +423,7 @@ __device__ __forceinline__ void rng_load_state(RngArgs& ra) {
 }
 enum { RNG_RELEASE_MAX_GRID = 512 };
 
-template <class F, int T, bool FUSE_MUL, bool NT, bool LAZY, bool RNG, bool REC = false>
+template <class F, int T, bool FUSE_MUL, bool NT, bool RNG, bool REC = false>
 __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __restrict__ a,
                                                   const typename F::elem* __restrict__ b,
                                                   const typename F::elem* __restrict__ coef, size_t cstride,
@@ -514,41 +514,21 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             }
         }
         if constexpr (!F::BINARY && T >= 1) {
-            // The parties' points are the consecutive integers 1..m (thresha.py:55-61), so the polynomial is
-            // evaluated by FORWARD DIFFERENCES: f(x) = f(x-1) + D1, D1 += D2, ... -- T modular additions per
-            // share and no multiplication (Horner: T multiply-adds by the point, ~4x the instructions; this is
-            // what the kernels with the in-register ChaCha draw are bound by).  D_j = j! sum_i S(i, j) c_i with
-            // the Stirling numbers of the second kind: the same residues as Horner's, in any commutative ring.
-            W dd[TT][P::N];
+            // prime fields: forward differences over the consecutive party points (fields.hpp share_diff_*): T modular
+            // additions per share and no multiplication (Horner: T multiply-adds by the point, ~4x the instructions --
+            // what the kernels with the in-register ChaCha draw are bound by)
+            W dd[P::N][TT];
 #pragma unroll
             for (int q = 0; q < P::N; ++q) {
-                if constexpr (T == 1) {
-                    dd[0][q] = c[0][q];
-                } else if constexpr (T == 2) {
-                    dd[1][q] = f.add(c[1][q], c[1][q]);
-                    dd[0][q] = f.add(c[0][q], c[1][q]);
-                } else if constexpr (T == 3) {
-                    const W c3x6 = f.muladd_small(c[2][q], 5u, c[2][q]);
-                    dd[2][q] = c3x6;
-                    dd[1][q] = f.add(f.add(c[1][q], c[1][q]), c3x6);
-                    dd[0][q] = f.add(f.add(c[0][q], c[1][q]), c[2][q]);
-                } else {
-                    static_assert(T <= 4, "difference table written out for T <= 4");
-                    const W c3x6 = f.muladd_small(c[2][q], 5u, c[2][q]);
-                    dd[3][q] = f.muladd_small(c[3][q], 23u, c[3][q]);
-                    dd[2][q] = f.muladd_small(c[3][q], 36u, c3x6);
-                    dd[1][q] = f.muladd_small(c[3][q], 14u, f.add(f.add(c[1][q], c[1][q]), c3x6));
-                    dd[0][q] = f.add(f.add(c[0][q], c[1][q]), f.add(c[2][q], c[3][q]));
-                }
+                W cq[TT];
+#pragma unroll
+                for (int j = 0; j < T; ++j) cq[j] = c[j][q];
+                share_diff_init<F, TT>(f, cq, dd[q]);
             }
             P y = s;
             for (int party = 1; party <= m; ++party) {
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) {
-                    y.w[q] = f.add(y.w[q], dd[0][q]);
-#pragma unroll
-                    for (int j = 0; j + 1 < T; ++j) dd[j][q] = f.add(dd[j][q], dd[j + 1][q]);
-                }
+                for (int q = 0; q < P::N; ++q) y.w[q] = share_diff_next<F, TT>(f, y.w[q], dd[q]);
                 stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
         } else
@@ -556,20 +536,6 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             P y;
             if constexpr (T == 0) {
                 y = s;
-            } else if constexpr (LAZY) {
-                // public powers x^(j+1): wave-uniform, scalar unit
-                uint32_t xp[TT];
-                xp[0] = (uint32_t)party;
-#pragma unroll
-                for (int j = 1; j < T; ++j) xp[j] = xp[j - 1] * (uint32_t)party;
-#pragma unroll
-                for (int q = 0; q < P::N; ++q) {
-                    typename F::sacc acc;
-                    f.sacc_init(acc, s.w[q]);
-#pragma unroll
-                    for (int j = 0; j < T; ++j) f.sacc_mac(acc, c[j][q], xp[j]);
-                    y.w[q] = f.sacc_reduce(acc);
-                }
             } else {
 #pragma unroll
                 for (int q = 0; q < P::N; ++q) {
@@ -2598,24 +2564,11 @@ struct Launchers {
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
                          size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st,
                          const RngArgs& ra, const GateSrc<F>& gs, unsigned gy = 1) {
-        bool lazy = false;
-        if constexpr (F::HAS_SACC != 0 && T > 0) lazy = f.sacc_ok(T, m);
-        if constexpr (F::HAS_SACC != 0 && T > 0) {
-            if (lazy) {
-                if (nt || RNG)
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, true, true, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a,
-                                       b, coef, cstride, m, out, ostride, nvec, n, ra, gs);
-                else
-                    hipLaunchKernelGGL((k_split<F, T, FUSE, false, true, false>), dim3(grid), dim3(BLOCK), 0, st, f,
-                                       a, b, coef, cstride, m, out, ostride, nvec, n, ra, gs);
-                return;
-            }
-        }
         if (nt || RNG)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true, false, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a, b,
+            hipLaunchKernelGGL((k_split<F, T, FUSE, true, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a, b,
                                coef, cstride, m, out, ostride, nvec, n, ra, gs);
         else
-            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
+            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
                                coef, cstride, m, out, ostride, nvec, n, ra, gs);
     }
     template <bool FUSE, bool RNG>

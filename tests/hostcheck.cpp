@@ -5,12 +5,13 @@
 // product package; libffgpu.so has no CPU execution path.
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 #include "../mpyc_amd/csrc/policy_build.hpp"
 #include "../mpyc_amd/csrc/rng.hpp"
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SACC = 8, HC_SACC_OK = 9 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -88,24 +89,30 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 r = f.acc_reduce(s);
                 break;
             }
-            case HC_SACC: {
-                // a: secrets (n), c: k rows of n coefficients, x: party; share = s + sum_j C_j x^(j+1)
-                typename F::sacc s;
-                f.sacc_init(s, ldw<F>(a, i));
-                uint32_t xp = x;
-                for (int j = 0; j < k; ++j) {
-                    f.sacc_mac(s, ldw<F>(c, (size_t)j * n + i), xp);
-                    xp *= x;
-                }
-                r = f.sacc_reduce(s);
-                break;
-            }
-            case HC_SACC_OK: {
+            case HC_SHARE: {
+                // a: secrets (n), c: k rows of n coefficients, x: number of parties m; out: the share of party x, reached
+                // by x forward-difference steps from f(0) = s (fields.hpp share_diff_*; the kernels' share loop)
+                typename F::word cc[4], dd[4];
+                for (int j = 0; j < k && j < 4; ++j) cc[j] = ldw<F>(c, (size_t)j * n + i);
                 r = ldw<F>(a, i);
-                if (i == 0) *((unsigned char*)out + 0) = 0;
-                stw<F>(out, i, r);
-                if (i == 0) out[0] = (unsigned char)(F::HAS_SACC != 0 && f.sacc_ok(k, (int)x));
-                continue;
+                if constexpr (!F::BINARY) {
+                    auto walk = [&](auto tc) {
+                        constexpr int T = decltype(tc)::value;
+                        typename F::word c_[T], d_[T];
+                        for (int j = 0; j < T; ++j) c_[j] = cc[j];
+                        share_diff_init<F, T>(f, c_, d_);
+                        for (uint32_t pt = 1; pt <= x; ++pt) r = share_diff_next<F, T>(f, r, d_);
+                    };
+                    switch (k) {
+                        case 1: walk(std::integral_constant<int, 1>()); break;
+                        case 2: walk(std::integral_constant<int, 2>()); break;
+                        case 3: walk(std::integral_constant<int, 3>()); break;
+                        case 4: walk(std::integral_constant<int, 4>()); break;
+                        default: return 1;
+                    }
+                }
+                (void)dd;
+                break;
             }
             default: return 1;
         }

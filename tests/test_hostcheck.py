@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SACC, HC_SACC_OK = range(10)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE = range(9)
 
 
 def limbs3(x):
@@ -138,32 +138,30 @@ def test_dot(hostcheck, golden_fields):
             assert got == want, (name, k)
 
 
-def test_lazy_share_accumulator(hostcheck, golden_fields):
-    """share = s + sum_j C_j x^(j+1) accumulated unreduced and folded once (PM64/PM128 policies),
-    for every (t, m) the policy itself declares safe (sacc_ok), at extreme operands."""
+def test_share_evaluation_by_forward_differences(hostcheck, golden_fields):
+    """share_x = s + sum_j C_j x^(j+1) reached by x steps of the forward-difference recurrence from f(0) = s
+    (fields.hpp share_diff_init / share_diff_next -- the share loop of k_split), for every prime policy, t = 1..4,
+    at extreme operands and up to 300 parties."""
     checked = 0
     for name, case in golden_fields.items():
         F = field_of(case)
         if F.binary:
             continue
         q = F.order
-        for (t, m) in [(1, 3), (2, 5), (3, 7), (4, 9), (3, 255), (4, 255), (2, 65535), (1, 2**31)]:
-            if m >= q:
-                continue
-            ok, _ = run(hostcheck, F, HC_SACC_OK, [0], x=m, k=t)
-            if not ok[0] & 1:
-                continue
-            n = 40
-            ev = edge_values(F)
+        n = 40
+        ev = edge_values(F)
+        for t in (1, 2, 3, 4):
             s = ([q - 1] * 4 + ev + rand_values(F, n, 3))[:n]
             rows = [([q - 1] * 4 + rand_values(F, n, 10 + j))[:n] for j in range(t)]
             flat = [v for row in rows for v in row]
-            for party in {1, 2, m // 2 + 1, m}:
-                got, _ = run(hostcheck, F, HC_SACC, s, None, flat, x=party, k=t, n=n)
+            for party in (1, 2, 3, 7, 11, 300):
+                if party >= q:
+                    continue
+                got, _ = run(hostcheck, F, HC_SHARE, s, None, flat, x=party, k=t, n=n)
                 want = [(s[h] + sum(rows[j][h] * party**(j + 1) for j in range(t))) % q for h in range(n)]
-                assert got == want, (name, t, m, party)
+                assert got == want, (name, t, party)
                 checked += 1
-    assert checked > 50
+    assert checked > 300
 
 
 def test_dense_binary_moduli_take_the_bitserial_path(hostcheck):
@@ -232,15 +230,12 @@ def test_pseudo_mersenne_with_the_largest_admissible_c(hostcheck):
                 lam = [p - 1 if j % 2 == 0 else (p - c) % p for j in range(kk)]
                 got, _ = run(hostcheck, F, HC_DOT, [v for row in rows for v in row], lam=lam, k=kk, n=n)
                 assert got == [sum(lam[j] * rows[j][h] for j in range(kk)) % p for h in range(n)], (k, hex(p), kk)
-            # lazily reduced share generation wherever the policy declares it safe
-            for (t, m) in [(1, 3), (3, 7), (4, 255), (2, 65535)]:
-                ok, _ = run(hostcheck, F, HC_SACC_OK, [0], x=m, k=t)
-                if not ok[0] & 1:
-                    continue
+            # share evaluation (forward differences) at the largest operands
+            for (t, m) in [(1, 3), (3, 7), (4, 255)]:
                 n = 12
                 s = [p - 1] * n
                 rows = [[p - 1] * n for _ in range(t)]
-                got, _ = run(hostcheck, F, HC_SACC, s, None, [v for row in rows for v in row], x=m, k=t, n=n)
+                got, _ = run(hostcheck, F, HC_SHARE, s, None, [v for row in rows for v in row], x=m, k=t, n=n)
                 assert got == [(s[h] + sum(rows[j][h] * m**(j + 1) for j in range(t))) % p for h in range(n)], (k, hex(p), t, m)
 
 
@@ -349,3 +344,12 @@ def test_wide_primes_device_header_against_reference_vectors(hostcheck, golden_w
     test_random_mul(hostcheck, golden_wide)
     test_muladd_small(hostcheck, golden_wide)
     test_dot(hostcheck, golden_wide)
+    for name, case in golden_wide.items():                  # share evaluation over the three-limb policies
+        F = field_of(case)
+        q = F.order
+        for t in (1, 2, 3, 4):
+            s_ = [q - 1, 0, 1] + rand_values(F, 9, t)
+            rows = [[q - 1] + rand_values(F, 11, 20 + j) for j in range(t)]
+            for party in (1, 5, 40):
+                got, _ = run(hostcheck, F, HC_SHARE, s_, None, [v for r in rows for v in r], x=party, k=t, n=12)
+                assert got == [(s_[h] + sum(rows[j][h] * party**(j + 1) for j in range(t))) % q for h in range(12)], (name, t, party)

@@ -58,7 +58,7 @@ if 'stats' in what and os.path.exists(f'{G}/prof_{tag}/{tag}_kernel_stats.csv'):
         fh.write(f'# {tag} -- `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (MI355X)\n\n')
         fh.write(f'Raw file: profiles/{tag}_kernel_stats.csv (rocprofv3 `*_kernel_stats.csv`). Library kernels only below; the rest are '
                  'torch RNG/fill kernels that create the synthetic inputs outside the timed region.\n')
-        fh.write('Template arguments of k_split: <field policy, T, fused local product, non-temporal, lazy single reduction, '
+        fh.write('Template arguments of k_split: <field policy, T, fused local product, non-temporal, '
                  'in-kernel CSPRNG, factors given as recombinations (chain gate)>.\n\n')
         table(fh, rows)
         fh.write('\n## bench.py line of the same build (separate, unprofiled run)\n\n```\n')

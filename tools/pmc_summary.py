@@ -18,16 +18,16 @@ alg = {  # algorithmic bytes per launch at n = 10^7 64-bit elements
     'k_copy16': (80e6, 80e6),
     'k_ew2<PM64<false, true>, 2, true>': (160e6, 80e6),
     'k_ew2<PM64<true, false>, 2, true>': (160e6, 80e6),
-    'k_split<PM64<false, true>, 1, false, true, true, false, false>': (160e6, 240e6),
-    'k_split<PM64<false, true>, 1, true, true, true, false, false>': (240e6, 240e6),
-    'k_split<PM64<true, false>, 3, true, true, true, false, false>': (400e6, 560e6),
+    'k_split<PM64<false, true>, 1, false, true, false, false>': (160e6, 240e6),
+    'k_split<PM64<false, true>, 1, true, true, false, false>': (240e6, 240e6),
+    'k_split<PM64<true, false>, 3, true, true, false, false>': (400e6, 560e6),
     'k_recombine<PM64<false, true>, 3, true>': (240e6, 80e6),
-    'k_split<PM64<true, false>, 3, false, true, true, false, false>': (320e6, 560e6),
+    'k_split<PM64<true, false>, 3, false, true, false, false>': (320e6, 560e6),
     'k_recombine<PM64<true, false>, 7, true>': (560e6, 80e6),
     'k_ew2<PM96, 2, true>': (240e6, 120e6),      # 12-byte elements, one per lane (dwordx3)
     'k_ew2<PM96, 0, true>': (240e6, 120e6),
     'k_ew2<PM128<true>, 2, true>': (320e6, 160e6),            # 16-byte elements (configs[3])
-    'k_split<PM128<true>, 3, false, true, true, false, false>': (640e6, 1120e6),
+    'k_split<PM128<true>, 3, false, true, false, false>': (640e6, 1120e6),
     'k_recombine<PM128<true>, 7, true>': (1120e6, 160e6),
 }
 out, lines = {}, ['| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | read MB (2x FETCH) | write MB | traffic MB | algorithmic MB | traffic/alg |',
