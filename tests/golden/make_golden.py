@@ -254,17 +254,17 @@ def main():
 
 
 
-def prss_cases():
+def prss_cases(fields=None, fname='prss.json'):
     """PRSS golden vectors (thresha.py:135-266): PRF outputs and every party's shares."""
     from itertools import combinations
     out = {}
     key0 = int('0x00112233445566778899aabbccddeeff', 16).to_bytes(16, byteorder='little')   # tests/test_thresha.py:43
     uci = 'test uci'.encode()
     n = 9
-    for name, F in (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P128', finfields.GF(P128)),
-                    ('P80', finfields.GF(P80)), ('GF19', finfields.GF(19)), ('P63G', finfields.GF(P63G)),
-                    ('P128G', finfields.GF(P128G)), ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))),
-                    ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
+    for name, F in fields or (('P61', finfields.GF(P61)), ('P64', finfields.GF(P64)), ('P128', finfields.GF(P128)),
+                              ('P80', finfields.GF(P80)), ('GF19', finfields.GF(19)), ('P63G', finfields.GF(P63G)),
+                              ('P128G', finfields.GF(P128G)), ('GF2_8', finfields.GF(GF2X(BINARIES['GF2_8']))),
+                              ('GF2_128', finfields.GF(GF2X(BINARIES['GF2_128'])))):
         case = {'modulus': hx(int(F.modulus)), 'binary': not isinstance(F.modulus, int), 'uci': uci.hex(), 'n': n,
                 'settings': []}
         for (m, t) in ((1, 0), (3, 1), (5, 2), (4, 1)):
@@ -293,9 +293,9 @@ def prss_cases():
                 setting['secret'] = hxl(int(F(int(v)).value) for v in sec)
                 case['settings'].append(setting)
         out[name] = case
-    with open(os.path.join(OUT, 'prss.json'), 'w') as fh:
+    with open(os.path.join(OUT, fname), 'w') as fh:
         json.dump(out, fh, separators=(',', ':'))
-    print('wrote prss.json', os.path.getsize(os.path.join(OUT, 'prss.json')))
+    print('wrote', fname, os.path.getsize(os.path.join(OUT, fname)))
 
 
 def matmul_cases():
@@ -535,6 +535,8 @@ def wide_cases():
     with open(os.path.join(OUT, 'wide.json'), 'w') as fh:
         json.dump(cases, fh, separators=(',', ':'))
     print('wrote wide.json:', {k: v['modulus'] for k, v in cases.items()})
+    # PRSS over three-limb fields (np_random_bits draws these in np_lpsolver -i5: runtime.py:4247-4250)
+    prss_cases([(nm, finfields.GF(int(cases[nm]['modulus'], 16))) for nm in ('P136', 'P136R', 'P192')], 'prss_wide.json')
 
 
 if __name__ == '__main__':

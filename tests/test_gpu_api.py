@@ -274,8 +274,10 @@ def test_prss_matches_reference(api):
     (every party, several (m, t), bound = field order and a power of two); tests/test_thresha.py:56-86."""
     import json, os
     finfields, gfpx, thresha = api
-    with open(os.path.join(os.path.dirname(__file__), 'golden', 'prss.json')) as fh:
-        gold = json.load(fh)
+    gold = {}
+    for fname in ('prss.json', 'prss_wide.json'):            # prss_wide.json: three-limb prime fields
+        with open(os.path.join(os.path.dirname(__file__), 'golden', fname)) as fh:
+            gold.update(json.load(fh))
     for name, case in gold.items():
         mod = int(case['modulus'], 16)
         F = finfields.GF(gfpx.BinaryPolynomial(mod)) if case['binary'] else finfields.GF(mod)

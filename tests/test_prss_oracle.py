@@ -5,12 +5,15 @@ import os
 from oracle import pyoracle as po
 from fieldutil import unhex
 
-GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'prss.json')
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 
 def load():
-    with open(GOLDEN) as fh:
-        return json.load(fh)
+    out = {}
+    for fname in ('prss.json', 'prss_wide.json'):             # prss_wide.json: three-limb prime fields
+        with open(os.path.join(GOLDEN, fname)) as fh:
+            out.update(json.load(fh))
+    return out
 
 
 def settings(case):
