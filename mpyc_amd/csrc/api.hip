@@ -913,7 +913,7 @@ int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t 
 int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
                        const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream) {
     ARGCHK(ctx);
-    ARGCHK(ks >= 1 && d >= 1 && l >= 1 && l <= 64 && mask_bits >= 0 && mask_bits <= 128);
+    ARGCHK(ks >= 1 && d >= 1 && l >= 1 && l <= 64 && mask_bits >= 0 && mask_bits <= 192);
     if (n == 0) return FFGPU_OK;
     ARGCHK(host_streams && host_weights && out);
     for (int s = 0; s < ks; ++s) ARGCHK(host_streams[s]);

@@ -1048,8 +1048,15 @@ __device__ __forceinline__ typename F::word prss_draw(const F& f, const PrssArgs
     }
     // wide value mod order, limb by limb from the top: r = r * 2^(8 LB) + limb
     W R;
-    if constexpr (LB == 24) { R.lo = pa.r0; R.mid = pa.r1; R.hi = 0; }
-    else if constexpr (LB == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
+    if constexpr (LB == 24) {
+        // 2^192 mod p has up to three limbs for a prime of no special shape: (2^96 mod p)^2, by the policy's own means
+        W t96;
+        t96.lo = 0;
+        t96.mid = 1ull << 32;
+        t96.hi = 0;
+        t96 = f.reduce_raw(t96);
+        R = f.mul(t96, t96);
+    } else if constexpr (LB == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
     int top = (l - 1) / LB * LB;
     W r = f.reduce_raw(limb(top, l - top));
     for (int off = top - LB; off >= 0; off -= LB) r = f.add(f.mul(r, R), f.reduce_raw(limb(off, LB)));

@@ -131,6 +131,21 @@ def test_pm192_mirror_api_wire_and_full_size_round_trip(root_n):
     assert ints(M @ Minv) == [int(i == j) for i in range(6) for j in range(6)]
     w = A.to_wire()
     assert w == b''.join(v.to_bytes(17, 'little') for v in a) and ints(F.array.from_wire(w)) == a
+    # second-tier operations and array plumbing of the mirror over a three-limb field
+    sq = A * A
+    r = sq.sqrt()
+    assert ints(r * r) == ints(sq) and bool(sq.is_sqr().all())
+    assert ints(A ** 5) == [pow(x, 5, p) for x in a] and ints(A ** -1 * A) == [1] * 200
+    assert ints(A << 3) == [(x << 3) % p for x in a] and ints((A << 3) >> 3) == a
+    assert ints(np.cumsum(A[:17])) == [sum(a[:i + 1]) % p for i in range(17)]
+    A2 = A.reshape(10, 20)
+    assert ints(np.sum(A2, axis=0)) == [sum(a[i * 20 + j] for i in range(10)) % p for j in range(20)]
+    assert ints(A2 @ B.reshape(20, 10)) == [sum(a[i * 20 + k] * b[k * 10 + j] for k in range(20)) % p
+                                           for i in range(10) for j in range(10)]
+    C = np.concatenate((A[:3], B[-2:]))
+    C[1] = F(7)
+    assert ints(C) == [a[0], 7, a[2], b[-2], b[-1]] and bool((A == A.copy()).all()) and not bool((A == B).all())
+    assert ints(-A + A) == [0] * 200 and ints(A / A) == [1] * 200 if all(a) else True
     sh = thresha.np_random_split(F, A * B, 2, 5)                         # fused product + device CSPRNG
     y = thresha.np_recombine(F, [(x, sh[x - 1]) for x in (5, 1, 3)])
     assert ints(y) == [(x * y_) % p for x, y_ in zip(a, b)]
