@@ -531,21 +531,23 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                 for (int q = 0; q < P::N; ++q) y.w[q] = share_diff_next<F, TT>(f, y.w[q], dd[q]);
                 stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
-        } else
-        for (int party = 1; party <= m; ++party) {
-            P y;
-            if constexpr (T == 0) {
-                y = s;
-            } else {
+        } else {
+            // GF(2^n) (the points are field elements, not integers) and T = 0: Horner by the point
+            for (int party = 1; party <= m; ++party) {
+                P y;
+                if constexpr (T == 0) {
+                    y = s;
+                } else {
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) {
-                    W acc = c[T - 1][q];
+                    for (int q = 0; q < P::N; ++q) {
+                        W acc = c[T - 1][q];
 #pragma unroll
-                    for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
-                    y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
+                        for (int j = T - 2; j >= 0; --j) acc = f.muladd_small(acc, (uint32_t)party, c[j][q]);
+                        y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
+                    }
                 }
+                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
-            stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
         }
     };
     if (RNG && T > 0 && G > 1 && ra.spread) {
