@@ -27,6 +27,7 @@ done <<L
 ${DEMOS:-~pseudoinverse.py
 np_id3gini.py
 np_lpsolver.py
+np_lpsolver.py -i5
 ~np_lpsolverfxp.py
 np_bnnmnist.py -d0 -o 1234
 np_aes.py -1
