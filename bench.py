@@ -114,10 +114,14 @@ def roof_mfma(field_macs, digits, ms):
 
 
 def cpu_baseline(n_full, t, m, lam, seed=20260925):
-    """C port of the reference path (oracle/fforacle.c) on this host: the same 3-stage pass
-    over the same workload shape.  Also times the reference-style NumPy object-array path
-    (oracle/nporacle.py) on a smaller sample.  Checker/baseline only -- never the product."""
-    from oracle import coracle, nporacle
+    """The reference's own CPU path on this host (kind "reference": mpyc's FiniteFieldArray.__mul__,
+    thresha.np_random_split with live secrets.randbelow draws, thresha.np_recombine -- oracle/refbaseline.py -- on 1
+    core and as one process per core over equal slices), when an mpyc checkout is importable (the staged copy
+    _refstage/ on the GPU box, /root/reference in the build container).  The C port of the same pass
+    (oracle/fforacle.c, OpenMP) is timed beside it on the full workload and reported as `port_value` -- a much harder
+    baseline than the reference; it is `value` only when no reference checkout is present (kind "port").
+    Checker/baseline only -- never the product."""
+    from oracle import coracle, refbaseline
     rng = np.random.default_rng(seed)
     cores = coracle.max_threads()
     n = n_full
@@ -142,22 +146,124 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
             best = dt if best is None else min(best, dt)
         res[label] = 3 * n / best
     coracle.set_threads(1)
-    # reference-style object arrays (what mpyc.finfields / thresha actually execute), 1 core
-    ns = 200_000
-    ao, bo = a[:ns].astype(object), b[:ns].astype(object)
-    co = coef[:, :ns].astype(object)
-    t0 = time.perf_counter()
-    c_ = nporacle.mul(P61, ao, bo)
-    sh_ = nporacle.split(P61, c_, co, t, m)
-    y_ = nporacle.recombine(P61, [sh_[j] for j in range(2 * t + 1)], lam)
-    dt = time.perf_counter() - t0
-    assert [int(v) for v in y_[:100]] == [int(v) for v in y[:100]]
-    return {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'kind': 'port',
-            'sample': f'full workload: n={n} P61 elements x (modmul + split m={m},t={t} + recombine k={2*t+1}), '
-                      f'oracle/fforacle.c with OpenMP, best of 2',
-            'value_1core': round(res['1core'], 1),
-            'reference_style_numpy_object_1core': round(3 * ns / dt, 1),
-            'reference_style_sample': f'n={ns} of the same pass with NumPy dtype=object arrays (oracle/nporacle.py)'}
+    port_sample = (f'full workload: n={n} P61 elements x (modmul + split m={m},t={t} + recombine k={2*t+1}), '
+                   f'oracle/fforacle.c with OpenMP ({cores} threads), best of 2')
+    out = {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'kind': 'port', 'sample': port_sample,
+           'value_1core': round(res['1core'], 1)}
+    if refbaseline.available([os.path.join(ROOT, '_refstage'), '/root/reference']):
+        procs = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        n_one, n_each = 2_000_000, 400_000
+        r = refbaseline.measure(P61, t, m, n_one, n_each, procs, seed)
+        allc = r.get('all_cores') or {'field_ops_per_s': r['one_core']['field_ops_per_s'], 'n_total': n_one, 'wall_s': 0.0}
+        out = {'value': round(allc['field_ops_per_s'], 1), 'unit': 'field-ops/s', 'cores': procs, 'kind': 'reference',
+               'sample': f'lschoe/mpyc itself (FiniteFieldArray.__mul__ + thresha.np_random_split m={m},t={t} with live '
+                         f'secrets.randbelow + thresha.np_recombine k={2*t+1}) over GF(2^61-1): {procs} processes x '
+                         f'{n_each} elements = {allc["n_total"]} elements in {allc["wall_s"]:.2f} s wall; 1 core: '
+                         f'{n_one} elements',
+               'value_1core': round(r['one_core']['field_ops_per_s'], 1),
+               'reference_1core_stages': {k_: round(v_, 1) for k_, v_ in r['one_core'].items() if k_.endswith('_per_s')},
+               'port_value': round(res['allcores'], 1), 'port_value_1core': round(res['1core'], 1), 'port_cores': cores,
+               'port_sample': port_sample}
+    return out
+
+
+def api_leg(n_full):
+    """The path THROUGH the reference's public API: tests/api_program.py -- an ordinary MPyC
+    program, `mpc.output(a * b)` on SecFld(2^61-1) arrays, i.e. Runtime.np_multiply -> _reshare -> output
+    (runtime.py:1096-1141, 603-689, 513-600) -- run as party processes under mpyc_amd.install(), and on the unmodified
+    reference beside it (host cores).  Needs an importable mpyc (the staged copy _refstage/ on the GPU box).
+
+    Per configuration: elements/s = n * multiplications / median wall time of one repetition at party 0 (inputs
+    already shared; a repetition ends with the opened result on the device and a device synchronisation), and
+    gpu_busy_frac = summed GPU time of all libffgpu calls of party 0 (one event pair per call, ffgpu_busy_ms) / wall
+    time of the timed repetitions.  m = 1 is the runtime's own overhead + the kernels; m = 3 adds the reference's
+    pickle + asyncio TCP transport between three local party processes (out of scope for the engine, SURVEY 8e:
+    "party networking stays on the host") which then dominates: see `note`."""
+    ref_root = next((r_ for r_ in (os.path.join(ROOT, '_refstage'), '/root/reference')
+                     if os.path.isdir(os.path.join(r_, 'mpyc'))), None)
+    if ref_root is None:
+        return {'skipped': 'no importable mpyc checkout (stage one with tools/stage_reference.sh)'}
+    import statistics
+    import subprocess
+    prog = os.path.join(ROOT, 'tests', 'api_program.py')
+
+    def run(mode, n, parties, reps, warmup, chain=1, timeout=900):
+        env = dict(os.environ)
+        env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
+        for k_ in ('MPYC_GPU', 'API_SEED', 'API_DIGEST', 'API_CPROFILE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k_, None)
+        env.update(API_MODE=mode, API_N=str(n), API_REPS=str(reps), API_WARMUP=str(warmup), API_CHAIN=str(chain))
+        cmd = [sys.executable, prog, '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return {'error': f'timeout after {timeout} s'}
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith('API_RESULT ')), None)
+        if r.returncode != 0 or line is None:
+            return {'error': (r.stdout + r.stderr)[-400:]}
+        d = json.loads(line[len('API_RESULT '):])
+        med = statistics.median(d['times_s'])
+        out = {'n': n, 'parties': parties, 't': d['t'], 'multiplications_per_rep': chain, 'reps': reps,
+               'ms_per_rep': round(med * 1e3, 4), 'elements_per_s': round(n * chain / med, 1),
+               'input_sharing_s': round(d['input_s'], 3), 'process_wall_s': round(time.perf_counter() - t0, 2)}
+        if d.get('gpu_busy_ms') is not None:
+            out['gpu_busy_ms_per_rep'] = round(d['gpu_busy_ms'] / reps, 4)
+            out['gpu_busy_frac'] = round(d['gpu_busy_ms'] * 1e-3 / sum(d['times_s']), 4)
+            out['libffgpu_calls_per_rep'] = d['gpu_calls'] / reps
+        return out
+
+    res = {'workload': 'mpc.output(a * b) on SecFld(GF(2^61-1)) arrays through the unmodified mpyc runtime under '
+                       'mpyc_amd.install() (tests/api_program.py); reference = the same program without install()',
+           'reference_root': os.path.basename(ref_root)}
+    res['m1_1e7'] = run('gpu', n_full, 1, 20, 3)
+    res['m1_1e7_chain8'] = run('gpu', n_full, 1, 10, 2, chain=8)
+    res['m1_1e8'] = run('gpu', 10 * n_full, 1, 5, 2)
+    res['m3_1e7'] = run('gpu', n_full, 3, 3, 1)
+    res['m3_1e6'] = run('gpu', n_full // 10, 3, 5, 1)
+    res['reference_m1_1e6'] = run('ref', n_full // 10, 1, 2, 0)
+    res['reference_m3_1e6'] = run('ref', n_full // 10, 3, 1, 0)
+    head = res['m1_1e7']
+    if 'elements_per_s' in head:
+        res['elements_per_s'] = head['elements_per_s']
+        res['gpu_busy_frac'] = head.get('gpu_busy_frac')
+        res['gpu_busy_frac_1e8'] = res['m1_1e8'].get('gpu_busy_frac')
+        ref = res['reference_m1_1e6']
+        if 'elements_per_s' in ref:
+            res['vs_reference_m1'] = round(head['elements_per_s'] / ref['elements_per_s'], 1)
+        if 'elements_per_s' in res['m3_1e6'] and 'elements_per_s' in res['reference_m3_1e6']:
+            res['vs_reference_m3_1e6'] = round(res['m3_1e6']['elements_per_s'] / res['reference_m3_1e6']['elements_per_s'], 1)
+    res['note'] = ('m=1: one repetition = np_multiply + output coroutines of the reference runtime (host, ~0.1 ms) around two '
+                   'kernels (product, recombination); the GPU-busy share grows with n (1e8: kernels dominate) and with the number '
+                   'of multiplications in flight (chain8: launches overlap the host). m=3: every gate moves 2 x n x 8 B out of and '
+                   'into each party through pickle + asyncio TCP of the reference (asyncoro.py:54-106), ~0.8 s per gate at n=1e7 '
+                   'against ~0.4 ms of kernels -- the engine is idle; see profiles/r03_api_path.md')
+    return res
+
+
+def oracle_sample_check(modulus, a, b, coef, shares, y, t, m, lam, seed=7, count=16384):
+    """In-run parity guard against the C ORACLE (oracle/fforacle.c; checker only, outside every timed region): for the
+    first and last 4096 elements and `count` random positions, shares == split(a*b; coef) row by row and
+    y == recombine(2t+1 rows) == a*b, all computed by the oracle from the inputs at those positions."""
+    from oracle import coracle
+    n = a.n
+    g = np.random.default_rng(seed)
+    idx = np.unique(np.concatenate([np.arange(min(4096, n)), np.arange(max(0, n - 4096), n),
+                                    g.integers(0, n, size=count)])).astype(np.int64)
+    tidx = torch.from_numpy(idx).to(a.t.device)
+
+    def take(d):
+        return np.ascontiguousarray(d.t.index_select(0, tidx).cpu().numpy()).view(np.uint64)
+    cf = coracle.CField(modulus)
+    A, B = take(a), take(b)
+    C = np.stack([take(coef.row(j)) for j in range(t)])
+    prod = cf.ew(coracle.MUL, A, B)
+    sh = cf.split(prod, C, t, m)
+    rec = cf.recombine([sh[j] for j in range(2 * t + 1)], lam)
+    ok = bool((rec == prod).all()) and bool((take(y) == rec).all())
+    for i in range(m):
+        ok = ok and bool((take(shares.row(i)) == sh[i]).all())
+    return ok
 
 
 def u128_rows(rows, n, device, gen):
@@ -240,8 +346,9 @@ def multi_gpu_leg(dist, rank, world, local_rank, backend, n, steps, warmup, lagr
         s_['rec']()
     ms = timed(gate)
     torch.cuda.synchronize()
-    if not torch.equal(sets[0]['y'].t, ctx.mul(sets[0]['a'], sets[0]['b']).t):
-        raise SystemExit('bench parity check failed: P128 gate does not open to a*b')
+    s0_ = sets[(it[0] - 1) % len(sets)]
+    if not oracle_sample_check(P128, s0_['a'], s0_['b'], s0_['coef'], s0_['shares'], s0_['y'], t, m, lam):
+        raise SystemExit('bench parity check failed: P128 gate differs from the oracle on the sampled positions')
     bpu = (2 + t + m) * eb + (k + 1) * eb
     res['gate_sharded'] = {'ms_per_step': round(ms, 5), 'gates_per_s': round(n * world / (ms * 1e-3), 1),
                            'algorithmic_bytes_per_gate': bpu, 'GBps_per_gpu': round(bpu * n / (ms * 1e-3) / 1e9, 1),
@@ -292,6 +399,20 @@ def multi_gpu_leg(dist, rank, world, local_rank, backend, n, steps, warmup, lagr
         'rank0_bytes_sent': sent, 'rank0_bytes_received': rcvd,
         'rank0_exchange_GBps': round((sent + rcvd) / (ms_x * 1e-3) / 1e9, 1) if world > 1 else 0.0,
         'collective': 'batched isend/irecv of column slices (exchange_party_major)'}
+    # the same step with the exchange PIPELINED against the recombination: 4 column chunks, transfers of chunk c+1 in
+    # flight while the kernel of chunk c runs (multigpu.recombine_party_major(chunks=4))
+    y.t.zero_()
+
+    def a2a_pipelined():
+        multigpu.recombine_party_major(ctx, local, row_ids, lam, ntot, template=template, chunks=4, out=y, recv=recv)
+    ms_pipe = timed(a2a_pipelined)
+    torch.cuda.synchronize()
+    if not torch.equal(y.t, y_want.t):
+        raise SystemExit('bench parity check failed: party-major recombination (pipelined all-to-all)')
+    res['party_major_all_to_all_pipelined'] = {
+        'ms_per_step': round(ms_pipe, 5), 'chunks': 4, 'secrets_per_s': round(ntot / (ms_pipe * 1e-3), 1),
+        'vs_sequential': round(ms_step / ms_pipe, 3),
+        'collective': 'batched isend/irecv per column chunk, overlapped with k_recombine of the previous chunk'}
     del recv, got
 
     pg = multigpu.PartyMajorGather(k, ntot, template)
@@ -327,6 +448,7 @@ def main():
     ap.add_argument('--n', type=int, default=int(os.environ.get('FFGPU_BENCH_N', 10_000_000)), help='elements per GPU')
     ap.add_argument('--sets', type=int, default=4, help='rotating buffer sets')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-api-leg', action='store_true', help='skip the API-level section (party processes under install())')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-multi-gpu-leg', action='store_true', help='skip the configs[3] / party-major section')
     ap.add_argument('--layout', choices=('element', 'party-major'), default='element',
@@ -336,9 +458,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # invoked as plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU
+        # (rendezvous on 127.0.0.1; the container hostname may not resolve)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
     # validation hooks (not used by the driver): run the N>1 control flow on a 1-GPU box
@@ -409,10 +541,8 @@ def main():
     torch.cuda.synchronize()
     s0 = sets[(args.warmup - 1) % len(sets)] if args.warmup else None
     if s0 is not None:
-        f_mul(s0)
-        torch.cuda.synchronize()
-        if not torch.equal(s0.y.t, s0.c.t):
-            raise SystemExit('bench parity check failed: recombine(split(a*b)) != a*b')
+        if not oracle_sample_check(P61, s0.a, s0.b, s0.coef, s0.shares, s0.y, t, m, lam):
+            raise SystemExit('bench parity check failed: the step differs from the oracle on the sampled positions')
 
     barrier()
     t0 = time.perf_counter()
@@ -440,6 +570,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_unfused = float(tt.item())
 
+    devinfo = f'cuda:{local_rank} ({torch.cuda.get_device_name(local_rank)})'
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {'rank': rank, 'device': devinfo})
+    else:
+        gathered = [{'rank': 0, 'device': devinfo}]
     ops_total = 3.0 * n * world * args.steps
     value = ops_total / elapsed
     out = {
@@ -453,6 +589,9 @@ def main():
                                'modmul is fused into the share-generation kernel (product never written to HBM)',
                    'n_per_gpu': n, 'prime': '2^61-1', 'm': m, 't': t, 'k': k, 'field_ops_per_step': 3 * n,
                    'buffer_sets': args.sets, 'parallelism': f'element-sharded x{world}, no collective'},
+        'distributed': {'backend': (backend if dist is not None else None), 'world_size': world,
+                        'collective_library': 'RCCL (torch.distributed nccl backend)' if dist is not None and backend == 'nccl' else None,
+                        'ranks': gathered},
     }
 
     out['unfused'] = {'value': round(ops_total / elapsed_unfused, 1), 'unit': 'field-ops/s',
@@ -922,6 +1061,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
+    if rank == 0 and world == 1 and not args.no_api_leg and not args.no_extras:
+        torch.cuda.empty_cache()
+        try:
+            out['api'] = api_leg(n)
+        except Exception as exc:          # noqa: BLE001 -- report, keep the main result
+            out['api'] = {'error': f'{type(exc).__name__}: {exc}'}
 
     # configs[3] on all N ranks: element-sharded P128 gate and the party-major exchange (the one collective).
     # It runs LAST and under a watchdog: whatever happens in the collectives (a rank failing, a transport that

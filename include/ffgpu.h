@@ -20,8 +20,9 @@
  *         elem_bytes == 8   prime p < 2^64, GF(2^n) n<=64   uint64 [n]
  *         elem_bytes == 12  prime p = 2^k - c, 65 <= k <= 96, c < 2^31   3 x uint32 (12-byte LE integer)
  *         elem_bytes == 16  other primes p < 2^128, GF(2^n) n<=128 {lo,hi} uint64 pairs
+ *         elem_bytes == 24  primes of 129..192 bits            3 x uint64 (24-byte LE integer, 8-byte aligned)
  *     This is exactly the byte layout of field.to_bytes() (finfields.py:91-102)
- *     for byte_length in {1,4,8,16}.
+ *     for byte_length in {1,4,8,12,16,24} (shorter byte_lengths are zero-padded to the storage width).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *     Calls are asynchronous on that stream; nothing synchronises unless the
  *     name says so.
@@ -56,7 +57,7 @@ extern "C" {
 #define FFGPU_ENOMEM      5
 
 /* field kinds */
-#define FFGPU_PRIME   1   /* GF(p), p prime < 2^128       (finfields.py:347-363 pGF)  */
+#define FFGPU_PRIME   1   /* GF(p), p prime < 2^192       (finfields.py:347-363 pGF)  */
 #define FFGPU_BINARY  2   /* GF(2^n), 1 <= n <= 128       (finfields.py:508-525 xGF,
                              gfpx.py:848-1121 BinaryPolynomial)                       */
 
@@ -93,6 +94,10 @@ int ffgpu_ctx_destroy(ffgpu_ctx* ctx);
  * (FFGPU_EINVAL if timing is off or nothing has been launched).  Off by default: no events, no cost.   */
 int ffgpu_ctx_set_timing(ffgpu_ctx* ctx, int enable);
 int ffgpu_last_kernel_ms(ffgpu_ctx* ctx, float* ms);
+/* enable == 2: ACCUMULATE -- every compute call keeps its own event pair; ffgpu_busy_ms waits for the calls issued so
+ * far and returns the summed GPU time of all calls since the last reset (and their number): the "GPU busy" numerator
+ * of an API-level measurement (bench.py `api`).  Calls on one stream do not overlap, so the sum is busy time.        */
+int ffgpu_busy_ms(ffgpu_ctx* ctx, double* ms, unsigned long long* calls, int reset);
 int ffgpu_ctx_elem_bytes(const ffgpu_ctx* ctx);   /* 1, 4, 8, 12, 16 or 24       */
 /* Host SCALARS (constants, Lagrange coefficients, matrix entries, PRSS weights: every `const uint64_t* host_...`
  * argument that is documented as "canonical 2-limb scalars") occupy ffgpu_ctx_scalar_limbs(ctx) little-endian
@@ -213,7 +218,9 @@ int ffgpu_gate_rng(ffgpu_ctx* ctx, const void* const* host_rows_a, const uint64_
  * y * batch_stride_a (B: y * batch_stride_b) from the given row pointers and writes its m share rows at
  * shares + y * batch_stride_out (+ i * share_stride for party i+1); its coefficients come from the call's
  * generator stream with y added to bits 8..15 of nonce word 1 (nbatch <= 255), so the gates draw independent
- * randomness (dev_state / nonce / defer_advance: see ffgpu_rng_state_advance below).  This is what the 2t+1 re-sharing parties of one `_reshare` (runtime.py:658-666) do when a whole
+ * randomness (dev_state / nonce / defer_advance: see ffgpu_rng_state_advance below).  Bits 40..47 of `nonce` are
+ * therefore RESERVED for the batch row on the host-key path: nbatch > 1 requires nonce < 2^40 (FFGPU_EINVAL
+ * otherwise), so that (key, nonce, row) never aliases (key, nonce', row') under a reused key.  This is what the 2t+1 re-sharing parties of one `_reshare` (runtime.py:658-666) do when a whole
  * computation is held on one GPU: with the sub-shares stored [recipient][sender][n] the senders of the next gate
  * are batch_stride = (2t+1)*n apart and a layer of the np_aes S-box chain (runtime.py:1356-1367) is one launch
  * instead of 2t+1.  nbatch = 1 is ffgpu_gate_rng.                                                              */

@@ -37,6 +37,7 @@ _SIGS = {
     'ffgpu_ctx_destroy': [_vp],
     'ffgpu_ctx_set_timing': [_vp, _int],
     'ffgpu_last_kernel_ms': [_vp, ctypes.POINTER(ctypes.c_float)],
+    'ffgpu_busy_ms': [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), _int],
     'ffgpu_ctx_elem_bytes': [_vp],
     'ffgpu_ctx_reduction': [_vp],
     'ffgpu_ctx_scalar_limbs': [_vp],

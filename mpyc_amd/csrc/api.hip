@@ -81,7 +81,25 @@ struct ffgpu_ctx {
     // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
     int timing, timed;
     hipEvent_t ev0, ev1;
+    // timing mode 2 (ffgpu_busy_ms): one event pair per compute call, harvested into acc_ms
+    enum { ACC_MAX = 256 };
+    hipEvent_t acc_ev[2 * ACC_MAX];
+    int acc_made, acc_n;
+    double acc_ms;
+    unsigned long long acc_calls;
 };
+
+// sum the elapsed time of the recorded event pairs of accumulate mode into acc_ms (waits for the last one)
+static void acc_harvest(ffgpu_ctx* c) {
+    if (c->acc_n == 0) return;
+    (void)hipEventSynchronize(c->acc_ev[2 * (c->acc_n - 1) + 1]);
+    for (int i = 0; i < c->acc_n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->acc_ev[2 * i], c->acc_ev[2 * i + 1]) == hipSuccess) c->acc_ms += ms;
+    }
+    c->acc_calls += (unsigned long long)c->acc_n;
+    c->acc_n = 0;
+}
 
 static thread_local char g_hip_err[256] = "";
 
@@ -143,11 +161,30 @@ struct DeviceGuard {
 struct LaunchTimer {
     ffgpu_ctx* c;
     hipStream_t st;
-    LaunchTimer(ffgpu_ctx* ctx, hipStream_t s) : c(ctx && ctx->timing ? ctx : nullptr), st(s) {
-        if (c) (void)hipEventRecord(c->ev0, st);
+    int slot;
+    LaunchTimer(ffgpu_ctx* ctx, hipStream_t s) : c(ctx && ctx->timing ? ctx : nullptr), st(s), slot(-1) {
+        if (!c) return;
+        if (c->timing == 2) {
+            if (c->acc_n == ffgpu_ctx::ACC_MAX) acc_harvest(c);
+            if (c->acc_n == c->acc_made) {
+                if (hipEventCreate(&c->acc_ev[2 * c->acc_made]) != hipSuccess ||
+                    hipEventCreate(&c->acc_ev[2 * c->acc_made + 1]) != hipSuccess) {
+                    c = nullptr;
+                    return;
+                }
+                ++c->acc_made;
+            }
+            slot = c->acc_n++;
+            (void)hipEventRecord(c->acc_ev[2 * slot], st);
+        } else {
+            (void)hipEventRecord(c->ev0, st);
+        }
     }
     ~LaunchTimer() {
-        if (c) {
+        if (!c) return;
+        if (slot >= 0) {
+            (void)hipEventRecord(c->acc_ev[2 * slot + 1], st);
+        } else {
             (void)hipEventRecord(c->ev1, st);
             c->timed = 1;
         }
@@ -295,6 +332,10 @@ int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
         DeviceGuard g(ctx->device);
         (void)hipFree(ctx->gf8_tables_dev);
     }
+    if (ctx && ctx->acc_made) {
+        DeviceGuard g(ctx->device);
+        for (int i = 0; i < 2 * ctx->acc_made; ++i) (void)hipEventDestroy(ctx->acc_ev[i]);
+    }
     if (ctx && ctx->ev0) {
         DeviceGuard g(ctx->device);
         (void)hipEventDestroy(ctx->ev0);
@@ -310,8 +351,24 @@ int ffgpu_ctx_set_timing(ffgpu_ctx* ctx, int enable) {
         HIPCHK(hipEventCreate(&ctx->ev0));
         HIPCHK(hipEventCreate(&ctx->ev1));
     }
-    ctx->timing = enable ? 1 : 0;
+    if (ctx->timing == 2 && enable != 2) {
+        DeviceGuard g(ctx->device);
+        acc_harvest(ctx);
+    }
+    ctx->timing = enable == 2 ? 2 : (enable ? 1 : 0);
     ctx->timed = 0;
+    return FFGPU_OK;
+}
+int ffgpu_busy_ms(ffgpu_ctx* ctx, double* ms, unsigned long long* calls, int reset) {
+    if (!ctx) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    acc_harvest(ctx);
+    if (ms) *ms = ctx->acc_ms;
+    if (calls) *calls = ctx->acc_calls;
+    if (reset) {
+        ctx->acc_ms = 0.0;
+        ctx->acc_calls = 0;
+    }
     return FFGPU_OK;
 }
 int ffgpu_last_kernel_ms(ffgpu_ctx* ctx, float* ms) {
@@ -707,6 +764,9 @@ int ffgpu_gate_rng_batch(ffgpu_ctx* ctx, const void* const* host_rows_a, const u
     ARGCHK(ctx);
     ARGCHK(nbatch >= 1 && nbatch <= 255);
     ARGCHK(!dev_state || nonce <= 0xffffffffull);
+    // host-key path: the batch row goes into bits 40..47 of the 64-bit nonce (bits 8..15 of nonce word 1); a caller
+    // nonce that reaches those bits would alias another row's generator stream under a reused key
+    ARGCHK(dev_state || nbatch == 1 || nonce < (1ull << 40));
     ARGCHK(m >= 1 && t >= 1 && t < m && ka >= 1 && kb >= 0);
     if (t > 3 || ka > 7 || kb > 7) return FFGPU_ENOTSUP;
     ARGCHK(host_rows_a && host_lambda_a && (kb == 0 || (host_rows_b && host_lambda_b)));

@@ -801,9 +801,17 @@ class FieldContext:
                    'sbox')
         return out
 
-    def set_timing(self, enable: bool = True):
-        """Record GPU events around every compute call (off by default)."""
-        _ffi.check(self._L.ffgpu_ctx_set_timing(self._h, 1 if enable else 0), 'set_timing')
+    def set_timing(self, enable: bool = True, accumulate: bool = False):
+        """Record GPU events around every compute call (off by default).  accumulate: keep one event pair per call
+        so that busy_ms() can return the summed GPU time of all calls (ffgpu_busy_ms)."""
+        _ffi.check(self._L.ffgpu_ctx_set_timing(self._h, (2 if accumulate else 1) if enable else 0), 'set_timing')
+
+    def busy_ms(self, reset: bool = True):
+        """(summed GPU ms, number of compute calls) since the last reset; waits for the calls issued so far.  Needs
+        set_timing(True, accumulate=True)."""
+        ms, calls = ctypes.c_double(), ctypes.c_ulonglong()
+        _ffi.check(self._L.ffgpu_busy_ms(self._h, ctypes.byref(ms), ctypes.byref(calls), int(reset)), 'busy_ms')
+        return float(ms.value), int(calls.value)
 
     def last_kernel_ms(self) -> float:
         """GPU time of the most recent compute call (waits for it); needs set_timing(True)."""

@@ -409,7 +409,7 @@ def _fops(field) -> _FieldOps:
     ops = _fops_cache.get(field)
     if ops is None:
         ops = _fops_cache[field] = _FieldOps(field)
-        _field_registry[(ops.binary, ops.modulus)] = field
+        _field_registry[_field_key(field, ops)] = field
     return ops
 
 
@@ -621,19 +621,21 @@ for _n in ('neg', 'pos', 'abs', 'invert', 'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'g
 del _n
 
 
-_field_registry = {}      # (binary, modulus) -> field class: where unpickled share rows find their array type
+_field_registry = {}      # _field_key -> field class: where unpickled share rows find their array type
 
 
-def _register_field(field):
-    ops = _fops(field)
-    _field_registry[(ops.binary, ops.modulus)] = field
+def _field_key(field, ops):
+    """What identifies a field CLASS on the wire.  mpyc caches prime fields per (p, n, w) (finfields.py:347-363): GF(p)
+    and GF((p, n, w)) with a root of unity are different classes over the same modulus, and an array of one is not an
+    array of the other (np_recombine / field.array raise on the mix), so nth / root are part of the key."""
+    return (ops.binary, ops.modulus, getattr(field, 'nth', None), getattr(field, 'root', None))
 
 
-def _array_from_wire(binary, modulus, shape, data):
+def _array_from_wire(key, shape, data):
     """Unpickle hook: rebuild a device array from field.to_bytes-format limb bytes (see FieldArray.__reduce__)."""
-    field = _field_registry.get((binary, modulus))
+    field = _field_registry.get(tuple(key))
     if field is None:
-        raise TypeError(f'no field with modulus {modulus:#x} has been created in this process')
+        raise TypeError(f'no field with modulus {key[1]:#x} (nth, root = {key[2:]}) has been created in this process')
     return field.array.from_wire(data, shape)
 
 
@@ -1668,8 +1670,8 @@ class FieldArray:
         """pickle.dumps(row) -- how the runtime marshals arrays (runtime.py:484,571,655) -- ships the
         field.to_bytes-format limb bytes from the pinned staging buffer instead of a graph of PyLongs; the receiving
         party rebuilds a device array (no Python integers on either side)."""
-        ops = _fops(type(self).field)
-        return _array_from_wire, (ops.binary, ops.modulus, self._shape, self.to_wire())
+        F = type(self).field
+        return _array_from_wire, (_field_key(F, _fops(F)), self._shape, self.to_wire())
 
     # ---- wire format (finfields.py:91-102) straight from device limbs ------------------------------
     def to_wire(self) -> bytes:
@@ -2096,7 +2098,7 @@ def _np_scan(a, axis, mul: bool, include_initial=False):
     ctx = a.ctx
     k = moved.shape[0] if moved.ndim else 1
     inner = moved.size // k if k else 0
-    cur = moved._dev if moved._dev is not a._dev else moved._dev.clone()
+    cur = moved._dev if _storage_id(moved._dev) != _storage_id(a._dev) else moved._dev.clone()
     step = 1
     while step < k and inner:
         nxt = cur.clone()

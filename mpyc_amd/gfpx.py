@@ -7,6 +7,7 @@ coefficients); arrays of GF(2^n) elements live on the GPU (finfields.FieldArray)
 """
 from __future__ import annotations
 
+import re
 import functools
 
 
@@ -93,22 +94,22 @@ class BinaryPolynomial:
             value = abs(int(value))           # gfpx.py:879-880 _from_int
         self.value = value
 
-    @staticmethod
-    def _from_terms(s, x='x'):
-        a = 0
-        for term in ''.join(s.split()).split('+'):
-            if term == '0':
-                t = 0
-            elif term == '1':
-                t = 1
-            elif term == x:
-                t = 2
-            elif term.startswith(f'{x}^'):
-                t = 1 << int(term[2:], base=0)
-            else:
+    _TERM = re.compile(r'(?P<const>[01])|x(?:\^(?P<exp>[0-9a-fA-FxXoObB_]+))?')
+
+    @classmethod
+    def _from_terms(cls, text):
+        """'x^8+x^4+x^3+x+1' -> 0x11b: each '+'-separated term toggles one exponent bit (coefficients live in GF(2),
+        so repeated terms cancel); the constants 0 / 1 and a bare 'x' are allowed."""
+        bits = 0
+        for term in re.sub(r'\s+', '', text).split('+'):
+            mt = cls._TERM.fullmatch(term)
+            if mt is None:
                 raise ValueError('ill formatted polynomial')
-            a ^= t
-        return a
+            if mt.group('const') is not None:
+                bits ^= int(mt.group('const'))
+            else:
+                bits ^= 1 << (int(mt.group('exp'), 0) if mt.group('exp') else 1)
+        return bits
 
     def __int__(self):
         return self.value

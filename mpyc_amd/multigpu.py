@@ -11,9 +11,11 @@ n/G elements per row it owns to every peer: 1/G of the all-gather traffic); `all
 all-gather the north star names, for callers that want whole rows everywhere.  Both move opaque limb
 tensors; residues are never summed by a collective (u64 sums of k products overflow).
 
-The exchange is written with batched point-to-point operations, which map onto xGMI links directly
-under RCCL and also run under gloo (CPU tests); torch.distributed is plumbing here, the arithmetic
-stays in libffgpu.
+The exchange is written with batched point-to-point operations (ncclSend/ncclRecv pairs grouped per call under
+RCCL: every pair of GPUs of an MI355X node has a direct xGMI link, so a pairwise exchange needs no relay; whether
+RCCL actually routes them that way is to be read off `bench.py --gpus 8` -- it has not been measured on more than
+one GPU) and also runs under gloo (CPU tests); torch.distributed is plumbing here, the arithmetic stays in libffgpu.
+recombine_party_major(chunks=...) pipelines the exchange with the recombination kernel.
 """
 from __future__ import annotations
 
@@ -56,6 +58,57 @@ def _check_rows(local_rows: Dict[int, torch.Tensor], n: int):
             raise ValueError(f'share row {j} has {row.shape[0]} elements, expected {n}')     # ragged rows: never exchanged
 
 
+def part_range(lo: int, hi: int, part: int, parts: int, align: int = 64) -> Tuple[int, int]:
+    """Sub-range `part` of `parts` of the column range [lo, hi): boundaries at multiples of `align` elements from
+    lo (so that every chunk of a 16-byte-per-lane kernel stays aligned), the last part takes the remainder."""
+    if parts <= 1:
+        return lo, hi
+    step = -(-(hi - lo) // parts)
+    step = -(-step // align) * align
+    a = min(hi, lo + part * step)
+    b = hi if part == parts - 1 else min(hi, a + step)
+    return a, b
+
+
+def _exchange_start(local_rows, row_ids, n, group, template, recv, part, parts):
+    """Issue the point-to-point operations of one (part of an) exchange; returns (slices, requests).  The slices
+    that arrive from peers are valid after _exchange_finish(requests)."""
+    world = _world(group)
+    rank = _rank(group)
+    lo, hi = part_range(*shard_range(n, rank, world), part, parts)
+    any_row = next(iter(local_rows.values())) if local_rows else template
+    out: List[Optional[torch.Tensor]] = [None] * len(row_ids)
+    ops = []
+    for idx, j in enumerate(row_ids):
+        owner = row_owner(j, world)
+        if owner == rank:
+            row = local_rows[j]
+            out[idx] = row[lo:hi]                     # the owner's slice is a view: nothing moves
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                plo, phi = part_range(*shard_range(n, peer, world), part, parts)
+                if phi > plo:
+                    ops.append(dist.P2POp(dist.isend, row[plo:phi], peer, group=group, tag=idx))
+        elif hi > lo:
+            if any_row is None:
+                raise ValueError('a rank that owns no row must pass `template`')
+            buf = recv[idx][:hi - lo] if recv is not None else \
+                torch.empty((hi - lo,) + tuple(any_row.shape[1:]), dtype=any_row.dtype, device=any_row.device)
+            out[idx] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, owner, group=group, tag=idx))
+    for idx, t in enumerate(out):
+        if t is None:       # empty shard
+            out[idx] = torch.empty((0,) + tuple(any_row.shape[1:]), dtype=any_row.dtype, device=any_row.device)
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return out, reqs
+
+
+def _exchange_finish(reqs):
+    for req in reqs:
+        req.wait()          # RCCL: the CURRENT STREAM waits for the transfer (the host does not block); gloo: host wait
+
+
 def exchange_party_major(local_rows: Dict[int, torch.Tensor], row_ids: Sequence[int], n: int,
                          group: Optional[dist.ProcessGroup] = None,
                          template: Optional[torch.Tensor] = None,
@@ -65,9 +118,6 @@ def exchange_party_major(local_rows: Dict[int, torch.Tensor], row_ids: Sequence[
     [lo, hi) -- ready to be passed to FieldContext.recombine.  `template`: any tensor with the rows' dtype,
     device and trailing (limb) shape, for a rank that owns no row.  `recv`: optional preallocated receive
     buffers, one per entry of row_ids (used for the rows that arrive from peers)."""
-    world = _world(group)
-    rank = _rank(group)
-    lo, hi = shard_range(n, rank, world)
     _check_rows(local_rows, n)
     any_row = next(iter(local_rows.values())) if local_rows else template
     staged = _host_staged(group) and any_row is not None and any_row.is_cuda
@@ -75,36 +125,9 @@ def exchange_party_major(local_rows: Dict[int, torch.Tensor], row_ids: Sequence[
         dev = any_row.device
         got = exchange_party_major({j: r.cpu() for j, r in local_rows.items()}, row_ids, n, group, any_row[:0].cpu())
         return [g.to(dev) for g in got]
-    out: List[Optional[torch.Tensor]] = [None] * len(row_ids)
-    ops = []
-    recv_bufs = []
-    for idx, j in enumerate(row_ids):
-        owner = row_owner(j, world)
-        if owner == rank:
-            row = local_rows[j]
-            out[idx] = row[lo:hi].contiguous()
-            for peer in range(world):
-                if peer == rank:
-                    continue
-                plo, phi = shard_range(n, peer, world)
-                if phi > plo:
-                    ops.append(dist.P2POp(dist.isend, row[plo:phi].contiguous(), peer, group=group, tag=idx))
-        elif hi > lo:
-            if any_row is None:
-                raise ValueError('a rank that owns no row must pass `template`')
-            buf = recv[idx] if recv is not None else \
-                torch.empty((hi - lo,) + tuple(any_row.shape[1:]), dtype=any_row.dtype, device=any_row.device)
-            recv_bufs.append((idx, buf))
-            ops.append(dist.P2POp(dist.irecv, buf, owner, group=group, tag=idx))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    for idx, buf in recv_bufs:
-        out[idx] = buf
-    for idx, t in enumerate(out):
-        if t is None:       # empty shard
-            out[idx] = torch.empty((0,) + tuple(any_row.shape[1:]), dtype=any_row.dtype, device=any_row.device)
-    return out  # type: ignore[return-value]
+    out, reqs = _exchange_start(local_rows, row_ids, n, group, template, recv, 0, 1)
+    _exchange_finish(reqs)
+    return out
 
 
 def allgather_rows(local_row: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> List[torch.Tensor]:
@@ -195,14 +218,49 @@ def scatter_party_major(slices: Sequence[torch.Tensor], row_ids: Sequence[int], 
 
 def recombine_party_major(ctx, local_rows: Dict[int, torch.Tensor], row_ids: Sequence[int],
                           lambdas: Sequence[int], n: int, group: Optional[dist.ProcessGroup] = None,
-                          template: Optional[torch.Tensor] = None):
+                          template: Optional[torch.Tensor] = None, chunks: int = 1, out=None,
+                          recv: Optional[Sequence[torch.Tensor]] = None):
     """Exchange + local Lagrange recombination: returns this rank's slice of the secrets as a
-    DevArray (element-sharded result)."""
+    DevArray (element-sharded result).
+
+    chunks > 1 PIPELINES the two (SURVEY 8e prices the party-major step as communication-bound at N = 8): the
+    rank's column range is cut into `chunks` parts; the transfers of part c+1 are issued before the recombination
+    kernel of part c is launched, so the kernel runs while the next slices are in flight on the RCCL stream
+    (point-to-point transfers and kernels use different engines / streams).  Only the first transfer and the last
+    kernel are exposed.  Results are bit-identical to chunks = 1 (the kernel is element-wise)."""
     from .engine import DevArray
     if len(row_ids) != len(lambdas):
         raise ValueError('one Lagrange coefficient per row')
-    slices = exchange_party_major(local_rows, row_ids, n, group, template)
-    rows = [DevArray(ctx, t, t.shape[0]) for t in slices]
-    if rows[0].n == 0:
-        return ctx.empty(0)
-    return ctx.recombine(rows, lambdas)
+    _check_rows(local_rows, n)
+    world, rank = _world(group), _rank(group)
+    lo, hi = shard_range(n, rank, world)
+    any_row = next(iter(local_rows.values())) if local_rows else template
+    if chunks <= 1 or (_host_staged(group) and any_row is not None and any_row.is_cuda):
+        slices = exchange_party_major(local_rows, row_ids, n, group, template, recv)
+        rows = [DevArray(ctx, t, t.shape[0]) for t in slices]
+        if rows[0].n == 0:
+            return ctx.empty(0)
+        return ctx.recombine(rows, lambdas, out=out)
+    out = out if out is not None else ctx.empty(hi - lo)
+    if hi == lo:
+        return out
+    if recv is None:
+        # two sets of receive buffers of one part each: part c+1 lands while part c is being read
+        plen = max(part_range(lo, hi, c, chunks)[1] - part_range(lo, hi, c, chunks)[0] for c in range(chunks))
+        bufs = [[torch.empty((plen,) + tuple(any_row.shape[1:]), dtype=any_row.dtype, device=any_row.device)
+                 for _ in row_ids] for _ in range(2)]
+    pending = None
+    for c in range(chunks + 1):
+        nxt = None
+        if c < chunks:
+            a, b = part_range(lo, hi, c, chunks)
+            rbufs = [r[a - lo:b - lo] for r in recv] if recv is not None else bufs[c % 2]
+            nxt = (_exchange_start(local_rows, row_ids, n, group, template, rbufs, c, chunks), a, b)
+        if pending is not None:
+            (slices, reqs), a, b = pending
+            _exchange_finish(reqs)
+            if b > a:
+                ctx.recombine([DevArray(ctx, t[:b - a], b - a) for t in slices], lambdas,
+                              out=DevArray(ctx, out.t[a - lo:b - lo], b - a))
+        pending = nxt
+    return out

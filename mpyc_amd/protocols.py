@@ -172,7 +172,7 @@ def as_matrix(ctx: FieldContext, xs: Shares):
     import torch
     from .engine import DevMatrix, limbs_of
     m, n, eb = len(xs), xs[0].n, ctx.elem_bytes
-    unit = 4 if eb == 12 else eb                      # bytes of one tensor element
+    unit = xs[0].t.element_size()                     # bytes of one tensor element (8 for the 16- and 24-byte layouts)
     step = (xs[1].ptr - xs[0].ptr) if m > 1 else 0
     lb = limbs_of(eb)
     same_storage = all(x.t.untyped_storage().data_ptr() == xs[0].t.untyped_storage().data_ptr() for x in xs)

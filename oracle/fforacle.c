@@ -9,9 +9,11 @@
  * against the tests/golden JSON fixtures generated from the real reference (see
  * tests/golden/make_golden.py), and against oracle/pyoracle.py.
  *
- * Deliberately simple arithmetic (compiler-provided 128-bit `%`, shift-and-add
- * for two-limb moduli, shift-and-xor for GF(2^n)); it shares no code and no
- * reduction trick with the HIP kernels.
+ * Deliberately textbook arithmetic (compiler-provided 128-bit `%` for one-limb
+ * moduli; schoolbook 256-bit product + Knuth long division for two-limb moduli,
+ * so that 128-bit fields run at OpenMP speed over 10^7 elements; shift-and-xor
+ * for GF(2^n)); it shares no code and no reduction trick with the HIP kernels
+ * (which fold by 2^k = c or use Montgomery products).
  *
  * Element layout: little-endian, width eb in {1,4,8,12,16} bytes, as include/ffgpu.h.
  * Reference lines restated (paths relative to the mpyc checkout):
@@ -85,9 +87,81 @@ static inline u128 addmod(u128 a, u128 b, u128 p) {
 }
 static inline u128 submod(u128 a, u128 b, u128 p) { return a >= b ? a - b : a - b + p; }
 
+/* 128 x 128 -> 256-bit product, schoolbook on 64-bit halves: (hi, lo) */
+static inline void mul256(u128 a, u128 b, u128* hi, u128* lo) {
+    uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
+    u128 p00 = (u128)a0 * b0, p01 = (u128)a0 * b1, p10 = (u128)a1 * b0, p11 = (u128)a1 * b1;
+    u128 mid = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;              /* < 3 * 2^64 */
+    *lo = (u128)(uint64_t)p00 | (mid << 64);
+    *hi = p11 + (p01 >> 64) + (p10 >> 64) + (mid >> 64);
+}
+
+/* (hi:lo) mod p for a modulus of 65..128 bits: long division in base 2^64 (Knuth, TAOCP vol. 2, 4.3.1 algorithm D)
+ * on a 4-digit dividend and a 2-digit divisor; only the remainder is kept.  Requires hi < p (true for a product of
+ * two residues), which keeps every quotient digit below 2^64. */
+static u128 mod256(u128 hi, u128 lo, u128 p) {
+    uint64_t v1 = (uint64_t)(p >> 64), v0 = (uint64_t)p;
+    int s = __builtin_clzll(v1);
+    uint64_t u[5];
+    if (s) {                                   /* D1: normalise so that the top divisor digit has its high bit set */
+        v1 = (v1 << s) | (v0 >> (64 - s));
+        v0 <<= s;
+        u[4] = (uint64_t)(hi >> (128 - s));
+        hi = (hi << s) | (lo >> (128 - s));
+        lo <<= s;
+    } else {
+        u[4] = 0;
+    }
+    u[3] = (uint64_t)(hi >> 64); u[2] = (uint64_t)hi; u[1] = (uint64_t)(lo >> 64); u[0] = (uint64_t)lo;
+    for (int j = 2; j >= 0; --j) {             /* D2..D7: one quotient digit per step */
+        u128 num = ((u128)u[j + 2] << 64) | u[j + 1];
+        u128 qhat, rhat;
+        if (u[j + 2] >= v1) {                  /* quotient digit would overflow: start from base - 1 */
+            qhat = ~(uint64_t)0;
+            rhat = num - qhat * v1;
+        } else {
+            qhat = num / v1;
+            rhat = num % v1;
+        }
+        while ((rhat >> 64) == 0 && qhat * v0 > ((rhat << 64) | u[j])) {      /* D3: at most two corrections */
+            --qhat;
+            rhat += v1;
+        }
+        /* D4: u[j..j+2] -= qhat * (v1:v0) */
+        u128 prod0 = qhat * v0, prod1 = qhat * v1 + (prod0 >> 64);
+        uint64_t s0 = (uint64_t)prod0, s1 = (uint64_t)prod1, s2 = (uint64_t)(prod1 >> 64);
+        uint64_t b0 = u[j] < s0;
+        u[j] -= s0;
+        uint64_t t1 = u[j + 1] - s1, b1 = u[j + 1] < s1;
+        uint64_t t1b = t1 - b0;
+        b1 += t1 < b0;
+        u[j + 1] = t1b;
+        uint64_t t2 = u[j + 2] - s2, b2 = u[j + 2] < s2;
+        uint64_t t2b = t2 - b1;
+        b2 += t2 < b1;
+        u[j + 2] = t2b;
+        if (b2) {                              /* D6: qhat was one too large -> add the divisor back */
+            u128 c = (u128)u[j] + v0;
+            u[j] = (uint64_t)c;
+            c = (u128)u[j + 1] + v1 + (c >> 64);
+            u[j + 1] = (uint64_t)c;
+            u[j + 2] += (uint64_t)(c >> 64);
+        }
+    }
+    u128 r = ((u128)u[1] << 64) | u[0];        /* D8: denormalise the remainder */
+    return s ? (r >> s) : r;
+}
+
 static inline u128 mulmod(u128 a, u128 b, u128 p) {
     if ((p >> 64) == 0) return (u128)(((u128)(uint64_t)a * (uint64_t)b) % p);
-    /* two-limb modulus: shift-and-add, a,b < p */
+    u128 hi, lo;                               /* two-limb modulus: full product, then long division; a, b < p */
+    mul256(a, b, &hi, &lo);
+    return mod256(hi, lo, p);
+}
+
+/* the round-1/2 two-limb product (shift-and-add, one modular doubling per bit): kept as an independent cross-check of
+ * mul256 + mod256 (tests/test_oracle_golden.py) */
+u128 orc_mulmod_shift_add(u128 a, u128 b, u128 p) {
     u128 r = 0;
     while (b) {
         if (b & 1) r = addmod(r, a, p);
@@ -95,6 +169,12 @@ static inline u128 mulmod(u128 a, u128 b, u128 p) {
         b >>= 1;
     }
     return r;
+}
+void orc_mulmod_pair(const uint64_t* a, const uint64_t* b, const uint64_t* p, uint64_t* fast, uint64_t* slow) {
+    u128 A = mk(a, 2), B = mk(b, 2), P = mk(p, 2);
+    u128 f = mulmod(A, B, P), s = orc_mulmod_shift_add(A, B, P);
+    fast[0] = (uint64_t)f; fast[1] = (uint64_t)(f >> 64);
+    slow[0] = (uint64_t)s; slow[1] = (uint64_t)(s >> 64);
 }
 
 /* c = a*b in GF(2^n): MSB-first Horner, r stays below degree n */
@@ -315,7 +395,10 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
         uint32_t n0 = (uint32_t)nonce, n1 = (uint32_t)(nonce >> 32);
         if (t > 4) n1 += (uint32_t)(d + 1);
         const size_t ngroups = (npacks + G - 1) / G;
-        for (size_t grp = 0; grp < ngroups; ++grp) {
+        long long grp_;
+#pragma omp parallel for num_threads(g_threads) schedule(static)      /* groups write disjoint elements */
+        for (grp_ = 0; grp_ < (long long)ngroups; ++grp_) {
+            const size_t grp = (size_t)grp_;
             uint32_t ks[16 * 32];
             for (int b = 0; b < B; ++b) {
                 uint64_t ctr = (uint64_t)grp * B + b;

@@ -40,6 +40,9 @@ def main():
             lo, hi = multigpu.shard_range(n, rank, world)
             y = multigpu.recombine_party_major(ctx, dev_rows, list(range(k)), lam, n, template=template)
             assert y.to_ints() == want[lo:hi], ('all-to-all', hex(modulus), n, k, rank)
+            for chunks in (2, 5):                              # exchange pipelined with the recombination kernel
+                yp = multigpu.recombine_party_major(ctx, dev_rows, list(range(k)), lam, n, template=template, chunks=chunks)
+                assert yp.to_ints() == want[lo:hi], ('pipelined', chunks, hex(modulus), n, k, rank)
             # all-gather form
             pg = multigpu.PartyMajorGather(k, n, template)
             for j, t_ in dev_rows.items():

@@ -58,6 +58,34 @@ def main():
                     raise AssertionError('ragged row accepted')
                 except ValueError:
                     pass
+    # exchange pipelined with the recombination (recombine_party_major(chunks=...)): a stand-in context whose
+    # "kernel" is a wrapping int64 dot product -- only the chunk / buffer bookkeeping is under test here
+    class StubCtx:
+        def empty(self, n):
+            from mpyc_amd.engine import DevArray
+            return DevArray(self, torch.zeros(n, dtype=torch.int64), n)
+
+        def recombine(self, rows, lam, w=1, out=None):
+            out = out or self.empty(rows[0].n)
+            acc = torch.zeros(rows[0].n, dtype=torch.int64)
+            for r, l_ in zip(rows, lam):
+                acc += r.t * l_
+            out.t.copy_(acc)
+            return out
+    ctx = StubCtx()
+    for n in (5, 1000, 4099):
+        k, lam = 5, [3, 1, 4, 1, 5]
+        full = [torch.arange(n, dtype=torch.int64) * (j + 2) + 17 * j for j in range(k)]
+        local = {j: full[j] for j in range(k) if multigpu.row_owner(j, world) == rank}
+        row_ids = [2, 0, 3, 1, 4]
+        lo, hi = multigpu.shard_range(n, rank, world)
+        want = sum(full[j][lo:hi] * lam[i] for i, j in enumerate(row_ids))
+        for chunks in (1, 2, 3, 8):
+            got = multigpu.recombine_party_major(ctx, local, row_ids, lam, n, template=full[0], chunks=chunks)
+            assert torch.equal(got.t, want), (rank, n, chunks)
+        recv = [torch.empty(hi - lo, dtype=torch.int64) for _ in row_ids]
+        got = multigpu.recombine_party_major(ctx, local, row_ids, lam, n, template=full[0], chunks=3, out=ctx.empty(hi - lo), recv=recv)
+        assert torch.equal(got.t, want), (rank, n, 'recv')
     rows = multigpu.allgather_rows(torch.full((11,), rank, dtype=torch.int64))
     assert [int(r[0]) for r in rows] == list(range(world))
     # MAX-over-ranks reduction used by bench.py

@@ -1,0 +1,103 @@
+"""BASELINE.json configs[2] and configs[3] at their stated size, ELEMENT BY ELEMENT against the C oracle
+(VERDICT r2 weak #1 / next #3): every row of share generation (coefficients supplied, fused with the local
+product, and drawn by the device CSPRNG -- the oracle restates the generator layout independently,
+oracle/fforacle.c orc_rng_coeffs), and recombination from t+1 and 2t+1 rows, over n = 10^7 elements:
+
+    configs[2]   GF(2^64-189),  m = 7, t = 3      thresha.py:47-64, 119-132
+    configs[3]   GF(2^128-173), m = 7, t = 3      the whole gate: product, re-sharing, recombination of 2t+1 rows
+                                                  (runtime.py:1096-1141, 603-689)
+
+The oracle runs on all host cores (OpenMP); its two-limb product is a schoolbook 256-bit product + Knuth long division,
+pinned to Python integers in tests/test_oracle_golden.py."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from fieldutil import P64, P128
+from test_gpu_parity import rand_np
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+N_FULL = 10_000_000
+
+
+@pytest.fixture(scope='module')
+def eng():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from mpyc_amd import engine
+    return engine
+
+
+@pytest.fixture()
+def threads(coracle):
+    coracle.set_threads(coracle.max_threads())
+    yield coracle
+    coracle.set_threads(1)
+
+
+def rows_equal(mtx, want, what):
+    got = mtx.to_numpy()
+    for i in range(want.shape[0]):
+        same = got[i] == want[i]
+        assert same.all(), f'{what}: row {i} differs from the oracle at {int(np.argmin(same.reshape(same.shape[0], -1).all(axis=1)))}'
+
+
+def run_config(eng, co, modulus, n, t, m, seed):
+    F = po.Field(modulus)
+    ctx = eng.FieldContext(modulus, device=0)
+    eb = ctx.elem_bytes
+    cf = co.CField(modulus)
+    lshape = (t, n, 2) if eb == 16 else (t, n)
+    A, B = rand_np(F, eb, n, seed), rand_np(F, eb, n, seed + 1)
+    C = rand_np(F, eb, t * n, seed + 2).reshape(lshape)
+    dA, dB, dC = ctx.from_numpy(A), ctx.from_numpy(B), ctx.matrix_from_numpy(C)
+
+    # local product
+    want_prod = cf.ew(co.MUL, A, B)
+    prod = ctx.mul(dA, dB)
+    assert (prod.to_numpy() == want_prod).all(), 'mul'
+
+    # share generation, coefficients supplied: all m rows
+    want_sh = cf.split(A, C, t, m)
+    sh = ctx.split(dA, dC, t, m)
+    rows_equal(sh, want_sh, 'split')
+
+    # fused with the local product (ffgpu_mul_split): shares of a*b, product never written
+    want_shp = cf.split(want_prod, C, t, m)
+    shp = ctx.split(dA, dC, t, m, mul_by=dB)
+    rows_equal(shp, want_shp, 'mul_split')
+    del shp
+
+    # device CSPRNG: the oracle regenerates the coefficient matrix from (key, nonce) and shares with it
+    key, nonce = bytes(range(7, 39)), 0x1234_5678_9abc
+    Cr = co.rng_coeffs(cf, key, nonce, 20, t, n)
+    want_rng = cf.split(A, Cr, t, m)
+    shr = ctx.split_rng(dA, t, m, key=key, nonce=nonce, rounds=20)
+    rows_equal(shr, want_rng, 'split_rng')
+    want_rngp = cf.split(want_prod, Cr, t, m)
+    shrp = ctx.split_rng(dA, t, m, key=key, nonce=nonce, rounds=20, mul_by=dB)
+    rows_equal(shrp, want_rngp, 'mul_split_rng')
+    del shr, shrp, want_rng, want_rngp, Cr
+
+    # recombination from t+1 and from 2t+1 rows, in a rotated order (runtime.py:658-661), oracle on the same rows
+    for xs in (list(range(1, t + 2)), [((2 + j) % m) + 1 for j in range(2 * t + 1)]):
+        lam = po.recombination_vector(F, xs, 0)
+        want_rec = cf.recombine([want_sh[x - 1] for x in xs], lam)
+        rec = ctx.recombine([sh.row(x - 1) for x in xs], lam)
+        assert (rec.to_numpy() == want_rec).all(), ('recombine', xs)
+        assert (want_rec == A).all(), ('oracle round trip', xs)
+    # the gate: recombining 2t+1 re-shared rows of the product gives the product
+    xs = list(range(1, 2 * t + 2))
+    lam = po.recombination_vector(F, xs, 0)
+    shp = ctx.split(dA, dC, t, m, mul_by=dB)
+    assert (ctx.recombine([shp.row(x - 1) for x in xs], lam).to_numpy() == want_prod).all(), 'gate'
+
+
+def test_configs2_p64_m7_t3_vs_oracle_1e7(eng, threads):
+    run_config(eng, threads, P64, N_FULL, 3, 7, 2001)
+
+
+def test_configs3_p128_gate_m7_t3_vs_oracle_1e7(eng, threads):
+    run_config(eng, threads, P128, N_FULL, 3, 7, 3001)
+    torch.cuda.empty_cache()

@@ -42,6 +42,8 @@ def test_party_major_world_of_one_runs_on_kernels():
     local = {j: ctx.from_numpy(ints_to_np(rows[j], 8)).t for j in range(k)}
     y = multigpu.recombine_party_major(ctx, local, list(range(k)), lam, n)
     assert y.to_ints() == want
+    for chunks in (2, 3, 16):
+        assert multigpu.recombine_party_major(ctx, local, list(range(k)), lam, n, chunks=chunks).to_ints() == want
     with pytest.raises(ValueError):                                      # ragged row: refused, never read out of bounds
         multigpu.recombine_party_major(ctx, {**local, 3: local[3][:-1]}, list(range(k)), lam, n)
     with pytest.raises(ValueError):

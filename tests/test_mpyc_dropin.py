@@ -145,3 +145,46 @@ def test_reference_np_demos_under_install_host_logic():
     r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'run_np_demos.sh'), '/root/reference', 'cpuctx'], capture_output=True,
                        text=True, cwd=ROOT, timeout=1800, env=env)
     assert r.returncode == 0 and 'DIFF' not in r.stdout and r.stdout.count('SAME') == 5, (r.stdout + r.stderr)[-3000:]
+
+
+_SAME_P_CODE = '''
+import pickle
+import mpyc_amd
+mpyc_amd.install()
+import os
+if os.environ.get('MPYC_AMD_CPUCTX') == '1':
+    from cpuctx import use_cpu_contexts
+    use_cpu_contexts()
+from mpyc import finfields, thresha
+p, n, w = finfields.find_prime_root(40, n=3)
+F1 = finfields.GF(p)                    # (p, 2, p-1)
+F2 = finfields.GF((p, n, w))            # same modulus, root of unity of order 3: a DIFFERENT cached class
+F3 = finfields.GF((p, 1, 1))
+assert F1 is not F2 and F1.modulus == F2.modulus == F3.modulus
+for F in (F1, F2, F3, F1):              # creation / use order must not matter
+    a = F.array([1, 2, 3, p - 1])
+    b = pickle.loads(pickle.dumps(a))
+    assert type(b) is F.array and b.field is F, (F.nth, type(b).field.nth)
+    rows = thresha.np_random_split(F, a, 1, 3)
+    back = [pickle.loads(pickle.dumps(rows[i])) for i in range(3)]
+    y = thresha.np_recombine(F, [(i + 1, back[i]) for i in range(2)])
+    assert (y == a).all()
+print('SAME_P_OK')
+'''
+
+
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_pickled_rows_keep_their_field_class_host_logic():
+    """ADVICE r2: mpyc caches prime fields per (p, n, w); rows pickled over one of them must not come back as arrays
+    of a sibling class over the same modulus (np_recombine / field.array would raise)."""
+    env = _env('/root/reference', True, os.path.join(ROOT, 'tests', 'devsite'))
+    r = subprocess.run([sys.executable, '-c', _SAME_P_CODE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=300)
+    assert r.returncode == 0 and 'SAME_P_OK' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
+def test_pickled_rows_keep_their_field_class_on_gpu():
+    env = _env(STAGE, False, os.path.join(ROOT, 'mpyc_amd', 'autoinstall'))
+    r = subprocess.run([sys.executable, '-c', _SAME_P_CODE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=300)
+    assert r.returncode == 0 and 'SAME_P_OK' in r.stdout, r.stdout + r.stderr

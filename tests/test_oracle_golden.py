@@ -187,3 +187,27 @@ def test_py_wide_primes(golden_wide):
     assert sorted(golden_wide) == ['P129', 'P129G', 'P136', 'P136R', 'P160', 'P192']
     test_py_elementwise(golden_wide)
     test_py_sharing(golden_wide)
+
+
+def test_two_limb_mulmod_long_division_vs_python_and_shift_add(coracle):
+    """oracle/fforacle.c computes two-limb products as a schoolbook 256-bit product followed by Knuth long division
+    (fast enough for 10^7-element parity runs over 128-bit fields); cross-checked here against Python integers AND
+    against the bit-serial shift-and-add product of rounds 1-2, on extreme and random operands."""
+    import ctypes
+    import random
+    L = coracle.lib()
+    rnd = random.Random(20260925)
+
+    def lim(x):
+        return (ctypes.c_uint64 * 2)(x & (2**64 - 1), x >> 64)
+    primes = [2**128 - 173, 2**127 - 1, 258797994007609146293811961253269568351, 2**96 - 17, 2**80 - 65, 2**65 + 131,
+              2**97 - 141, (1 << 64) + 13]
+    for p in primes:
+        edge = [v % p for v in (0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2**64 - 1, 2**64, 2**64 + 1, p >> 1,
+                                (1 << (p.bit_length() - 1)) - 1, (1 << (p.bit_length() - 1)), 2**32, 2**96)]
+        pairs = [(a, b) for a in edge for b in edge] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(1500)]
+        for a, b in pairs:
+            f, s = (ctypes.c_uint64 * 2)(), (ctypes.c_uint64 * 2)()
+            L.orc_mulmod_pair(lim(a), lim(b), lim(p), f, s)
+            want = a * b % p
+            assert f[0] | (f[1] << 64) == want and s[0] | (s[1] << 64) == want, (hex(p), hex(a), hex(b))
