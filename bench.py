@@ -466,9 +466,14 @@ def main():
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
+        # (`--n` is an ambiguous abbreviation for torch.distributed.run's own parser: it travels in the environment)
+        fwd = ['--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup), '--sets', str(args.sets),
+               '--layout', args.layout]
+        fwd += [f_ for f_, on in (('--no-cpu-baseline', args.no_cpu_baseline), ('--no-extras', args.no_extras),
+                                  ('--no-api-leg', args.no_api_leg), ('--no-multi-gpu-leg', args.no_multi_gpu_leg)) if on]
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + fwd
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, FFGPU_BENCH_N=str(args.n))))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
     if not torch.cuda.is_available():

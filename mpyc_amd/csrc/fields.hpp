@@ -1164,6 +1164,10 @@ struct GF2W64 {
         if (!(fast & 1)) return mul_bitserial(a, b);
         uint64_t hi, lo;
         ff_clmul64(a, b, hi, lo);
+        return reduce_product(hi, lo);
+    }
+    // (hi:lo) = an unreduced carry-less product of two residues (degree <= 2n-2) -> residue; sparse moduli only (fast & 1)
+    FF_HD uint64_t reduce_product(uint64_t hi, uint64_t lo) const {
         ff_u128 t = ff_make128(hi, lo);
         const int folds = (int)((fast >> 8) & 0xff);
         for (int it = 0; it < folds; ++it) {
@@ -1244,6 +1248,10 @@ struct GF2W128 {
         if (!(fast & 1)) return mul_bitserial(a, b);
         uint64_t p[4];
         ff_clmul128(a.lo, a.hi, b.lo, b.hi, p);
+        return reduce_product(p);
+    }
+    // p[0..3] = an unreduced carry-less product of two residues (degree <= 2n-2) -> residue; sparse moduli only (fast & 1)
+    FF_HD u128e reduce_product(const uint64_t p[4]) const {
         const uint32_t r = (uint32_t)red_lo;
         // H = P >> n (two limbs), L = P & mask;  T = L ^ H*r  (three limbs, H*r < 2^(n+27))
         uint64_t h0, h1;

@@ -812,136 +812,224 @@ int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable,
     return 0;
 }
 
+// LDS read at an ABSOLUTE byte offset of the workgroup's allocation (ds_read with the constant part of the address
+// as the instruction's immediate; a pointer derived from the `extern __shared__` symbol costs one v_add per access)
+template <class L>
+__device__ __forceinline__ L lds_entry(uint32_t byte_offset) {
+    typedef uint32_t vec __attribute__((ext_vector_type(sizeof(L) / 4)));
+    const vec v = *reinterpret_cast<const __attribute__((address_space(3))) vec*>(byte_offset);
+    L r;
+    __builtin_memcpy(&r, &v, sizeof(L));
+    return r;
+}
+// byte offset of an LDS object inside the workgroup's allocation (0 for the only / first one: folds to a constant)
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(const char*)p;
+}
+
 // ---- GF(2^n), 9 <= n <= 128: recombination through shared nibble tables -----------------------------
 // out[h] = sum_j lambda_j * rows[j][h].  The Lagrange coefficients are wave-uniform, and x -> lambda*x
-// is GF(2)-linear, so each workgroup first builds, for every row j, nibble position pos and nibble
-// value v, the entry  T[j][pos][v] = lambda_j * (v * x^(4 pos)) mod f  (K * NPOS * 16 entries, built
+// is GF(2)-linear, so each workgroup first builds, for every row j with a DENSE coefficient, nibble position pos
+// and nibble value v, the entry  T[j][pos][v] = lambda_j * (v * x^(4 pos)) mod f  (KT * NPOS * 16 entries, built
 // cooperatively with the in-register carry-less product), and then every element costs NPOS look-ups
 // + xors per row instead of a full field multiplication.  An entry's bank depends only on v (16
-// consecutive 16-byte slots per position), so the data-dependent reads are conflict-free.
-template <int LIMBS, int K>
+// consecutive 16-byte slots per position), so the data-dependent reads are conflict-free
+// (SQ_LDS_BANK_CONFLICT = 0, profiles/r03_gf2w.md).
+//
+// Rows whose coefficient is 1 are XORed in without any table (and rows with coefficient 0 are dropped by the
+// launcher): when the interpolation points together with 0 are closed under XOR -- parties 1..3 or 1..7, i.e. every
+// recombination of 2t+1 = m rows in `_reshare` for m = 3, 7 (runtime.py:658-661) -- ALL Lagrange coefficients at 0
+// are 1 (prod_{l != j} x_l / (x_l + x_j) runs over the same set in numerator and denominator), and the
+// recombination is a plain XOR of the rows at the HBM rate.
+//
+// Round 3: the look-ups of a row are issued 16 at a time into registers before any of them is consumed (the
+// round-2 kernel waited after every second ds_read: 53 % of its wave cycles were s_waitcnt, SQ_WAIT_ANY), the
+// nibble -> byte-offset conversion is one masked byte select per look-up (pre-shifted copies of the words), results
+// are folded with 3-input XORs, and 512-thread workgroups share one table (16 waves per CU at k = 7).
+enum { REC_BLOCK = 512, REC_MAXK = 9 };
+
+template <int LIMBS>
 struct Gf2wRecArgs {
-    const void* rows[K];
-    uint64_t lam_lo[K], lam_hi[K];
+    const void* trow[REC_MAXK];      // rows with a dense coefficient (tables)
+    const void* prow[REC_MAXK];      // rows with coefficient 1 (plain XOR)
+    uint64_t lam_lo[REC_MAXK], lam_hi[REC_MAXK];
+    int kp;
 };
 
-template <int LIMBS, int K>
-__global__ __launch_bounds__(BLOCK) void k_gf2w_recombine_tab(typename Gf2wTraits<LIMBS>::F f, Gf2wRecArgs<LIMBS, K> ra,
-                                                               typename Gf2wTraits<LIMBS>::E* __restrict__ out, size_t n) {
+template <int LIMBS, int KT>
+__global__ __launch_bounds__(REC_BLOCK) void k_gf2w_recombine_tab(typename Gf2wTraits<LIMBS>::F f, Gf2wRecArgs<LIMBS> ra,
+                                                                   typename Gf2wTraits<LIMBS>::E* __restrict__ out, size_t n) {
     typedef Gf2wTraits<LIMBS> Tr;
     typedef typename Tr::L L;
     typedef typename Tr::E E;
     constexpr int NPOS = 16 * LIMBS;
+    constexpr int NW = 2 * LIMBS;                            // 32-bit words per element
+    constexpr int SH = LIMBS == 2 ? 4 : 3;                   // log2(sizeof(L))
+    constexpr uint32_t AMASK = 15u << SH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    L* T = reinterpret_cast<L*>(smem);                       // [K][NPOS][16]
-    for (int e = threadIdx.x; e < K * NPOS * 16; e += BLOCK) {
-        const int j = e / (NPOS * 16), pos = (e / 16) % NPOS, v = e % 16;
-        uint64_t clo = 0, chi = 0;
-        if (4 * pos < 64) clo = (uint64_t)v << (4 * pos); else chi = (uint64_t)v << (4 * pos - 64);
-        uint64_t rlo, rhi;
-        if constexpr (LIMBS == 2) {
-            // the constant may exceed degree n only if 4*pos+3 >= n: reduce it first
-            u128e c;
-            c.lo = clo;
-            c.hi = chi;
-            if (f.n < 128) c = f.reduce_raw(c);
-            u128e lam;
-            lam.lo = ra.lam_lo[j];
-            lam.hi = ra.lam_hi[j];
-            u128e r = f.mul(lam, c);
-            rlo = r.lo;
-            rhi = r.hi;
-        } else {
-            uint64_t c = f.n < 64 ? f.reduce_raw(clo) : clo;
-            rlo = f.mul(ra.lam_lo[j], c);
-            rhi = 0;
-        }
-        T[e] = Tr::pack(rlo, rhi);
-    }
-    __syncthreads();
-    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    const size_t gsz = (size_t)gridDim.x * BLOCK;
-    for (size_t i = gid; i < n; i += gsz) {
-        uint64_t alo = 0, ahi = 0;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            uint64_t xlo, xhi;
+    if constexpr (KT > 0) {
+        L* T = reinterpret_cast<L*>(smem);                   // [KT][NPOS][16]
+        for (int e = threadIdx.x; e < KT * NPOS * 16; e += REC_BLOCK) {
+            const int j = e / (NPOS * 16), pos = (e / 16) % NPOS, v = e % 16;
+            uint64_t clo = 0, chi = 0;
+            if (4 * pos < 64) clo = (uint64_t)v << (4 * pos); else chi = (uint64_t)v << (4 * pos - 64);
+            uint64_t rlo, rhi;
             if constexpr (LIMBS == 2) {
-                u128e x = reinterpret_cast<const u128e*>(ra.rows[j])[i];
-                xlo = x.lo;
-                xhi = x.hi;
+                // the constant may exceed degree n only if 4*pos+3 >= n: reduce it first
+                u128e c;
+                c.lo = clo;
+                c.hi = chi;
+                if (f.n < 128) c = f.reduce_raw(c);
+                u128e lam;
+                lam.lo = ra.lam_lo[j];
+                lam.hi = ra.lam_hi[j];
+                u128e r = f.mul(lam, c);
+                rlo = r.lo;
+                rhi = r.hi;
             } else {
-                xlo = reinterpret_cast<const uint64_t*>(ra.rows[j])[i];
-                xhi = 0;
+                uint64_t c = f.n < 64 ? f.reduce_raw(clo) : clo;
+                rlo = f.mul(ra.lam_lo[j], c);
+                rhi = 0;
             }
-            const L* Tj = T + j * NPOS * 16;
+            T[e] = Tr::pack(rlo, rhi);
+        }
+        __syncthreads();
+    }
+    // dynamic LDS starts at offset 0 of the workgroup's allocation (the kernel has no static LDS), so the table offsets
+    // below are the look-ups' immediates; checked once, uniformly
+    if (lds_offset_of(smem) != 0) __builtin_trap();
+    constexpr uint32_t tbase = 0;
+    const size_t gid = (size_t)blockIdx.x * REC_BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * REC_BLOCK;
+    for (size_t i = gid; i < n; i += gsz) {
+        uint32_t acc[NW];
 #pragma unroll
-            for (int pos = 0; pos < NPOS; ++pos) {
-                uint32_t v = pos < 16 ? (uint32_t)(xlo >> (4 * pos)) & 15u : (uint32_t)(xhi >> (4 * (pos - 16))) & 15u;
-                uint64_t tlo, thi;
-                Tr::unpack(Tj[pos * 16 + v], tlo, thi);
-                alo ^= tlo;
-                ahi ^= thi;
+        for (int q = 0; q < NW; ++q) acc[q] = 0;
+        // all operand loads of the element first (they stream; the look-ups below run in their shadow)
+        uint32_t xw[KT > 0 ? KT : 1][NW];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if constexpr (LIMBS == 2) {
+                const uint4 x = ldg<true>(reinterpret_cast<const uint4*>(ra.trow[j]) + i);
+                xw[j][0] = x.x; xw[j][1] = x.y; xw[j][2] = x.z; xw[j][3] = x.w;
+            } else {
+                const uint2 x = reinterpret_cast<const uint2*>(ra.trow[j])[i];
+                xw[j][0] = x.x; xw[j][1] = x.y;
+            }
+        }
+        for (int p = 0; p < ra.kp; ++p) {                    // coefficient 1: XOR, no table (wave-uniform trip count)
+            if constexpr (LIMBS == 2) {
+                const uint4 x = ldg<true>(reinterpret_cast<const uint4*>(ra.prow[p]) + i);
+                acc[0] ^= x.x; acc[1] ^= x.y; acc[2] ^= x.z; acc[3] ^= x.w;
+            } else {
+                const uint2 x = reinterpret_cast<const uint2*>(ra.prow[p])[i];
+                acc[0] ^= x.x; acc[1] ^= x.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+#pragma unroll
+            for (int q0 = 0; q0 < NW; q0 += 2) {             // 16 look-ups (two words of the operand) per batch
+                L t[16];
+                // byte offset of entry v inside its position's 16-entry block = v << SH: mask the nibbles of a word in
+                // place (one AND for the four high nibbles, shift + AND for the four low ones), then every look-up
+                // address is ONE byte extraction; the block's own offset is the instruction's immediate
+                uint32_t mh[2], ml[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t w = xw[j][q0 + e];
+                    mh[e] = (SH == 4 ? w : (w >> (4 - SH))) & (AMASK * 0x01010101u);
+                    ml[e] = (w << SH) & (AMASK * 0x01010101u);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int e = u >> 3, b = (u & 7) >> 1, hi = u & 1;
+                    uint32_t a;                                  // byte b of the masked word: ONE v_bfe_u32 (the compiler
+                    //                                              splits the intrinsic into shift + and)
+                    asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(a) : "v"(hi ? mh[e] : ml[e]), "n"(8 * b));
+                    const int pos = 8 * (q0 + e) + 2 * b + hi;
+                    t[u] = lds_entry<L>(tbase + (uint32_t)(((j * NPOS + pos) * 16 << SH) + a));
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    acc[0] = ff_xor3(acc[0], t[u].x, t[u + 1].x);
+                    acc[1] = ff_xor3(acc[1], t[u].y, t[u + 1].y);
+                    if constexpr (LIMBS == 2) {
+                        acc[2] = ff_xor3(acc[2], t[u].z, t[u + 1].z);
+                        acc[3] = ff_xor3(acc[3], t[u].w, t[u + 1].w);
+                    }
+                }
             }
         }
         if constexpr (LIMBS == 2) {
-            u128e r;
-            r.lo = alo;
-            r.hi = ahi;
-            out[i] = r;
+            stg<true>(reinterpret_cast<uint4*>(out) + i, make_uint4(acc[0], acc[1], acc[2], acc[3]));
         } else {
-            out[i] = alo;
+            reinterpret_cast<uint2*>(out)[i] = make_uint2(acc[0], acc[1]);
         }
     }
 }
 
-template <int LIMBS, int K>
-static int launch_gf2w_rec(const void* policy, int device, const void* const* rows, const uint64_t* lam2, void* out,
-                           size_t n, hipStream_t st) {
+template <int LIMBS, int KT>
+static int launch_gf2w_rec(const void* policy, int device, const Gf2wRecArgs<LIMBS>& ra, void* out, size_t n, hipStream_t st) {
     typedef Gf2wTraits<LIMBS> Tr;
     const typename Tr::F& f = *reinterpret_cast<const typename Tr::F*>(policy);
-    Gf2wRecArgs<LIMBS, K> ra;
-    for (int j = 0; j < K; ++j) {
-        ra.rows[j] = rows[j];
-        ra.lam_lo[j] = lam2[2 * j];
-        ra.lam_hi[j] = lam2[2 * j + 1];
-    }
-    const size_t lds = (size_t)K * 16 * LIMBS * 16 * sizeof(typename Tr::L);
+    const size_t lds = (size_t)KT * 16 * LIMBS * 16 * sizeof(typename Tr::L);
     LaunchCfg lc = launch_cfg(device);
-    // persistent grid: the table build (2K field multiplications per thread) is amortised over many elements
-    int per_cu = (int)(160 * 1024 / (lds + 256));
-    if (per_cu > 4) per_cu = 4;
-    if (per_cu < 1) per_cu = 1;
-    LaunchCfg capped = lc;
-    capped.blocks_per_cu = per_cu;
-    unsigned grid = grid_for(n, capped);
+    size_t want = (n + REC_BLOCK - 1) / REC_BLOCK, cap;
+    if (KT > 0) {
+        // persistent grid: the table build (a few field multiplications per thread) is amortised over many elements
+        int per_cu = (int)(160 * 1024 / (lds + 256));
+        if (per_cu > 4) per_cu = 4;          // 4 x 512 threads = 32 waves: the CU's limit
+        if (per_cu < 1) per_cu = 1;
+        cap = (size_t)per_cu * (size_t)lc.num_cu;
+    } else {
+        cap = 0x7fffffff;                    // plain XOR of the rows: one element per thread, like the streaming kernels
+    }
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
     if (lds > 48 * 1024) {
         static bool raised = false;     // per instantiation: allow more than the default dynamic LDS
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gf2w_recombine_tab<LIMBS, K>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gf2w_recombine_tab<LIMBS, KT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((k_gf2w_recombine_tab<LIMBS, K>), dim3(grid), dim3(BLOCK), lds, st, f, ra,
+    hipLaunchKernelGGL((k_gf2w_recombine_tab<LIMBS, KT>), dim3(grid ? grid : 1), dim3(REC_BLOCK), lds, st, f, ra,
                        (typename Tr::E*)out, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
 }
 
-// k rows (1..9), one output row; limbs selects GF2W64 / GF2W128.  Returns 2 if the shape is not covered.
-int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
-                                int k, void* out, size_t n, hipStream_t st) {
-#define GF2W_REC_CASE(KK)                                                                                        \
-    case KK:                                                                                                     \
-        return limbs == 2 ? launch_gf2w_rec<2, KK>(policy, device, rows, lam2, out, n, st)                       \
-                          : launch_gf2w_rec<1, KK>(policy, device, rows, lam2, out, n, st);
-    switch (k) {
-        GF2W_REC_CASE(1) GF2W_REC_CASE(2) GF2W_REC_CASE(3) GF2W_REC_CASE(4) GF2W_REC_CASE(5)
+template <int LIMBS>
+static int dispatch_gf2w_rec(const void* policy, int device, const void* const* rows, const uint64_t* lam2, int k, void* out,
+                             size_t n, hipStream_t st) {
+    Gf2wRecArgs<LIMBS> ra;
+    memset(&ra, 0, sizeof(ra));
+    int kt = 0;
+    for (int j = 0; j < k; ++j) {
+        const uint64_t lo = lam2[2 * j], hi = lam2[2 * j + 1];
+        if (lo == 0 && hi == 0) continue;                                  // coefficient 0: the row does not contribute
+        if (lo == 1 && hi == 0) { ra.prow[ra.kp++] = rows[j]; continue; }  // coefficient 1: plain XOR
+        ra.trow[kt] = rows[j];
+        ra.lam_lo[kt] = lo;
+        ra.lam_hi[kt] = hi;
+        ++kt;
+    }
+#define GF2W_REC_CASE(KK) case KK: return launch_gf2w_rec<LIMBS, KK>(policy, device, ra, out, n, st);
+    switch (kt) {
+        GF2W_REC_CASE(0) GF2W_REC_CASE(1) GF2W_REC_CASE(2) GF2W_REC_CASE(3) GF2W_REC_CASE(4) GF2W_REC_CASE(5)
         GF2W_REC_CASE(6) GF2W_REC_CASE(7) GF2W_REC_CASE(8) GF2W_REC_CASE(9)
         default: return 2;
     }
 #undef GF2W_REC_CASE
+}
+
+// k rows (1..9), one output row; limbs selects GF2W64 / GF2W128.  Returns 2 if the shape is not covered.
+int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
+                                int k, void* out, size_t n, hipStream_t st) {
+    if (k < 1 || k > REC_MAXK) return 2;
+    return limbs == 2 ? dispatch_gf2w_rec<2>(policy, device, rows, lam2, k, out, n, st)
+                      : dispatch_gf2w_rec<1>(policy, device, rows, lam2, k, out, n, st);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst,

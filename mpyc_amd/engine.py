@@ -679,6 +679,19 @@ class FieldContext:
         torch.cuda.current_stream().synchronize()
         return stage[:flat.numel()].numpy()
 
+    def upload_bytes(self, data, dtype: torch.dtype, shape) -> torch.Tensor:
+        """Host bytes (any buffer: a message off the wire) -> device tensor of `dtype` / `shape`: ONE host copy into
+        the pinned staging buffer, then an asynchronous copy at PCIe speed (a pageable source costs an extra pass
+        and transfers at a fraction of that rate)."""
+        src = np.frombuffer(data, dtype=np.uint8)
+        nbytes = src.size
+        stage = self._stage(nbytes)
+        stage[:nbytes].numpy()[:] = src
+        dev = torch.empty(nbytes, dtype=torch.uint8, device=self.torch_device)
+        dev.copy_(stage[:nbytes], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()        # the staging buffer is reused by the next transfer
+        return dev.view(dtype).reshape(shape)
+
     def shake128_streams(self, msgs: Sequence[bytes], out_len: int, threads: int = 0) -> List[torch.Tensor]:
         """SHAKE128(msg).digest(out_len) for every msg, expanded in parallel on host threads into pinned
         buffers (libffgpu's ffgpu_shake128_expand) and uploaded: the XOF streams of a PRSS call

@@ -1701,6 +1701,15 @@ class FieldArray:
         n = len(data) // r
         if shape is not None and int(np.prod(shape, dtype=np.int64)) != n:
             raise ValueError(f'{n} elements on the wire do not fill shape {tuple(shape)}')
+        if r == eb and n:
+            # the usual case (64-, 96-, 128-, 192-bit fields): the wire bytes ARE the limb layout -- one copy into the
+            # pinned staging buffer, one transfer, no NumPy intermediates
+            from .engine import _torch_dtype
+            t = ctx.upload_bytes(data, _torch_dtype(eb), (n, ctx.limbs) if ctx.limbs else (n,))
+            dev = DevArray(ctx, t, n)
+            if check:
+                dev = ctx.reduce(dev, out=dev)
+            return cls._wrap(dev, shape if shape is not None else (n,))
         b = np.frombuffer(data, dtype=np.uint8).reshape(n, r)
         if r < eb:
             b = np.concatenate([b, np.zeros((n, eb - r), dtype=np.uint8)], axis=1)

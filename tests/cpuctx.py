@@ -218,6 +218,9 @@ class CpuFieldContext(engine.FieldContext):
     def download_bytes(self, t):
         return t.contiguous().view(torch.uint8).reshape(-1).numpy()
 
+    def upload_bytes(self, data, dtype, shape):
+        return torch.frombuffer(bytearray(data), dtype=torch.uint8).view(dtype).reshape(shape)
+
     def shake128_streams(self, msgs, out_len, threads=0):
         return [torch.frombuffer(bytearray(hashlib.shake_128(mg).digest(out_len)), dtype=torch.uint8) if out_len
                 else torch.empty(0, dtype=torch.uint8) for mg in msgs]

@@ -303,6 +303,31 @@ def test_binary_fields_dense_and_small(eng, coracle):
         assert (rec.to_numpy() == want).all(), hex(mod)
 
 
+def test_wide_binary_products_all_degrees(eng, coracle):
+    """GF(2^n), 33 <= n <= 128, sparse moduli: element-wise products at every degree around the word and top-bit
+    boundaries, extreme and random operands, in place, against the oracle."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    for deg in (33, 40, 60, 61, 62, 63, 64, 65, 96, 100, 124, 125, 126, 127, 128):
+        mod = int(BinaryPolynomial.next_irreducible(1 << deg))
+        assert mod.bit_length() - 1 == deg
+        F = po.Field(mod, True)
+        ctx = ctx_for(eng, mod, True)
+        eb = ctx.elem_bytes
+        cf = coracle.CField(mod, True)
+        n = 16384 + 4099
+        A, B = rand_np(F, eb, n, 700 + deg), rand_np(F, eb, n, 800 + deg)
+        top = pack([F.order - 1, F.order >> 1, (F.order >> 1) | 1, 7 << (deg - 3), 5 << (deg - 3), 1 << (deg - 1)], eb)
+        A[100:100 + len(top)] = top
+        B[100:100 + len(top)] = top[::-1]
+        A[200:200 + len(top)] = top
+        B[200:200 + len(top)] = top
+        dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+        want = cf.ew(coracle.MUL, A, B)
+        assert (ctx.mul(dA, dB).to_numpy() == want).all(), (deg, hex(mod))
+        ctx.mul(dA, dB, out=dA)                                    # in place
+        assert (dA.to_numpy() == want).all(), deg
+
+
 def test_wide_binary_recombination_tables(eng, coracle):
     """GF(2^n), 9 <= n <= 128: recombination of large arrays goes through per-workgroup nibble tables of
     the Lagrange coefficients (k_gf2w_recombine_tab); same bits as the plain kernel and the oracle."""
@@ -327,6 +352,17 @@ def test_wide_binary_recombination_tables(eng, coracle):
         lam = [random.Random(9).randrange(F.order) for _ in range(6)]
         out = ctx.recombine([ctx.from_numpy(r) for r in rows], lam, w=2)
         assert (out.to_numpy() == cf.recombine(rows, lam, w=2)).all()
+        # coefficients 1 are XORed in without a table, coefficients 0 dropped: all-ones (the parties 1..7 / 1..3 at
+        # x = 0: thresha._recombination_vector gives [1, ..., 1] over GF(2^n)), mixes, and the all-zero vector
+        rows = [rand_np(F, eb, n, 450 + j) for j in range(7)]
+        dev_rows = [ctx.from_numpy(r) for r in rows]
+        dense = random.Random(10).randrange(2, F.order)
+        for lam in (po.recombination_vector(F, [1, 2, 3, 4, 5, 6, 7], 0), [1, 0, dense, 1, 0, 1, dense ^ 1], [0] * 7,
+                    [0, 0, 0, 0, 0, 0, 1], [dense] + [0] * 6):
+            got = ctx.recombine(dev_rows, lam).to_numpy()
+            assert (got == cf.recombine(rows, lam)).all(), (hex(mod), lam)
+        assert po.recombination_vector(F, [1, 2, 3, 4, 5, 6, 7], 0) == [1] * 7
+        assert po.recombination_vector(F, [3, 1, 2], 0) == [1] * 3
 
 
 @pytest.mark.parametrize('modulus,binary', FIELDS)
