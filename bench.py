@@ -843,8 +843,18 @@ def main():
                     plans = [cb_.recombine_plan([shb[i_].row(j) for j in range(kk)], lamb, bufs[i_][2]) for i_ in range(2)]
                     ms = time_launches(lambda pl: pl(), plans, reps)
                     bpu = (kk + 1) * ebg
-                    kern[f'recombine_{label}_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu, bound_note='LDS tables / ALU',
-                                                            units_per_s=round(n / (ms * 1e-3), 1))
+                    kern[f'recombine_{label}_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                            bound_note='Lagrange coefficients of parties 1..k at 0 (all ones for k = 7: '
+                                                                       'plain XOR of the rows); LDS nibble tables for dense ones',
+                                                            coefficients=[hex(v) for v in lamb][:4], units_per_s=round(n / (ms * 1e-3), 1))
+                    # worst case for the same shape: k dense (random) coefficients -> every row goes through the LDS tables
+                    import random as _rnd
+                    lamd = [_rnd.Random(1000 + kk).randrange(2, 1 << (8 * ebg)) for _ in range(kk)]
+                    plans = [cb_.recombine_plan([shb[i_].row(j) for j in range(kk)], lamd, bufs[i_][2]) for i_ in range(2)]
+                    ms = time_launches(lambda pl: pl(), plans, reps)
+                    kern[f'recombine_{label}_k{kk}_dense'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,
+                                                                  bound_note='LDS tables (16 B x 32 look-ups per row) + VALU',
+                                                                  units_per_s=round(n / (ms * 1e-3), 1))
                 cb_.split(bufs[0][0], cfb, t2, m2, out=shb[0])
                 lamb = [int(v) for v in gth._recombination_vector(Fb, tuple(range(1, t2 + 2)), 0)]
                 if not torch.equal(cb_.recombine([shb[0].row(j) for j in range(t2 + 1)], lamb).t, bufs[0][0].t):

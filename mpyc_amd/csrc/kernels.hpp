@@ -891,13 +891,62 @@ struct ExpArgs {
     int nbits;       // bit length of the exponent (>= 1)
 };
 
-// left-to-right square and multiply, exponent wave-uniform (scalar branch per bit)
+// a^e for a public (wave-uniform) exponent e >= 1: left-to-right SLIDING WINDOWS of up to 4 bits over the odd powers
+// a, a^3, ..., a^15 (one squaring + 7 products to build them), so a run of set bits costs one product per 4 bits
+// instead of one per bit -- the inversion exponent q - 2 of the default primes is almost all ones: 2^61 - 3 takes
+// 60 squarings + 23 products instead of 60 + 59.  Every branch is on the exponent (scalar); the table lives in
+// registers and is selected by a uniform switch (no dynamic register indexing, no scratch).  Short exponents
+// (nbits <= 4: squares, cubes, the Legendre-free cases) skip the table.
 template <class F>
 __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
-    typename F::word r = a;
-    for (int i = ex.nbits - 2; i >= 0; --i) {
-        r = f.mul(r, r);
-        if ((ex.e[i >> 6] >> (i & 63)) & 1) r = f.mul(r, a);
+    typedef typename F::word W;
+    auto bit = [&](int i) -> uint32_t { return (uint32_t)(ex.e[i >> 6] >> (i & 63)) & 1u; };
+    int ones = 0;
+    for (int q = 0; q < 3; ++q) ones += __builtin_popcountll(ex.e[q]);
+    if (ex.nbits <= 4 || ones <= 8 + ex.nbits / 8) {      // few set bits (e.g. (p+1)/4 = 2^59): plain square-and-multiply
+        W r = a;
+        for (int i = ex.nbits - 2; i >= 0; --i) {
+            r = f.mul(r, r);
+            if (bit(i)) r = f.mul(r, a);
+        }
+        return r;
+    }
+    const W a2 = f.mul(a, a);
+    const W t1 = a, t3 = f.mul(t1, a2), t5 = f.mul(t3, a2), t7 = f.mul(t5, a2), t9 = f.mul(t7, a2), t11 = f.mul(t9, a2),
+            t13 = f.mul(t11, a2), t15 = f.mul(t13, a2);
+    auto odd = [&](uint32_t v) -> W {            // v odd, 1..15, wave-uniform
+        switch (v >> 1) {
+            case 0: return t1;
+            case 1: return t3;
+            case 2: return t5;
+            case 3: return t7;
+            case 4: return t9;
+            case 5: return t11;
+            case 6: return t13;
+            default: return t15;
+        }
+    };
+    W r = a;
+    bool first = true;
+    int i = ex.nbits - 1;
+    while (i >= 0) {
+        if (!bit(i)) {                           // (never taken before the first window: the top bit is set)
+            r = f.mul(r, r);
+            --i;
+            continue;
+        }
+        int j = i - 3 > 0 ? i - 3 : 0;
+        while (!bit(j)) ++j;                     // the window ends on a set bit: its value is odd
+        uint32_t v = 0;
+        for (int q = i; q >= j; --q) v = (v << 1) | bit(q);
+        if (first) {
+            r = odd(v);
+            first = false;
+        } else {
+            for (int q = i; q >= j; --q) r = f.mul(r, r);
+            r = f.mul(r, odd(v));
+        }
+        i = j - 1;
     }
     return r;
 }
@@ -924,51 +973,103 @@ __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __re
 }
 
 // ---- out = a^-1, batched (finfields.py:1278-1281, :1416-1422) ----------------------------------
-// Montgomery's trick inside each thread: CH packs -> prefix products, ONE exponentiation by q-2,
-// back-substitution: 3 multiplications per element + (1.5 log2 q)/(CH*N).  Zero inputs give zero
-// and set *flag (the reference raises ZeroDivisionError; the host wrapper checks the flag).
-template <class F, int CH, bool NT>
+// Montgomery's trick inside each thread over G independent groups of CH packs: prefix products per group (G chains
+// the scheduler interleaves), ONE exponentiation by q-2 of the product of the group totals (sliding windows: 83
+// products for a 61-bit prime), the groups' inverses from it, back-substitution per group:
+// 3 multiplications per element + (pow + 3 G) / (G CH N).  Only the PREFIX products are kept in registers; the
+// operands themselves are read a second time for the back-substitution (they come back from L2 / the Infinity Cache:
+// a thread re-reads what it read a few microseconds earlier; HBM traffic stays one read and one write per element),
+// which halves the register footprint and lets one exponentiation serve twice as many elements.
+// Zero inputs give zero and set *flag (the reference raises ZeroDivisionError; the host wrapper checks the flag): one
+// bit per element in a 64-bit mask, and the patch-up of the outputs is skipped by a scalar branch unless some lane of
+// the wave met a zero.
+template <class F, int CH, int G, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
                                                       int* __restrict__ flag) {
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
+    static_assert(CH * G * P::N <= 64, "zero mask has 64 bits");
     const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
     MP* __restrict__ ov = reinterpret_cast<MP*>(o);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     uint32_t anyzero = 0;
-    for (size_t i0 = gid; i0 < nvec; i0 += gsz * CH) {
-        W x[CH][P::N], pre[CH][P::N];
-        uint32_t zm[CH][P::N];
-        W run = ff_one(f);
+    for (size_t i0 = gid; i0 < nvec; i0 += gsz * (CH * G)) {
+        W pre[G][CH][P::N], tot[G];
+        uint64_t zbits = 0;                     // bit ((g * CH + c) * N + q): that operand was zero
+#pragma unroll
+        for (int g = 0; g < G; ++g) tot[g] = ff_one(f);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            size_t j = i0 + (size_t)c * gsz;
-            P t_;
-            if (j < nvec) t_ = ldg<NT>(av + j);
 #pragma unroll
-            for (int q = 0; q < P::N; ++q) {
-                W v = (j < nvec) ? t_.w[q] : ff_one(f);
-                v = ff_zero_fix(f, v, zm[c][q]);
-                anyzero |= (j < nvec) ? zm[c][q] : 0u;
-                x[c][q] = v;
-                pre[c][q] = run;            // product of everything BEFORE this element
-                run = f.mul(run, v);
+            for (int g = 0; g < G; ++g) {
+                const size_t j = i0 + (size_t)(g * CH + c) * gsz;
+                P t_;
+                if (j < nvec) t_ = ldg<false>(av + j);      // (kept cacheable: read again below)
+#pragma unroll
+                for (int q = 0; q < P::N; ++q) {
+                    uint32_t zq;
+                    W v = (j < nvec) ? t_.w[q] : ff_one(f);
+                    v = ff_zero_fix(f, v, zq);
+                    if constexpr (F::EPW > 1) {
+                        // packed sub-elements: keep the per-byte mask of this word (at most 4 words per thread here)
+                        zbits |= (uint64_t)zq << (8 * (((g * CH + c) * P::N + q) & 7));
+                        static_assert(F::EPW == 1 || CH * G * P::N <= 8, "packed fields: 8 words per batch");
+                    } else {
+                        zbits |= (uint64_t)(zq & 1u) << ((g * CH + c) * P::N + q);
+                    }
+                    pre[g][c][q] = tot[g];      // product of everything BEFORE this element in its group
+                    tot[g] = f.mul(tot[g], v);
+                }
             }
         }
-        W inv = ff_pow(f, run, ex);         // (prod of all)^-1
+        anyzero |= zbits != 0;
+        W all = tot[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) all = f.mul(all, tot[g]);
+        const W inv_all = ff_pow(f, all, ex);   // (product of all)^-1
+        W ginv[G];
+        if constexpr (G == 1) {
+            ginv[0] = inv_all;
+        } else if constexpr (G == 2) {
+            ginv[0] = f.mul(inv_all, tot[1]);
+            ginv[1] = f.mul(inv_all, tot[0]);
+        } else {
+            W suf = tot[G - 1], acc = inv_all, sufs[G];
+#pragma unroll
+            for (int g = G - 2; g >= 0; --g) {
+                sufs[g] = suf;                  // product of the totals AFTER g
+                suf = f.mul(suf, tot[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ginv[g] = g == G - 1 ? acc : f.mul(acc, sufs[g]);
+                acc = f.mul(acc, tot[g]);       // inv_all * product of the totals up to g
+            }
+        }
+        const bool wave_has_zero = __any(zbits != 0);
 #pragma unroll
         for (int c = CH - 1; c >= 0; --c) {
-            size_t j = i0 + (size_t)c * gsz;
-            P r;
 #pragma unroll
-            for (int q = P::N - 1; q >= 0; --q) {
-                r.w[q] = ff_zero_apply(f, f.mul(inv, pre[c][q]), zm[c][q]);
-                inv = f.mul(inv, x[c][q]);
+            for (int g = 0; g < G; ++g) {
+                const size_t j = i0 + (size_t)(g * CH + c) * gsz;
+                P t_, r;
+                if (j < nvec) t_ = ldg<NT>(av + j);         // second read of the operands (cache hit)
+#pragma unroll
+                for (int q = P::N - 1; q >= 0; --q) {
+                    W v = (j < nvec) ? t_.w[q] : ff_one(f);
+                    r.w[q] = f.mul(ginv[g], pre[g][c][q]);
+                    if (wave_has_zero) {                     // scalar branch: rare
+                        uint32_t zq;
+                        v = ff_zero_fix(f, v, zq);
+                        r.w[q] = ff_zero_apply(f, r.w[q], zq);
+                    }
+                    ginv[g] = f.mul(ginv[g], v);
+                }
+                if (j < nvec) stg<NT>(ov + j, r);
             }
-            if (j < nvec) stg<NT>(ov + j, r);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -2802,10 +2903,12 @@ struct Launchers {
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && al(out);
         size_t nvec = vec ? n / EPV : 0;
-        constexpr int CH = sizeof(W) == 16 ? 8 : 8;   // packs per thread
-        size_t iters = nvec ? (nvec + CH - 1) / CH : n;
+        // packs per thread: ONE exponentiation (83 products for a 61-bit prime) is shared by G x CH packs, and the
+        // 2 x G x CH x N operand / prefix words stay in registers
+        constexpr int CH = F::EPW > 1 ? 2 : 8, G = (F::EPW > 1 || sizeof(W) > 8) ? 1 : 2;     // packed bytes: 8 words per batch (zero mask)
+        size_t iters = nvec ? (nvec + CH * G - 1) / (CH * G) : n;
         unsigned grid = grid_for(iters, lc);
-        hipLaunchKernelGGL((k_inv_batch<F, CH, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out,
+        hipLaunchKernelGGL((k_inv_batch<F, CH, G, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out,
                            nvec, n, flag);
         FFGPU_CHECK_LAUNCH();
         return 0;

@@ -856,8 +856,8 @@ struct Gf2wRecArgs {
     int kp;
 };
 
-template <int LIMBS, int KT>
-__global__ __launch_bounds__(REC_BLOCK) void k_gf2w_recombine_tab(typename Gf2wTraits<LIMBS>::F f, Gf2wRecArgs<LIMBS> ra,
+template <int LIMBS, int KT, bool DEEP>      // DEEP: register budget of 4 waves per SIMD -> whole batches of look-ups in flight
+__global__ __launch_bounds__(REC_BLOCK) __attribute__((amdgpu_waves_per_eu(DEEP ? 4 : 1, DEEP ? 4 : 8))) void k_gf2w_recombine_tab(typename Gf2wTraits<LIMBS>::F f, Gf2wRecArgs<LIMBS> ra,
                                                                    typename Gf2wTraits<LIMBS>::E* __restrict__ out, size_t n) {
     typedef Gf2wTraits<LIMBS> Tr;
     typedef typename Tr::L L;
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(REC_BLOCK) void k_gf2w_recombine_tab(typename Gf2wT
     }
 }
 
-template <int LIMBS, int KT>
+template <int LIMBS, int KT, bool DEEP>
 static int launch_gf2w_rec(const void* policy, int device, const Gf2wRecArgs<LIMBS>& ra, void* out, size_t n, hipStream_t st) {
     typedef Gf2wTraits<LIMBS> Tr;
     const typename Tr::F& f = *reinterpret_cast<const typename Tr::F*>(policy);
@@ -989,12 +989,12 @@ static int launch_gf2w_rec(const void* policy, int device, const Gf2wRecArgs<LIM
     if (lds > 48 * 1024) {
         static bool raised = false;     // per instantiation: allow more than the default dynamic LDS
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gf2w_recombine_tab<LIMBS, KT>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gf2w_recombine_tab<LIMBS, KT, DEEP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((k_gf2w_recombine_tab<LIMBS, KT>), dim3(grid ? grid : 1), dim3(REC_BLOCK), lds, st, f, ra,
+    hipLaunchKernelGGL((k_gf2w_recombine_tab<LIMBS, KT, DEEP>), dim3(grid ? grid : 1), dim3(REC_BLOCK), lds, st, f, ra,
                        (typename Tr::E*)out, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
@@ -1015,7 +1015,11 @@ static int dispatch_gf2w_rec(const void* policy, int device, const void* const* 
         ra.lam_hi[kt] = hi;
         ++kt;
     }
-#define GF2W_REC_CASE(KK) case KK: return launch_gf2w_rec<LIMBS, KK>(policy, device, ra, out, n, st);
+    static const bool deep = !(getenv("FFGPU_GF2W_REC_DEEP") && atoi(getenv("FFGPU_GF2W_REC_DEEP")) == 0);
+#define GF2W_REC_CASE(KK)                                                                         \
+    case KK:                                                                                      \
+        return deep && KK > 0 ? launch_gf2w_rec<LIMBS, KK, true>(policy, device, ra, out, n, st)  \
+                              : launch_gf2w_rec<LIMBS, KK, false>(policy, device, ra, out, n, st);
     switch (kt) {
         GF2W_REC_CASE(0) GF2W_REC_CASE(1) GF2W_REC_CASE(2) GF2W_REC_CASE(3) GF2W_REC_CASE(4) GF2W_REC_CASE(5)
         GF2W_REC_CASE(6) GF2W_REC_CASE(7) GF2W_REC_CASE(8) GF2W_REC_CASE(9)

@@ -525,12 +525,42 @@ class HostView(np.ndarray):
 
     __array_priority__ = 0
 
-    lazy_min = None     # None: `.value` is lazy only when read by the runtime's three hot-path methods (below) and
+    lazy_min = None     # None: `.value` is lazy only when read by a registered reader (below) and
     #                     carries the REAL values in its buffer everywhere else, so that it behaves like the
     #                     reference's ndarray in every context, including C-level ones that no Python hook can
     #                     intercept (`b[mask] = x.value`, runtime.py:1285).  An int: also lazy from that size on.
-    lazy_callers = frozenset(('_reshare', 'output', '_distribute'))     # runtime.py:643, 561, 494: `.value` is only
-    #                     reshaped, handed to thresha and pickled there
+    # Readers for which `.value` may stay on the device: CODE OBJECTS, registered explicitly
+    # (register_lazy_reader).  Under install() these are the reference runtime's three hot-path coroutines
+    # (runtime.py:643 _reshare, :561 output, :494 _distribute), where `.value` is only reshaped, handed to thresha
+    # and pickled; they are looked up on the imported mpyc.runtime module itself, so a user function that happens to
+    # carry one of those names -- in whatever file -- never gets the lazy view, and a renamed upstream method simply
+    # is not registered (the view is then materialised: slower, never wrong).
+    lazy_codes = set()
+    _runtime_scanned = False
+    RUNTIME_LAZY_READERS = ('_reshare', 'output', '_distribute')
+
+    @classmethod
+    def register_lazy_reader(cls, func):
+        """Declare that `func` (a function / coroutine function, possibly wrapped by decorators that set
+        __wrapped__) only reshapes `.value`, passes it to thresha / the array constructor, or pickles it."""
+        import inspect
+        code = getattr(inspect.unwrap(func), '__code__', None)
+        if code is None:
+            raise TypeError('register_lazy_reader needs a Python function')
+        cls.lazy_codes.add(code)
+
+    @classmethod
+    def _scan_runtime(cls):
+        """Once mpyc.runtime has been imported (importing it here would parse sys.argv and start a runtime), register
+        its hot-path readers.  Called from FieldArray.value until the module shows up."""
+        rt = sys.modules.get('mpyc.runtime')
+        if rt is None or not hasattr(rt, 'Runtime'):
+            return
+        cls._runtime_scanned = True
+        for name in cls.RUNTIME_LAZY_READERS:
+            fn = getattr(rt.Runtime, name, None)
+            if fn is not None:
+                cls.register_lazy_reader(fn)
 
     def __new__(cls, fa, lazy=None):
         if lazy is None:
@@ -826,8 +856,9 @@ class FieldArray:
         BinaryPolynomial objects for GF(2^n)) as a lazy HostView: shape / reshape / pickling / being handed back to
         thresha or the array ctor stay on the device; any other use materialises the object ndarray once
         (read-only snapshot)."""
-        code = sys._getframe(1).f_code
-        if code.co_name in HostView.lazy_callers and code.co_filename.endswith('runtime.py'):
+        if not HostView._runtime_scanned:
+            HostView._scan_runtime()
+        if HostView.lazy_codes and sys._getframe(1).f_code in HostView.lazy_codes:
             return HostView(self, lazy=True)
         return HostView(self)
 
