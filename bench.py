@@ -974,31 +974,47 @@ def main():
 
                 def opened(mtx):
                     return protocols.open_(ctx8, F8, [mtx.row(i_) for i_ in range(3)], 1).t
-                res = protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8)
-                if not torch.equal(opened(res), want8):
-                    raise SystemExit('bench parity check failed for the secure S-box layer')
-                del res
+                VALU_PEAK = 256 * 4 * 16 * 2.4e9           # lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+                for fused_ in (True, False):
+                    res = protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8, fused=fused_)
+                    if not torch.equal(opened(res), want8):
+                        raise SystemExit(f'bench parity check failed for the secure S-box layer (fused={fused_})')
+                    del res
+                # (a) ONE kernel for the whole layer (ffgpu_gf256_sbox_layer): the parties' shares of four bytes travel
+                # through the 11 gates, the opening and the affine fold in registers.  HBM traffic 10 m = 30 B per secure
+                # byte; the kernel is bound by VALU work (ChaCha20 for 33 coefficient words + 33 GF(2^8) products per 4
+                # bytes, ~970 lane-operations per secure byte, profiles/r03_sbox_layer.md), so both fractions are given
                 ms = time_launches(lambda s_: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
-                # algorithmic bytes per secure byte, all 3 parties (t = 1, k = 3 senders): x^254 as 11 chain gates, each
-                # sender reading its factors as 1 (plain share) or 3 (pending sub-shares) rows and writing 3 rows:
-                # (4+6+6+7+6+6+7+6+9+9+6) x 3 = 216; opening the masked value from 2 parties: 6 rows + 16 bit shares
-                # + 1 = 23; bits + affine map + recomposition: (1 + 8 + 1) x 3 = 30
+                ops_per_byte = 970.0
+                kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(
+                    roof(30 * n8, ms), algorithmic_bytes_per_unit=30, units_per_s=round(n8 / (ms * 1e-3), 1), kernels_per_layer=1,
+                    bound='valu', valu_lane_ops_per_unit=ops_per_byte,
+                    valu_frac=round(ops_per_byte * n8 / (ms * 1e-3) / VALU_PEAK, 4),
+                    hbm_frac_at_unfused_269B=round(269 * n8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    note='frac = HBM fraction for the 30 B the fused kernel moves; hbm_frac_at_unfused_269B = the same time priced at the '
+                         '269 B per secure byte of the 13-kernel composition (the accounting of rounds 1-2)')
+                # (b) the 13-launch composition (11 batched chain gates + masked opening + bits/affine/fold), 269 B per secure
+                # byte: (4+6+6+7+6+6+7+6+9+9+6) x 3 = 216 for the gates, 23 for the opening, 30 for the fold
                 bpu = 269
-                kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
-                                                             units_per_s=round(n8 / (ms * 1e-3), 1),
-                                                             kernels_per_layer=13)
+                ms = time_launches(lambda s_: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8, fused=False), [0], 5 if n8 < 10**8 else 2)
+                kern[f'secure_sbox_layer_m3t1_{tag}_13_kernels'] = dict(roof(bpu * n8, ms), algorithmic_bytes_per_unit=bpu,
+                                                                        units_per_s=round(n8 / (ms * 1e-3), 1), kernels_per_layer=13)
                 if n8 <= 10**6:
-                    # the same layer captured once in a HIP graph (device-resident generator state: fresh
+                    # the same layers captured once in a HIP graph (device-resident generator state: fresh
                     # randomness on every replay) -- the launch-bound regime is where graphs pay
-                    st8 = ctx8.rng_state()
-                    cg8 = CapturedLaunches(lambda: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8, rng=st8))
-                    cg8.replay()
-                    if not torch.equal(opened(cg8.result), want8):
-                        raise SystemExit('bench parity check failed for the graph-replayed secure S-box layer')
-                    msg = time_launches(lambda s_: cg8.replay(), [0], 20)
-                    kern[f'secure_sbox_layer_m3t1_{tag}_hipgraph'] = dict(roof(bpu * n8, msg), algorithmic_bytes_per_unit=bpu,
-                                                                           units_per_s=round(n8 / (msg * 1e-3), 1))
-                    del cg8
+                    for fused_, key_ in ((True, f'secure_sbox_layer_m3t1_{tag}_hipgraph'), (False, f'secure_sbox_layer_m3t1_{tag}_13_kernels_hipgraph')):
+                        st8 = ctx8.rng_state()
+                        cg8 = CapturedLaunches(lambda: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8, rng=st8, fused=fused_))
+                        cg8.replay()
+                        if not torch.equal(opened(cg8.result), want8):
+                            raise SystemExit('bench parity check failed for the graph-replayed secure S-box layer')
+                        msg = time_launches(lambda s_: cg8.replay(), [0], 20)
+                        bb = 30 if fused_ else 269
+                        kern[key_] = dict(roof(bb * n8, msg), algorithmic_bytes_per_unit=bb, units_per_s=round(n8 / (msg * 1e-3), 1))
+                        if fused_:
+                            kern[key_].update(bound='valu', valu_frac=round(ops_per_byte * n8 / (msg * 1e-3) / VALU_PEAK, 4),
+                                              hbm_frac_at_unfused_269B=round(269 * n8 / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                        del cg8
                     # one launch per party and step (what each MPyC party does in its own process): 49 launches, 345 B
                     xl, rl = [xs.row(i_) for i_ in range(3)], [rbits.row(i_) for i_ in range(3)]
                     ms = time_launches(lambda s_: protocols.sbox_layer(ctx8, F8, xl, rl, 1, A8, B8), [0], 5)

@@ -368,6 +368,23 @@ int ffgpu_gf256_bits_affine_fold(ffgpu_ctx* ctx, const uint64_t* host_matrix, co
                                  const void* rbits, size_t rbits_batch_stride, void* out, size_t out_batch_stride, size_t n,
                                  int nbatch, void* stream);
 
+/* The WHOLE secure AES S-box layer (demos/np_aes.py:37-43) for all m parties of a computation held on one GPU, in ONE
+ * launch: x^254 by the reference's addition chain (11 secure multiplications: local products of the 2t+1 senders,
+ * re-sharing with coefficients from the device CSPRNG, recombination with host_lambda = the Lagrange vector of the
+ * senders 1..2t+1 at 0; runtime.py:1356-1367, 1096-1141, 603-689), np_to_bits (opening of y + r_modl from parties
+ * 1..t+1 with host_mu, bits + r_bits; runtime.py:4411-4423), the GF(2) affine map host_matrix / host_bias on the bit
+ * shares and np_from_bits.  Everything is element-wise, so a thread carries the m shares of four bytes through the
+ * whole protocol in registers: 10 m bytes of HBM traffic per secure byte instead of the 269 of the per-step kernels.
+ * x / out: m rows of n bytes (row strides in bytes, multiples of 4); rbits: m rows of 8 n bit shares (stride a
+ * multiple of 16).  GF(2^8) only; (m, t) in {(3,1), (4,1), (5,1), (5,2), (7,2), (7,3)}, n a multiple of 4 --
+ * FFGPU_ENOTSUP otherwise (compose the layer from ffgpu_gate_rng_batch / ffgpu_gf256_mask_open /
+ * ffgpu_gf256_bits_affine_fold then).  Randomness: as ffgpu_gate_rng_batch (host key + nonce + rounds, or dev_state
+ * with `nonce` as offset and defer_advance).  Scalars: canonical 2-limb host scalars.                              */
+int ffgpu_gf256_sbox_layer(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, const uint64_t* host_lambda,
+                           const uint64_t* host_mu, int t, int m, const void* x, size_t x_stride, const void* rbits,
+                           size_t rbits_stride, void* out, size_t out_stride, size_t n, const uint8_t* host_key32, uint64_t nonce,
+                           int rounds, void* dev_state, int defer_advance, void* stream);
+
 /* out[h] = A * bits(in[h]^254) + B packed back to a byte, with the 8x8 GF(2)
  * matrix given as 8 row bytes (bit c of host_rows8[r] = A[r][c]) and B as a byte.
  * replaces: demos/np_aes.py:37-43 sbox() evaluated on public values.           */

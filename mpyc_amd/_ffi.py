@@ -86,6 +86,8 @@ _SIGS = {
     'ffgpu_gf256_to_bits': [_vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_gf256_mask_open': [_vp, ctypes.POINTER(_vp), _u64p, _int, ctypes.POINTER(_vp), _u64p, _int, _vp, _sz, _vp],
     'ffgpu_gf256_bits_affine_fold': [_vp, _u64p, _u64p, _vp, _vp, _sz, _vp, _sz, _sz, _int, _vp],
+    'ffgpu_gf256_sbox_layer': [_vp, _u64p, _u64p, _u64p, _u64p, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _sz, ctypes.c_char_p,
+                               ctypes.c_uint64, _int, _vp, _int, _vp],
     'ffgpu_gf256_sbox': [_vp, _vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint8, _vp, _sz, _vp],
     'ffgpu_time_mul': [_vp, _vp, _vp, _vp, _sz, _int, _vp, _fp],
     'ffgpu_time_split': [_vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],

@@ -45,6 +45,11 @@ int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
 int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
                                 int k, void* out, size_t n, hipStream_t st);
+int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, size_t xs, const void* r, size_t rs, void* out,
+                                size_t os, const void* tables_dev, const uint64_t* lam2, const uint64_t* mu2, int t, int m,
+                                size_t n, hipStream_t st, const ffgpu::RngArgs* rng);
+void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, const uint64_t* m2, const uint64_t* bias2,
+                                 unsigned char* out);
 int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable, int device, const void* a,
                               const void* b, void* out, size_t n, hipStream_t st);
 int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, const void* b, void* out, size_t n,
@@ -78,6 +83,10 @@ struct ffgpu_ctx {
     } scratch[8];
     std::mutex* scratch_mu;
     void* gf8_tables_dev;   // device copy of gf8_tables (lazily, for the fused GF(2^n<=8) product)
+    // tables of the fused S-box layer (ffgpu_gf256_sbox_layer) for the last affine map used with this context
+    void* sbl_tables_dev;
+    unsigned char sbl_key[72];
+    int sbl_valid;
     // opt-in timing of the most recent compute call (ffgpu_ctx_set_timing / ffgpu_last_kernel_ms)
     int timing, timed;
     hipEvent_t ev0, ev1;
@@ -331,6 +340,10 @@ int ffgpu_ctx_destroy(ffgpu_ctx* ctx) {
     if (ctx && ctx->gf8_tables_dev) {
         DeviceGuard g(ctx->device);
         (void)hipFree(ctx->gf8_tables_dev);
+    }
+    if (ctx && ctx->sbl_tables_dev) {
+        DeviceGuard g(ctx->device);
+        (void)hipFree(ctx->sbl_tables_dev);
     }
     if (ctx && ctx->acc_made) {
         DeviceGuard g(ctx->device);
@@ -1025,6 +1038,56 @@ int ffgpu_gf256_bits_affine_fold(ffgpu_ctx* ctx, const uint64_t* host_matrix, co
     return launch_status(ffgpu_launch_gf8_bits_affine_fold(ctx->policy, ctx->device, host_matrix, host_bias, c, rbits,
                                                            rbits_batch_stride, out, out_batch_stride, n, nbatch,
                                                            (hipStream_t)stream));
+}
+
+int ffgpu_gf256_sbox_layer(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, const uint64_t* host_lambda,
+                           const uint64_t* host_mu, int t, int m, const void* x, size_t x_stride, const void* rbits,
+                           size_t rbits_stride, void* out, size_t out_stride, size_t n, const uint8_t* host_key32, uint64_t nonce,
+                           int rounds, void* dev_state, int defer_advance, void* stream) {
+    ARGCHK(ctx && host_matrix && host_lambda && host_mu);
+    if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1 || !ctx->gf8_tab_min) return FFGPU_ENOTSUP;
+    ARGCHK(t >= 1 && m >= 2 * t + 1);
+    if (t > 3 || m > 7) return FFGPU_ENOTSUP;
+    ARGCHK(!dev_state || nonce <= 0xffffffffull);
+    RngArgs ra;
+    if (dev_state) {
+        memset(&ra, 0, sizeof(ra));
+        ra.rk.rounds = 20;
+        ra.dev_key = (const RngKey*)dev_state;
+        ra.nonce_off = (uint32_t)nonce;
+        ra.no_advance = defer_advance ? 1 : 0;
+    } else {
+        int rc = make_rng(ctx, host_key32, nonce, rounds, &ra);
+        if (rc != FFGPU_OK) return rc;
+    }
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(x && rbits && out && x_stride >= n && out_stride >= n && rbits_stride >= 8 * n);
+    DeviceGuard g(ctx->device);
+    // tables: log / antilog of the field, np_from_bits, affine fold -- cached on the device per (matrix, bias)
+    unsigned char key[72];
+    for (int i = 0; i < 64; ++i) key[i] = (unsigned char)(host_matrix[2 * i] & 0xffu);
+    for (int i = 0; i < 8; ++i) key[64 + i] = host_bias ? (unsigned char)(host_bias[2 * i] & 0xffu) : 0;
+    {
+        static std::mutex mu_;
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!ctx->sbl_tables_dev) {
+            void* d = nullptr;
+            if (hipMalloc(&d, 1536 + 2304 + 2304) != hipSuccess) return FFGPU_ENOMEM;
+            ctx->sbl_tables_dev = d;
+            ctx->sbl_valid = 0;
+        }
+        if (!ctx->sbl_valid || memcmp(key, ctx->sbl_key, sizeof(key)) != 0) {
+            unsigned char host_tables[1536 + 2304 + 2304];
+            ffgpu_gf8_sbox_layer_tables(ctx->policy, ctx->gf8_tables, host_matrix, host_bias, host_tables);
+            // (synchronous copy: not inside a stream capture -- engine.CapturedLaunches warms the call up first)
+            HIPCHK(hipMemcpy(ctx->sbl_tables_dev, host_tables, sizeof(host_tables), hipMemcpyHostToDevice));
+            memcpy(ctx->sbl_key, key, sizeof(key));
+            ctx->sbl_valid = 1;
+        }
+    }
+    LaunchTimer lt(ctx, (hipStream_t)stream);
+    return launch_status(ffgpu_launch_gf8_sbox_layer(ctx->policy, ctx->device, x, x_stride, rbits, rbits_stride, out, out_stride,
+                                                     ctx->sbl_tables_dev, host_lambda, host_mu, t, m, n, (hipStream_t)stream, &ra));
 }
 
 int ffgpu_gf256_sbox(ffgpu_ctx* ctx, const void* in, const uint8_t* host_rows8, uint8_t b, void* out,

@@ -519,6 +519,191 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
     return 0;
 }
 
+// ---- GF(2^8): the WHOLE secure S-box layer of all parties in one kernel (demos/np_aes.py:37-43) ------------------
+// Every step of the layer is element-wise: byte h of the result depends on byte h of the parties' shares and on
+// the 8 bit shares of position h only.  With all m parties of a computation on one GPU a thread can therefore carry
+// the m shares of four bytes (one SWAR word per party) through the entire protocol in registers:
+//   * x^254 by the reference's addition chain (runtime.py:1356-1367): 11 secure multiplications, each = local
+//     products of the k = 2t+1 senders (log/antilog tables in LDS), their re-sharing with t fresh coefficients per
+//     sender and byte from the in-register ChaCha stream, and the recipients' recombination (runtime.py:1096-1141,
+//     603-689).  The recombination is linear, so party j's new share
+//         sum_i lam_i (p_i + sum_q c_iq x_j^q)  =  (sum_i lam_i p_i) + sum_q (sum_i lam_i c_iq) x_j^q
+//     is evaluated in the second form: the same field elements, K + K T constant products instead of K M;
+//   * np_to_bits (runtime.py:4411-4423): c = open(y + r_modl) from the first t+1 parties, bits(c) + r_bits;
+//   * the GF(2) affine map on the bit shares and np_from_bits (np_aes.py:40-42), both as byte-table look-ups.
+// HBM traffic: the m share rows in, the m x 8 bit-share rows in, m rows out = 10 m bytes per secure byte instead of
+// the 269 of the 13-kernel composition, and ONE launch -- the layer is bound by ChaCha and the GF(2^8) products.
+struct Gf8SboxLayerArgs {
+    const uint8_t* x;       // shares of the parties: row j at x + j * xs, n bytes
+    const uint8_t* r;       // their shares of 8 random bits per byte: row j at r + j * rs, 8 n bytes
+    uint8_t* out;           // row j at out + j * os
+    size_t xs, rs, os;
+    const uint8_t* tables;  // device: Gf8Tables (log / antilog), then Gf8ByteTables of np_from_bits, then of the affine fold
+    uint32_t lam[7];        // Lagrange coefficients at 0 of the senders 1..2t+1
+    uint32_t mu[4];         // ... of the opening parties 1..t+1
+};
+enum { SBL_TABLE_BYTES = 1536 + 2304 + 2304 };
+
+template <int M, int T>
+__global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nwords) {
+    constexpr int K = 2 * T + 1;
+    constexpr int NWORDS_RNG = 11 * K * T;                    // keystream words per thread
+    constexpr int NBLK = (NWORDS_RNG + 15) / 16;
+    __shared__ uint32_t lds32[SBL_TABLE_BYTES / 4];
+    for (int i = threadIdx.x; i < SBL_TABLE_BYTES / 4; i += BLOCK) lds32[i] = reinterpret_cast<const uint32_t*>(a.tables)[i];
+    __syncthreads();
+    const uint16_t* lg = reinterpret_cast<const uint16_t*>(lds32);
+    const uint8_t* ex = reinterpret_cast<const uint8_t*>(lds32) + 512;
+    const uint8_t* tbits = reinterpret_cast<const uint8_t*>(lds32) + 1536;
+    const uint8_t* tfold = tbits + 2304;
+    rng_load_state(ra);
+    const int rounds = (int)ra.rk.rounds;
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    // constant product lam * w (lam wave-uniform): Horner over the bits of lam, scalar branches
+    auto cmul = [&](uint32_t lam, uint32_t w) -> uint32_t {
+        GF2P8::acc acc;
+        f.acc_zero(acc);
+        f.acc_mac(acc, lam, w);
+        return f.acc_reduce(acc);
+    };
+    auto tabmul = [&](uint32_t u, uint32_t v) -> uint32_t {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const uint32_t lsum = (uint32_t)lg[(u >> (8 * k8)) & 0xffu] + (uint32_t)lg[(v >> (8 * k8)) & 0xffu];
+            acc |= (uint32_t)ex[lsum] << (8 * k8);
+        }
+        return acc;
+    };
+    for (size_t i = gid; i < nwords; i += gsz) {
+        uint32_t d[M], c[M], e[M];
+        uint4 rb[M][2];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            d[j] = reinterpret_cast<const uint32_t*>(a.x + (size_t)j * a.xs)[i];
+            const uint4* rv = reinterpret_cast<const uint4*>(a.r + (size_t)j * a.rs);
+            rb[j][0] = ldg<true>(rv + 2 * i);
+            rb[j][1] = ldg<true>(rv + 2 * i + 1);
+        }
+        uint32_t ks[16];
+        int kpos = 16, kblk = 0;
+        auto next_word = [&]() -> uint32_t {
+            if (kpos == 16) {
+                const uint64_t ctr = (uint64_t)i * NBLK + (uint64_t)kblk;
+                chacha_block(ra.rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), ra.rk.nonce[0], ra.rk.nonce[1], rounds, ks);
+                ++kblk;
+                kpos = 0;
+            }
+            return ks[kpos++];
+        };
+        // one secure multiplication for all parties: o <- shares of u * v
+        auto gate = [&](const uint32_t (&u)[M], const uint32_t (&v)[M], uint32_t (&o)[M]) {
+            uint32_t P = 0, C[T];
+#pragma unroll
+            for (int q = 0; q < T; ++q) C[q] = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < K; ++s_) {
+                P ^= cmul(a.lam[s_], tabmul(u[s_], v[s_]));
+#pragma unroll
+                for (int q = 0; q < T; ++q) C[q] ^= cmul(a.lam[s_], next_word() & f.emask);
+            }
+            uint32_t res[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                uint32_t h = C[T - 1];
+#pragma unroll
+                for (int q = T - 2; q >= 0; --q) h = f.muladd_small(h, (uint32_t)(j + 1), C[q]);
+                res[j] = f.muladd_small(h, (uint32_t)(j + 1), P);
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) o[j] = res[j];
+        };
+        gate(d, d, c);          // x^2
+        gate(c, c, c);          // x^4
+        gate(c, c, c);          // x^8
+        gate(c, d, c);          // x^9
+        gate(c, c, c);          // x^18
+        gate(c, d, e);          // x^19   (c, d = c*c, c*d: both from the old c)
+        gate(c, c, c);          // x^36
+#pragma unroll
+        for (int j = 0; j < M; ++j) d[j] = e[j];
+        gate(c, d, e);          // x^55
+        gate(c, c, c);          // x^72
+#pragma unroll
+        for (int j = 0; j < M; ++j) d[j] = e[j];
+        gate(c, d, c);          // x^127
+        gate(c, c, c);          // x^254
+        // np_to_bits: open c + r_modl from the first t+1 parties
+        uint32_t opened = 0;
+#pragma unroll
+        for (int p_ = 0; p_ <= T; ++p_) {
+            const uint32_t rmod = gf8_tab_group(tbits, rb[p_][0].x, rb[p_][0].y) | (gf8_tab_group(tbits, rb[p_][0].z, rb[p_][0].w) << 8) |
+                                  (gf8_tab_group(tbits, rb[p_][1].x, rb[p_][1].y) << 16) |
+                                  (gf8_tab_group(tbits, rb[p_][1].z, rb[p_][1].w) << 24);
+            opened ^= cmul(a.mu[p_], c[p_] ^ rmod);
+        }
+        // bits(opened) + r_bits -> affine map -> np_from_bits, per party
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const uint32_t b0 = tfold[2048 + (opened & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].x, rb[j][0].y);
+            const uint32_t b1 = tfold[2048 + ((opened >> 8) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].z, rb[j][0].w);
+            const uint32_t b2 = tfold[2048 + ((opened >> 16) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][1].x, rb[j][1].y);
+            const uint32_t b3 = tfold[2048 + (opened >> 24)] ^ gf8_tab_group(tfold, rb[j][1].z, rb[j][1].w);
+            reinterpret_cast<uint32_t*>(a.out + (size_t)j * a.os)[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+    }
+    rng_state_release(ra);
+}
+
+// tables_dev: SBL_TABLE_BYTES of device memory (the caller caches it per matrix); returns 2 when the shape is not
+// covered (m, t combination, n not a multiple of 4, rows not 4- / 16-byte aligned): the caller composes the layer
+// from the per-step kernels then.
+int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, size_t xs, const void* r, size_t rs, void* out,
+                                size_t os, const void* tables_dev, const uint64_t* lam2, const uint64_t* mu2, int t, int m,
+                                size_t n, hipStream_t st, const RngArgs* rng) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    if (f.n != 8 || (n & 3) || (((uintptr_t)x | (uintptr_t)out | xs | os) & 3) || (((uintptr_t)r | rs) & 15)) return 2;
+    Gf8SboxLayerArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const uint8_t*)x; a.r = (const uint8_t*)r; a.out = (uint8_t*)out;
+    a.xs = xs; a.rs = rs; a.os = os;
+    a.tables = (const uint8_t*)tables_dev;
+    for (int i = 0; i < 2 * t + 1; ++i) a.lam[i] = (uint32_t)(lam2[2 * i] & 0xffu);
+    for (int i = 0; i <= t; ++i) a.mu[i] = (uint32_t)(mu2[2 * i] & 0xffu);
+    RngArgs ra = *rng;
+    const size_t nwords = n / 4;
+    size_t want = (nwords + BLOCK - 1) / BLOCK;
+    if (want < 1) want = 1;
+    if (want > 0x7fffffff) want = 0x7fffffff;
+    const unsigned grid = (unsigned)want;
+    ra.release = (ra.dev_key && !ra.no_advance && grid <= (unsigned)RNG_RELEASE_MAX_GRID) ? 1 : 0;
+#define SBL_CASE(MM, TT)                                                                                      \
+    if (m == MM && t == TT) {                                                                                 \
+        hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nwords);     \
+        FFGPU_CHECK_LAUNCH();                                                                                 \
+        if (ra.dev_key && !ra.release && !ra.no_advance)                                                      \
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u); \
+        return 0;                                                                                             \
+    }
+    SBL_CASE(3, 1) SBL_CASE(4, 1) SBL_CASE(5, 1) SBL_CASE(5, 2) SBL_CASE(7, 2) SBL_CASE(7, 3)
+#undef SBL_CASE
+    (void)device;
+    return 2;
+}
+
+// host: the three tables of the layer in the layout the kernel expects
+void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, const uint64_t* m2, const uint64_t* bias2,
+                                 unsigned char* out) {
+    const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
+    memcpy(out, mul_tables, 1536);
+    Gf8ByteTables tb;
+    gf8_byte_tables(f, nullptr, nullptr, tb);
+    memcpy(out + 1536, &tb, 2304);
+    gf8_byte_tables(f, m2, bias2, tb);
+    memcpy(out + 1536 + 2304, &tb, 2304);
+}
+
 // ---- GF(2^n), n <= 8: multiplication through log / antilog tables in LDS ---------------------
 // c = exp[log a + log b].  log[0] = 2*(q-1) so that any sum involving a zero operand lands in the
 // zero-padded tail of exp[] (no zero test, no select).  Both tables come from the host (built at

@@ -800,6 +800,32 @@ class FieldContext:
                                                         n, rbits.rows, self._stream()), 'gf256_bits_affine_fold')
         return out
 
+    def gf256_sbox_layer(self, X: DevMatrix, R: DevMatrix, t: int, lam: Sequence[int], mu: Sequence[int],
+                         matrix: Sequence[Sequence[int]], bias: Optional[Sequence[int]] = None, key: Optional[bytes] = None,
+                         nonce: int = 0, rounds: int = 20, state: Optional['RngState'] = None,
+                         out: Optional[DevMatrix] = None) -> DevMatrix:
+        """The whole secure S-box layer of np_aes.py:37-43 for all parties in ONE launch (ffgpu_gf256_sbox_layer): X
+        = the parties' shares (one row each), R = their shares of 8 random bits per byte.  Raises
+        NotImplementedError for shapes the fused kernel does not cover (the caller composes the layer from the
+        per-step kernels then)."""
+        import secrets as _secrets
+        m, n = X.rows, X.n
+        if R.rows != m or R.n != 8 * n:
+            raise ValueError('need 8 bit shares per byte and party')
+        out = self._out_matrix(out, m, n)
+        mm = self._scalars([v for row in matrix for v in row])
+        bb = self._scalars(bias) if bias is not None else None
+        if state is None and key is None:
+            key = _secrets.token_bytes(32)
+        defer = 0
+        if state is not None:
+            nonce, defer = state.take_offset(), 1
+        _ffi.check(self._L.ffgpu_gf256_sbox_layer(self._h, mm, bb, self._scalars(lam), self._scalars(mu), t, m, X.ptr, X.stride,
+                                                  R.ptr, R.stride, out.ptr, out.stride, n, key, nonce, rounds,
+                                                  state.ptr if state is not None else None, defer, self._stream()),
+                   'gf256_sbox_layer')
+        return out
+
     def to_bits(self, x: DevArray, addend: Optional[DevArray] = None, out: Optional[DevArray] = None) -> DevArray:
         """GF(2^n<=8): bits of PUBLIC bytes as field elements (8 per byte), plus `addend` (runtime.py:4418-4423)."""
         out = out or self.empty(8 * x.n)

@@ -220,9 +220,12 @@ def _gate_all(ctx: FieldContext, x, y, t: int, m: int, lam, rng):
     return _Block(out, k, lam)
 
 
-def sbox_layer_all(ctx: FieldContext, field, xs, rbits, t: int, A: Sequence[Sequence[int]], B: Sequence[int], rng=None):
+def sbox_layer_all(ctx: FieldContext, field, xs, rbits, t: int, A: Sequence[Sequence[int]], B: Sequence[int], rng=None,
+                   fused: bool = True):
     """sbox_layer() with all parties in every launch (see above): xs / rbits are Shares lists or DevMatrix (one row
-    per party); returns a DevMatrix of the parties' shares of S-box(x).  GF(2^8), t <= 3."""
+    per party); returns a DevMatrix of the parties' shares of S-box(x).  GF(2^8), t <= 3.  fused (default): the
+    whole layer as ONE kernel (ffgpu_gf256_sbox_layer) where it applies; fused=False: the 13-launch composition
+    (11 batched chain gates + masked opening + bits/affine/fold)."""
     from .engine import DevMatrix
     X = xs if isinstance(xs, DevMatrix) else as_matrix(ctx, xs)
     R = rbits if isinstance(rbits, DevMatrix) else as_matrix(ctx, rbits)
@@ -230,6 +233,15 @@ def sbox_layer_all(ctx: FieldContext, field, xs, rbits, t: int, A: Sequence[Sequ
     if m < k or R.rows != m:
         raise ValueError('multiplication needs m >= 2t+1 parties, and bit shares for each of them')
     lam = _lagrange(field, range(1, k + 1))
+    if fused and ctx.elem_bytes == 1:
+        # everything below is element-wise: one kernel carries the parties' shares through the whole layer in registers
+        try:
+            out = ctx.gf256_sbox_layer(X, R, t, lam, _lagrange(field, range(1, t + 2)), A, B, state=rng)
+            if rng is not None:
+                rng.commit()
+            return out
+        except NotImplementedError:
+            pass                                        # shape not covered: per-step kernels
     mul = lambda a, b: _gate_all(ctx, a, b, t, m, lam, rng)
     d = X                                               # x^254 by the reference's addition chain, runtime.py:1356-1367
     c = mul(d, d)

@@ -407,10 +407,13 @@ def test_gf256_mask_open_and_bits_affine_fold_match_the_step_by_step_kernels(mod
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('t,m', [(1, 3), (2, 5), (1, 4), (3, 7)])
-def test_sbox_layer_all_parties_in_one_launch(mods, t, m):
-    """protocols.sbox_layer_all (13 launches: 11 batched chain gates + 2 fused bit-decomposition kernels) opens to
-    the FIPS-197 S-box of every byte value, like the per-party layer."""
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('t,m', [(1, 3), (2, 5), (1, 4), (3, 7), (1, 5), (2, 7), (2, 6)])
+def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
+    """protocols.sbox_layer_all -- fused: the whole layer as ONE kernel (ffgpu_gf256_sbox_layer; shapes it does not
+    cover, here n not a multiple of 4 and (m, t) = (6, 2), fall back); not fused: 13 launches (11 batched chain gates +
+    2 bit-decomposition kernels) -- opens to the FIPS-197 S-box of every byte value, like the per-party layer, from
+    any t+1 parties."""
     engine, finfields, gfpx, protocols = mods
     g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
     F = finfields.GF(gfpx.GFpX(2)(0x11b))
@@ -425,9 +428,15 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m):
         rbits = protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m)
         X = protocols.as_matrix(ctx, xs)
         assert X.t.data_ptr() == xs[0].ptr                                   # a view, not a copy
-        out = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B)
+        out = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, fused=fused)
         shares = [out.row(i) for i in range(m)]
         want = [g['table'][v] for v in x]
+        if fused and n % 4 == 0 and (m, t) != (6, 2):
+            # the one-kernel path really ran: a second call re-shares with fresh randomness inside the chain, but the
+            # OUTPUT shares depend only on the opened masked value and the bit shares -> identical; and the direct call works
+            direct = ctx.gf256_sbox_layer(X, protocols.as_matrix(ctx, rbits), t, protocols._lagrange(F, range(1, 2 * t + 2)),
+                                          protocols._lagrange(F, range(1, t + 2)), A, B)
+            assert torch.equal(direct.t[:, :n], out.t[:, :n])
         assert unpack(protocols.open_(ctx, F, shares, t).to_numpy(), 1) == want
         # any t+1 parties open it, and the shares are not the value itself
         sub = shares[m - t - 1:]
@@ -488,7 +497,16 @@ def test_sbox_layer_all_in_a_hip_graph_deferred_nonce(mods):
     A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
     B = [(g['b'] >> r) & 1 for r in range(8)]
     st = ctx.rng_state()
-    cg = engine.CapturedLaunches(lambda: protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, rng=st))
+    # the one-kernel layer in a graph: one nonce per replay
+    cgf = engine.CapturedLaunches(lambda: protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, rng=st))
+    assert st.pending == 0
+    n0 = st.nonce()
+    for _ in range(3):
+        cgf.replay()
+        torch.cuda.synchronize()
+        assert unpack(protocols.open_(ctx, F, [cgf.result.row(i) for i in range(m)], t).to_numpy(), 1) == [g['table'][v] for v in x]
+    assert st.nonce() == n0 + 3
+    cg = engine.CapturedLaunches(lambda: protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, rng=st, fused=False))
     assert st.pending == 0
     n0 = st.nonce()
     seen = []
