@@ -1059,9 +1059,9 @@ def main():
                                ms_per_launch=kern[dom]['ms_per_launch'],
                                frac_of_measured_copy=round(kern[dom]['achieved'] / kern['device_copy']['achieved'], 4))
         # HBM traffic per launch from PMC counters (collected separately with rocprofv3 --pmc, see
-        # profiles/r02_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
+        # profiles/r03_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
         try:
-            pmc_file = next(f_ for f_ in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+            pmc_file = next(f_ for f_ in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                             if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
             with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                 pmc = json.load(fh)

@@ -18,6 +18,7 @@ that read it directly (runtime.py:561,643,...) or pickle it for the wire.
 from __future__ import annotations
 
 import functools
+import os
 import random as _random
 import sys
 from typing import Optional
@@ -502,7 +503,8 @@ def _src_dev(src) -> DevArray:
 
 
 _POISON = np.array(None, dtype=object)
-_HV_OWN = frozenset(('_fa', '_real', '_is_lazy', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
+_HV_OWN = frozenset(('_fa', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_operand', '_binop', '_shift_left',
+                     '_bits_and', '_outer_src', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
                      '__reduce_ex__', '__setitem__', '__array_function__', '__array_ufunc__', '__array_finalize__',
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
 
@@ -536,18 +538,24 @@ class HostView(np.ndarray):
     # carry one of those names -- in whatever file -- never gets the lazy view, and a renamed upstream method simply
     # is not registered (the view is then materialised: slower, never wrong).
     lazy_codes = set()
+    lazy_codes_prime = set()      # readers that compute with integer operators on `.value`: device-resident for PRIME fields
     _runtime_scanned = False
     RUNTIME_LAZY_READERS = ('_reshare', 'output', '_distribute')
+    # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273: every use of `.value` in these coroutines is a Python-level
+    # operator / NumPy function handled below (audited for v0.11.2); binary fields take their own branches there
+    # (np.vectorize(int) over BinaryPolynomial objects: C-level), so for them `.value` stays materialised
+    RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits')
 
     @classmethod
-    def register_lazy_reader(cls, func):
+    def register_lazy_reader(cls, func, prime_only=False):
         """Declare that `func` (a function / coroutine function, possibly wrapped by decorators that set
-        __wrapped__) only reshapes `.value`, passes it to thresha / the array constructor, or pickles it."""
+        __wrapped__) only reshapes `.value`, passes it to thresha / the array constructor, or pickles it --
+        or, with prime_only, computes on it with the integer operators HostView implements on the device."""
         import inspect
         code = getattr(inspect.unwrap(func), '__code__', None)
         if code is None:
             raise TypeError('register_lazy_reader needs a Python function')
-        cls.lazy_codes.add(code)
+        (cls.lazy_codes_prime if prime_only else cls.lazy_codes).add(code)
 
     @classmethod
     def _scan_runtime(cls):
@@ -561,8 +569,13 @@ class HostView(np.ndarray):
             fn = getattr(rt.Runtime, name, None)
             if fn is not None:
                 cls.register_lazy_reader(fn)
+        if os.environ.get('MPYC_AMD_LAZY_INTS', '1') != '0':
+            for name in cls.RUNTIME_LAZY_READERS_PRIME:
+                fn = getattr(rt.Runtime, name, None)
+                if fn is not None:
+                    cls.register_lazy_reader(fn, prime_only=True)
 
-    def __new__(cls, fa, lazy=None):
+    def __new__(cls, fa, lazy=None, exact=True, thunk=None):
         if lazy is None:
             lazy = cls.lazy_min is not None and fa.size >= cls.lazy_min
         if lazy:
@@ -571,27 +584,183 @@ class HostView(np.ndarray):
             obj = fa._host_value().view(cls)
         obj._fa = fa
         obj._is_lazy = bool(lazy)
+        obj._exact = bool(exact)        # True: the integers ARE the canonical residues in _fa
+        obj._thunk = thunk              # else: () -> the true object ndarray (same NumPy expression on the parents)
+        obj._true = None
+        obj._outer_src = None
         return obj
 
     def __array_finalize__(self, obj):
         pass
 
+    # ---- integer arithmetic that stays on the device (the runtime's protocols: np_trunc, np_to_bits, np_from_bits,
+    #      np_random_bits -- runtime.py:838-873, 4391-4484, 4187-4273) --------------------------------------------
+    # Those protocols compute on `.value` with INTEGER operators (<<, +, -, *, **, sum) and hand the result back to
+    # `field.array(...)`, which reduces it: every such operator is a ring homomorphism onto GF(p), so the device can
+    # compute the RESIDUES and the reduction at the end is already done.  A derived view therefore carries
+    #     _fa      the residues (a device array: what field.array(view) takes, no host round trip),
+    #     _exact   whether the residues ARE the integers (true for `.value` itself, for `% p`, `& mask`, ...),
+    #     _thunk   how to compute the true integers on the host from the parents (the same NumPy expression),
+    # and anything that is not a homomorphism (`&`, `% 2^l`, `>>`, comparisons, printing, iteration, any NumPy function
+    # not handled below) either runs on the device when _exact holds or falls back to the true integers through
+    # _thunk: always the reference's result, never an approximation.  Prime fields only.
     def _real(self) -> np.ndarray:
-        return object.__getattribute__(self, '_fa')._host_value()
+        thunk = object.__getattribute__(self, '_thunk')
+        if thunk is None:
+            return object.__getattribute__(self, '_fa')._host_value()
+        true = object.__getattribute__(self, '_true')
+        if true is None:
+            true = thunk()
+            self._true = true
+        return true
 
     def __getattribute__(self, name):
         if name in _HV_OWN:
             return object.__getattribute__(self, name)
-        return getattr(object.__getattribute__(self, '_fa')._host_value(), name)
+        return getattr(object.__getattribute__(self, '_real')(), name)
+
+    def _dev_ok(self) -> bool:
+        return self._is_lazy and not _fops(type(self._fa).field).binary
+
+    def _derive(self, fa, exact, thunk):
+        return HostView(fa, lazy=True, exact=exact, thunk=thunk)
+
+    def _operand(self, other):
+        """-> (device operand for FieldArray arithmetic, host operand for the thunk) or None"""
+        if isinstance(other, HostView):
+            if type(other._fa).field is not type(self._fa).field:
+                return None
+            return other._fa, other._real
+        if isinstance(other, (int, np.integer)) and not isinstance(other, (bool, np.bool_)):
+            return int(other), (lambda v=int(other): v)
+        if isinstance(other, np.ndarray) and other.dtype.kind in 'iu' and other.size <= (1 << 16):
+            return type(self._fa)(other), (lambda v=other: v)          # small public integer arrays (shifts, masks)
+        return None
+
+    def _binop(self, other, name, reflected=False):
+        opd = self._operand(other) if self._dev_ok() else None
+        if opd is None:
+            a, b = self._real(), _hv_unwrap(other)
+            return getattr(np, name)(b, a) if reflected else getattr(np, name)(a, b)
+        dev, host = opd
+        fa = self._fa
+        if name == 'add':
+            res = fa + dev
+        elif name == 'subtract':
+            res = (dev - fa) if reflected else (fa - dev)
+        else:
+            res = fa * dev
+        mine = self._real
+        fn = getattr(np, name)
+        thunk = (lambda: fn(host(), mine())) if reflected else (lambda: fn(mine(), host()))
+        return self._derive(res, False, thunk)
+
+    def _shift_left(self, k):
+        if self._dev_ok():
+            p = _fops(type(self._fa).field).modulus
+            if isinstance(k, (int, np.integer)) and int(k) >= 0:
+                return self._derive(self._fa * pow(2, int(k), p), False, lambda: self._real() << int(k))
+            if isinstance(k, np.ndarray) and k.dtype.kind in 'iu' and k.size <= (1 << 16) and (k >= 0).all():
+                pw = type(self._fa)(np.array([pow(2, int(v), p) for v in k.reshape(-1)], dtype=object).reshape(k.shape))
+                return self._derive(self._fa * pw, False, lambda: self._real() << k)
+        return self._real() << _hv_unwrap(k)
+
+    def _bits_and(self, mask):
+        """x & mask for exact views: limb-wise AND on the device (mask = 1: the bit itself, returned as a real int8
+        array -- what np.int8(... & 1) consumes, runtime.py:4443)."""
+        src = self._outer_src
+        if src is not None and isinstance(mask, (int, np.integer)) and int(mask) == 1:
+            fa, shifts = src
+            return fa._bit_matrix(shifts)
+        if self._dev_ok() and self._exact and isinstance(mask, (int, np.integer)) and int(mask) >= 0:
+            mask = int(mask)
+            res = self._fa._and_mask(mask)
+            if mask == 1:
+                return res._small_ints(np.int8)
+            return self._derive(res, True, None)
+        return self._real() & _hv_unwrap(mask)
 
     # -- stays on the device --
     def reshape(self, *shape, **kw):
-        return HostView(self._fa.reshape(*shape, **kw), lazy=self._is_lazy or None)
+        if self._thunk is None:
+            return HostView(self._fa.reshape(*shape, **kw), lazy=self._is_lazy or None)
+        return self._derive(self._fa.reshape(*shape, **kw), self._exact, lambda: self._real().reshape(*shape, **kw))
+
+    def __add__(self, other):
+        return self._binop(other, 'add')
+
+    __radd__ = __add__
+    __iadd__ = __add__
+
+    def __sub__(self, other):
+        return self._binop(other, 'subtract')
+
+    __isub__ = __sub__
+
+    def __rsub__(self, other):
+        return self._binop(other, 'subtract', reflected=True)
+
+    def __mul__(self, other):
+        return self._binop(other, 'multiply')
+
+    __rmul__ = __mul__
+    __imul__ = __mul__
+
+    def __lshift__(self, k):
+        return self._shift_left(k)
+
+    __ilshift__ = __lshift__
+
+    def __pow__(self, e):
+        if self._dev_ok() and isinstance(e, (int, np.integer)) and 0 <= int(e) <= 64:
+            return self._derive(self._fa ** int(e), False, lambda: self._real() ** int(e))
+        return self._real() ** _hv_unwrap(e)
+
+    def __mod__(self, m):
+        if self._dev_ok() and isinstance(m, (int, np.integer)):
+            m = int(m)
+            if m == _fops(type(self._fa).field).modulus:
+                return self._derive(self._fa, True, None)              # the canonical residues are x mod p
+            if self._exact and m > 0 and m & (m - 1) == 0:
+                return self._bits_and(m - 1)
+        return self._real() % _hv_unwrap(m)
+
+    __imod__ = __mod__
+
+    def __and__(self, mask):
+        return self._bits_and(mask)
+
+    __rand__ = __and__
+    __iand__ = __and__
+
+    def __ne__(self, other):
+        if self._dev_ok() and self._exact and isinstance(other, (int, np.integer)):
+            return self._fa != int(other)
+        return self._real() != _hv_unwrap(other)
+
+    def __eq__(self, other):
+        if self._dev_ok() and self._exact and isinstance(other, (int, np.integer)):
+            return self._fa == int(other)
+        return self._real() == _hv_unwrap(other)
+
+    def __getitem__(self, key):
+        if self._dev_ok() and (isinstance(key, np.ndarray) or isinstance(key, (slice, tuple))):
+            try:
+                sub = self._fa[key]
+            except (IndexError, TypeError, ValueError):
+                return self._real()[_hv_unwrap(key)]
+            if isinstance(sub, FieldArray):
+                if self._thunk is None:
+                    return HostView(sub, lazy=True)
+                return self._derive(sub, self._exact, lambda: self._real()[key])
+        return self._real()[_hv_unwrap(key)]
 
     def __setitem__(self, key, value):
         """`a.value[key] = v` writes through to the array, as it does in the reference where `.value` IS the
         storage (e.g. runtime.py:3975)."""
         fa = self._fa
+        if self._thunk is not None:
+            raise ValueError('assignment into a derived integer view')
         real = fa._host_value()
         real.flags.writeable = True
         try:
@@ -602,10 +771,12 @@ class HostView(np.ndarray):
         fa._cache = real
 
     def __reduce__(self):
+        if self._thunk is not None:
+            return self._real().__reduce__()           # derived integers: pickle the true values
         return self._fa.__reduce__()
 
     def __reduce_ex__(self, protocol):
-        return self._fa.__reduce__()
+        return self.__reduce__()
 
     def __copy__(self):
         return HostView(self._fa)
@@ -615,9 +786,46 @@ class HostView(np.ndarray):
 
     # -- everything else: the materialised ndarray --
     def __array_function__(self, func, types, args, kwargs):
+        name = func.__name__
+        if name == 'sum' and args and isinstance(args[0], HostView) and args[0]._dev_ok():
+            v = args[0]
+            axis = kwargs.get('axis', args[1] if len(args) > 1 else None)
+            if isinstance(axis, (int, np.integer)) and v.ndim > 1 and set(kwargs) <= {'axis'} and len(args) <= 2:
+                return v._derive(v._fa.sum(axis=int(axis)), False, lambda: np.sum(v._real(), axis=int(axis)))
+        if name == 'count_nonzero' and len(args) == 1 and not kwargs and args[0]._dev_ok() and args[0]._exact:
+            return int(np.count_nonzero(args[0]._fa != 0))
         return func(*_hv_unwrap(args), **_hv_unwrap(kwargs))
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        name = ufunc.__name__
+        if not kwargs or set(kwargs) <= {'axis'}:
+            a = inputs[0]
+            if method == '__call__' and len(inputs) == 2:
+                b = inputs[1]
+                first = isinstance(a, HostView)
+                me, other = (a, b) if first else (b, a)
+                if name in ('add', 'subtract', 'multiply') and not kwargs:
+                    return me._binop(other, name, reflected=not first)
+                if name == 'left_shift' and first and not kwargs:
+                    return me._shift_left(other)
+                if name == 'bitwise_and' and not kwargs:
+                    return me._bits_and(other)
+                if name == 'remainder' and first and not kwargs:
+                    return me.__mod__(other)
+            if method == 'reduce' and name == 'add' and isinstance(a, HostView) and a._dev_ok() and a.ndim > 1:
+                axis = kwargs.get('axis', 0)
+                if isinstance(axis, (int, np.integer)):
+                    return a._derive(a._fa.sum(axis=int(axis)), False, lambda: np.add.reduce(a._real(), axis=int(axis)))
+            if method == 'outer' and name == 'right_shift' and len(inputs) == 2 and isinstance(a, HostView) and \
+                    a._dev_ok() and a._exact and isinstance(inputs[1], np.ndarray) and inputs[1].dtype.kind in 'iu' and \
+                    inputs[1].size <= 512 and (inputs[1] >= 0).all() and not kwargs:
+                # np.right_shift.outer(c, shifts) (runtime.py:4443): kept symbolic; `& 1` extracts the bits on the device
+                shifts = inputs[1]
+                out = np.broadcast_to(_POISON, a.shape + shifts.shape).view(HostView)
+                out._fa, out._is_lazy, out._exact, out._true = a._fa, True, True, None
+                out._thunk = lambda: np.right_shift.outer(a._real(), shifts)
+                out._outer_src = (a._fa, shifts)
+                return out
         return getattr(ufunc, method)(*_hv_unwrap(inputs), **_hv_unwrap(kwargs))
 
     __hash__ = None
@@ -642,13 +850,16 @@ def _hv_delegate(name):
 
 for _n in ('add', 'sub', 'mul', 'matmul', 'truediv', 'floordiv', 'mod', 'divmod', 'pow', 'lshift', 'rshift',
            'and', 'or', 'xor'):
-    setattr(HostView, f'__{_n}__', _hv_delegate(f'__{_n}__'))
-    setattr(HostView, f'__r{_n}__', _hv_delegate(f'__r{_n}__'))
-    setattr(HostView, f'__i{_n}__', _hv_delegate(f'__{_n}__'))      # the snapshot is read-only: x op= y rebinds
+    for _m in (f'__{_n}__', f'__r{_n}__'):
+        if _m not in HostView.__dict__:
+            setattr(HostView, _m, _hv_delegate(_m))
+    if f'__i{_n}__' not in HostView.__dict__:
+        setattr(HostView, f'__i{_n}__', _hv_delegate(f'__{_n}__'))      # the snapshot is read-only: x op= y rebinds
 for _n in ('neg', 'pos', 'abs', 'invert', 'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'getitem', 'iter', 'contains', 'bool',
            'repr', 'str', 'int', 'float', 'index', 'array', 'format'):
-    setattr(HostView, f'__{_n}__', _hv_delegate(f'__{_n}__'))
-del _n
+    if f'__{_n}__' not in HostView.__dict__:
+        setattr(HostView, f'__{_n}__', _hv_delegate(f'__{_n}__'))
+del _n, _m
 
 
 _field_registry = {}      # _field_key -> field class: where unpickled share rows find their array type
@@ -858,8 +1069,12 @@ class FieldArray:
         (read-only snapshot)."""
         if not HostView._runtime_scanned:
             HostView._scan_runtime()
-        if HostView.lazy_codes and sys._getframe(1).f_code in HostView.lazy_codes:
-            return HostView(self, lazy=True)
+        if HostView.lazy_codes:
+            code = sys._getframe(1).f_code
+            if code in HostView.lazy_codes:
+                return HostView(self, lazy=True)
+            if code in HostView.lazy_codes_prime and not _fops(type(self).field).binary:
+                return HostView(self, lazy=True)
         return HostView(self)
 
     def _host_value(self) -> np.ndarray:
@@ -1313,6 +1528,45 @@ class FieldArray:
 
     __hash__ = None
 
+    # ---- bit-level views of CANONICAL residues (for HostView's exact integer operations) --------------------
+    def _limb_bits(self):
+        return 32 if self.ctx.elem_bytes in (4, 12) else (8 if self.ctx.elem_bytes == 1 else 64)
+
+    def _and_mask(self, mask: int) -> 'FieldArray':
+        """element-wise x & mask on the limbs (x canonical, so is the result)"""
+        W = self._limb_bits()
+        t = self._dev.t
+        signed = lambda v: v - (1 << W) if v >> (W - 1) else v
+        if self.ctx.limbs:
+            out = torch.empty_like(t)
+            for q in range(self.ctx.limbs):
+                out[..., q] = t[..., q] & signed((mask >> (W * q)) & ((1 << W) - 1))
+        else:
+            out = t & signed(mask & ((1 << W) - 1)) if W > 8 else t & (mask & 0xff)
+        return self._wrap(DevArray(self.ctx, out, self._dev.n), self._shape)
+
+    def _small_ints(self, dtype) -> np.ndarray:
+        """the values as a NumPy integer array of `dtype` (caller knows they fit): low limb only"""
+        t = self._dev.t
+        low = t[..., 0] if self.ctx.limbs else t
+        return low.cpu().numpy().astype(dtype).reshape(self._shape)
+
+    def _bit_matrix(self, shifts: np.ndarray) -> np.ndarray:
+        """(x >> shifts[j]) & 1 for every element and shift: int8 array of shape self.shape + shifts.shape"""
+        W = self._limb_bits()
+        t = self._dev.t
+        cols = []
+        for k in shifts.reshape(-1).tolist():
+            q, b = divmod(int(k), W)
+            nl = self.ctx.limbs or 1
+            if q >= nl:
+                cols.append(torch.zeros(self._dev.n, dtype=torch.int8, device=t.device))
+                continue
+            limb = t[..., q] if self.ctx.limbs else t
+            cols.append(((limb >> b) & 1).to(torch.int8))
+        out = torch.stack(cols, dim=-1) if cols else torch.zeros((self._dev.n, 0), dtype=torch.int8, device=t.device)
+        return out.cpu().numpy().reshape(self._shape + tuple(shifts.shape))
+
     # ---- integer views (finfields.py:1375-1406) --------------------------------------------------
     def unsigned_(self):
         return np.array(self._dev.to_ints(), dtype=object).reshape(self._shape)
@@ -1604,7 +1858,7 @@ class FieldArray:
     @classmethod
     def _raw(cls, a):
         if isinstance(a, HostView):
-            return a._fa, True
+            return a._fa, ('lazy' if a._is_lazy else True)   # (a derived view's residues are the field elements it stands for)
         if isinstance(a, FieldArray):
             return a, True
         if isinstance(a, np.ndarray):
@@ -1613,6 +1867,8 @@ class FieldArray:
 
     @staticmethod
     def _unraw(r, is_array):
+        if is_array == 'lazy':
+            return HostView(r, lazy=True)                # the argument was a device-resident view: so is the result
         if is_array:
             return np.array(r._host_value())             # writable copy, as the reference returns a fresh array
         return r._host_value().reshape(-1)[0]

@@ -11,7 +11,8 @@ rows8 = [sum(r_[(c_ - j_) % 8] << c_ for c_ in range(8)) for j_ in range(8)]
 A = [[(rows8[r] >> c) & 1 for c in range(8)] for r in range(8)]
 B = [(0x63 >> r) & 1 for r in range(8)]
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(3)
-for n in (10**6, 10**7, 10**8):
+import os as _os
+for n in ([int(_os.environ["SBOX_N"])] if _os.environ.get("SBOX_N") else [10**6, 10**7, 10**8]):
     xpub = DevArray(ctx, torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda:0', generator=gen), n)
     xs = protocols.as_matrix(ctx, protocols.share(ctx, xpub, 1, 3))
     rb = DevArray(ctx, torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0', generator=gen), 8 * n)
