@@ -504,7 +504,7 @@ def _src_dev(src) -> DevArray:
 
 _POISON = np.array(None, dtype=object)
 _HV_OWN = frozenset(('_fa', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_operand', '_binop', '_shift_left',
-                     '_bits_and', '_outer_src', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
+                     '_bits_and', '_outer_src', '_outer_T', '_lift', 'T', 'transpose', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
                      '__reduce_ex__', '__setitem__', '__array_function__', '__array_ufunc__', '__array_finalize__',
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
 
@@ -541,10 +541,10 @@ class HostView(np.ndarray):
     lazy_codes_prime = set()      # readers that compute with integer operators on `.value`: device-resident for PRIME fields
     _runtime_scanned = False
     RUNTIME_LAZY_READERS = ('_reshare', 'output', '_distribute')
-    # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273: every use of `.value` in these coroutines is a Python-level
+    # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273, 3622-3690: every use of `.value` in these coroutines is a Python-level
     # operator / NumPy function handled below (audited for v0.11.2); binary fields take their own branches there
     # (np.vectorize(int) over BinaryPolynomial objects: C-level), so for them `.value` stays materialised
-    RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits')
+    RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits', 'np_sgn')
 
     @classmethod
     def register_lazy_reader(cls, func, prime_only=False):
@@ -588,6 +588,7 @@ class HostView(np.ndarray):
         obj._thunk = thunk              # else: () -> the true object ndarray (same NumPy expression on the parents)
         obj._true = None
         obj._outer_src = None
+        obj._outer_T = False
         return obj
 
     def __array_finalize__(self, obj):
@@ -633,8 +634,8 @@ class HostView(np.ndarray):
             return other._fa, other._real
         if isinstance(other, (int, np.integer)) and not isinstance(other, (bool, np.bool_)):
             return int(other), (lambda v=int(other): v)
-        if isinstance(other, np.ndarray) and other.dtype.kind in 'iu' and other.size <= (1 << 16):
-            return type(self._fa)(other), (lambda v=other: v)          # small public integer arrays (shifts, masks)
+        if isinstance(other, np.ndarray) and other.dtype.kind in 'iub':
+            return type(self._fa)(other), (lambda v=other: v)          # public integer arrays (shifts, masks, bits)
         return None
 
     def _binop(self, other, name, reflected=False):
@@ -671,7 +672,8 @@ class HostView(np.ndarray):
         src = self._outer_src
         if src is not None and isinstance(mask, (int, np.integer)) and int(mask) == 1:
             fa, shifts = src
-            return fa._bit_matrix(shifts)
+            bits = fa._bit_matrix(shifts)
+            return bits.T if self._outer_T else bits
         if self._dev_ok() and self._exact and isinstance(mask, (int, np.integer)) and int(mask) >= 0:
             mask = int(mask)
             res = self._fa._and_mask(mask)
@@ -679,6 +681,67 @@ class HostView(np.ndarray):
                 return res._small_ints(np.int8)
             return self._derive(res, True, None)
         return self._real() & _hv_unwrap(mask)
+
+    def transpose(self, *axes):
+        if self._outer_src is not None and not axes and len(self.shape) == 2:
+            out = np.broadcast_to(_POISON, self.shape[::-1]).view(HostView)
+            out._fa, out._is_lazy, out._exact, out._true = self._fa, True, True, None
+            mine = self._real
+            out._thunk = lambda: mine().T
+            out._outer_src, out._outer_T = self._outer_src, not self._outer_T
+            return out
+        if self._dev_ok() and self._outer_src is None:
+            mine = self._real
+            return self._derive(self._fa.transpose(*axes), self._exact, lambda: mine().transpose(*axes))
+        return self._real().transpose(*axes)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    # shape-only / additive NumPy functions commute with reduction mod p: run them on the device arrays
+    _LIFTED = frozenset(('vstack', 'hstack', 'concatenate', 'stack', 'cumsum', 'transpose', 'reshape', 'ravel', 'flip',
+                         'roll', 'squeeze', 'expand_dims', 'swapaxes', 'moveaxis', 'tile', 'repeat', 'diff'))
+
+    @staticmethod
+    def _lift(func, args, kwargs):
+        """func(*args) where some (nested) arguments are device views of ONE prime field and the rest public integer
+        arrays: evaluate on FieldArrays; None if an argument does not fit"""
+        cls = [None]
+
+        def find(x):
+            if isinstance(x, HostView):
+                if not x._dev_ok() or x._outer_src is not None:
+                    raise LookupError
+                c = type(x._fa)
+                if cls[0] is not None and cls[0].field is not c.field:
+                    raise LookupError
+                cls[0] = c
+            elif isinstance(x, (list, tuple)):
+                for y in x:
+                    find(y)
+
+        def dev(x):
+            if isinstance(x, HostView):
+                return x._fa
+            if isinstance(x, np.ndarray):
+                if x.dtype.kind not in 'iubO':
+                    raise LookupError
+                return cls[0](x)
+            if isinstance(x, (list, tuple)):
+                return type(x)(dev(y) for y in x)
+            return x
+        try:
+            find(args)
+            if cls[0] is None:
+                return None
+            dargs = dev(args)
+            res = func(*dargs, **kwargs)
+        except (LookupError, TypeError, ValueError, NotImplementedError):
+            return None
+        if not isinstance(res, FieldArray):
+            return None
+        return HostView(res, lazy=True, exact=False, thunk=lambda: func(*_hv_unwrap(args), **_hv_unwrap(kwargs)))
 
     # -- stays on the device --
     def reshape(self, *shape, **kw):
@@ -794,6 +857,10 @@ class HostView(np.ndarray):
                 return v._derive(v._fa.sum(axis=int(axis)), False, lambda: np.sum(v._real(), axis=int(axis)))
         if name == 'count_nonzero' and len(args) == 1 and not kwargs and args[0]._dev_ok() and args[0]._exact:
             return int(np.count_nonzero(args[0]._fa != 0))
+        if name in HostView._LIFTED and not any(isinstance(v, HostView) for v in kwargs.values()):
+            res = HostView._lift(func, args, kwargs)
+            if res is not None:
+                return res
         return func(*_hv_unwrap(args), **_hv_unwrap(kwargs))
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
@@ -824,7 +891,7 @@ class HostView(np.ndarray):
                 out = np.broadcast_to(_POISON, a.shape + shifts.shape).view(HostView)
                 out._fa, out._is_lazy, out._exact, out._true = a._fa, True, True, None
                 out._thunk = lambda: np.right_shift.outer(a._real(), shifts)
-                out._outer_src = (a._fa, shifts)
+                out._outer_src, out._outer_T = (a._fa, shifts), False
                 return out
         return getattr(ufunc, method)(*_hv_unwrap(inputs), **_hv_unwrap(kwargs))
 
@@ -932,8 +999,21 @@ class FieldArray:
                                  for v in flat], dtype=object)
             if check and ctx.elem_bytes <= 8 and not _fops(F).binary:
                 fast = self._limbs_one_word(flat, ctx.elem_bytes, _fops(F).modulus)
+        signed_wide = None
+        if check and flat.size and fast is None and ctx.elem_bytes > 8 and not _fops(F).binary and flat.dtype.kind in 'iO':
+            signed_wide = self._signed_words(flat)
         if not flat.size:
             self._dev = ctx.empty(0)
+        elif signed_wide is not None:
+            # multi-limb prime (p > 2^64) and every value fits a signed 64-bit word (weights, +-1, small constants):
+            # upload the magnitudes as the low limb -- already canonical -- and negate on the device where the sign
+            # was set; the alternative is a Python-level `%` per element (finfields.py:724 does exactly that)
+            mag, neg = signed_wide
+            dev = ctx.from_numpy(ints_to_np(mag, ctx.elem_bytes))
+            if neg is not None:
+                mask = torch.from_numpy(neg).to(dev.t.device)
+                dev.t.copy_(torch.where(mask.unsqueeze(-1), ctx.neg(dev).t, dev.t))
+            self._dev = dev
         elif fast is not None:
             self._dev = ctx.reduce(ctx.from_numpy(fast))
         elif not check:
@@ -947,6 +1027,22 @@ class FieldArray:
             # the host while marshalling (the reference does the same `%` on the host for every input)
             self._dev = ctx.from_numpy(ints_to_np(self._canonical_host(flat, F), ctx.elem_bytes))
         self._shape = tuple(shape)
+
+    @staticmethod
+    def _signed_words(flat):
+        """-> (|v| as uint64, boolean mask of the negative entries or None) if every value fits a signed 64-bit word,
+        else None"""
+        try:
+            a64 = flat if flat.dtype.kind == 'i' else flat.astype(np.int64)
+        except (OverflowError, TypeError):
+            return None
+        a64 = a64.astype(np.int64, copy=False)
+        neg = a64 < 0
+        if not neg.any():
+            return a64.view(np.uint64) if a64.dtype == np.int64 else a64.astype(np.uint64), None
+        if (a64 == np.iinfo(np.int64).min).any():
+            return None
+        return np.abs(a64).astype(np.uint64), neg
 
     @staticmethod
     def _limbs_one_word(flat, eb, p):

@@ -97,6 +97,40 @@ def _run(F, seed):
         assert isinstance(root, HostView) and root._is_lazy
         assert ((np.asarray(root._real()) ** 2 - (r * r)) % p == 0).all()
 
+    # --- np_sgn (runtime.py:3646-3690): slices, transposes, vstack / cumsum of views and public arrays ---
+    l = 7
+    rb2 = rnd(((l + 1) * n,))
+    shifts2 = np.arange(l - 1, -1, -1)
+    cc = rnd((n,))
+    rdl = rnd((n,))
+
+    def sgn_expr(R, C, RD, wrap):
+        s_sign = (R[-n:] << 1) - 1
+        R = R[:l * n].reshape((n, l))
+        r_modl = np.sum(R << shifts2, axis=1)
+        a_r = wrap(av).reshape((n,)) + (1 << l) + r_modl
+        opened_arg = a_r + (RD << l)
+        c_ = C & ((1 << l) - 1)
+        z_ = c_ - a_r
+        c_bits = np.right_shift.outer(c_, shifts2).T & 1
+        Rt = R.T
+        Xor = c_bits + Rt - (c_bits * Rt << 1)
+        zeros = np.zeros((1, n), dtype=object)
+        ones = np.ones((1, n), dtype=object)
+        SumXors = np.cumsum(np.vstack((zeros, Xor)), axis=0)
+        e_ = s_sign - np.vstack((c_bits - Rt, ones)) + 3 * SumXors
+        g_ = (np.arange(n) % 3 == 0)
+        h_ = (1 - (g_ << 1)) * s_sign + 3
+        z2 = z_ + (h_ << l - 1)
+        return opened_arg, e_, 1 - Xor, z2, c_bits
+    want5 = sgn_expr(rb2, cc, rdl, lambda x: x)
+    got5 = sgn_expr(lazy(rb2), lazy(cc), lazy(rdl), lazy)
+    for w_, g_ in zip(want5[:4], got5[:4]):
+        assert isinstance(g_, HostView) and g_._is_lazy, type(g_)
+        same_field_array(g_, w_)
+        assert (g_._real() == w_).all()
+    assert (np.asarray(got5[4]) == want5[4]).all()
+
     # --- everything else falls back to the reference's integers ---
     v = lazy(c) + 5
     assert (np.asarray(v // 3) == (c + 5) // 3).all()
