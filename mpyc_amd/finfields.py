@@ -539,6 +539,9 @@ class HostView(np.ndarray):
     # is not registered (the view is then materialised: slower, never wrong).
     lazy_codes = set()
     lazy_codes_prime = set()      # readers that compute with integer operators on `.value`: device-resident for PRIME fields
+    lazy_ints_min = int(os.environ.get('MPYC_AMD_LAZY_INTS_MIN', '4096'))   # ... from this many elements on: below it a
+    #                     protocol's dozens of tiny launches cost more than boxing a few thousand integers (measured on
+    #                     np_lpsolver -i5: 136-bit field, arrays of ~100 elements)
     _runtime_scanned = False
     RUNTIME_LAZY_READERS = ('_reshare', 'output', '_distribute')
     # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273, 3622-3690: every use of `.value` in these coroutines is a Python-level
@@ -999,6 +1002,8 @@ class FieldArray:
                                  for v in flat], dtype=object)
             if check and ctx.elem_bytes <= 8 and not _fops(F).binary:
                 fast = self._limbs_one_word(flat, ctx.elem_bytes, _fops(F).modulus)
+        elif flat.dtype.kind == 'i' and flat.size and check and ctx.elem_bytes <= 8 and not _fops(F).binary:
+            fast = self._limbs_one_word(flat, ctx.elem_bytes, _fops(F).modulus)      # signed NumPy integers (weights, +-1)
         signed_wide = None
         if check and flat.size and fast is None and ctx.elem_bytes > 8 and not _fops(F).binary and flat.dtype.kind in 'iO':
             signed_wide = self._signed_words(flat)
@@ -1169,7 +1174,7 @@ class FieldArray:
             code = sys._getframe(1).f_code
             if code in HostView.lazy_codes:
                 return HostView(self, lazy=True)
-            if code in HostView.lazy_codes_prime and not _fops(type(self).field).binary:
+            if code in HostView.lazy_codes_prime and self.size >= HostView.lazy_ints_min and not _fops(type(self).field).binary:
                 return HostView(self, lazy=True)
         return HostView(self)
 
@@ -1651,16 +1656,15 @@ class FieldArray:
         """(x >> shifts[j]) & 1 for every element and shift: int8 array of shape self.shape + shifts.shape"""
         W = self._limb_bits()
         t = self._dev.t
-        cols = []
-        for k in shifts.reshape(-1).tolist():
-            q, b = divmod(int(k), W)
-            nl = self.ctx.limbs or 1
-            if q >= nl:
-                cols.append(torch.zeros(self._dev.n, dtype=torch.int8, device=t.device))
-                continue
-            limb = t[..., q] if self.ctx.limbs else t
-            cols.append(((limb >> b) & 1).to(torch.int8))
-        out = torch.stack(cols, dim=-1) if cols else torch.zeros((self._dev.n, 0), dtype=torch.int8, device=t.device)
+        ks = shifts.reshape(-1).astype(np.int64)
+        nl = self.ctx.limbs or 1
+        if ks.size == 0:
+            return np.zeros(self._shape + tuple(shifts.shape), dtype=np.int8)
+        tl = t if self.ctx.limbs else t.unsqueeze(-1)                       # (n, limbs)
+        q = torch.from_numpy(np.minimum(ks // W, nl - 1)).to(t.device)       # limb of every shift ...
+        b = torch.from_numpy(ks % W).to(device=t.device, dtype=tl.dtype)     # ... and the bit inside it
+        live = torch.from_numpy((ks // W < nl)).to(t.device)                 # shifts beyond the element width give 0
+        out = ((tl.index_select(-1, q) >> b) & 1).to(torch.int8) * live.to(torch.int8)    # three launches for any number of shifts
         return out.cpu().numpy().reshape(self._shape + tuple(shifts.shape))
 
     # ---- integer views (finfields.py:1375-1406) --------------------------------------------------

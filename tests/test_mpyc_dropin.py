@@ -100,8 +100,9 @@ print("WIRING_OK", len(names))
 
 @pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
 def test_reference_suite_under_install_host_logic():
-    """lschoe/mpyc's own tests, unmodified, with install() active (list path routed to the device functions too)."""
-    out = _run_reference_tests('/root/reference', True, REF_FILES, {'MPYC_AMD_LIST_MIN': '0'})
+    """lschoe/mpyc's own tests, unmodified, with install() active (list path routed to the device functions too, and the
+    device-resident integer views of `.value` switched on for arrays of any size: MPYC_AMD_LAZY_INTS_MIN=0)."""
+    out = _run_reference_tests('/root/reference', True, REF_FILES, {'MPYC_AMD_LIST_MIN': '0', 'MPYC_AMD_LAZY_INTS_MIN': '0'})
     assert ' passed' in out and 'failed' not in out
 
 
@@ -117,7 +118,7 @@ def test_np_aes_demo_under_install_host_logic():
 @pytest.mark.gpu
 @pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
 def test_reference_suite_under_install_on_gpu():
-    out = _run_reference_tests(STAGE, False, REF_FILES, {'MPYC_AMD_LIST_MIN': '0'})
+    out = _run_reference_tests(STAGE, False, REF_FILES, {'MPYC_AMD_LIST_MIN': '0', 'MPYC_AMD_LAZY_INTS_MIN': '0'})
     assert ' passed' in out and 'failed' not in out
 
 
