@@ -155,6 +155,7 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
         n_one, n_each = 2_000_000, 400_000
         r = refbaseline.measure(P61, t, m, n_one, n_each, procs, seed)
         allc = r.get('all_cores') or {'field_ops_per_s': r['one_core']['field_ops_per_s'], 'n_total': n_one, 'wall_s': 0.0}
+        procs = r.get('procs', procs)
         out = {'value': round(allc['field_ops_per_s'], 1), 'unit': 'field-ops/s', 'cores': procs, 'kind': 'reference',
                'sample': f'lschoe/mpyc itself (FiniteFieldArray.__mul__ + thresha.np_random_split m={m},t={t} with live '
                          f'secrets.randbelow + thresha.np_recombine k={2*t+1}) over GF(2^61-1): {procs} processes x '
@@ -162,6 +163,7 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
                          f'{n_one} elements',
                'value_1core': round(r['one_core']['field_ops_per_s'], 1),
                'reference_1core_stages': {k_: round(v_, 1) for k_, v_ in r['one_core'].items() if k_.endswith('_per_s')},
+               'process_count_probe': r.get('probe'),
                'port_value': round(res['allcores'], 1), 'port_value_1core': round(res['1core'], 1), 'port_cores': cores,
                'port_sample': port_sample}
     return out

@@ -63,13 +63,23 @@ def measure(modulus, t, m, n_one, n_each, procs, seed=20260925):
     out = {'one_core': one, 'procs': procs}
     if procs > 1:
         ctx = mp.get_context('fork')
-        with ctx.Pool(procs) as pool:
-            pool.map(one_pass, [(modulus, 1000, t, m, seed + 1 + i) for i in range(procs)])       # start + warm every worker
-            t0 = time.perf_counter()
-            res = pool.map(one_pass, [(modulus, n_each, t, m, seed + 1000 + i) for i in range(procs)], chunksize=1)
-            wall = time.perf_counter() - t0
-        total = sum(r[3] for r in res)
-        out['all_cores'] = {'n_total': total, 'n_each': n_each, 'wall_s': wall, 'field_ops_per_s': 3 * total / wall}
+
+        def run(nproc, n_per):
+            with ctx.Pool(nproc) as pool:
+                pool.map(one_pass, [(modulus, 1000, t, m, seed + 1 + i) for i in range(nproc)])       # start + warm every worker
+                t0 = time.perf_counter()
+                res = pool.map(one_pass, [(modulus, n_per, t, m, seed + 1000 + i) for i in range(nproc)], chunksize=1)
+                wall = time.perf_counter() - t0
+            total = sum(r[3] for r in res)
+            return {'procs': nproc, 'n_total': total, 'n_each': n_per, 'wall_s': wall, 'field_ops_per_s': 3 * total / wall}
+        # the reference does not scale to every logical CPU (its coefficient draws go through the kernel CSPRNG): pick the
+        # process count that gives it the HIGHEST throughput on a short probe, then measure at that count
+        cands = sorted({c for c in (procs, procs // 2, procs // 4, procs // 8) if c >= 2})
+        probe = [run(c, max(20_000, n_each // 4)) for c in cands] if len(cands) > 1 else []
+        best = max(probe, key=lambda r: r['field_ops_per_s'])['procs'] if probe else procs
+        out['all_cores'] = run(best, n_each)
+        out['procs'] = best
+        out['probe'] = [{'procs': r['procs'], 'field_ops_per_s': round(r['field_ops_per_s'], 1)} for r in probe]
     return out
 
 
