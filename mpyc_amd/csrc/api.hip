@@ -1079,6 +1079,8 @@ int ffgpu_gf256_sbox_layer(ffgpu_ctx* ctx, const uint64_t* host_matrix, const ui
         if (!ctx->sbl_valid || memcmp(key, ctx->sbl_key, sizeof(key)) != 0) {
             unsigned char host_tables[1536 + 2304 + 2304];
             ffgpu_gf8_sbox_layer_tables(ctx->policy, ctx->gf8_tables, host_matrix, host_bias, host_tables);
+            // a DIFFERENT affine map than the cached one: launches that still read the old tables (on any stream) finish first
+            if (ctx->sbl_valid) HIPCHK(hipDeviceSynchronize());
             // (synchronous copy: not inside a stream capture -- engine.CapturedLaunches warms the call up first)
             HIPCHK(hipMemcpy(ctx->sbl_tables_dev, host_tables, sizeof(host_tables), hipMemcpyHostToDevice));
             memcpy(ctx->sbl_key, key, sizeof(key));
