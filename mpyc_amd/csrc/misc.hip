@@ -1035,9 +1035,13 @@ enum { REC_BLOCK = 512, REC_MAXK = 9 };
 
 template <int LIMBS>
 struct Gf2wRecArgs {
-    const void* trow[REC_MAXK];      // rows with a dense coefficient (tables)
+    const void* trow[REC_MAXK];      // one row per GROUP of rows that share a dense coefficient ...
+    const void* erow[REC_MAXK][3];   // ... and up to three more rows of the group: XORed first, they go through ONE table
+    int gcnt[REC_MAXK];              // rows in group g (1..4).  Over GF(2^n) the coefficients of parties 1..5 at 0 are two
+    //                                  distinct dense values twice each and a 1.  (All indices into these arrays are
+    //                                  compile-time constants: a runtime index would demote the arguments to scratch.)
     const void* prow[REC_MAXK];      // rows with coefficient 1 (plain XOR)
-    uint64_t lam_lo[REC_MAXK], lam_hi[REC_MAXK];
+    uint64_t lam_lo[REC_MAXK], lam_hi[REC_MAXK];     // per group
     int kp;
 };
 
@@ -1100,6 +1104,18 @@ __global__ __launch_bounds__(REC_BLOCK) __attribute__((amdgpu_waves_per_eu(DEEP 
             } else {
                 const uint2 x = reinterpret_cast<const uint2*>(ra.trow[j])[i];
                 xw[j][0] = x.x; xw[j][1] = x.y;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r + 1 < ra.gcnt[j]) {                        // scalar branch: taken only when coefficients repeat
+                    if constexpr (LIMBS == 2) {
+                        const uint4 x = ldg<true>(reinterpret_cast<const uint4*>(ra.erow[j][r]) + i);
+                        xw[j][0] ^= x.x; xw[j][1] ^= x.y; xw[j][2] ^= x.z; xw[j][3] ^= x.w;
+                    } else {
+                        const uint2 x = reinterpret_cast<const uint2*>(ra.erow[j][r])[i];
+                        xw[j][0] ^= x.x; xw[j][1] ^= x.y;
+                    }
+                }
             }
         }
         for (int p = 0; p < ra.kp; ++p) {                    // coefficient 1: XOR, no table (wave-uniform trip count)
@@ -1190,14 +1206,23 @@ static int dispatch_gf2w_rec(const void* policy, int device, const void* const* 
                              size_t n, hipStream_t st) {
     Gf2wRecArgs<LIMBS> ra;
     memset(&ra, 0, sizeof(ra));
-    int kt = 0;
+    int kt = 0;                                                            // groups = tables
+    bool used[REC_MAXK] = {false};
     for (int j = 0; j < k; ++j) {
         const uint64_t lo = lam2[2 * j], hi = lam2[2 * j + 1];
-        if (lo == 0 && hi == 0) continue;                                  // coefficient 0: the row does not contribute
+        if (used[j] || (lo == 0 && hi == 0)) continue;                     // coefficient 0: the row does not contribute
         if (lo == 1 && hi == 0) { ra.prow[ra.kp++] = rows[j]; continue; }  // coefficient 1: plain XOR
-        ra.trow[kt] = rows[j];
         ra.lam_lo[kt] = lo;
         ra.lam_hi[kt] = hi;
+        ra.trow[kt] = rows[j];
+        ra.gcnt[kt] = 1;
+        used[j] = true;
+        for (int j2 = j + 1; j2 < k && ra.gcnt[kt] < 4; ++j2)             // up to three more rows with this coefficient
+            if (!used[j2] && lam2[2 * j2] == lo && lam2[2 * j2 + 1] == hi) {
+                used[j2] = true;
+                ra.erow[kt][ra.gcnt[kt] - 1] = rows[j2];
+                ++ra.gcnt[kt];
+            }
         ++kt;
     }
     static const bool deep = !(getenv("FFGPU_GF2W_REC_DEEP") && atoi(getenv("FFGPU_GF2W_REC_DEEP")) == 0);

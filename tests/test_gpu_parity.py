@@ -358,6 +358,8 @@ def test_wide_binary_recombination_tables(eng, coracle):
         dev_rows = [ctx.from_numpy(r) for r in rows]
         dense = random.Random(10).randrange(2, F.order)
         for lam in (po.recombination_vector(F, [1, 2, 3, 4, 5, 6, 7], 0), [1, 0, dense, 1, 0, 1, dense ^ 1], [0] * 7,
+                    [dense, dense ^ 5, dense, 1, dense ^ 5, dense, 0], [dense] * 7,        # repeated coefficients: grouped rows
+                    po.recombination_vector(F, [1, 2, 3, 4, 5], 0) + [0, 0],
                     [0, 0, 0, 0, 0, 0, 1], [dense] + [0] * 6):
             got = ctx.recombine(dev_rows, lam).to_numpy()
             assert (got == cf.recombine(rows, lam)).all(), (hex(mod), lam)

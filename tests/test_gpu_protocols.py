@@ -420,7 +420,7 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
     ctx = engine.FieldContext(0x11b, True, device=0)
     A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
     B = [(g['b'] >> r) & 1 for r in range(8)]
-    for x in (list(range(256)) * 5 + [0x53, 0x00, 0xff], list(range(256)) * 1100, [0x53]):
+    for x in (list(range(256)) * 5 + [0x53, 0x00, 0xff], list(range(256)) * 1100, [0x53], [0x53, 0x00, 0xff, 0x01], list(range(252))):
         n = len(x)
         xpub = ctx.from_numpy(np.array(x, dtype=np.uint8))
         xs = protocols.share(ctx, xpub, t, m)
