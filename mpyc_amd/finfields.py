@@ -544,10 +544,10 @@ class HostView(np.ndarray):
     #                     np_lpsolver -i5: 136-bit field, arrays of ~100 elements)
     _runtime_scanned = False
     RUNTIME_LAZY_READERS = ('_reshare', 'output', '_distribute')
-    # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273, 3622-3690: every use of `.value` in these coroutines is a Python-level
+    # runtime.py:838-873, 4391-4472, 4475-4484, 4187-4273, 3622-3690, 3581-3620, 1798-1822: every use of `.value` in these coroutines is a Python-level
     # operator / NumPy function handled below (audited for v0.11.2); binary fields take their own branches there
     # (np.vectorize(int) over BinaryPolynomial objects: C-level), so for them `.value` stays materialised
-    RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits', 'np_sgn')
+    RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits', 'np_sgn', '_np_is_zero', 'np_lsb')
 
     @classmethod
     def register_lazy_reader(cls, func, prime_only=False):
@@ -704,7 +704,7 @@ class HostView(np.ndarray):
 
     # shape-only / additive NumPy functions commute with reduction mod p: run them on the device arrays
     _LIFTED = frozenset(('vstack', 'hstack', 'concatenate', 'stack', 'cumsum', 'transpose', 'reshape', 'ravel', 'flip',
-                         'roll', 'squeeze', 'expand_dims', 'swapaxes', 'moveaxis', 'tile', 'repeat', 'diff'))
+                         'roll', 'squeeze', 'expand_dims', 'swapaxes', 'moveaxis', 'tile', 'repeat', 'diff', 'where'))
 
     @staticmethod
     def _lift(func, args, kwargs):
@@ -728,7 +728,9 @@ class HostView(np.ndarray):
             if isinstance(x, HostView):
                 return x._fa
             if isinstance(x, np.ndarray):
-                if x.dtype.kind not in 'iubO':
+                if x.dtype.kind == 'b':
+                    return x                   # conditions / masks stay what they are (np.where)
+                if x.dtype.kind not in 'iuO':
                     raise LookupError
                 return cls[0](x)
             if isinstance(x, (list, tuple)):

@@ -131,6 +131,30 @@ def _run(F, seed):
         assert (g_._real() == w_).all()
     assert (np.asarray(got5[4]) == want5[4]).all()
 
+    # --- _np_is_zero (runtime.py:3597-3616) and np_lsb (runtime.py:1817-1819): broadcasts, np.where ---
+    kk = 5
+    a1, r1, z1, u1 = rnd((n,)), rnd((kk, n)), (rnd((kk, n)) & 1), rnd((kk, n))
+    c_w = a1 * r1 + (1 - (z1 << 1)) * u1
+    c_g = lazy(a1).reshape((n,)) * lazy(r1).reshape((kk, n)) + (1 - (lazy(z1) << 1)) * lazy(u1)
+    same_field_array(c_g, c_w)
+    copen = c_w % p
+    copen[0, :3] = 0
+    zw = np.where(copen == 0, 0, z1)
+    zg = np.where(lazy(copen) == 0, 0, lazy(z1))
+    assert isinstance(zg, HostView) and zg._is_lazy
+    same_field_array(zg, zw)
+    sq_mask = (np.arange(kk * n).reshape((kk, n)) % 2 == 0)
+    cw2 = np.where(sq_mask, 1 - zw, zw)
+    cg2 = np.where(sq_mask, 1 - zg, zg)
+    same_field_array(cg2, cw2)
+    bw, rr = F.array(rnd((n,)) & 1), rnd((n,))
+    lsb_w = F.array(av) + ((1 << 10) + (rr << 1) + np.asarray(bw.value))
+    lsb_g = F.array(av) + ((1 << 10) + (lazy(rr) << 1) + HostView(bw, lazy=True))
+    assert (np.asarray(lsb_g.value) == np.asarray(lsb_w.value)).all()
+    x_w = np.where(c & 1, 1 - bw, bw)
+    x_g = np.where(lazy(c) & 1, 1 - bw, bw)
+    assert (np.asarray(x_g.value) == np.asarray(x_w.value)).all()
+
     # --- everything else falls back to the reference's integers ---
     v = lazy(c) + 5
     assert (np.asarray(v // 3) == (c + 5) // 3).all()
