@@ -503,8 +503,8 @@ def _src_dev(src) -> DevArray:
 
 
 _POISON = np.array(None, dtype=object)
-_HV_OWN = frozenset(('_fa', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_operand', '_binop', '_shift_left',
-                     '_bits_and', '_outer_src', '_outer_T', '_lift', 'T', 'transpose', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
+_HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_operand', '_binop', '_shift_left',
+                     '_bits_and', '_outer_src', '_outer_T', '_shift_src', '_lift', 'T', 'transpose', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
                      '__reduce_ex__', '__setitem__', '__array_function__', '__array_ufunc__', '__array_finalize__',
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
 
@@ -526,6 +526,9 @@ class HostView(np.ndarray):
     operation instead of yielding wrong numbers."""
 
     __array_priority__ = 0
+    # defaults for views created by .view(HostView) without __new__ (the symbolic shift-outer objects)
+    _fa_value = _fa_make = _thunk = _true = _outer_src = _shift_src = None
+    _exact, _outer_T, _is_lazy = True, False, False
 
     lazy_min = None     # None: `.value` is lazy only when read by a registered reader (below) and
     #                     carries the REAL values in its buffer everywhere else, so that it behaves like the
@@ -578,24 +581,43 @@ class HostView(np.ndarray):
                 if fn is not None:
                     cls.register_lazy_reader(fn, prime_only=True)
 
-    def __new__(cls, fa, lazy=None, exact=True, thunk=None):
+    def __new__(cls, fa, lazy=None, exact=True, thunk=None, shape=None):
+        """fa: the device array -- or, with `shape`, a callable that makes it on first use (a derived view whose residues
+        may never be needed, e.g. `bits << shifts` that is only summed)."""
+        make = None
+        if shape is not None:
+            make, fa = fa, None
         if lazy is None:
             lazy = cls.lazy_min is not None and fa.size >= cls.lazy_min
         if lazy:
-            obj = np.broadcast_to(_POISON, fa._shape).view(cls)
+            obj = np.broadcast_to(_POISON, fa._shape if make is None else tuple(shape)).view(cls)
         else:
             obj = fa._host_value().view(cls)
-        obj._fa = fa
+        obj._fa_value = fa
+        obj._fa_make = make
         obj._is_lazy = bool(lazy)
         obj._exact = bool(exact)        # True: the integers ARE the canonical residues in _fa
         obj._thunk = thunk              # else: () -> the true object ndarray (same NumPy expression on the parents)
         obj._true = None
         obj._outer_src = None
         obj._outer_T = False
+        obj._shift_src = None
         return obj
 
     def __array_finalize__(self, obj):
         pass
+
+    @property
+    def _fa(self):
+        fa = object.__getattribute__(self, '_fa_value')
+        if fa is None:
+            fa = object.__getattribute__(self, '_fa_make')()
+            self._fa_value, self._fa_make = fa, None
+        return fa
+
+    @_fa.setter
+    def _fa(self, fa):
+        self._fa_value, self._fa_make = fa, None
 
     # ---- integer arithmetic that stays on the device (the runtime's protocols: np_trunc, np_to_bits, np_from_bits,
     #      np_random_bits -- runtime.py:838-873, 4391-4484, 4187-4273) --------------------------------------------
@@ -624,7 +646,11 @@ class HostView(np.ndarray):
         return getattr(object.__getattribute__(self, '_real')(), name)
 
     def _dev_ok(self) -> bool:
-        return self._is_lazy and not _fops(type(self._fa).field).binary
+        if not self._is_lazy:
+            return False
+        if self._fa_value is None:
+            return True                       # deferred views are only ever created on the prime-field device path
+        return not _fops(type(self._fa_value).field).binary
 
     def _derive(self, fa, exact, thunk):
         return HostView(fa, lazy=True, exact=exact, thunk=thunk)
@@ -665,8 +691,13 @@ class HostView(np.ndarray):
             if isinstance(k, (int, np.integer)) and int(k) >= 0:
                 return self._derive(self._fa * pow(2, int(k), p), False, lambda: self._real() << int(k))
             if isinstance(k, np.ndarray) and k.dtype.kind in 'iu' and k.size <= (1 << 16) and (k >= 0).all():
-                pw = type(self._fa)(np.array([pow(2, int(v), p) for v in k.reshape(-1)], dtype=object).reshape(k.shape))
-                return self._derive(self._fa * pw, False, lambda: self._real() << k)
+                fa = self._fa
+                pw = type(fa)(np.array([pow(2, int(v), p) for v in k.reshape(-1)], dtype=object).reshape(k.shape))
+                shape = tuple(np.broadcast_shapes(self.shape, k.shape))
+                out = HostView(lambda: fa * pw, lazy=True, exact=False, thunk=lambda: self._real() << k, shape=shape)
+                if k.ndim == 1 and self.ndim >= 2 and self.shape[-1] == k.shape[0]:
+                    out._shift_src = (fa, pw)          # sum(x << shifts, axis=-1) is ONE matrix-vector product
+                return out
         return self._real() << _hv_unwrap(k)
 
     def _bits_and(self, mask):
@@ -859,7 +890,14 @@ class HostView(np.ndarray):
             v = args[0]
             axis = kwargs.get('axis', args[1] if len(args) > 1 else None)
             if isinstance(axis, (int, np.integer)) and v.ndim > 1 and set(kwargs) <= {'axis'} and len(args) <= 2:
-                return v._derive(v._fa.sum(axis=int(axis)), False, lambda: np.sum(v._real(), axis=int(axis)))
+                ax = int(axis) if int(axis) >= 0 else int(axis) + v.ndim
+                if v._shift_src is not None and ax == v.ndim - 1:
+                    # np.sum(bits << shifts, axis=-1) (np_trunc, np_to_bits, np_from_bits, np_sgn): the weighted row sums
+                    # straight from the un-shifted array, one pass (x @ [2^k mod p])
+                    src, pw = v._shift_src
+                    rows = src.reshape(-1, src.shape[-1]) @ pw
+                    return v._derive(rows.reshape(src.shape[:-1]), False, lambda: np.sum(v._real(), axis=ax))
+                return v._derive(v._fa.sum(axis=ax), False, lambda: np.sum(v._real(), axis=ax))
         if name == 'count_nonzero' and len(args) == 1 and not kwargs and args[0]._dev_ok() and args[0]._exact:
             return int(np.count_nonzero(args[0]._fa != 0))
         if name in HostView._LIFTED and not any(isinstance(v, HostView) for v in kwargs.values()):
