@@ -320,6 +320,9 @@ int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t 
  * GPU lanes; the C(m, t) subset keys of a PRSS call can be spread over host cores.  Outputs go to caller
  * buffers (pin them and upload them as the `host_streams` of ffgpu_prss_combine).
  * replaces: thresha.py:255 `shake_128(self.key + s).digest(n * self.byte_length)`, once per key.         */
+/* 1 if ffgpu_shake128_expand squeezes through the system's libcrypto (loaded at run time, checked against the
+ * SHAKE128("") known answer), 0 if through the portable Keccak-f[1600] of the library (also with FFGPU_SHAKE_OWN=1). */
+int ffgpu_shake128_backend(void);
 int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* msg_lens, int nstreams, size_t out_len,
                           uint8_t* const* outs, int threads);
 

@@ -79,6 +79,7 @@ _SIGS = {
     'ffgpu_group_matvec': [_vp, _u64p, _u64p, _int, _int, _vp, _vp, _sz, _vp],
     'ffgpu_dot': [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_sum': [_vp, _vp, _vp, _vp, _sz, _vp],
+    'ffgpu_shake128_backend': [],
     'ffgpu_shake128_expand': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), _int, _sz,
                               ctypes.POINTER(ctypes.c_void_p), _int],
     'ffgpu_prss_combine': [_vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _u64p, _int, _vp, _sz, _vp],

@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <stdlib.h>
+#include <dlfcn.h>
 #include <thread>
 #include <vector>
 #include <atomic>
@@ -129,7 +131,74 @@ void shake128(const uint8_t* msg, size_t mlen, uint8_t* out, size_t outlen) {
     }
 }
 
+// The system's OpenSSL (the library behind hashlib.shake_128) squeezes 2.5-3x faster than the portable permutation
+// above (assembly with BMI / AVX-512 dispatch); it is used when libcrypto can be loaded -- from C threads, so that the
+// streams of a call expand in parallel, which hashlib under the GIL cannot do.  FFGPU_SHAKE_OWN=1 forces the portable
+// code (the tests run both against hashlib and the FIPS 202 vector).
+struct Ossl {
+    void* (*ctx_new)();
+    const void* (*md_shake128)();
+    int (*init)(void*, const void*, void*);
+    int (*update)(void*, const void*, size_t);
+    int (*final_xof)(void*, unsigned char*, size_t);
+    void (*ctx_free)(void*);
+    bool ok;
+};
+
+Ossl load_ossl() {
+    Ossl o;
+    memset(&o, 0, sizeof(o));
+    const char* own = getenv("FFGPU_SHAKE_OWN");
+    if (own && atoi(own) != 0) return o;
+    void* h = nullptr;
+    for (const char* name : {"libcrypto.so.3", "libcrypto.so.1.1", "libcrypto.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return o;
+    o.ctx_new = reinterpret_cast<void* (*)()>(dlsym(h, "EVP_MD_CTX_new"));
+    o.md_shake128 = reinterpret_cast<const void* (*)()>(dlsym(h, "EVP_shake128"));
+    o.init = reinterpret_cast<int (*)(void*, const void*, void*)>(dlsym(h, "EVP_DigestInit_ex"));
+    o.update = reinterpret_cast<int (*)(void*, const void*, size_t)>(dlsym(h, "EVP_DigestUpdate"));
+    o.final_xof = reinterpret_cast<int (*)(void*, unsigned char*, size_t)>(dlsym(h, "EVP_DigestFinalXOF"));
+    o.ctx_free = reinterpret_cast<void (*)(void*)>(dlsym(h, "EVP_MD_CTX_free"));
+    o.ok = o.ctx_new && o.md_shake128 && o.init && o.update && o.final_xof && o.ctx_free;
+    if (o.ok) {                                      // known answer before trusting it: SHAKE128("") starts 7f9c2ba4e88f827d
+        unsigned char out[8];
+        void* c = o.ctx_new();
+        const bool good = c && o.init(c, o.md_shake128(), nullptr) == 1 && o.final_xof(c, out, sizeof(out)) == 1 &&
+                          memcmp(out, "\x7f\x9c\x2b\xa4\xe8\x8f\x82\x7d", 8) == 0;
+        if (c) o.ctx_free(c);
+        o.ok = good;
+    }
+    return o;
+}
+
+const Ossl& ossl() {
+    static const Ossl o = load_ossl();        // (thread-safe one-time initialisation)
+    return o;
+}
+
+void shake128_any(const uint8_t* msg, size_t mlen, uint8_t* out, size_t outlen) {
+    const Ossl& o = ossl();
+    if (o.ok) {
+        void* c = o.ctx_new();
+        if (c && o.init(c, o.md_shake128(), nullptr) == 1 && (mlen == 0 || o.update(c, msg, mlen) == 1) &&
+            o.final_xof(c, out, outlen) == 1) {
+            o.ctx_free(c);
+            return;
+        }
+        if (c) o.ctx_free(c);
+    }
+    shake128(msg, mlen, out, outlen);
+}
+
 }  // namespace
+
+// which implementation ffgpu_shake128_expand uses: 1 = the system's libcrypto, 0 = the portable permutation of this file
+extern "C" int ffgpu_shake128_backend(void) {
+    return ossl().ok ? 1 : 0;
+}
 
 extern "C" int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* msg_lens, int nstreams, size_t out_len,
                                      uint8_t* const* outs, int threads) {
@@ -140,7 +209,7 @@ extern "C" int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* m
     int nt = threads <= 0 ? (int)std::thread::hardware_concurrency() : threads;
     if (nt > nstreams) nt = nstreams;
     if (nt <= 1) {
-        for (int i = 0; i < nstreams; ++i) shake128(msgs[i], msg_lens[i], outs[i], out_len);
+        for (int i = 0; i < nstreams; ++i) shake128_any(msgs[i], msg_lens[i], outs[i], out_len);
         return FFGPU_OK;
     }
     std::atomic<int> next(0);
@@ -149,7 +218,7 @@ extern "C" int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* m
     for (int w = 0; w < nt; ++w)
         pool.emplace_back([&]() {
             for (int i = next.fetch_add(1); i < nstreams; i = next.fetch_add(1))
-                shake128(msgs[i], msg_lens[i], outs[i], out_len);
+                shake128_any(msgs[i], msg_lens[i], outs[i], out_len);
         });
     for (auto& th : pool) th.join();
     return FFGPU_OK;
