@@ -325,6 +325,15 @@ int ffgpu_sum(ffgpu_ctx* ctx, const void* a, void* out, void* workspace, size_t 
 int ffgpu_shake128_backend(void);
 int ffgpu_shake128_expand(const uint8_t* const* msgs, const size_t* msg_lens, int nstreams, size_t out_len,
                           uint8_t* const* outs, int threads);
+/* The same streams, RESUMABLE: open absorbs the nstreams messages (*handle owns the sponge states), every squeeze
+ * call writes the NEXT nbytes of stream i to outs[i] (nstreams host pointers; up to `threads` host threads, <= 0: all
+ * cores), close frees the handle.  This is how the mirror runs a large PRSS call: a slice of every stream is squeezed
+ * into one half of a bounded pinned buffer while the previous slice uploads and ffgpu_prss_combine consumes it on the
+ * device (measured on the MI355X box, m = 7, t = 3, 10^7 draws: profiles/r03_api_path.md).
+ * replaces: the same line, thresha.py:255 (hashlib squeezes a stream in one piece).                                */
+int ffgpu_shake128_open(const uint8_t* const* msgs, const size_t* msg_lens, int nstreams, void** handle);
+int ffgpu_shake128_squeeze(void* handle, uint8_t* const* outs, size_t nbytes, int threads);
+void ffgpu_shake128_close(void* handle);
 
 /* out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * weights[s][j]   (mod modulus)
  * host_streams: HOST array of ks DEVICE pointers to the raw SHAKE128 output of subset s

@@ -82,6 +82,9 @@ _SIGS = {
     'ffgpu_shake128_backend': [],
     'ffgpu_shake128_expand': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), _int, _sz,
                               ctypes.POINTER(ctypes.c_void_p), _int],
+    'ffgpu_shake128_open': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), _int, ctypes.POINTER(_vp)],
+    'ffgpu_shake128_squeeze': [_vp, ctypes.POINTER(ctypes.c_void_p), _sz, _int],
+    'ffgpu_shake128_close': [_vp],
     'ffgpu_prss_combine': [_vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _u64p, _int, _vp, _sz, _vp],
     'ffgpu_gf256_bit_affine': [_vp, _u64p, _u64p, _int, _vp, _vp, _sz, _vp],
     'ffgpu_gf256_to_bits': [_vp, _vp, _vp, _vp, _sz, _vp],
@@ -97,7 +100,7 @@ _SIGS = {
     'ffgpu_copy': [_vp, _vp, _vp, _sz, _vp],
 }
 _RESTYPES = {'ffgpu_strerror': ctypes.c_char_p, 'ffgpu_last_hip_error': ctypes.c_char_p,
-             'ffgpu_rng_state_bytes': ctypes.c_size_t}
+             'ffgpu_rng_state_bytes': ctypes.c_size_t, 'ffgpu_shake128_close': None}
 
 EXPORTED = tuple(_SIGS)
 

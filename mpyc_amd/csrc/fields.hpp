@@ -95,20 +95,66 @@ struct PM64 {
             if (u < tl) u += c;                        // wrapped: 2^64 == c
             return csub(u);
         }
-        uint64_t xh = (uint64_t)(x >> k);
+        return csub(fold128(x));
+    }
+    // 33 <= k <= 63 and x < 2^(2k+1): x mod p up to one multiple of p, value <= 2^k + 1 for c == 1 (< 2p otherwise).
+    // The 128-bit shifts by k are written on the two words (64 - k is in 1..31): a generic `x >> k` makes the compiler
+    // guard k >= 64 and k == 0 with selects, ~10 instructions of the ~45 a product costs -- the exponentiation-bound
+    // kernels (inverse, square root, pow) are VALU-bound on exactly this.
+    FF_HD uint64_t fold128(ff_u128 x) const {
+        const uint32_t s = 64 - k;
+        uint64_t xh = (ff_hi(x) << s) | (ff_lo(x) >> k);
         uint64_t xl = ff_lo(x) & mask;
         if (C1) {
-            uint64_t w = xl + xh;  // < 2^(k+1)
-            uint64_t u = (w & mask) + (w >> k);
-            return csub(u);
+            uint64_t w = xl + xh;  // < 2^(k+2)
+            return (w & mask) + (w >> k);
         }
         ff_u128 w = (ff_u128)xh * c + xl;
-        uint64_t wh = (uint64_t)(w >> k);
-        uint64_t u = (ff_lo(w) & mask) + wh * (uint64_t)c;  // < 2p
-        return csub(u);
+        uint64_t wh = (ff_hi(w) << s) | (ff_lo(w) >> k);
+        return (ff_lo(w) & mask) + wh * (uint64_t)c;  // < 2p
     }
 
-    FF_HD uint64_t mul(uint64_t a, uint64_t b) const { return red128((ff_u128)a * b); }
+    // p = 2^k - 1 (C1; 33 <= k <= 61, i.e. 2^61 - 1): the product is never formed as a 128-bit number.  With
+    // a = a1 2^32 + a0 and 2^k == 1:   a b == p11 2^(64-k) + (m >> (k-32)) + ((m mod 2^(k-32)) << 32) + (p00 mod 2^k) + (p00 >> k),
+    // p00 = a0 b0, m = a0 b1 + a1 b0, p11 = a1 b1 -- four v_mad_u64_u32 whose 64-bit results are used as they are (the
+    // schoolbook 128-bit product chains them through carries and register shuffles), one shift per term, plain adds.
+    // Operands <= 2^k + 2 (PARTIALLY reduced) give S < 2^(k+2); fold(S) <= 2^k + 2 again, so chains of products
+    // (ff_pow, the batched inverse) subtract p once at the end (`canon`): ~21 VALU issue slots per product instead of
+    // the 45 of the generic 2^k - c path below.
+    FF_HD uint64_t presum(uint64_t a, uint64_t b) const {
+        const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+        const uint64_t p00 = (uint64_t)a0 * b0;
+        const uint64_t m = (uint64_t)a0 * b1 + (uint64_t)a1 * b0;      // < 2^(k+2)
+        const uint64_t p11 = (uint64_t)a1 * b1;                        // <= 2^(2k-64)
+        return presum_terms(p00, m, p11);
+    }
+    FF_HD uint64_t presum_sqr(uint64_t a) const {
+        const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+        return presum_terms((uint64_t)a0 * a0, ((uint64_t)a0 * a1) << 1, (uint64_t)a1 * a1);
+    }
+    FF_HD uint64_t presum_terms(uint64_t p00, uint64_t m, uint64_t p11) const {
+        const uint32_t kk = k - 32;
+        uint64_t s = (p11 << (64 - k)) + (m >> kk);
+        s += (uint64_t)((uint32_t)m & (uint32_t)(mask >> 32)) << 32;
+        s += p00 & mask;
+        s += p00 >> k;
+        return s;
+    }
+    FF_HD uint64_t fold64(uint64_t s) const { return (s & mask) + (s >> k); }
+
+    FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
+        if (!K64 && C1) return csub(fold64(presum(a, b)));
+        return red128((ff_u128)a * b);
+    }
+    FF_HD uint64_t mul_lazy(uint64_t a, uint64_t b) const {
+        if (!K64 && C1) return fold64(presum(a, b));
+        return mul(a, b);
+    }
+    FF_HD uint64_t sqr_lazy(uint64_t a) const {
+        if (!K64 && C1) return fold64(presum_sqr(a));
+        return mul(a, a);
+    }
+    FF_HD uint64_t canon(uint64_t x) const { return (!K64 && C1) ? csub(x) : x; }
     FF_HD uint64_t reduce_raw(uint64_t x) const {
         if (K64) return csub(x);
         return red128((ff_u128)x);
@@ -143,6 +189,7 @@ struct PM64 {
     FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const {
         // a*b + c < p^2 + p < 2^(2k) for k<64; may wrap 128 bits only if k==64
         if (K64) return add(mul(a, b), cadd);
+        if (C1) return csub(fold64(presum(a, b) + cadd));
         return red128((ff_u128)a * b + cadd);
     }
 

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <utility>
 #include "fields.hpp"
 #include "rng.hpp"
 
@@ -827,6 +828,29 @@ __global__ __launch_bounds__(BLOCK) void k_recombine_any(F f, RecArgsAny<F> ra, 
 
 
 // ---- helpers for the exponentiation / inversion kernels ---------------------------------------
+// Policies that can carry partially reduced values through a chain of products expose mul_lazy / canon (PM64 for
+// p = 2^k - 1, fields.hpp); every other policy multiplies canonically and canon is the identity.
+template <class F, class = void>
+struct HasLazyMul : std::false_type {};
+template <class F>
+struct HasLazyMul<F, std::void_t<decltype(std::declval<const F&>().mul_lazy(std::declval<typename F::word>(),
+                                                                              std::declval<typename F::word>()))> >
+    : std::true_type {};
+template <class F>
+FF_HD typename F::word ff_mul_lazy(const F& f, typename F::word a, typename F::word b) {
+    if constexpr (HasLazyMul<F>::value) return f.mul_lazy(a, b);
+    else return f.mul(a, b);
+}
+template <class F>
+FF_HD typename F::word ff_sqr_lazy(const F& f, typename F::word a) {
+    if constexpr (HasLazyMul<F>::value) return f.sqr_lazy(a);
+    else return f.mul(a, a);
+}
+template <class F>
+FF_HD typename F::word ff_canon(const F& f, typename F::word a) {
+    if constexpr (HasLazyMul<F>::value) return f.canon(a);
+    else return a;
+}
 template <class F>
 FF_HD typename F::word ff_one(const F&) {
     if constexpr (sizeof(typename F::word) == 24) {
@@ -891,29 +915,63 @@ struct ExpArgs {
     int nbits;       // bit length of the exponent (>= 1)
 };
 
-// a^e for a public (wave-uniform) exponent e >= 1: left-to-right SLIDING WINDOWS of up to 4 bits over the odd powers
-// a, a^3, ..., a^15 (one squaring + 7 products to build them), so a run of set bits costs one product per 4 bits
-// instead of one per bit -- the inversion exponent q - 2 of the default primes is almost all ones: 2^61 - 3 takes
-// 60 squarings + 23 products instead of 60 + 59.  Every branch is on the exponent (scalar); the table lives in
-// registers and is selected by a uniform switch (no dynamic register indexing, no scratch).  Short exponents
-// (nbits <= 4: squares, cubes, the Legendre-free cases) skip the table.
+// a^e for a public (wave-uniform) exponent e >= 1.  Every branch is on the exponent (scalar); intermediates are
+// partially reduced where the policy allows it (ff_mul_lazy), the result is canonical.
+//  * A LEADING RUN of r >= 12 set bits -- the inversion exponent q - 2 and the Legendre exponent (q - 1) / 2 of the
+//    default primes are almost all ones -- is raised by doubling: a^(2^(2k) - 1) = (a^(2^k - 1))^(2^k) * a^(2^k - 1),
+//    r - 1 squarings + about log2(r) + popcount(r) products (2^61 - 3: 60 squarings + 10 products in all, where
+//    4-bit windows take 60 + 23 and the binary method 60 + 59).
+//  * The remaining bits: plain square-and-multiply when few are set ((p + 1) / 4 = 2^59, the tail of q - 2), otherwise
+//    left-to-right SLIDING WINDOWS of up to 4 bits over the odd powers a, a^3, ..., a^15 (one squaring + 7 products
+//    to build them; the table lives in registers and is selected by a uniform switch -- no dynamic register
+//    indexing, no scratch).
 template <class F>
 __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
     typedef typename F::word W;
     auto bit = [&](int i) -> uint32_t { return (uint32_t)(ex.e[i >> 6] >> (i & 63)) & 1u; };
-    int ones = 0;
-    for (int q = 0; q < 3; ++q) ones += __builtin_popcountll(ex.e[q]);
-    if (ex.nbits <= 4 || ones <= 8 + ex.nbits / 8) {      // few set bits (e.g. (p+1)/4 = 2^59): plain square-and-multiply
-        W r = a;
-        for (int i = ex.nbits - 2; i >= 0; --i) {
-            r = f.mul(r, r);
-            if (bit(i)) r = f.mul(r, a);
-        }
-        return r;
+    int run = 0;                                 // length of the leading run of set bits (word at a time: scalar clz)
+    for (int top = ex.nbits - 1; top >= 0;) {
+        const int pos = top & 63;
+        const uint64_t inv = ~(ex.e[top >> 6] << (63 - pos));
+        int lz = inv ? __builtin_clzll(inv) : 64;
+        if (lz > pos + 1) lz = pos + 1;
+        run += lz;
+        if (lz < pos + 1) break;
+        top -= pos + 1;
     }
-    const W a2 = f.mul(a, a);
-    const W t1 = a, t3 = f.mul(t1, a2), t5 = f.mul(t3, a2), t7 = f.mul(t5, a2), t9 = f.mul(t7, a2), t11 = f.mul(t9, a2),
-            t13 = f.mul(t11, a2), t15 = f.mul(t13, a2);
+    W r = a;
+    int i = ex.nbits - 2;                        // next bit to consume (the top bit is a itself)
+    if (run >= 12) {
+        int have = 1;                            // r = a^(2^have - 1)
+        for (int b = 30 - __builtin_clz((unsigned)run); b >= 0; --b) {
+            W t = r;
+            for (int q = 0; q < have; ++q) t = ff_sqr_lazy(f, t);
+            r = ff_mul_lazy(f, t, r);
+            have *= 2;
+            if ((run >> b) & 1) {
+                r = ff_mul_lazy(f, ff_sqr_lazy(f, r), a);
+                ++have;
+            }
+        }
+        i = ex.nbits - 1 - run;
+    }
+    int ones = 0;                                // set bits among the remaining bits i..0
+    for (int q = 0; q < 3; ++q) {
+        const int hi = i - 64 * q;                // highest remaining bit within word q
+        if (hi >= 63) ones += __builtin_popcountll(ex.e[q]);
+        else if (hi >= 0) ones += __builtin_popcountll(ex.e[q] & ((2ull << hi) - 1));
+    }
+    if (i < 4 || ones <= 8 + (i + 1) / 8) {
+        for (; i >= 0; --i) {
+            r = ff_sqr_lazy(f, r);
+            if (bit(i)) r = ff_mul_lazy(f, r, a);
+        }
+        return ff_canon(f, r);
+    }
+    const W a2 = ff_sqr_lazy(f, a);
+    const W t1 = a, t3 = ff_mul_lazy(f, t1, a2), t5 = ff_mul_lazy(f, t3, a2), t7 = ff_mul_lazy(f, t5, a2),
+            t9 = ff_mul_lazy(f, t7, a2), t11 = ff_mul_lazy(f, t9, a2), t13 = ff_mul_lazy(f, t11, a2),
+            t15 = ff_mul_lazy(f, t13, a2);
     auto odd = [&](uint32_t v) -> W {            // v odd, 1..15, wave-uniform
         switch (v >> 1) {
             case 0: return t1;
@@ -926,12 +984,9 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
             default: return t15;
         }
     };
-    W r = a;
-    bool first = true;
-    int i = ex.nbits - 1;
     while (i >= 0) {
-        if (!bit(i)) {                           // (never taken before the first window: the top bit is set)
-            r = f.mul(r, r);
+        if (!bit(i)) {
+            r = ff_sqr_lazy(f, r);
             --i;
             continue;
         }
@@ -939,16 +994,11 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
         while (!bit(j)) ++j;                     // the window ends on a set bit: its value is odd
         uint32_t v = 0;
         for (int q = i; q >= j; --q) v = (v << 1) | bit(q);
-        if (first) {
-            r = odd(v);
-            first = false;
-        } else {
-            for (int q = i; q >= j; --q) r = f.mul(r, r);
-            r = f.mul(r, odd(v));
-        }
+        for (int q = i; q >= j; --q) r = ff_sqr_lazy(f, r);
+        r = ff_mul_lazy(f, r, odd(v));
         i = j - 1;
     }
-    return r;
+    return ff_canon(f, r);
 }
 
 // ---- out = a^e, public exponent e >= 1 (finfields.py:1159-1187, :1408-1414) ------------------
@@ -983,6 +1033,11 @@ __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __re
 // Zero inputs give zero and set *flag (the reference raises ZeroDivisionError; the host wrapper checks the flag): one
 // bit per element in a 64-bit mask, and the patch-up of the outputs is skipped by a scalar branch unless some lane of
 // the wave met a zero.
+//
+// (Measured and NOT kept, round 3: pooling the totals of a workgroup -- XOR butterfly over the lanes, wave totals through
+// LDS, ONE wave per workgroup raising the pooled total -- replaces 3/4 of the exponentiations by 15 products per thread,
+// but the three waves that wait at the barrier leave their SIMDs with one runnable wave: 61.3 us against 56.0 us at
+// n = 10^7 over 2^61 - 1.)
 template <class F, int CH, int G, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
@@ -1021,32 +1076,32 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
                         zbits |= (uint64_t)(zq & 1u) << ((g * CH + c) * P::N + q);
                     }
                     pre[g][c][q] = tot[g];      // product of everything BEFORE this element in its group
-                    tot[g] = f.mul(tot[g], v);
+                    tot[g] = ff_mul_lazy(f, tot[g], v);
                 }
             }
         }
         anyzero |= zbits != 0;
         W all = tot[0];
 #pragma unroll
-        for (int g = 1; g < G; ++g) all = f.mul(all, tot[g]);
+        for (int g = 1; g < G; ++g) all = ff_mul_lazy(f, all, tot[g]);
         const W inv_all = ff_pow(f, all, ex);   // (product of all)^-1
         W ginv[G];
         if constexpr (G == 1) {
             ginv[0] = inv_all;
         } else if constexpr (G == 2) {
-            ginv[0] = f.mul(inv_all, tot[1]);
-            ginv[1] = f.mul(inv_all, tot[0]);
+            ginv[0] = ff_mul_lazy(f, inv_all, tot[1]);
+            ginv[1] = ff_mul_lazy(f, inv_all, tot[0]);
         } else {
             W suf = tot[G - 1], acc = inv_all, sufs[G];
 #pragma unroll
             for (int g = G - 2; g >= 0; --g) {
                 sufs[g] = suf;                  // product of the totals AFTER g
-                suf = f.mul(suf, tot[g]);
+                suf = ff_mul_lazy(f, suf, tot[g]);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                ginv[g] = g == G - 1 ? acc : f.mul(acc, sufs[g]);
-                acc = f.mul(acc, tot[g]);       // inv_all * product of the totals up to g
+                ginv[g] = g == G - 1 ? acc : ff_mul_lazy(f, acc, sufs[g]);
+                acc = ff_mul_lazy(f, acc, tot[g]);       // inv_all * product of the totals up to g
             }
         }
         const bool wave_has_zero = __any(zbits != 0);
@@ -1060,13 +1115,13 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
 #pragma unroll
                 for (int q = P::N - 1; q >= 0; --q) {
                     W v = (j < nvec) ? t_.w[q] : ff_one(f);
-                    r.w[q] = f.mul(ginv[g], pre[g][c][q]);
+                    r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
                     if (wave_has_zero) {                     // scalar branch: rare
                         uint32_t zq;
                         v = ff_zero_fix(f, v, zq);
                         r.w[q] = ff_zero_apply(f, r.w[q], zq);
                     }
-                    ginv[g] = f.mul(ginv[g], v);
+                    ginv[g] = ff_mul_lazy(f, ginv[g], v);
                 }
                 if (j < nvec) stg<NT>(ov + j, r);
             }
@@ -2903,9 +2958,35 @@ struct Launchers {
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && al(out);
         size_t nvec = vec ? n / EPV : 0;
-        // packs per thread: ONE exponentiation (83 products for a 61-bit prime) is shared by G x CH packs, and the
-        // 2 x G x CH x N operand / prefix words stay in registers
-        constexpr int CH = F::EPW > 1 ? 2 : 8, G = (F::EPW > 1 || sizeof(W) > 8) ? 1 : 2;     // packed bytes: 8 words per batch (zero mask)
+        // packs per thread: ONE exponentiation (70 products for 2^61 - 1) is shared by G x CH packs, and the
+        // G x CH x N prefix words stay in registers (two waves per SIMD at CH = 8..12 for one-word fields)
+        if constexpr (F::EPW == 1 && sizeof(W) == 8) {
+            // All waves of the launch take the same time and two fit on a SIMD, so the launch runs in ROUNDS of
+            // 2 x 4 x num_cu waves: 10^7 elements at CH = 8 are 4883 waves = 2.4 rounds -- three rounds of time for
+            // 2.4 of work (measured: 56 us).  More packs per thread amortise the exponentiation better AND change the
+            // number of rounds; pick the CH with the least rounds x (products per thread).
+            const size_t slots = (size_t)lc.num_cu * 4 * 2;
+            int best = 8;
+            double best_cost = 0;
+            for (int ch : {8, 10}) {                    // (CH = 12: 296 VGPRs, one wave per SIMD)
+                const size_t waves = (nvec / (size_t)(ch * 2) + 63) / 64 + 1;
+                const size_t rounds = (waves + slots - 1) / slots;
+                const double cost = (double)rounds * (3.0 * ch * 2 * (double)EPV + 73.0);
+                if (ch == 8 || cost < best_cost * 0.97) {
+                    best = ch;
+                    best_cost = ch == 8 ? cost : (cost < best_cost ? cost : best_cost);
+                }
+            }
+            if (best == 10) return launch_inv<10, 2>(f, lc, a, ex, out, nvec, n, flag, st);
+            return launch_inv<8, 2>(f, lc, a, ex, out, nvec, n, flag, st);
+        } else {
+            constexpr int CH = F::EPW > 1 ? 2 : 8;          // packed bytes: 8 words per batch (zero mask)
+            return launch_inv<CH, 1>(f, lc, a, ex, out, nvec, n, flag, st);
+        }
+    }
+    template <int CH, int G>
+    static int launch_inv(const F& f, const LaunchCfg& lc, const void* a, const ExpArgs* ex, void* out, size_t nvec, size_t n,
+                          int* flag, hipStream_t st) {
         size_t iters = nvec ? (nvec + CH * G - 1) / (CH * G) : n;
         unsigned grid = grid_for(iters, lc);
         hipLaunchKernelGGL((k_inv_batch<F, CH, G, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out,

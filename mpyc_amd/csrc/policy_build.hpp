@@ -77,7 +77,7 @@ inline int build_prime_policy(PolicyBlob* c, ff_u128 p) {
         bool k64 = (k == 64);
         if (cc < ((ff_u128)1 << cb) && !(k64 && cc == 1)) {
             uint64_t mask = k64 ? ~0ull : ((1ull << k) - 1);
-            if (!k64 && cc == 1) {
+            if (!k64 && cc == 1 && k <= 61) {             // (k = 62, 63 would overflow PM64<.,true>::presum: general path)
                 PM64<false, true> f;
                 f.p = p64; f.mask = mask; f.c = 1; f.k = (uint32_t)k;
                 store_policy(c, f, POL_PM64_MERSENNE, PB_RED_PM);

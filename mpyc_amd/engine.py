@@ -714,6 +714,48 @@ class FieldContext:
         devs = [dev[j * pitch:j * pitch + out_len] for j in range(k)]
         return devs
 
+    PRSS_SLICE_BYTES = 8 << 20        # per stream and slice: 10 ms of one host thread, 160 MB per half for 20 keys
+
+    def prss_streamed(self, msgs: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int, mask_bits: int,
+                      out: DevArray, accumulate: bool, slice_bytes: int = 0, threads: int = 0) -> DevArray:
+        """The PRSS combination of `prss_combine` with the XOF streams SHAKE128(msg) produced on the fly
+        (ffgpu_shake128_open / _squeeze): every stream is squeezed a slice (~slice_bytes) at a time on host threads into
+        one half of a pinned staging buffer; the slice is uploaded and combined into its range of `out` on the device
+        while the host squeezes the next slice into the other half.  Pinned memory: 2 * len(msgs) * slice_bytes."""
+        k = len(msgs)
+        slice_bytes = slice_bytes or self.PRSS_SLICE_BYTES
+        per = d * l                                                  # XOF bytes per output element and stream
+        step = max(256, slice_bytes // per // 256 * 256)             # elements per slice (aligned ranges of `out`)
+        pitch = (step * per + 255) // 256 * 256
+        stage = self._stage(2 * k * pitch)
+        keep = [ctypes.create_string_buffer(mg, max(len(mg), 1)) for mg in msgs]
+        mp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in keep])
+        ml = (ctypes.c_size_t * k)(*[len(mg) for mg in msgs])
+        handle = ctypes.c_void_p()
+        _ffi.check(self._L.ffgpu_shake128_open(mp, ml, k, ctypes.byref(handle)), 'shake128_open')
+        free = [None, None]                                          # event: the half has been uploaded
+        try:
+            for c, h0 in enumerate(range(0, n, step)):
+                cnt = min(step, n - h0)
+                half = c & 1
+                base = stage.data_ptr() + half * k * pitch
+                if free[half] is not None:
+                    free[half].synchronize()
+                op = (ctypes.c_void_p * k)(*[base + j * pitch for j in range(k)])
+                _ffi.check(self._L.ffgpu_shake128_squeeze(handle, op, cnt * per, threads), 'shake128_squeeze')
+                dev = torch.empty(k * pitch, dtype=torch.uint8, device=self.torch_device)
+                dev.copy_(stage[half * k * pitch:(half + 1) * k * pitch], non_blocking=True)
+                free[half] = torch.cuda.Event()
+                free[half].record()
+                self.prss_combine([dev[j * pitch:j * pitch + cnt * per] for j in range(k)], d, l, weights, cnt,
+                                  mask_bits=mask_bits, out=DevArray(self, out.t[h0:h0 + cnt], cnt), accumulate=accumulate)
+        finally:
+            self._L.ffgpu_shake128_close(handle)
+            for ev in free:
+                if ev is not None:
+                    ev.synchronize()                                 # the staging buffer is reused by the next call
+        return out
+
     def prss_combine(self, streams: Sequence, d: int, l: int, weights: Sequence[int], n: int,
                      mask_bits: int = 0, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
         """out[h] (+)= sum_s sum_j draw_s[h*d+j] * weights[s*d+j]; streams are the raw XOF outputs, n*d*l

@@ -551,17 +551,37 @@ class HostView(np.ndarray):
     # operator / NumPy function handled below (audited for v0.11.2); binary fields take their own branches there
     # (np.vectorize(int) over BinaryPolynomial objects: C-level), so for them `.value` stays materialised
     RUNTIME_LAZY_READERS_PRIME = ('np_trunc', 'np_to_bits', 'np_from_bits', 'np_random_bits', 'np_sgn', '_np_is_zero', 'np_lsb')
+    # Readers that are lazy on SOME of their lines only: {code: line numbers}.  runtime.py:1251-1294 np_reciprocal reads
+    # `.value` four times; the one every call executes is `np.count_nonzero(ar.value) < n` (a NumPy function: counted on the
+    # device), the other three sit on the ar == 0 branch and feed `b[mask] = ... .value` -- a C-level item assignment no
+    # Python hook sees, which needs the real integers.  The lines are found in the function's SOURCE by pattern at
+    # registration; no source or no match: not registered (materialised: slower, never wrong).
+    lazy_lines = {}
+    RUNTIME_LAZY_LINES = {'np_reciprocal': r'np\.count_nonzero\(\s*\w+\.value\s*\)'}
 
     @classmethod
-    def register_lazy_reader(cls, func, prime_only=False):
+    def register_lazy_reader(cls, func, prime_only=False, line_pattern=None):
         """Declare that `func` (a function / coroutine function, possibly wrapped by decorators that set
         __wrapped__) only reshapes `.value`, passes it to thresha / the array constructor, or pickles it --
-        or, with prime_only, computes on it with the integer operators HostView implements on the device."""
+        or, with prime_only, computes on it with the integer operators HostView implements on the device --
+        or, with line_pattern (a regex), does so on the source lines that match and nowhere else."""
         import inspect
         code = getattr(inspect.unwrap(func), '__code__', None)
         if code is None:
             raise TypeError('register_lazy_reader needs a Python function')
+        if line_pattern is not None:
+            import re
+            try:
+                lines, first = inspect.getsourcelines(inspect.unwrap(func))
+            except (OSError, TypeError):
+                return False
+            hits = frozenset(first + k for k, ln in enumerate(lines) if re.search(line_pattern, ln))
+            if not hits:
+                return False
+            cls.lazy_lines[code] = hits
+            return True
         (cls.lazy_codes_prime if prime_only else cls.lazy_codes).add(code)
+        return True
 
     @classmethod
     def _scan_runtime(cls):
@@ -575,6 +595,10 @@ class HostView(np.ndarray):
             fn = getattr(rt.Runtime, name, None)
             if fn is not None:
                 cls.register_lazy_reader(fn)
+        for name, pattern in cls.RUNTIME_LAZY_LINES.items():
+            fn = getattr(rt.Runtime, name, None)
+            if fn is not None:
+                cls.register_lazy_reader(fn, line_pattern=pattern)
         if os.environ.get('MPYC_AMD_LAZY_INTS', '1') != '0':
             for name in cls.RUNTIME_LAZY_READERS_PRIME:
                 fn = getattr(rt.Runtime, name, None)
@@ -1211,8 +1235,11 @@ class FieldArray:
         if not HostView._runtime_scanned:
             HostView._scan_runtime()
         if HostView.lazy_codes:
-            code = sys._getframe(1).f_code
+            frame = sys._getframe(1)
+            code = frame.f_code
             if code in HostView.lazy_codes:
+                return HostView(self, lazy=True)
+            if code in HostView.lazy_lines and frame.f_lineno in HostView.lazy_lines[code]:
                 return HostView(self, lazy=True)
             if code in HostView.lazy_codes_prime and self.size >= HostView.lazy_ints_min and not _fops(type(self).field).binary:
                 return HostView(self, lazy=True)

@@ -294,6 +294,9 @@ def _f_S_i(field, m, i, S):
     return _recombination_vector(field, xs, i + 1)[0]       # only the point at x = 0 carries a 1
 
 
+PRSS_STREAM_MIN = 16 << 20       # XOF bytes per subset key above which a PRSS call is squeezed and combined in slices
+
+
 def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
     ops = _fops(field)
     ctx = _context(field)
@@ -339,6 +342,12 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
     for k0 in range(0, len(items), per):
         chunk = items[k0:k0 + per]
         if all(type(prf) is PRF for _, prf in chunk):
+            if n * d * l > PRSS_STREAM_MIN and hasattr(ctx, 'prss_streamed'):
+                # long streams: squeeze, upload and combine slice by slice (bounded pinned memory, host and device overlap)
+                ctx.prss_streamed([prf.key + uci for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits,
+                                  out, not first_launch)
+                first_launch = False
+                continue
             streams = ctx.shake128_streams([prf.key + uci for _, prf in chunk], n * d * l)
         else:                                   # foreign PRF objects (e.g. the reference's own class)
             streams = [prf.raw(uci, n * d) if hasattr(prf, 'raw') else shake_128(prf.key + uci).digest(n * d * l)

@@ -11,7 +11,7 @@
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -112,6 +112,27 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                     }
                 }
                 (void)dd;
+                break;
+            }
+            case HC_LAZY: {
+                // the product chains of ff_pow / k_inv_batch (kernels.hpp): partially reduced intermediates, one canon at
+                // the end.  x != 0: the operands 0, 1, 2 enter as p, p + 1, p + 2 (the largest values a chain can carry).
+                if constexpr (std::is_same<F, PM64<false, true> >::value || std::is_same<F, PM64<false, false> >::value ||
+                              std::is_same<F, PM64<true, false> >::value) {
+                    typename F::word u = ldw<F>(a, i), v = ldw<F>(b, i);
+                    if (x && std::is_same<F, PM64<false, true> >::value) {
+                        if (u <= 2) u += f.p;
+                        if (v <= 2) v += f.p;
+                    }
+                    r = f.mul_lazy(u, v);
+                    for (int j = 0; j < 6; ++j) {
+                        r = f.sqr_lazy(r);
+                        r = f.mul_lazy(r, (j & 1) ? u : v);
+                    }
+                    r = f.canon(r);
+                } else {
+                    return 2;
+                }
                 break;
             }
             default: return 1;

@@ -320,6 +320,30 @@ def test_prss_matches_reference(api):
     assert ints(z) == [0] * n
 
 
+def test_prss_streamed_equals_one_shot(api, monkeypatch):
+    """Large PRSS calls squeeze / upload / combine the XOF streams slice by slice (engine.prss_streamed over
+    ffgpu_shake128_open / _squeeze); the one-shot path is the one pinned to the reference's vectors above.  Slices of 4 KiB
+    here, so that 20 011 draws cross many slice boundaries, the last slice is partial and the two staging halves alternate;
+    prime (one, two and three limbs) and binary fields, the share and the zero-sharing (d = t draws per element)."""
+    import itertools
+    finfields, gfpx, thresha = api
+    from mpyc_amd import engine
+    n, m, t = 20011, 5, 2
+    for F in (finfields.GF(2**61 - 1), finfields.GF(2**128 - 173), finfields.GF(finfields.find_prime_root(136)[0]),
+              finfields.GF(gfpx.BinaryPolynomial((1 << 64) | 27)), finfields.GF(gfpx.BinaryPolynomial(283))):
+        for i in (0, m - 1):
+            keys = {S: bytes([7 * sum(S) % 251, len(S)]) * 8 for S in itertools.combinations(range(m), m - t) if i in S}
+            for bound in (F.order, 1 << 7):
+                prfs = {S: thresha.PRF(k, bound) for S, k in keys.items()}
+                want = ints(thresha.np_pseudorandom_share(F, m, i, prfs, b'slices', n))
+                want0 = ints(thresha.np_pseudorandom_share_0(F, m, i, prfs, b'slices', n))
+                with monkeypatch.context() as mp:
+                    mp.setattr(thresha, 'PRSS_STREAM_MIN', 0)
+                    mp.setattr(engine.FieldContext, 'PRSS_SLICE_BYTES', 4096)
+                    assert ints(thresha.np_pseudorandom_share(F, m, i, prfs, b'slices', n)) == want, (F, i, bound)
+                    assert ints(thresha.np_pseudorandom_share_0(F, m, i, prfs, b'slices', n)) == want0, (F, i, bound)
+
+
 def test_matmul_operator(api):
     """tests/test_finfields.py:389-404: `@` on arrays over the 2^127-1 prime vs NumPy object ints."""
     finfields, gfpx, _ = api

@@ -253,11 +253,17 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
             e >>= 1
         return r
 
-    for e in (0, 1, 2, 3, 254, 65537, q - 2, q - 1, (q + 1) // 4 if q > 4 else 1):
+    # exponent shapes of ff_pow (kernels.hpp): leading runs of ones (raised by doubling) of lengths around the
+    # threshold and across limb boundaries, runs followed by sparse and by dense tails (plain / sliding windows), powers of 2
+    shapes = [2**11 - 1, 2**12 - 1, 2**13 - 1, 2**40 - 1, (2**17 - 1) << 20 | 0xABCDE, (2**12 - 1) << 3, (2**29 - 1) << 40 | 1,
+              2**59, (q - 1) // 2, q // 3 | 1, 0x9E3779B97F4A7C15F39CC0605CEDC834 % q]
+    if q.bit_length() > 64:
+        shapes += [2**64 - 1, 2**65 - 1, (2**70 - 1) << 5 | 9, 2**64, 2**63]
+    for e in [0, 1, 2, 3, 254, 65537, q - 2, q - 1, (q + 1) // 4 if q > 4 else 1] + [e for e in shapes if 0 < e < q]:
         if e < 0:
             continue
         got = unpack(ctx.pow(dA, e).to_numpy(), eb)
-        sample = range(0, n, 97) if eb >= 12 and e > 1000 else range(n)
+        sample = range(0, n, 97) if (eb >= 12 or binary) and e > 1000 else range(n)
         assert all(got[i] == fpow(vals[i], e) for i in sample), (hex(modulus), e)
     # inverse: zeros are flagged (ZeroDivisionError) and map to 0 when unchecked
     with pytest.raises(ZeroDivisionError):

@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE = range(9)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY = range(10)
 
 
 def limbs3(x):
@@ -353,3 +353,40 @@ def test_wide_primes_device_header_against_reference_vectors(hostcheck, golden_w
             for party in (1, 5, 40):
                 got, _ = run(hostcheck, F, HC_SHARE, s_, None, [v for r in rows for v in r], x=party, k=t, n=12)
                 assert got == [(s_[h] + sum(rows[j][h] * party**(j + 1) for j in range(t))) % q for h in range(12)], (name, t, party)
+
+
+def test_mersenne_policy_and_lazy_chains(hostcheck):
+    """PM64<false,true> (p = 2^k - 1, 33 <= k <= 61; fields.hpp presum / fold64): the product that never forms the 128-bit
+    number, and the partially reduced chains of ff_pow / k_inv_batch, for EVERY k the policy accepts (only 2^61 - 1 is
+    prime; the arithmetic must hold for the others too, the C ABI takes any modulus) -- and k = 62, 63 go to the general
+    2^k - c policy."""
+    from types import SimpleNamespace
+    PM64_MERS, PM64_GEN = 1, 3
+    rng = random.Random(61)
+    for k in list(range(33, 64)):
+        p = 2**k - 1
+        F = SimpleNamespace(modulus=p, binary=False, order=p)
+        edge = [0, 1, 2, 3, p - 1, p - 2, 2**32 - 1, 2**32, 2**32 + 1, (p >> 1), (p >> 1) + 1, 2**(k - 1), 2**(k - 1) - 1,
+                (2**32 - 1) << (k - 32) & p, p - 2**32, p - 2**32 + 1]
+        edge = [e % p for e in edge] + [rng.randrange(p) for _ in range(12)]
+        a, b = cross(edge)
+        got, pk = run(hostcheck, F, HC_MUL, a, b)
+        assert pk == (PM64_MERS if k <= 61 else PM64_GEN), (k, pk)
+        assert got == [x * y % p for x, y in zip(a, b)], k
+        c = list(reversed(a))
+        got, _ = run(hostcheck, F, HC_MULADD, a, b, c)
+        assert got == [(x * y + z) % p for x, y, z in zip(a, b, c)], k
+        for noncanon in (0, 1):
+            got, _ = run(hostcheck, F, HC_LAZY, a, b, x=noncanon)
+            want = []
+            for u, v in zip(a, b):
+                r = u * v % p
+                for j in range(6):
+                    r = r * r % p
+                    r = r * (u if j & 1 else v) % p
+                want.append(r)
+            assert got == want, (k, noncanon)
+        ra = [rng.randrange(p) for _ in range(3000)]
+        rb = [rng.randrange(p) for _ in range(3000)]
+        got, _ = run(hostcheck, F, HC_MUL, ra, rb)
+        assert got == [x * y % p for x, y in zip(ra, rb)], k

@@ -189,3 +189,82 @@ def test_pickled_rows_keep_their_field_class_on_gpu():
     env = _env(STAGE, False, os.path.join(ROOT, 'mpyc_amd', 'autoinstall'))
     r = subprocess.run([sys.executable, '-c', _SAME_P_CODE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=300)
     assert r.returncode == 0 and 'SAME_P_OK' in r.stdout, r.stdout + r.stderr
+
+
+_RECIPROCAL_CODE = '''
+import os, sys
+import mpyc_amd
+mpyc_amd.install()
+if os.environ.get('MPYC_AMD_CPUCTX') == '1':
+    from cpuctx import use_cpu_contexts
+    use_cpu_contexts()
+sys.argv = [sys.argv[0], '--no-log']
+from mpyc.runtime import mpc
+import mpyc_amd.finfields as gff
+import numpy as np
+
+p = 2**61 - 1
+secfld = mpc.SecFld(p)
+n = 6000
+vals = [(7 * i * i + 3 * i + 1) % p or 1 for i in range(n)]
+boxed = []                       # arrays whose integers were materialised (FieldArray._host_value)
+orig_host = gff.FieldArray._host_value
+def counting(self):
+    if self._cache is None:
+        boxed.append(self.size)
+    return orig_host(self)
+gff.FieldArray._host_value = counting
+
+async def main():
+    async with mpc:
+        a = secfld.array(np.array(vals, dtype=object))
+        del boxed[:]
+        b = mpc.np_reciprocal(a)
+        y = await mpc.output(b)
+        common = list(boxed)
+        del boxed[:]
+        assert [int(v) for v in y.value] == [pow(v, -1, p) for v in vals]
+        # the branch behind `np.count_nonzero(ar.value) < n`: some mask r is zero (probability n / p in real runs)
+        orig = mpc._np_randoms
+        calls = []
+        def with_zeros(field, m, bound=None):
+            r = orig(field, m, bound) if bound is not None else orig(field, m)
+            if not calls:
+                calls.append(1)
+                r = r.copy() if hasattr(r, 'copy') else r
+                r[3] = 0
+                r[m - 1] = 0
+            return r
+        mpc._np_randoms = with_zeros
+        b2 = mpc.np_reciprocal(a)
+        y2 = await mpc.output(b2)
+        mpc._np_randoms = orig
+        rare = list(boxed)
+        assert [int(v) for v in y2.value[:50]] == [pow(v, -1, p) for v in vals[:50]]
+        assert [int(v) for v in y2.value] == [pow(v, -1, p) for v in vals]
+    return common, rare
+
+common, rare = mpc.run(main())
+assert gff.HostView.lazy_lines, 'np_reciprocal was not registered'
+assert not any(s >= n for s in common), common          # common path: the opened a*r is counted on the device
+assert any(s >= n - 2 for s in rare), rare              # zero branch: real integers for the item assignments
+print('RECIPROCAL_OK', common, rare)
+'''
+
+
+@pytest.mark.skipif(_ref_root(False) is None, reason='reference checkout not present')
+def test_np_reciprocal_reader_host_logic():
+    """runtime.py:1251-1294 under install(): `np.count_nonzero(ar.value)` is answered on the device (no integers are boxed
+    on the path every call takes), and the ar == 0 branch -- `b[mask] = x.value`, a C-level assignment -- still gets the real
+    integers (HostView.lazy_lines: lazy on the matching source line only)."""
+    env = _env('/root/reference', True, os.path.join(ROOT, 'tests', 'devsite'))
+    r = subprocess.run([sys.executable, '-c', _RECIPROCAL_CODE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
+    assert r.returncode == 0 and 'RECIPROCAL_OK' in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_ref_root(True) is None, reason='no staged reference copy (_refstage/)')
+def test_np_reciprocal_reader_on_gpu():
+    env = _env(STAGE, False, os.path.join(ROOT, 'mpyc_amd', 'autoinstall'))
+    r = subprocess.run([sys.executable, '-c', _RECIPROCAL_CODE], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
+    assert r.returncode == 0 and 'RECIPROCAL_OK' in r.stdout, (r.stdout + r.stderr)[-3000:]

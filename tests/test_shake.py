@@ -48,3 +48,32 @@ def test_shake128_many_keys_in_parallel():
     assert par[7] == hashlib.shake_128(msgs[7]).digest(out_len)
     assert np.frombuffer(par[3], dtype=np.uint8).std() > 60          # looks like random bytes
     assert (t2 - t1) < 2.0 * (t1 - t0) + 0.05
+
+
+def test_shake128_resumable_streams():
+    """ffgpu_shake128_open / _squeeze / _close (the sliced PRSS path, engine.prss_streamed): whatever the slice sizes --
+    within a 168-byte block, across blocks, zero -- the concatenation is hashlib's stream, for every message length around
+    the rate; and a closed / null handle is refused, not dereferenced."""
+    from mpyc_amd import _ffi
+    L = _ffi.lib()
+    rng = random.Random(303)
+    msgs = [bytes(rng.randrange(256) for _ in range(mlen)) for mlen in (0, 3, 19, 167, 168, 169, 336, 400)]
+    k = len(msgs)
+    keep = [ctypes.create_string_buffer(m, max(len(m), 1)) for m in msgs]
+    mp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in keep])
+    ml = (ctypes.c_size_t * k)(*[len(m) for m in msgs])
+    h = ctypes.c_void_p()
+    assert L.ffgpu_shake128_open(mp, ml, k, ctypes.byref(h)) == 0 and h.value
+    outs = [bytearray() for _ in msgs]
+    for nb in (1, 7, 160, 168, 169, 1000, 4096, 0, 333, 167, 1, 100_000):
+        bufs = [np.zeros(max(nb, 1), dtype=np.uint8) for _ in msgs]
+        op = (ctypes.c_void_p * k)(*[b.ctypes.data for b in bufs])
+        assert L.ffgpu_shake128_squeeze(h, op, nb, rng.choice([1, 3, 0])) == 0
+        for o, b in zip(outs, bufs):
+            o += bytes(b[:nb])
+    L.ffgpu_shake128_close(h)
+    for m, o in zip(msgs, outs):
+        assert bytes(o) == hashlib.shake_128(m).digest(len(o)), len(m)
+    assert L.ffgpu_shake128_squeeze(None, None, 10, 1) != 0
+    assert L.ffgpu_shake128_open(None, None, 1, ctypes.byref(h)) != 0
+    L.ffgpu_shake128_close(None)
