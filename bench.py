@@ -189,8 +189,9 @@ def api_leg(n_full):
     import subprocess
     prog = os.path.join(ROOT, 'tests', 'api_program.py')
 
-    def run(mode, n, parties, reps, warmup, chain=1, timeout=900):
+    def run(mode, n, parties, reps, warmup, chain=1, timeout=900, ipc_wire=False):
         env = dict(os.environ)
+        env['MPYC_AMD_IPC_WIRE'] = '1' if ipc_wire else '0'
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
         for k_ in ('MPYC_GPU', 'API_SEED', 'API_DIGEST', 'API_CPROFILE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
             env.pop(k_, None)
@@ -216,6 +217,9 @@ def api_leg(n_full):
             out['gpu_busy_frac'] = round(d['gpu_busy_ms'] / reps * 1e-3 / med, 4)
             out['gpu_busy_frac_mean'] = round(d['gpu_busy_ms'] * 1e-3 / sum(d['times_s']), 4)
             out['libffgpu_calls_per_rep'] = d['gpu_calls'] / reps
+        if parties > 1:
+            out['wire'] = 'device buffers by interprocess handle (MPYC_AMD_IPC_WIRE=1)' if d.get('ipc_wire') else 'limb bytes through the TCP mesh'
+            out['bytes_sent_party0'] = d.get('bytes_sent')
         return out
 
     res = {'workload': 'mpc.output(a * b) on SecFld(GF(2^61-1)) arrays through the unmodified mpyc runtime under '
@@ -226,6 +230,11 @@ def api_leg(n_full):
     res['m1_1e8'] = run('gpu', 10 * n_full, 1, 5, 2)
     res['m3_1e7'] = run('gpu', n_full, 3, 3, 1)
     res['m3_1e6'] = run('gpu', n_full // 10, 3, 5, 1)
+    # the same three local parties with the device-side wire: share rows cross between the party processes as
+    # interprocess handles of the device buffers (mpyc_amd/finfields.py _array_from_ipc), not as bytes through TCP
+    res['m3_1e7_ipc'] = run('gpu', n_full, 3, 10, 2, ipc_wire=True)
+    res['m3_1e7_chain8_ipc'] = run('gpu', n_full, 3, 5, 1, chain=8, ipc_wire=True)
+    res['m3_1e6_ipc'] = run('gpu', n_full // 10, 3, 10, 2, ipc_wire=True)
     res['reference_m1_1e6'] = run('ref', n_full // 10, 1, 2, 0)
     res['reference_m3_1e6'] = run('ref', n_full // 10, 3, 1, 0)
     head = res['m1_1e7']
@@ -238,6 +247,9 @@ def api_leg(n_full):
             res['vs_reference_m1'] = round(head['elements_per_s'] / ref['elements_per_s'], 1)
         if 'elements_per_s' in res['m3_1e6'] and 'elements_per_s' in res['reference_m3_1e6']:
             res['vs_reference_m3_1e6'] = round(res['m3_1e6']['elements_per_s'] / res['reference_m3_1e6']['elements_per_s'], 1)
+            if 'elements_per_s' in res['m3_1e6_ipc']:
+                res['vs_reference_m3_1e6_ipc'] = round(res['m3_1e6_ipc']['elements_per_s'] / res['reference_m3_1e6']['elements_per_s'], 1)
+        res['gpu_busy_frac_m3_1e7_ipc'] = res['m3_1e7_ipc'].get('gpu_busy_frac')
     res['note'] = ('m=1: one repetition = np_multiply + output coroutines of the reference runtime (host, ~0.1 ms) around two '
                    'kernels (product, recombination); the GPU-busy share grows with n (1e8: kernels dominate) and with the number '
                    'of multiplications in flight (chain8: launches overlap the host). m=3: every gate moves 2 x n x 8 B out of and '
@@ -671,6 +683,35 @@ def main():
             ms = time_launches(lambda s: ctx.pow(s.a, (P61 + 1) // 4, out=s.c), sets, 3)
             kern['sqrt_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
                                     units_per_s=round(n / (ms * 1e-3), 1))
+            # both are bound by integer VALU work, not by HBM: instructions per element from rocprofv3 --pmc SQ_INSTS_VALU
+            # (profiles/r03_alu.md), against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = one wave64 instruction per 4 cycles
+            valu_peak = 256 * 4 * 16 * 2.4e9
+            for key_, ops_ in (('inv_p61', 109.3), ('sqrt_p61', 877.0)):
+                kern[key_].update(bound='valu', valu_lane_ops_per_unit=ops_,
+                                  valu_frac=round(ops_ * n / (kern[key_]['ms_per_launch'] * 1e-3) / valu_peak, 4),
+                                  note='frac = HBM fraction of one read + one write per element; valu_frac = VALU issue rate '
+                                       '(v_mad_u64_u32 counted once although it takes two slots)')
+            # PRSS (thresha.py:163-173) for one party of m = 7, t = 3: 20 subset keys x n x 28 B of SHAKE128 on 20 host
+            # threads, squeezed / uploaded / combined in slices -- bound by the host sponge, the device part is hidden
+            import itertools
+            from mpyc_amd import finfields as gff, thresha as gth
+            F61 = gff.GF(P61)
+            keys7 = {S: bytes([sum(S) % 256]) * 16 + bytes(S) for S in itertools.combinations(range(7), 4) if 2 in S}
+            prfs7 = {S: gth.PRF(kk_, F61.order) for S, kk_ in keys7.items()}
+            npr = min(n, 2 * 10**6)
+            gth.np_pseudorandom_share(F61, 7, 2, prfs7, b'warm', npr)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            gth.np_pseudorandom_share(F61, 7, 2, prfs7, b'uci', npr)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0_
+            lb_ = next(iter(prfs7.values())).byte_length
+            kern['prss_share_p61_m7t3'] = {'ms_per_launch': round(dt_ * 1e3, 2), 'bound': 'host', 'unit': 'GB/s',
+                                           'achieved': round(len(prfs7) * npr * lb_ / dt_ / 1e9, 2), 'frac': 0.0,
+                                           'units_per_s': round(npr / dt_, 1), 'n': npr, 'subset_keys': len(prfs7),
+                                           'xof_bytes_per_draw': lb_,
+                                           'note': 'achieved = SHAKE128 output bytes/s over all subset keys (host threads, '
+                                                   'ffgpu_shake128_squeeze); upload and ffgpu_prss_combine overlap it'}
             # boundary handed HOST buffers (pinned): h2d of both operands + mulmod + d2h of the product, end to end
             # through ffgpu_h2d / ffgpu_mul / ffgpu_d2h.  Reported for DESIGN.md only -- never the headline value.
             from mpyc_amd import _ffi
@@ -835,6 +876,11 @@ def main():
                 ms = time_launches(lambda s: cb_.mul(s[0], s[1], out=s[2]), bufs, reps)
                 kern[f'mul_{label}'] = dict(roof(3 * ebg * n, ms), algorithmic_bytes_per_unit=3 * ebg, bound_note='integer ALU (carry-less product)',
                                             units_per_s=round(n / (ms * 1e-3), 1))
+                if label == 'gf2_128':
+                    # no carry-less multiply on gfx950: 9 x 16 v_mad_u64_u32 + logic, 545 VALU instructions per element
+                    # (SQ_INSTS_VALU, profiles/r03_gf2w.md; the 144 multiplies take two issue slots each: 689 slots)
+                    kern['mul_gf2_128'].update(bound='valu', valu_lane_ops_per_unit=545.0, valu_issue_slots_per_unit=689.0,
+                                               valu_frac=round(689.0 * n / (ms * 1e-3) / (256 * 4 * 16 * 2.4e9), 4))
                 cfb = cb_.empty_matrix(t2, n)
                 for j in range(t2):
                     cfb.row(j).t.copy_(bufs[j][1].t)

@@ -421,6 +421,26 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,
                     int reps, void* stream, float* ms_per_launch);
 
+/* ---- device-side wire: share rows between CO-LOCATED party processes -------------------------------------
+ * The reference marshals every share row with pickle.dumps and moves the bytes through its asyncio TCP mesh
+ * (runtime.py:484-495, 655-661, 571-577; asyncoro.py:54-106): at n = 10^7 that is 80 MB per row and message, 0.5-0.7 s
+ * per gate among three local parties against 0.4 ms of kernels.  When the parties are processes on one node (one per
+ * GPU, or several on one GPU) the row need not leave the device: the exporting party sends a 64-byte interprocess
+ * handle + offset instead of the limb bytes, the receiving party opens it and copies device-to-device (over xGMI
+ * between GPUs).  The host side (mpyc_amd/ipcwire.py) keeps the exported buffer alive until every receiver has
+ * acknowledged its copy.
+ *   export: synchronises `stream` (the row is complete), returns the handle of the ALLOCATION that contains ptr and
+ *           ptr's offset in it (hipMemGetAddressRange + hipIpcGetMemHandle);
+ *   open:   maps the exporter's allocation into this process (hipIpcOpenMemHandle; not valid in the exporting
+ *           process itself -- the host side short-circuits that case); close unmaps it;
+ *   read:   copies `bytes` from base + offset into dst and synchronises `stream`.
+ * replaces: pickle.dumps(row) / pickle.loads(bytes) of the np path for co-located parties.                      */
+#define FFGPU_IPC_HANDLE_BYTES 64
+int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, unsigned char* handle, unsigned long long* offset, void* stream);
+int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base);
+int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes, void* stream);
+int ffgpu_ipc_close(ffgpu_ctx* ctx, void* base);
+
 #ifdef __cplusplus
 }
 #endif

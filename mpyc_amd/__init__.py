@@ -54,6 +54,9 @@ def install():
 
     @functools.cache
     def arrayGF(field, modulus):
+        from . import ipcwire
+        if ipcwire.ENABLED:
+            ipcwire.ensure_runtime_hooks()       # (fields are made after mpyc.runtime is imported, before any gate runs)
         if not supported(field):
             return orig_arrayGF(field, modulus)
         array = type(f'Array{field.__name__}', (DeviceFieldArray,), {'__slots__': ()})

@@ -421,6 +421,45 @@ int ffgpu_d2h(ffgpu_ctx* ctx, void* host_dst, const void* src, size_t bytes, voi
     HIPCHK(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return FFGPU_OK;
 }
+// ---- device buffers across co-located party processes (include/ffgpu.h "device-side wire") ----
+int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, unsigned char* handle, unsigned long long* offset, void* stream) {
+    if (!ctx || !ptr || !handle || !offset) return FFGPU_EINVAL;
+    static_assert(sizeof(hipIpcMemHandle_t) == FFGPU_IPC_HANDLE_BYTES, "handle size");
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // the row is complete before anybody can open it
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    HIPCHK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr));
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, base));
+    memcpy(handle, &h, sizeof(h));
+    *offset = (unsigned long long)((const char*)ptr - (const char*)base);
+    return FFGPU_OK;
+}
+int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base) {
+    if (!ctx || !handle || !base) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    HIPCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *base = p;
+    return FFGPU_OK;
+}
+int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes, void* stream) {
+    if (!ctx || (bytes && (!base || !dst))) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipMemcpyAsync(dst, (const char*)base + offset, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // the copy HAS run when the caller acknowledges the row
+    return FFGPU_OK;
+}
+int ffgpu_ipc_close(ffgpu_ctx* ctx, void* base) {
+    if (!ctx || !base) return FFGPU_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipIpcCloseMemHandle(base));
+    return FFGPU_OK;
+}
+
 int ffgpu_stream_sync(ffgpu_ctx* ctx, void* stream) {
     if (!ctx) return FFGPU_EINVAL;
     DeviceGuard g(ctx->device);

@@ -126,21 +126,27 @@ struct PM64 {
         const uint64_t p00 = (uint64_t)a0 * b0;
         const uint64_t m = (uint64_t)a0 * b1 + (uint64_t)a1 * b0;      // < 2^(k+2)
         const uint64_t p11 = (uint64_t)a1 * b1;                        // <= 2^(2k-64)
-        return presum_terms(p00, m, p11);
+        return presum_terms<0>(p00, m, p11);
     }
     FF_HD uint64_t presum_sqr(uint64_t a) const {
         const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
-        return presum_terms((uint64_t)a0 * a0, ((uint64_t)a0 * a1) << 1, (uint64_t)a1 * a1);
+        return presum_terms<1>((uint64_t)a0 * a0, (uint64_t)a0 * a1, (uint64_t)a1 * a1);     // middle term 2 a0 a1
     }
-    FF_HD uint64_t presum_terms(uint64_t p00, uint64_t m, uint64_t p11) const {
+    // x mod 2^k for k >= 33: the low word passes, one AND on the high word (with `x & mask` the compiler cannot know
+    // that the low word of the run-time mask is all ones)
+    FF_HD uint64_t low_k(uint64_t x) const {
+        return ((uint64_t)((uint32_t)(x >> 32) & (uint32_t)(mask >> 32)) << 32) | (uint32_t)x;
+    }
+    template <int DBL = 0>
+    FF_HD uint64_t presum_terms(uint64_t p00, uint64_t m, uint64_t p11) const {          // the middle term is m << DBL
         const uint32_t kk = k - 32;
-        uint64_t s = (p11 << (64 - k)) + (m >> kk);
-        s += (uint64_t)((uint32_t)m & (uint32_t)(mask >> 32)) << 32;
-        s += p00 & mask;
+        uint64_t s = (p11 << (64 - k)) + (m >> (kk - DBL));
+        s += (uint64_t)(((uint32_t)m << DBL) & (uint32_t)(mask >> 32)) << 32;
+        s += low_k(p00);
         s += p00 >> k;
         return s;
     }
-    FF_HD uint64_t fold64(uint64_t s) const { return (s & mask) + (s >> k); }
+    FF_HD uint64_t fold64(uint64_t s) const { return low_k(s) + (s >> k); }
 
     FF_HD uint64_t mul(uint64_t a, uint64_t b) const {
         if (!K64 && C1) return csub(fold64(presum(a, b)));

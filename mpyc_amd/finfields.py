@@ -1006,6 +1006,21 @@ def _field_key(field, ops):
     return (ops.binary, ops.modulus, getattr(field, 'nth', None), getattr(field, 'root', None))
 
 
+def _array_from_ipc(key, shape, n, desc):
+    """Unpickle hook of the device-side wire for co-located parties (mpyc_amd/ipcwire.py): the message carried an
+    interprocess handle of the peer's device buffer, not the limb bytes -- copy the row device-to-device."""
+    field = _field_registry.get(tuple(key))
+    if field is None:
+        raise TypeError(f'no field with modulus {key[1]:#x} (nth, root = {key[2:]}) has been created in this process')
+    ctx = _context(field)
+    from . import ipcwire
+    t = ipcwire.fetch(ctx, desc)
+    dev = DevArray(ctx, t, n)
+    if desc[0] != os.getpid():
+        dev = ctx.reduce(dev, out=dev)                       # a peer's data: canonical before any kernel sees it
+    return field.array._wrap(dev, tuple(shape))
+
+
 def _array_from_wire(key, shape, data):
     """Unpickle hook: rebuild a device array from field.to_bytes-format limb bytes (see FieldArray.__reduce__)."""
     field = _field_registry.get(tuple(key))
@@ -2125,7 +2140,17 @@ class FieldArray:
         field.to_bytes-format limb bytes from the pinned staging buffer instead of a graph of PyLongs; the receiving
         party rebuilds a device array (no Python integers on either side)."""
         F = type(self).field
-        return _array_from_wire, (_field_key(F, _fops(F)), self._shape, self.to_wire())
+        key = _field_key(F, _fops(F))
+        from . import ipcwire
+        if ipcwire.ENABLED:
+            ctx = self.ctx
+            ipcwire.ensure_runtime_hooks()
+            if ipcwire.want_descriptor(ctx, self.size * ctx.elem_bytes):
+                dev = self._dev
+                if dev.t.is_cuda and dev.t.is_contiguous():
+                    return _array_from_ipc, (key, self._shape, self.size, ipcwire.export(ctx, dev.t))
+            ipcwire.stats['inline'] += 1
+        return _array_from_wire, (key, self._shape, self.to_wire())
 
     # ---- wire format (finfields.py:91-102) straight from device limbs ------------------------------
     def to_wire(self) -> bytes:

@@ -1,0 +1,216 @@
+"""Device-side wire for CO-LOCATED parties (include/ffgpu.h, section "device-side wire").
+
+The reference's runtime marshals the share rows of the np path with `pickle.dumps(row)` and moves the bytes through
+its own asyncio TCP mesh (runtime.py:484-495 `_distribute`, :655-661 `_reshare`, :571-577 `output`;
+asyncoro.py:54-106).  mpyc_amd does not replace that mesh.  At n = 10^7 a row is 80 MB: a gate among three local
+parties costs 0.5-0.7 s of framing and socket copies against 0.4 ms of kernels (profiles/r03_api_path.md).  When every
+party is a process on the SAME node -- one per GPU, or several on one GPU -- the rows need not leave the device(s):
+
+  exporter   FieldArray.__reduce__ (finfields.py), when called from the runtime's own marshalling, returns a
+             descriptor instead of the limb bytes: (pid, export id, 64-byte hipIpc handle of the allocation, offset,
+             size) -- a few hundred bytes on the TCP mesh.  The device buffer is parked in `_pending` so that the
+             allocator cannot recycle it.
+  receiver   `_array_from_ipc` (the unpickle hook) opens the handle (ffgpu_ipc_open; opened allocations are cached),
+             copies the row device-to-device into its own memory (ffgpu_ipc_read; over xGMI between GPUs),
+             synchronises, and ACKNOWLEDGES with an 8-byte datagram to the exporter's abstract UNIX socket.
+  release    the exporter counts how many times a descriptor left the process (`Runtime._send_message` is wrapped
+             to look for the descriptor's token in small payloads) and drops the parked buffer when as many
+             acknowledgements have arrived -- `output` sends ONE marshalled share to up to t peers (runtime.py:571-577),
+             `_distribute` unmarshals the sender's own row locally (runtime.py:490-508; an interprocess handle cannot
+             be opened by the process that made it: the descriptor then resolves to the parked buffer itself).
+
+Scope of the switch: descriptors are only produced while the RUNTIME marshals (`mpyc.runtime.pickle` is replaced by a
+shim that raises a flag around `dumps`); `pickle.dumps(array)` anywhere else keeps producing the limb bytes.  Opt-in,
+on every party: MPYC_AMD_IPC_WIRE=1 (or mpyc_amd.ipcwire.enable()).  A descriptor is meaningless on another host;
+receiving one there fails loudly in ffgpu_ipc_open.
+"""
+import atexit
+import ctypes
+import os
+import socket
+import struct
+import sys
+import time
+from collections import OrderedDict
+
+import torch
+
+from . import _ffi
+
+ENABLED = os.environ.get('MPYC_AMD_IPC_WIRE', '0') == '1'
+MIN_BYTES = int(os.environ.get('MPYC_AMD_IPC_WIRE_MIN', str(1 << 16)))      # smaller rows travel inline
+TOKEN = b'MPYCAMD-IPC:'
+HANDLE_BYTES = 64
+OPEN_CACHE = 16           # exporter allocations kept mapped (the caching allocator hands out the same segments again)
+
+_in_transport = 0         # > 0 while the runtime's pickle.dumps runs (set by the shim below)
+_hooked = False
+_pending = {}             # export id -> [tensor, times sent, acknowledgements, resolved locally]
+_next_id = 0
+_sock = None              # this process's acknowledgement socket (abstract namespace: no file to clean up)
+_ack_socks = {}           # exporter pid -> connected datagram socket
+_opened = OrderedDict()   # (exporter pid, handle bytes) -> (base pointer, ctx)
+stats = {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0}
+
+
+def enable(on=True):
+    global ENABLED
+    ENABLED = bool(on)
+
+
+def _sock_name(pid):
+    return b'\0mpyc_amd_ipc_%d' % pid
+
+
+def _ack_socket():
+    global _sock
+    if _sock is None:
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
+        s.bind(_sock_name(os.getpid()))
+        s.setblocking(False)
+        _sock = s
+        atexit.register(_linger)
+    return _sock
+
+
+def drain():
+    """Collect acknowledgements; release every parked buffer all of whose receivers have copied it."""
+    if _sock is None:
+        return
+    while True:
+        try:
+            msg = _sock.recv(64)
+        except (BlockingIOError, InterruptedError):
+            break
+        if len(msg) == 8:
+            ent = _pending.get(struct.unpack('<Q', msg)[0])
+            if ent is not None:
+                ent[2] += 1
+    for eid in [e for e, ent in _pending.items() if ent[2] >= ent[1] and (ent[1] > 0 or ent[3])]:
+        del _pending[eid]
+        stats['released'] += 1
+
+
+def _linger():
+    """At interpreter exit: give receivers a moment to finish copying rows this process still owes them."""
+    t0 = time.time()
+    while any(ent[2] < ent[1] for ent in _pending.values()) and time.time() - t0 < 5.0:
+        drain()
+        time.sleep(0.002)
+
+
+# ---- the two hooks into the runtime (both looked up on the imported module; absent -> the wire stays off) -----------
+class _PickleShim:
+    """Stands in for the `pickle` module inside mpyc.runtime: dumps raises the transport flag around the real call."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def dumps(self, obj, *args, **kwargs):
+        global _in_transport
+        _in_transport += 1
+        try:
+            return self._real.dumps(obj, *args, **kwargs)
+        finally:
+            _in_transport -= 1
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+
+def ensure_runtime_hooks():
+    """Install the marshalling flag and the send counter on the imported mpyc.runtime.  Returns True when both are in
+    place (then, and only then, descriptors are produced)."""
+    global _hooked
+    if _hooked:
+        return True
+    rt = sys.modules.get('mpyc.runtime')
+    if rt is None or not hasattr(rt, 'Runtime') or not hasattr(rt.Runtime, '_send_message') or not hasattr(rt, 'pickle'):
+        return False
+    orig_send = rt.Runtime._send_message
+
+    def _send_message(self, peer_pid, data):
+        if len(data) < 4096:
+            at = data.find(TOKEN)
+            while at >= 0:
+                ent = _pending.get(int(data[at + len(TOKEN):at + len(TOKEN) + 16], 16))
+                if ent is not None:
+                    ent[1] += 1
+                at = data.find(TOKEN, at + 1)
+        return orig_send(self, peer_pid, data)
+
+    rt.Runtime._send_message = _send_message
+    if not isinstance(rt.pickle, _PickleShim):
+        rt.pickle = _PickleShim(rt.pickle)
+    _hooked = True
+    return True
+
+
+# ---- exporter ---------------------------------------------------------------------------------------------------------
+def want_descriptor(ctx, nbytes):
+    return (ENABLED and _in_transport > 0 and nbytes >= MIN_BYTES and getattr(ctx, 'torch_device', None) is not None
+            and _hooked)
+
+
+def export(ctx, t):
+    """Park the device tensor t and return its descriptor (plain picklable values)."""
+    global _next_id
+    _ack_socket()
+    drain()
+    handle = ctypes.create_string_buffer(HANDLE_BYTES)
+    offset = ctypes.c_ulonglong()
+    _ffi.check(ctx._L.ffgpu_ipc_export(ctx._h, t.data_ptr(), handle, ctypes.byref(offset), ctx._stream()), 'ipc_export')
+    _next_id += 1
+    eid = _next_id
+    _pending[eid] = [t, 0, 0, False]
+    if len(_pending) > 1024:            # descriptors that were made but never sent nor resolved (nothing in the runtime does that)
+        for old in [e for e, ent in _pending.items() if e < eid - 1024 and ent[1] == 0 and not ent[3]]:
+            del _pending[old]
+    stats['exported'] += 1
+    nbytes = t.numel() * t.element_size()
+    return (os.getpid(), TOKEN + b'%016x' % eid, handle.raw, int(offset.value), nbytes, str(t.dtype).replace('torch.', ''),
+            tuple(t.shape))
+
+
+# ---- receiver ---------------------------------------------------------------------------------------------------------
+def fetch(ctx, desc):
+    """The row behind a descriptor as a tensor in THIS party's memory."""
+    pid, token, handle, offset, nbytes, dtype, shape = desc
+    eid = int(token[len(TOKEN):], 16)
+    if pid == os.getpid():
+        ent = _pending.get(eid)
+        if ent is None:
+            raise RuntimeError('device-side wire: this process no longer holds the buffer of its own descriptor')
+        ent[3] = True
+        stats['local'] += 1
+        t = ent[0]
+        drain()
+        return t
+    key = (pid, handle)
+    got = _opened.get(key)
+    if got is None:
+        base = ctypes.c_void_p()
+        rc = ctx._L.ffgpu_ipc_open(ctx._h, handle, ctypes.byref(base))
+        if rc != 0:
+            raise RuntimeError('MPYC_AMD_IPC_WIRE: cannot open the device buffer of party process %d (%s) -- the '
+                               'device-side wire needs every party on the same node with its GPUs visible to the others'
+                               % (pid, ctx._L.ffgpu_last_hip_error().decode() or ctx._L.ffgpu_strerror(rc).decode()))
+        got = _opened[key] = (base.value, ctx)
+        while len(_opened) > OPEN_CACHE:
+            _, (old, octx) = _opened.popitem(last=False)
+            octx._L.ffgpu_ipc_close(octx._h, old)
+    else:
+        _opened.move_to_end(key)
+    t = torch.empty(shape, dtype=getattr(torch, dtype), device=ctx.torch_device)
+    _ffi.check(ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, ctx._stream()), 'ipc_read')
+    s = _ack_socks.get(pid)
+    if s is None:
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
+        s.connect(_sock_name(pid))
+        _ack_socks[pid] = s
+    try:
+        s.send(struct.pack('<Q', eid))
+    except OSError:                     # the exporter is gone (its memory with it; our copy is complete)
+        _ack_socks.pop(pid, None)
+    stats['imported'] += 1
+    return t

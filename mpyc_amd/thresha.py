@@ -150,6 +150,8 @@ def np_random_split(field, s, t, m) -> ShareMatrix:
     party (thresha.py:47-64)."""
     if not 0 <= t < m:
         raise ValueError('need 0 <= t < m')
+    if _ipcwire.ENABLED:
+        _ipcwire.ensure_runtime_hooks()
     S = _as_field_array(field, s)
     return ShareMatrix(field, _split_device(field, S, t, m, np_convention=True))
 
@@ -293,6 +295,8 @@ def _f_S_i(field, m, i, S):
     xs = (0,) + tuple(x + 1 for x in range(m) if x not in S)
     return _recombination_vector(field, xs, i + 1)[0]       # only the point at x = 0 carries a 1
 
+
+from . import ipcwire as _ipcwire  # noqa: E402
 
 PRSS_STREAM_MIN = 16 << 20       # XOF bytes per subset key above which a PRSS call is squeezed and combined in slices
 

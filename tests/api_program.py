@@ -158,8 +158,11 @@ async def main():
         want = [w * int(v) % P for w, v in zip(want, xb[:4].tolist())]
     got = [int(e) for e in (y[:4].value if MODE == 'ref' else np.asarray(y[:4].value)).tolist()]
     assert got == want, (got, want)
+    sent = sum(getattr(pty.protocol, 'nbytes_sent', 0) for pty in mpc.parties if getattr(pty, 'protocol', None) is not None)
     await mpc.shutdown()
-    res = {'pid': pid, 'm': m, 't': mpc.threshold, 'n': N, 'prime_bits': P.bit_length(), 'mode': MODE, 'chain': CHAIN,
+    ipcw = sys.modules.get('mpyc_amd.ipcwire')
+    ipc = bool(ipcw is not None and ipcw.ENABLED and ipcw.stats['exported'] + ipcw.stats['imported'] > 0) if MODE == 'gpu' else False
+    res = {'pid': pid, 'ipc_wire': ipc, 'ipc_stats': dict(ipcw.stats) if ipcw is not None else None, 'bytes_sent': sent, 'm': m, 't': mpc.threshold, 'n': N, 'prime_bits': P.bit_length(), 'mode': MODE, 'chain': CHAIN,
            'input_s': t_input, 'times_s': times, 'gpu_busy_ms': busy_ms, 'gpu_calls': calls, 'digests': digests}
     if DIGEST:
         with open(f'{DIGEST}.{pid}.json', 'w') as fh:

@@ -23,8 +23,9 @@ STAGE = os.path.join(ROOT, '_refstage')
 PROG = os.path.join(ROOT, 'tests', 'api_program.py')
 
 
-def run_program(ref, mode, n, parties, tmp, seed=11, reps=2, prime=None, chain=1, timeout=1500):
+def run_program(ref, mode, n, parties, tmp, seed=11, reps=2, prime=None, chain=1, timeout=1500, ipc_wire=False):
     env = dict(os.environ)
+    env['MPYC_AMD_IPC_WIRE'] = '1' if ipc_wire else '0'
     env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref])
     env.update(API_MODE=mode, API_N=str(n), API_REPS=str(reps), API_SEED=str(seed), API_CHAIN=str(chain),
                API_DIGEST=os.path.join(tmp, f'dg_{mode}_{parties}'))
@@ -91,4 +92,22 @@ def test_api_path_chain_wide_prime_on_gpu(tmp_path):
     n = 100_000
     ref = run_program(STAGE, 'ref', n, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1)
     dev = run_program(STAGE, 'gpu', n, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1)
+    compare(ref, dev, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(STAGE, 'mpyc')), reason='no staged reference copy (_refstage/)')
+def test_api_path_device_side_wire_on_gpu(tmp_path):
+    """Three co-located parties with MPYC_AMD_IPC_WIRE=1: the pickled share rows carry an interprocess handle of the
+    device buffer instead of the limb bytes (mpyc_amd/finfields.py, _array_from_ipc); what every party splits, receives,
+    recombines and opens is still the reference's, digest for digest -- for 10^6 elements over 2^61 - 1 and for a chain
+    of three gates over the two-limb prime 2^128 - 173.  The messages shrink from n x 8 B to a few hundred bytes."""
+    n = 1_000_000
+    ref = run_program(STAGE, 'ref', n, 3, str(tmp_path), reps=1)
+    dev = run_program(STAGE, 'gpu', n, 3, str(tmp_path), reps=2, ipc_wire=True)
+    assert dev[0]['ipc_wire'] is True
+    compare(ref, run_program(STAGE, 'gpu', n, 3, str(tmp_path), reps=1, ipc_wire=True), 3, 1)
+    assert dev[0]['bytes_sent'] < 200_000, dev[0]['bytes_sent']          # inline rows would be >= 4 x 8 MB per repetition
+    ref = run_program(STAGE, 'ref', 100_000, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1)
+    dev = run_program(STAGE, 'gpu', 100_000, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1, ipc_wire=True)
     compare(ref, dev, 3, 1)

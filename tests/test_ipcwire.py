@@ -1,0 +1,135 @@
+"""Host logic of the device-side wire (mpyc_amd/ipcwire.py) without a GPU: the marshalling flag is only up inside the
+runtime's pickle.dumps, descriptors that leave the process are counted by the wrapped Runtime._send_message, a parked
+buffer is released exactly when as many acknowledgements have come in (or when the exporter resolved its own
+descriptor locally and nobody else got it), and anything else stays parked.  libffgpu's interprocess entry points are
+replaced by host-memory stand-ins here; the real thing runs in tests/test_api_path.py -m gpu."""
+import ctypes
+import os
+import pickle
+import socket
+import struct
+import sys
+import types
+
+import pytest
+import torch
+
+
+class FakeLib:
+    def ffgpu_ipc_export(self, h, ptr, handle, offset, stream):
+        ctypes.memmove(handle, struct.pack('<Q', ptr) + bytes(56), 64)
+        offset._obj.value = 0
+        return 0
+
+    def ffgpu_last_hip_error(self):
+        return b''
+
+
+class FakeCtx:
+    torch_device = torch.device('cpu')
+    _h = None
+    _L = FakeLib()
+
+    def _stream(self):
+        return None
+
+
+@pytest.fixture
+def wire(monkeypatch):
+    from mpyc_amd import ipcwire
+    rt = types.ModuleType('mpyc.runtime')
+    sent = []
+
+    class Runtime:
+        def _send_message(self, peer_pid, data):
+            sent.append((peer_pid, data))
+    rt.Runtime = Runtime
+    rt.pickle = pickle
+    monkeypatch.setitem(sys.modules, 'mpyc.runtime', rt)
+    for name, val in (('ENABLED', True), ('_hooked', False), ('_pending', {}), ('_next_id', 0), ('_in_transport', 0), ('_sock', None),
+                      ('stats', {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0})):
+        monkeypatch.setattr(ipcwire, name, val)
+    yield ipcwire, rt, sent
+    if ipcwire._sock is not None:
+        ipcwire._sock.close()
+
+
+def ack(ipcwire, eid):
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
+    s.connect(ipcwire._sock_name(os.getpid()))
+    s.send(struct.pack('<Q', eid))
+    s.close()
+
+
+class Row:
+    """stands for a FieldArray: __reduce__ asks the wire whether to ship a descriptor"""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __reduce__(self):
+        from mpyc_amd import ipcwire
+        ctx = FakeCtx()
+        ipcwire.ensure_runtime_hooks()
+        if ipcwire.want_descriptor(ctx, self.t.numel() * 8):
+            return (tuple, (ipcwire.export(ctx, self.t),))
+        return (bytes, (b'inline',))
+
+
+def test_descriptor_only_inside_runtime_marshalling(wire):
+    ipcwire, rt, sent = wire
+    row = Row(torch.arange(20000, dtype=torch.int64))
+    assert ipcwire.ensure_runtime_hooks() and isinstance(rt.pickle, ipcwire._PickleShim)
+    assert pickle.loads(pickle.dumps(row)) == b'inline'                      # a user's pickle: the data
+    blob = rt.pickle.dumps(row)                                              # the runtime's marshal: a descriptor
+    desc = pickle.loads(blob)
+    assert desc[0] == os.getpid() and desc[1].startswith(ipcwire.TOKEN) and len(desc[2]) == 64 and desc[4] == 160000
+    assert ipcwire._in_transport == 0 and len(blob) < 400
+    small = Row(torch.arange(10, dtype=torch.int64))
+    assert pickle.loads(rt.pickle.dumps(small)) == b'inline'                 # below MIN_BYTES
+    ipcwire.enable(False)
+    assert pickle.loads(rt.pickle.dumps(row)) == b'inline'
+    ipcwire.enable(True)
+
+
+def test_release_after_as_many_acknowledgements_as_sends(wire):
+    ipcwire, rt, sent = wire
+    assert ipcwire.ensure_runtime_hooks()            # (install() does this when the first field is made)
+    r = rt.Runtime()
+    rows = [Row(torch.full((20000,), j, dtype=torch.int64)) for j in range(3)]
+    blobs = [rt.pickle.dumps(x) for x in rows]
+    ids = sorted(ipcwire._pending)
+    assert len(ids) == 3 and all(ent[1] == 0 for ent in ipcwire._pending.values())
+    r._send_message(1, blobs[1])                                             # _distribute: row j to party j ...
+    r._send_message(2, blobs[2])
+    r._send_message(1, b'x' * 10000 + blobs[0])                              # (large payloads are not scanned)
+    assert [ipcwire._pending[i][1] for i in ids] == [0, 1, 1] and len(sent) == 3
+    ipcwire.drain()
+    assert len(ipcwire._pending) == 3                                        # nothing acknowledged yet, row 0 unresolved
+    own = ipcwire.fetch(FakeCtx(), pickle.loads(blobs[0]))                   # ... and the own row is unmarshalled locally
+    assert own is rows[0].t and ipcwire.stats['local'] == 1
+    assert ids[0] not in ipcwire._pending and len(ipcwire._pending) == 2     # released: nobody else holds its descriptor
+    ack(ipcwire, ids[1])
+    ipcwire.drain()
+    assert sorted(ipcwire._pending) == [ids[2]]
+    # output(): ONE marshalled share goes to two peers -- two acknowledgements before the buffer may be recycled
+    share = rt.pickle.dumps(Row(torch.ones(20000, dtype=torch.int64)))
+    sid = max(ipcwire._pending)
+    r._send_message(1, share)
+    r._send_message(2, share)
+    ack(ipcwire, sid)
+    ipcwire.drain()
+    assert sid in ipcwire._pending and ipcwire._pending[sid][1:3] == [2, 1]
+    ack(ipcwire, sid)
+    ack(ipcwire, ids[2])
+    ipcwire.drain()
+    assert not ipcwire._pending and ipcwire.stats['released'] == 4
+    with pytest.raises(RuntimeError):
+        ipcwire.fetch(FakeCtx(), pickle.loads(blobs[0]))                     # a second local resolution: the buffer is gone
+
+
+def test_wire_stays_off_without_the_runtime_hooks(wire, monkeypatch):
+    ipcwire, rt, sent = wire
+    del rt.Runtime._send_message                                             # an upstream without the choke point
+    assert ipcwire.ensure_runtime_hooks() is False
+    assert pickle.loads(rt.pickle.dumps(Row(torch.arange(20000, dtype=torch.int64)))) == b'inline'
