@@ -52,10 +52,37 @@ def install():
             return False
         return ops.modulus.bit_length() <= 129 if ops.binary else gff.device_supports_prime(ops.modulus)
 
+    picked = []
+
+    def pick_device():
+        """One party process per GPU: with several GPUs visible, party i computes on GPU i mod count (MPYC_AMD_DEVICE=
+        <index> pins one, MPYC_AMD_DEVICE=current keeps torch's current device).  Decided once, when the first field is
+        made -- mpyc.runtime has parsed the party index by then."""
+        if picked:
+            return
+        picked.append(True)
+        import os
+        import sys
+        import torch
+        if not torch.cuda.is_available():
+            return
+        want = os.environ.get('MPYC_AMD_DEVICE', 'party')
+        if want == 'current':
+            return
+        if want.isdigit():
+            torch.cuda.set_device(int(want))
+            return
+        rt = sys.modules.get('mpyc.runtime')
+        mpc = getattr(rt, 'mpc', None)
+        count = torch.cuda.device_count()
+        if mpc is not None and count > 1 and len(getattr(mpc, 'parties', ())) > 1:
+            torch.cuda.set_device(mpc.pid % count)
+
     @functools.cache
     def arrayGF(field, modulus):
         from . import ipcwire
-        if ipcwire.ENABLED:
+        pick_device()
+        if ipcwire.resolve_auto():
             ipcwire.ensure_runtime_hooks()       # (fields are made after mpyc.runtime is imported, before any gate runs)
         if not supported(field):
             return orig_arrayGF(field, modulus)

@@ -20,9 +20,10 @@ party is a process on the SAME node -- one per GPU, or several on one GPU -- the
              be opened by the process that made it: the descriptor then resolves to the parked buffer itself).
 
 Scope of the switch: descriptors are only produced while the RUNTIME marshals (`mpyc.runtime.pickle` is replaced by a
-shim that raises a flag around `dumps`); `pickle.dumps(array)` anywhere else keeps producing the limb bytes.  Opt-in,
-on every party: MPYC_AMD_IPC_WIRE=1 (or mpyc_amd.ipcwire.enable()).  A descriptor is meaningless on another host;
-receiving one there fails loudly in ffgpu_ipc_open.
+shim that raises a flag around `dumps`); `pickle.dumps(array)` anywhere else keeps producing the limb bytes.
+MPYC_AMD_IPC_WIRE=1 switches the wire on, =0 off; unset, it is on exactly when the runtime's party list puts every party
+on this host (`-M<m>`: all 'localhost').  A descriptor is meaningless on another host; receiving one there fails loudly
+in ffgpu_ipc_open (set MPYC_AMD_IPC_WIRE=0 on every party, e.g. for containers that share a loopback but not the GPUs).
 """
 import atexit
 import ctypes
@@ -37,7 +38,10 @@ import torch
 
 from . import _ffi
 
-ENABLED = os.environ.get('MPYC_AMD_IPC_WIRE', '0') == '1'
+_MODE = os.environ.get('MPYC_AMD_IPC_WIRE', 'auto')          # '1' on, '0' off, 'auto': on when every party is on this host
+ENABLED = _MODE == '1'
+_auto = _MODE == 'auto'
+_LOOPBACK = ('localhost', '127.0.0.1', '::1', '')
 MIN_BYTES = int(os.environ.get('MPYC_AMD_IPC_WIRE_MIN', str(1 << 16)))      # smaller rows travel inline
 TOKEN = b'MPYCAMD-IPC:'
 HANDLE_BYTES = 64
@@ -54,8 +58,27 @@ stats = {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0}
 
 
 def enable(on=True):
-    global ENABLED
+    global ENABLED, _auto
     ENABLED = bool(on)
+    _auto = False
+
+
+def resolve_auto():
+    """MPYC_AMD_IPC_WIRE unset: the wire is switched on when the runtime's party list says that every party runs on
+    this host (`-M<m>` local parties: runtime.py:5193 gives them 'localhost' addresses) and there is more than one.
+    Called once the runtime has been imported (mpyc_amd.install -> arrayGF); explicit '0' / '1' always win."""
+    global ENABLED, _auto
+    if not _auto:
+        return ENABLED
+    rt = sys.modules.get('mpyc.runtime')
+    mpc = getattr(rt, 'mpc', None)
+    parties = getattr(mpc, 'parties', None)
+    if parties is None:
+        return ENABLED
+    _auto = False
+    hosts = [getattr(pty, 'host', None) for pty in parties]
+    ENABLED = len(parties) > 1 and all(h is None or h in _LOOPBACK for h in hosts) and torch.cuda.is_available()
+    return ENABLED
 
 
 def _sock_name(pid):

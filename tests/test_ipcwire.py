@@ -46,7 +46,7 @@ def wire(monkeypatch):
     rt.Runtime = Runtime
     rt.pickle = pickle
     monkeypatch.setitem(sys.modules, 'mpyc.runtime', rt)
-    for name, val in (('ENABLED', True), ('_hooked', False), ('_pending', {}), ('_next_id', 0), ('_in_transport', 0), ('_sock', None),
+    for name, val in (('ENABLED', True), ('_auto', False), ('_hooked', False), ('_pending', {}), ('_next_id', 0), ('_in_transport', 0), ('_sock', None),
                       ('stats', {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0})):
         monkeypatch.setattr(ipcwire, name, val)
     yield ipcwire, rt, sent
@@ -133,3 +133,23 @@ def test_wire_stays_off_without_the_runtime_hooks(wire, monkeypatch):
     del rt.Runtime._send_message                                             # an upstream without the choke point
     assert ipcwire.ensure_runtime_hooks() is False
     assert pickle.loads(rt.pickle.dumps(Row(torch.arange(20000, dtype=torch.int64)))) == b'inline'
+
+
+def test_auto_mode_follows_the_party_list(wire, monkeypatch):
+    """MPYC_AMD_IPC_WIRE unset: on exactly when the runtime lists more than one party and all of them on this host."""
+    ipcwire, rt, sent = wire
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+
+    class P:
+        def __init__(self, host):
+            self.host = host
+    for hosts, want in ((['localhost'] * 3, True), (['localhost'], False), (['localhost', '10.0.0.7', 'localhost'], False),
+                        ([None, None], True), (['127.0.0.1', ''], True)):
+        monkeypatch.setattr(ipcwire, '_auto', True)
+        monkeypatch.setattr(ipcwire, 'ENABLED', False)
+        rt.mpc = types.SimpleNamespace(parties=[P(h) for h in hosts])
+        assert ipcwire.resolve_auto() is want, hosts
+    monkeypatch.setattr(ipcwire, '_auto', False)                  # an explicit setting is not re-evaluated
+    monkeypatch.setattr(ipcwire, 'ENABLED', False)
+    rt.mpc = types.SimpleNamespace(parties=[P('localhost')] * 3)
+    assert ipcwire.resolve_auto() is False
