@@ -169,7 +169,7 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
     return out
 
 
-def api_leg(n_full):
+def api_leg(n_full, parties_on_gpus=False):
     """The path THROUGH the reference's public API: tests/api_program.py -- an ordinary MPyC
     program, `mpc.output(a * b)` on SecFld(2^61-1) arrays, i.e. Runtime.np_multiply -> _reshare -> output
     (runtime.py:1096-1141, 603-689, 513-600) -- run as party processes under mpyc_amd.install(), and on the unmodified
@@ -193,8 +193,10 @@ def api_leg(n_full):
         env = dict(os.environ)
         env['MPYC_AMD_IPC_WIRE'] = '1' if ipc_wire else '0'
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
-        for k_ in ('MPYC_GPU', 'API_SEED', 'API_DIGEST', 'API_CPROFILE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        for k_ in ('MPYC_GPU', 'API_SEED', 'API_DIGEST', 'API_CPROFILE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE',
+                   'GROUP_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
             env.pop(k_, None)
+        env['MPYC_AMD_DEVICE'] = 'party' if parties_on_gpus else 'current'
         env.update(API_MODE=mode, API_N=str(n), API_REPS=str(reps), API_WARMUP=str(warmup), API_CHAIN=str(chain))
         cmd = [sys.executable, prog, '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
         t0 = time.perf_counter()
@@ -220,11 +222,19 @@ def api_leg(n_full):
         if parties > 1:
             out['wire'] = 'device buffers by interprocess handle (MPYC_AMD_IPC_WIRE=1)' if d.get('ipc_wire') else 'limb bytes through the TCP mesh'
             out['bytes_sent_party0'] = d.get('bytes_sent')
+            out['device_party0'] = d.get('device')
         return out
 
     res = {'workload': 'mpc.output(a * b) on SecFld(GF(2^61-1)) arrays through the unmodified mpyc runtime under '
                        'mpyc_amd.install() (tests/api_program.py); reference = the same program without install()',
            'reference_root': os.path.basename(ref_root)}
+    if parties_on_gpus:
+        res = {'workload': 'mpc.output(a * b [* b ...]) on SecFld(GF(2^61-1)) arrays of 10^7 elements, THREE party processes on '
+                           'GPUs 0, 1, 2 of this node (MPYC_AMD_DEVICE=party), share rows exchanged as interprocess handles '
+                           '(device-side wire, mpyc_amd/ipcwire.py: peer copies between the GPUs)',
+               'm3_1e7_ipc': run('gpu', n_full, 3, 10, 2, ipc_wire=True, timeout=240),
+               'm3_1e7_chain8_ipc': run('gpu', n_full, 3, 5, 1, chain=8, ipc_wire=True, timeout=240)}
+        return res
     res['m1_1e7'] = run('gpu', n_full, 1, 20, 3)
     res['m1_1e7_chain8'] = run('gpu', n_full, 1, 10, 2, chain=8)
     res['m1_1e8'] = run('gpu', 10 * n_full, 1, 5, 2)
@@ -1187,6 +1197,16 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # N >= 3 GPUs: the m-party protocol itself with ONE PARTY PER GPU -- three MPyC party processes under install() on GPUs
+    # 0, 1, 2 (MPYC_AMD_DEVICE=party), share rows crossing between the GPUs as interprocess handles (device-side wire:
+    # xGMI peer copies).  Runs after every collective is done (the other ranks are idle or gone), as subprocesses with
+    # their own timeouts; an error is reported in the object, never raised.
+    if rank == 0 and world >= 3 and not args.no_api_leg and not args.no_extras:
+        torch.cuda.empty_cache()
+        try:
+            out['api_parties_on_gpus'] = api_leg(n, parties_on_gpus=True)
+        except Exception as exc:          # noqa: BLE001
+            out['api_parties_on_gpus'] = {'error': f'{type(exc).__name__}: {exc}'}
     finish()
 
 

@@ -162,7 +162,8 @@ async def main():
     await mpc.shutdown()
     ipcw = sys.modules.get('mpyc_amd.ipcwire')
     ipc = bool(ipcw is not None and ipcw.ENABLED and ipcw.stats['exported'] + ipcw.stats['imported'] > 0) if MODE == 'gpu' else False
-    res = {'pid': pid, 'ipc_wire': ipc, 'ipc_stats': dict(ipcw.stats) if ipcw is not None else None, 'bytes_sent': sent, 'm': m, 't': mpc.threshold, 'n': N, 'prime_bits': P.bit_length(), 'mode': MODE, 'chain': CHAIN,
+    dev_index = sync.current_device() if (sync is not None and MODE == 'gpu') else None
+    res = {'pid': pid, 'device': dev_index, 'ipc_wire': ipc, 'ipc_stats': dict(ipcw.stats) if ipcw is not None else None, 'bytes_sent': sent, 'm': m, 't': mpc.threshold, 'n': N, 'prime_bits': P.bit_length(), 'mode': MODE, 'chain': CHAIN,
            'input_s': t_input, 'times_s': times, 'gpu_busy_ms': busy_ms, 'gpu_calls': calls, 'digests': digests}
     if DIGEST:
         with open(f'{DIGEST}.{pid}.json', 'w') as fh:

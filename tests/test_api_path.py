@@ -111,3 +111,9 @@ def test_api_path_device_side_wire_on_gpu(tmp_path):
     ref = run_program(STAGE, 'ref', 100_000, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1)
     dev = run_program(STAGE, 'gpu', 100_000, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1, ipc_wire=True)
     compare(ref, dev, 3, 1)
+    # five parties, t = 2: `output` hands ONE marshalled share to two peers (two acknowledgements per descriptor),
+    # and only 2t + 1 = 5 of 5 parties re-share
+    ref = run_program(STAGE, 'ref', 100_000, 5, str(tmp_path), reps=1)
+    dev = run_program(STAGE, 'gpu', 100_000, 5, str(tmp_path), reps=3, ipc_wire=True)
+    assert dev[0]['ipc_wire'] is True and dev[0]['ipc_stats']['inline'] == 0
+    compare(ref, run_program(STAGE, 'gpu', 100_000, 5, str(tmp_path), reps=1, ipc_wire=True), 5, 2)
