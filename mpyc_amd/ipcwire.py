@@ -12,7 +12,8 @@ party is a process on the SAME node -- one per GPU, or several on one GPU -- the
              allocator cannot recycle it.
   receiver   `_array_from_ipc` (the unpickle hook) opens the handle (ffgpu_ipc_open; opened allocations are cached),
              copies the row device-to-device into its own memory (ffgpu_ipc_read; over xGMI between GPUs),
-             synchronises, and ACKNOWLEDGES with an 8-byte datagram to the exporter's abstract UNIX socket.
+             synchronises, and ACKNOWLEDGES with an 8-byte datagram to the exporter's abstract UNIX socket (its address ends
+             in a random tag and travels in the descriptor: only receivers of descriptors can acknowledge).
   release    the exporter counts how many times a descriptor left the process (`Runtime._send_message` is wrapped
              to look for the descriptor's token in small payloads) and drops the parked buffer when as many
              acknowledgements have arrived -- `output` sends ONE marshalled share to up to t peers (runtime.py:571-577),
@@ -81,15 +82,17 @@ def resolve_auto():
     return ENABLED
 
 
-def _sock_name(pid):
-    return b'\0mpyc_amd_ipc_%d' % pid
+_sock_addr = None         # abstract-namespace address of this process's acknowledgement socket; it ends in a random
+#                           tag and travels inside the descriptors, so only their receivers can acknowledge
 
 
 def _ack_socket():
-    global _sock
+    global _sock, _sock_addr
     if _sock is None:
+        import secrets
         s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
-        s.bind(_sock_name(os.getpid()))
+        _sock_addr = b'\0mpyc_amd_ipc_%d_%s' % (os.getpid(), secrets.token_hex(8).encode())
+        s.bind(_sock_addr)
         s.setblocking(False)
         _sock = s
         atexit.register(_linger)
@@ -192,13 +195,13 @@ def export(ctx, t):
     stats['exported'] += 1
     nbytes = t.numel() * t.element_size()
     return (os.getpid(), TOKEN + b'%016x' % eid, handle.raw, int(offset.value), nbytes, str(t.dtype).replace('torch.', ''),
-            tuple(t.shape))
+            tuple(t.shape), _sock_addr)
 
 
 # ---- receiver ---------------------------------------------------------------------------------------------------------
 def fetch(ctx, desc):
     """The row behind a descriptor as a tensor in THIS party's memory."""
-    pid, token, handle, offset, nbytes, dtype, shape = desc
+    pid, token, handle, offset, nbytes, dtype, shape, ack_addr = desc
     eid = int(token[len(TOKEN):], 16)
     if pid == os.getpid():
         ent = _pending.get(eid)
@@ -229,7 +232,7 @@ def fetch(ctx, desc):
     s = _ack_socks.get(pid)
     if s is None:
         s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
-        s.connect(_sock_name(pid))
+        s.connect(ack_addr)
         _ack_socks[pid] = s
     try:
         s.send(struct.pack('<Q', eid))

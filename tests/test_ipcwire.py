@@ -46,7 +46,7 @@ def wire(monkeypatch):
     rt.Runtime = Runtime
     rt.pickle = pickle
     monkeypatch.setitem(sys.modules, 'mpyc.runtime', rt)
-    for name, val in (('ENABLED', True), ('_auto', False), ('_hooked', False), ('_pending', {}), ('_next_id', 0), ('_in_transport', 0), ('_sock', None),
+    for name, val in (('ENABLED', True), ('_auto', False), ('_hooked', False), ('_pending', {}), ('_next_id', 0), ('_in_transport', 0), ('_sock', None), ('_sock_addr', None),
                       ('stats', {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0})):
         monkeypatch.setattr(ipcwire, name, val)
     yield ipcwire, rt, sent
@@ -56,7 +56,7 @@ def wire(monkeypatch):
 
 def ack(ipcwire, eid):
     s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
-    s.connect(ipcwire._sock_name(os.getpid()))
+    s.connect(ipcwire._sock_addr)
     s.send(struct.pack('<Q', eid))
     s.close()
 
