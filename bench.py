@@ -247,6 +247,31 @@ def api_leg(n_full, parties_on_gpus=False):
     res['m3_1e6_ipc'] = run('gpu', n_full // 10, 3, 10, 2, ipc_wire=True)
     res['reference_m1_1e6'] = run('ref', n_full // 10, 1, 2, 0)
     res['reference_m3_1e6'] = run('ref', n_full // 10, 3, 1, 0)
+    # the same runtime one protocol up: secure FIXED-POINT products (np_multiply + np_trunc -- random bits from PRSS, a masked
+    # opening, integer arithmetic on `.value` that the device-resident views of install() keep on the GPU), SecFxp(32)
+    def run_fxp(mode, n_, parties, timeout=600):
+        env = dict(os.environ)
+        env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
+        for k_ in ('MPYC_GPU', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'FXP_CHECK', 'FXP_RAW'):
+            env.pop(k_, None)
+        env.update(API_MODE=mode, API_N=str(n_))
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'fxp_api_probe.py'), '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return {'error': f'timeout after {timeout} s'}
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')), None)
+        if r.returncode != 0 or line is None:
+            return {'error': (r.stdout + r.stderr)[-300:]}
+        parts = line.split()
+        secs = float(parts[3])
+        return {'n': n_, 'parties': parties, 's_per_product_and_opening': secs, 'elements_per_s': round(n_ / secs, 1),
+                'max_abs_error_vs_float': float(parts[5])}
+    res['fxp_m1_1e6'] = run_fxp('gpu', n_full // 10, 1)
+    res['fxp_m3_1e6_ipc'] = run_fxp('gpu', n_full // 10, 3)
+    res['reference_fxp_m1_2e4'] = run_fxp('ref', n_full // 500, 1)
+    if 'elements_per_s' in res['fxp_m1_1e6'] and 'elements_per_s' in res['reference_fxp_m1_2e4']:
+        res['fxp_vs_reference_m1'] = round(res['fxp_m1_1e6']['elements_per_s'] / res['reference_fxp_m1_2e4']['elements_per_s'], 1)
     head = res['m1_1e7']
     if 'elements_per_s' in head:
         res['elements_per_s'] = head['elements_per_s']
