@@ -195,13 +195,22 @@ def export(ctx, t):
     stats['exported'] += 1
     nbytes = t.numel() * t.element_size()
     return (os.getpid(), TOKEN + b'%016x' % eid, handle.raw, int(offset.value), nbytes, str(t.dtype).replace('torch.', ''),
-            tuple(t.shape), _sock_addr)
+            tuple(t.shape), _sock_addr, _canary(t))
+
+
+def _canary(t):
+    """First and last 16 bytes of a row (the stream has been synchronised).  A receiver that reads through a CACHED
+    mapping compares them after its copy: should an exporter ever free an allocation and get the same handle bytes for
+    a new one, the stale mapping is detected (share rows are uniformly random: a false match has probability 2^-256),
+    dropped and reopened instead of yielding another buffer's contents."""
+    flat = t.reshape(-1).view(torch.uint8)
+    return bytes(torch.cat([flat[:16], flat[-16:]]).cpu().numpy())
 
 
 # ---- receiver ---------------------------------------------------------------------------------------------------------
 def fetch(ctx, desc):
     """The row behind a descriptor as a tensor in THIS party's memory."""
-    pid, token, handle, offset, nbytes, dtype, shape, ack_addr = desc
+    pid, token, handle, offset, nbytes, dtype, shape, ack_addr, canary = desc
     eid = int(token[len(TOKEN):], 16)
     if pid == os.getpid():
         ent = _pending.get(eid)
@@ -213,22 +222,32 @@ def fetch(ctx, desc):
         drain()
         return t
     key = (pid, handle)
-    got = _opened.get(key)
-    if got is None:
-        base = ctypes.c_void_p()
-        rc = ctx._L.ffgpu_ipc_open(ctx._h, handle, ctypes.byref(base))
-        if rc != 0:
-            raise RuntimeError('MPYC_AMD_IPC_WIRE: cannot open the device buffer of party process %d (%s) -- the '
-                               'device-side wire needs every party on the same node with its GPUs visible to the others'
-                               % (pid, ctx._L.ffgpu_last_hip_error().decode() or ctx._L.ffgpu_strerror(rc).decode()))
-        got = _opened[key] = (base.value, ctx)
-        while len(_opened) > OPEN_CACHE:
-            _, (old, octx) = _opened.popitem(last=False)
-            octx._L.ffgpu_ipc_close(octx._h, old)
-    else:
-        _opened.move_to_end(key)
     t = torch.empty(shape, dtype=getattr(torch, dtype), device=ctx.torch_device)
-    _ffi.check(ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, ctx._stream()), 'ipc_read')
+    for attempt in (0, 1):
+        got = _opened.get(key)
+        cached = got is not None
+        if not cached:
+            base = ctypes.c_void_p()
+            rc = ctx._L.ffgpu_ipc_open(ctx._h, handle, ctypes.byref(base))
+            if rc != 0:
+                raise RuntimeError('MPYC_AMD_IPC_WIRE: cannot open the device buffer of party process %d (%s) -- the '
+                                   'device-side wire needs every party on the same node with its GPUs visible to the others'
+                                   % (pid, ctx._L.ffgpu_last_hip_error().decode() or ctx._L.ffgpu_strerror(rc).decode()))
+            got = _opened[key] = (base.value, ctx)
+            stats['opened'] = stats.get('opened', 0) + 1
+            while len(_opened) > OPEN_CACHE:
+                _, (old, octx) = _opened.popitem(last=False)
+                octx._L.ffgpu_ipc_close(octx._h, old)
+        else:
+            _opened.move_to_end(key)
+        _ffi.check(ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, ctx._stream()), 'ipc_read')
+        if not (cached or attempt) or _canary(t) == canary:
+            break
+        if attempt:
+            raise RuntimeError('device-side wire: the row read through a fresh mapping does not match its descriptor')
+        _opened.pop(key)                                # a stale mapping: unmap, open the handle afresh, read again
+        ctx._L.ffgpu_ipc_close(ctx._h, got[0])
+        stats['stale'] = stats.get('stale', 0) + 1
     s = _ack_socks.get(pid)
     if s is None:
         s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
