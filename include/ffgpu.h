@@ -55,6 +55,7 @@ extern "C" {
 #define FFGPU_EHIP        3   /* a HIP runtime call failed; see ffgpu_last_hip_error */
 #define FFGPU_EMODULUS    4   /* modulus is not usable (even/zero/one, too wide)     */
 #define FFGPU_ENOMEM      5
+#define FFGPU_ESTALE      6   /* ffgpu_ipc_read: the mapping does not show the row the descriptor describes */
 
 /* field kinds */
 #define FFGPU_PRIME   1   /* GF(p), p prime < 2^192       (finfields.py:347-363 pGF)  */
@@ -434,11 +435,17 @@ int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,
  *   open:   maps the exporter's allocation into this process (hipIpcOpenMemHandle; not valid in the exporting
  *           process itself -- the host side short-circuits that case); close unmaps it;
  *   read:   copies `bytes` from base + offset into dst and synchronises `stream`.
+ *   canary: export also returns the first and last 16 bytes of the row (canary32, may be NULL); read, given them
+ *           (expect_canary32, may be NULL), compares them with what the mapping shows BEFORE copying and returns
+ *           FFGPU_ESTALE on a mismatch -- the guard for mappings a receiver keeps cached across messages, should an
+ *           exporter ever free an allocation and obtain the same handle bytes for a new one.
  * replaces: pickle.dumps(row) / pickle.loads(bytes) of the np path for co-located parties.                      */
 #define FFGPU_IPC_HANDLE_BYTES 64
-int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, unsigned char* handle, unsigned long long* offset, void* stream);
+int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, size_t bytes, unsigned char* handle, unsigned long long* offset,
+                     unsigned char* canary32, void* stream);
 int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base);
-int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes, void* stream);
+int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes,
+                   const unsigned char* expect_canary32, void* stream);
 int ffgpu_ipc_close(ffgpu_ctx* ctx, void* base);
 
 #ifdef __cplusplus

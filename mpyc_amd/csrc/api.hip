@@ -230,6 +230,7 @@ const char* ffgpu_strerror(int status) {
         case FFGPU_EINVAL: return "invalid argument";
         case FFGPU_ENOTSUP: return "field or size not supported by this build";
         case FFGPU_EHIP: return "HIP runtime error";
+        case FFGPU_ESTALE: return "interprocess mapping does not show the exported row (stale mapping)";
         case FFGPU_EMODULUS: return "unusable modulus";
         case FFGPU_ENOMEM: return "out of device memory";
         default: return "unknown status";
@@ -422,7 +423,14 @@ int ffgpu_d2h(ffgpu_ctx* ctx, void* host_dst, const void* src, size_t bytes, voi
     return FFGPU_OK;
 }
 // ---- device buffers across co-located party processes (include/ffgpu.h "device-side wire") ----
-int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, unsigned char* handle, unsigned long long* offset, void* stream) {
+// first and last 16 bytes of a row in one small synchronous copy (2 rows of 16 bytes, pitch = bytes - 16)
+static int ipc_canary(const void* row, size_t bytes, unsigned char* out32) {
+    if (bytes < 32) return FFGPU_EINVAL;
+    HIPCHK(hipMemcpy2D(out32, 16, row, bytes - 16, 16, 2, hipMemcpyDeviceToHost));
+    return FFGPU_OK;
+}
+int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, size_t bytes, unsigned char* handle, unsigned long long* offset,
+                     unsigned char* canary32, void* stream) {
     if (!ctx || !ptr || !handle || !offset) return FFGPU_EINVAL;
     static_assert(sizeof(hipIpcMemHandle_t) == FFGPU_IPC_HANDLE_BYTES, "handle size");
     DeviceGuard g(ctx->device);
@@ -434,6 +442,7 @@ int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, unsigned char* handle, uns
     HIPCHK(hipIpcGetMemHandle(&h, base));
     memcpy(handle, &h, sizeof(h));
     *offset = (unsigned long long)((const char*)ptr - (const char*)base);
+    if (canary32) return ipc_canary(ptr, bytes, canary32);
     return FFGPU_OK;
 }
 int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base) {
@@ -446,10 +455,18 @@ int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base) {
     *base = p;
     return FFGPU_OK;
 }
-int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes, void* stream) {
+int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes,
+                   const unsigned char* expect_canary32, void* stream) {
     if (!ctx || (bytes && (!base || !dst))) return FFGPU_EINVAL;
     DeviceGuard g(ctx->device);
-    HIPCHK(hipMemcpyAsync(dst, (const char*)base + offset, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const char* src = (const char*)base + offset;
+    if (expect_canary32) {
+        unsigned char got[32];
+        int rc = ipc_canary(src, bytes, got);
+        if (rc != FFGPU_OK) return rc;
+        if (memcmp(got, expect_canary32, 32) != 0) return FFGPU_ESTALE;
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // the copy HAS run when the caller acknowledges the row
     return FFGPU_OK;
 }

@@ -46,6 +46,7 @@ _LOOPBACK = ('localhost', '127.0.0.1', '::1', '')
 MIN_BYTES = int(os.environ.get('MPYC_AMD_IPC_WIRE_MIN', str(1 << 16)))      # smaller rows travel inline
 TOKEN = b'MPYCAMD-IPC:'
 HANDLE_BYTES = 64
+ESTALE = 6                # FFGPU_ESTALE
 OPEN_CACHE = 16           # exporter allocations kept mapped (the caching allocator hands out the same segments again)
 
 _in_transport = 0         # > 0 while the runtime's pickle.dumps runs (set by the shim below)
@@ -184,8 +185,10 @@ def export(ctx, t):
     _ack_socket()
     drain()
     handle = ctypes.create_string_buffer(HANDLE_BYTES)
+    canary = ctypes.create_string_buffer(32)
     offset = ctypes.c_ulonglong()
-    _ffi.check(ctx._L.ffgpu_ipc_export(ctx._h, t.data_ptr(), handle, ctypes.byref(offset), ctx._stream()), 'ipc_export')
+    nbytes = t.numel() * t.element_size()
+    _ffi.check(ctx._L.ffgpu_ipc_export(ctx._h, t.data_ptr(), nbytes, handle, ctypes.byref(offset), canary, ctx._stream()), 'ipc_export')
     _next_id += 1
     eid = _next_id
     _pending[eid] = [t, 0, 0, False]
@@ -193,18 +196,11 @@ def export(ctx, t):
         for old in [e for e, ent in _pending.items() if e < eid - 1024 and ent[1] == 0 and not ent[3]]:
             del _pending[old]
     stats['exported'] += 1
-    nbytes = t.numel() * t.element_size()
+    # canary = first and last 16 bytes of the row: a receiver that reads through a CACHED mapping has them compared with
+    # what the mapping shows (ffgpu_ipc_read) -- should an exporter ever free an allocation and get the same handle bytes
+    # for a new one, the stale mapping is detected (share rows are uniformly random), dropped and reopened
     return (os.getpid(), TOKEN + b'%016x' % eid, handle.raw, int(offset.value), nbytes, str(t.dtype).replace('torch.', ''),
-            tuple(t.shape), _sock_addr, _canary(t))
-
-
-def _canary(t):
-    """First and last 16 bytes of a row (the stream has been synchronised).  A receiver that reads through a CACHED
-    mapping compares them after its copy: should an exporter ever free an allocation and get the same handle bytes for
-    a new one, the stale mapping is detected (share rows are uniformly random: a false match has probability 2^-256),
-    dropped and reopened instead of yielding another buffer's contents."""
-    flat = t.reshape(-1).view(torch.uint8)
-    return bytes(torch.cat([flat[:16], flat[-16:]]).cpu().numpy())
+            tuple(t.shape), _sock_addr, canary.raw)
 
 
 # ---- receiver ---------------------------------------------------------------------------------------------------------
@@ -240,8 +236,10 @@ def fetch(ctx, desc):
                 octx._L.ffgpu_ipc_close(octx._h, old)
         else:
             _opened.move_to_end(key)
-        _ffi.check(ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, ctx._stream()), 'ipc_read')
-        if not (cached or attempt) or _canary(t) == canary:
+        rc = ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, canary if (cached or attempt) else None,
+                                   ctx._stream())
+        if rc != ESTALE:
+            _ffi.check(rc, 'ipc_read')
             break
         if attempt:
             raise RuntimeError('device-side wire: the row read through a fresh mapping does not match its descriptor')

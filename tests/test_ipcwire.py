@@ -16,7 +16,7 @@ import torch
 
 
 class FakeLib:
-    def ffgpu_ipc_export(self, h, ptr, handle, offset, stream):
+    def ffgpu_ipc_export(self, h, ptr, nbytes, handle, offset, canary, stream):
         ctypes.memmove(handle, struct.pack('<Q', ptr) + bytes(56), 64)
         offset._obj.value = 0
         return 0
