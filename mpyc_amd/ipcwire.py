@@ -14,6 +14,8 @@ party is a process on the SAME node -- one per GPU, or several on one GPU -- the
              copies the row device-to-device into its own memory (ffgpu_ipc_read; over xGMI between GPUs),
              synchronises, and ACKNOWLEDGES with an 8-byte datagram to the exporter's abstract UNIX socket (its address ends
              in a random tag and travels in the descriptor: only receivers of descriptors can acknowledge).
+             Rows read through a cached mapping are checked against the descriptor's canary (first and last 16 bytes)
+             before the copy; a mismatch drops the mapping and reopens the handle.
   release    the exporter counts how many times a descriptor left the process (`Runtime._send_message` is wrapped
              to look for the descriptor's token in small payloads) and drops the parked buffer when as many
              acknowledgements have arrived -- `output` sends ONE marshalled share to up to t peers (runtime.py:571-577),
