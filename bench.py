@@ -534,7 +534,8 @@ def main():
     force_dev = os.environ.get('FFGPU_BENCH_DEVICE')
     if force_dev is not None:
         local_rank = int(force_dev)
-    backend = os.environ.get('FFGPU_BENCH_BACKEND', 'nccl')
+    # (ranks forced onto ONE device cannot form an RCCL communicator -- "Duplicate GPU detected" -- so gloo is the default then)
+    backend = os.environ.get('FFGPU_BENCH_BACKEND', 'gloo' if (force_dev is not None and world > 1) else 'nccl')
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
