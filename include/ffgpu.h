@@ -446,6 +446,11 @@ int ffgpu_ipc_export(ffgpu_ctx* ctx, const void* ptr, size_t bytes, unsigned cha
 int ffgpu_ipc_open(ffgpu_ctx* ctx, const unsigned char* handle, void** base);
 int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t bytes,
                    const unsigned char* expect_canary32, void* stream);
+/* read + ffgpu_reduce in ONE pass: n field elements are read through the mapping, reduced to canonical form (a peer's data
+ * must be canonical before any kernel computes on it, as `field.array(unmarshal(r))` guarantees at runtime.py:508, 677)
+ * and written to dst; synchronises `stream`. */
+int ffgpu_ipc_read_reduced(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t n,
+                           const unsigned char* expect_canary32, void* stream);
 int ffgpu_ipc_close(ffgpu_ctx* ctx, void* base);
 
 #ifdef __cplusplus

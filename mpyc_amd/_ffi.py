@@ -101,6 +101,7 @@ _SIGS = {
     'ffgpu_ipc_export': [_vp, _vp, _sz, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_char_p, _vp],
     'ffgpu_ipc_open': [_vp, ctypes.c_char_p, ctypes.POINTER(_vp)],
     'ffgpu_ipc_read': [_vp, _vp, ctypes.c_ulonglong, _vp, _sz, ctypes.c_char_p, _vp],
+    'ffgpu_ipc_read_reduced': [_vp, _vp, ctypes.c_ulonglong, _vp, _sz, ctypes.c_char_p, _vp],
     'ffgpu_ipc_close': [_vp, _vp],
 }
 _RESTYPES = {'ffgpu_strerror': ctypes.c_char_p, 'ffgpu_last_hip_error': ctypes.c_char_p,

@@ -470,6 +470,23 @@ int ffgpu_ipc_read(ffgpu_ctx* ctx, const void* base, unsigned long long offset, 
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // the copy HAS run when the caller acknowledges the row
     return FFGPU_OK;
 }
+int ffgpu_ipc_read_reduced(ffgpu_ctx* ctx, const void* base, unsigned long long offset, void* dst, size_t n,
+                           const unsigned char* expect_canary32, void* stream) {
+    if (!ctx || (n && (!base || !dst))) return FFGPU_EINVAL;
+    const char* src = (const char*)base + offset;
+    if (expect_canary32) {
+        DeviceGuard g(ctx->device);
+        unsigned char got[32];
+        int rc = ipc_canary(src, n * (size_t)ctx->elem_bytes, got);
+        if (rc != FFGPU_OK) return rc;
+        if (memcmp(got, expect_canary32, 32) != 0) return FFGPU_ESTALE;
+    }
+    int rc = ffgpu_reduce(ctx, src, dst, n, stream);            // ONE pass: the peer's row is read through the mapping
+    if (rc != FFGPU_OK) return rc;
+    DeviceGuard g(ctx->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return FFGPU_OK;
+}
 int ffgpu_ipc_close(ffgpu_ctx* ctx, void* base) {
     if (!ctx || !base) return FFGPU_EINVAL;
     DeviceGuard g(ctx->device);

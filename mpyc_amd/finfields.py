@@ -1014,11 +1014,8 @@ def _array_from_ipc(key, shape, n, desc):
         raise TypeError(f'no field with modulus {key[1]:#x} (nth, root = {key[2:]}) has been created in this process')
     ctx = _context(field)
     from . import ipcwire
-    t = ipcwire.fetch(ctx, desc)
-    dev = DevArray(ctx, t, n)
-    if desc[0] != os.getpid():
-        dev = ctx.reduce(dev, out=dev)                       # a peer's data: canonical before any kernel sees it
-    return field.array._wrap(dev, tuple(shape))
+    t = ipcwire.fetch(ctx, desc, reduce_n=n)                 # a peer's data: canonical before any kernel sees it
+    return field.array._wrap(DevArray(ctx, t, n), tuple(shape))
 
 
 def _array_from_wire(key, shape, data):

@@ -206,8 +206,9 @@ def export(ctx, t):
 
 
 # ---- receiver ---------------------------------------------------------------------------------------------------------
-def fetch(ctx, desc):
-    """The row behind a descriptor as a tensor in THIS party's memory."""
+def fetch(ctx, desc, reduce_n=None):
+    """The row behind a descriptor as a tensor in THIS party's memory.  reduce_n: the row holds that many field elements
+    of ctx's field -- they are reduced to canonical form on the way (one pass instead of copy + reduce)."""
     pid, token, handle, offset, nbytes, dtype, shape, ack_addr, canary = desc
     eid = int(token[len(TOKEN):], 16)
     if pid == os.getpid():
@@ -238,8 +239,11 @@ def fetch(ctx, desc):
                 octx._L.ffgpu_ipc_close(octx._h, old)
         else:
             _opened.move_to_end(key)
-        rc = ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, canary if (cached or attempt) else None,
-                                   ctx._stream())
+        check = canary if (cached or attempt) else None
+        if reduce_n is not None:
+            rc = ctx._L.ffgpu_ipc_read_reduced(ctx._h, got[0], offset, t.data_ptr(), reduce_n, check, ctx._stream())
+        else:
+            rc = ctx._L.ffgpu_ipc_read(ctx._h, got[0], offset, t.data_ptr(), nbytes, check, ctx._stream())
         if rc != ESTALE:
             _ffi.check(rc, 'ipc_read')
             break
