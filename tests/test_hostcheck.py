@@ -390,3 +390,35 @@ def test_mersenne_policy_and_lazy_chains(hostcheck):
         rb = [rng.randrange(p) for _ in range(3000)]
         got, _ = run(hostcheck, F, HC_MUL, ra, rb)
         assert got == [x * y % p for x, y in zip(ra, rb)], k
+
+
+def test_pm64_general_policy_all_widths(hostcheck):
+    """PM64<false,false> (p = 2^k - c, 33 <= k <= 63, 1 < c < 2^min((k-1)/2, 31)): the two folds are written on the words
+    (fields.hpp fold128: `(hi << (64 - k)) | (lo >> k)`), so every k must be exercised -- edge values, values around the fold
+    boundaries and random ones, for small, large and borderline c; product, fused multiply-add, the 32-bit Horner step, the
+    unreduced accumulation."""
+    from types import SimpleNamespace
+    PM64_GEN = 3
+    rng = random.Random(3363)
+    for k in range(33, 64):
+        cb = min((k - 1) // 2, 31)
+        for c in sorted({3, 5, 87, (1 << cb) - 1, (1 << cb) - 3, rng.randrange(2, 1 << cb) | 1}):
+            p = (1 << k) - c
+            F = SimpleNamespace(modulus=p, binary=False, order=p)
+            edge = [0, 1, 2, c, c + 1, p - 1, p - 2, p - c, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, p >> 1, (p >> 1) + 1,
+                    (1 << (k - 1)) - 1, 1 << (k - 1), p - (1 << 32), ((1 << 32) - 1) << (k - 32) & ((1 << k) - 1)]
+            edge = [e % p for e in edge] + [rng.randrange(p) for _ in range(8)]
+            a, b = cross(edge)
+            got, pk = run(hostcheck, F, HC_MUL, a, b)
+            assert pk == PM64_GEN, (k, c, pk)
+            assert got == [x * y % p for x, y in zip(a, b)], (k, c)
+            z = list(reversed(a))
+            got, _ = run(hostcheck, F, HC_MULADD, a, b, z)
+            assert got == [(x * y + w) % p for x, y, w in zip(a, b, z)], (k, c)
+            for x in (3, 255, 2**31 - 1, 2**32 - 1):
+                got, _ = run(hostcheck, F, HC_MULADD_SMALL, a, None, z, x=x)
+                assert got == [(u * (x % p) + w) % p for u, w in zip(a, z)], (k, c, x)
+            rows = [[rng.randrange(p) for _ in range(64)] for _ in range(7)]
+            lam = [rng.randrange(p) for _ in range(7)]
+            got, _ = run(hostcheck, F, HC_DOT, [v for row in rows for v in row], lam=lam, k=7, n=64)
+            assert got == [sum(l * rows[j][i] for j, l in enumerate(lam)) % p for i in range(64)], (k, c)
