@@ -68,6 +68,9 @@ async def main():
     xa=rng.uniform(-100,100,N); xb=rng.uniform(-100,100,N)
     a=mpc.input(secfxp.array(xa), senders=0); b=mpc.input(secfxp.array(xb), senders=0)
     await mpc.gather(a,b)
+    prof=None
+    if os.environ.get('FXP_CPROFILE') and mpc.pid==0:
+        import cProfile; prof=cProfile.Profile(); prof.enable()
     t0=time.perf_counter()
     c=a*b
     y=await mpc.output(c)
@@ -83,6 +86,10 @@ async def main():
         good = 5
         print('RAW good idx', good, hex(int(vals[good])), 'float', flo[good], 'want', xa[good]*xb[good])
     dt=time.perf_counter()-t0
+    if prof is not None:
+        prof.disable()
+        import pstats, io
+        st=io.StringIO(); pstats.Stats(prof,stream=st).sort_stats('tottime').print_stats(22); print(st.getvalue()[:4500])
     diff=np.abs(np.asarray(y,dtype=float)-xa*xb)
     err=float(np.max(diff))
     bad=np.nonzero(diff>0.01)[0]
