@@ -153,3 +153,68 @@ def test_auto_mode_follows_the_party_list(wire, monkeypatch):
     monkeypatch.setattr(ipcwire, 'ENABLED', False)
     rt.mpc = types.SimpleNamespace(parties=[P('localhost')] * 3)
     assert ipcwire.resolve_auto() is False
+
+
+class RemoteLib(FakeLib):
+    """host-memory stand-in for the receiver's entry points: a `handle` is the address of the exporter's buffer"""
+
+    def __init__(self):
+        self.opens, self.closes, self.stale_next = 0, 0, False
+
+    def ffgpu_ipc_open(self, h, handle, base):
+        self.opens += 1
+        base._obj.value = struct.unpack('<Q', handle[:8])[0]
+        return 0
+
+    def ffgpu_ipc_close(self, h, base):
+        self.closes += 1
+        return 0
+
+    def _read(self, base, offset, dst, nbytes, expect):
+        if expect is not None and self.stale_next:
+            self.stale_next = False
+            return 6                                      # FFGPU_ESTALE: the cached mapping shows something else
+        ctypes.memmove(dst, base + offset, nbytes)
+        return 0
+
+    def ffgpu_ipc_read(self, h, base, offset, dst, nbytes, expect, stream):
+        return self._read(base, offset, dst, nbytes, expect)
+
+    def ffgpu_ipc_read_reduced(self, h, base, offset, dst, n, expect, stream):
+        return self._read(base, offset, dst, 8 * n, expect)
+
+    def ffgpu_strerror(self, rc):
+        return b'error %d' % rc
+
+
+def test_remote_fetch_acknowledges_and_survives_a_stale_mapping(wire, monkeypatch):
+    """The receiver's side with a peer simulated in this process (the descriptor carries another pid): the handle is opened
+    once and cached, every fetch is acknowledged to the exporter's socket, a cached mapping that fails the canary check is
+    unmapped, reopened and read again, and the exporter releases the buffer after the acknowledgement."""
+    ipcwire, rt, sent = wire
+    assert ipcwire.ensure_runtime_hooks()
+    monkeypatch.setattr(ipcwire, '_opened', type(ipcwire._opened)())
+    monkeypatch.setattr(ipcwire, '_ack_socks', {})
+    lib = RemoteLib()
+
+    class Ctx(FakeCtx):
+        _L = lib
+    r = rt.Runtime()
+    buf = torch.arange(60000, dtype=torch.int64) * 3                       # ONE allocation holding three rows
+    base_handle = struct.pack('<Q', buf.data_ptr()) + bytes(56)
+    for j in range(3):
+        row = Row(buf[20000 * j:20000 * (j + 1)])
+        blob = rt.pickle.dumps(row)
+        r._send_message(1, blob)
+        desc = list(pickle.loads(blob))
+        desc[0] = os.getpid() + 1                                          # "another process" exported it ...
+        desc[2], desc[3] = base_handle, 8 * 20000 * j                      # ... as (handle of the allocation, offset of the row)
+        if j == 2:
+            lib.stale_next = True                                          # the cached mapping fails the canary check once
+        t = ipcwire.fetch(Ctx(), tuple(desc), reduce_n=20000 if j == 1 else None)
+        assert torch.equal(t, row.t), j
+    assert lib.opens == 2 and lib.closes == 1                              # opened once, cached, reopened after the stale read
+    assert ipcwire.stats.get('stale') == 1
+    assert ipcwire.stats['imported'] == 3
+    ipcwire.drain()
+    assert not ipcwire._pending and ipcwire.stats['released'] == 3
