@@ -104,17 +104,20 @@ def _ack_socket():
 
 def drain():
     """Collect acknowledgements; release every parked buffer all of whose receivers have copied it."""
+    if _ack_backlog:
+        _flush_acks()
     if _sock is None:
         return
     while True:
         try:
-            msg = _sock.recv(64)
+            msg = _sock.recv(65536)
         except (BlockingIOError, InterruptedError):
             break
-        if len(msg) == 8:
-            ent = _pending.get(struct.unpack('<Q', msg)[0])
-            if ent is not None:
-                ent[2] += 1
+        if len(msg) % 8 == 0:
+            for (eid,) in struct.iter_unpack('<Q', msg):
+                ent = _pending.get(eid)
+                if ent is not None:
+                    ent[2] += 1
     for eid in [e for e, ent in _pending.items() if ent[2] >= ent[1] and (ent[1] > 0 or ent[3])]:
         del _pending[eid]
         stats['released'] += 1
@@ -123,7 +126,7 @@ def drain():
 def _linger():
     """At interpreter exit: give receivers a moment to finish copying rows this process still owes them."""
     t0 = time.time()
-    while any(ent[2] < ent[1] for ent in _pending.values()) and time.time() - t0 < 5.0:
+    while (any(ent[2] < ent[1] for ent in _pending.values()) or any(_ack_backlog.values())) and time.time() - t0 < 5.0:
         drain()
         time.sleep(0.002)
 
@@ -252,14 +255,44 @@ def fetch(ctx, desc, reduce_n=None):
         _opened.pop(key)                                # a stale mapping: unmap, open the handle afresh, read again
         ctx._L.ffgpu_ipc_close(ctx._h, got[0])
         stats['stale'] = stats.get('stale', 0) + 1
+    _acknowledge(pid, ack_addr, eid)
+    stats['imported'] += 1
+    return t
+
+
+_ack_backlog = {}         # exporter pid -> [acknowledgements its socket would not take yet]
+
+
+def _acknowledge(pid, ack_addr, eid):
+    """Tell the exporter that row `eid` has been copied.  Never blocks: a datagram socket whose receiver has a full queue
+    (the exporter collects acknowledgements when it next exports or imports) would otherwise stall this party inside a
+    message handler -- and two parties stalled on each other's queues would never drain them.  What does not fit is kept
+    and sent with the next acknowledgement or the next drain()."""
     s = _ack_socks.get(pid)
     if s is None:
         s = socket.socket(socket.AF_UNIX, socket.SOCK_DGRAM)
-        s.connect(ack_addr)
+        s.setblocking(False)
+        try:
+            s.connect(ack_addr)
+        except OSError:                 # the exporter is gone (its memory with it; our copy is complete)
+            s.close()
+            return
         _ack_socks[pid] = s
-    try:
-        s.send(struct.pack('<Q', eid))
-    except OSError:                     # the exporter is gone (its memory with it; our copy is complete)
-        _ack_socks.pop(pid, None)
-    stats['imported'] += 1
-    return t
+    _ack_backlog.setdefault(pid, []).append(struct.pack('<Q', eid))
+    _flush_acks(pid)
+
+
+def _flush_acks(pid=None):
+    for q in ([pid] if pid is not None else list(_ack_backlog)):
+        pend, s = _ack_backlog.get(q), _ack_socks.get(q)
+        while pend and s is not None:
+            batch = pend[:4096]         # one datagram carries every acknowledgement that is waiting (queues hold few datagrams)
+            try:
+                s.send(b''.join(batch))
+            except (ConnectionRefusedError, ConnectionResetError, FileNotFoundError, BrokenPipeError):
+                _ack_socks.pop(q, None)             # the exporter is gone (its memory with it)
+                pend.clear()
+                break
+            except OSError:             # EAGAIN / ENOBUFS: its queue is full -- later
+                break
+            del pend[:len(batch)]

@@ -218,3 +218,26 @@ def test_remote_fetch_acknowledges_and_survives_a_stale_mapping(wire, monkeypatc
     assert ipcwire.stats['imported'] == 3
     ipcwire.drain()
     assert not ipcwire._pending and ipcwire.stats['released'] == 3
+
+
+def test_acknowledgements_never_block(wire, monkeypatch):
+    """2000 acknowledgements to an exporter that is not collecting them (a datagram queue holds a few hundred): none of the
+    sends may block, what does not fit waits in the backlog, and after the exporter drains everything arrives."""
+    ipcwire, rt, sent = wire
+    monkeypatch.setattr(ipcwire, '_ack_socks', {})
+    monkeypatch.setattr(ipcwire, '_ack_backlog', {})
+    ipcwire._ack_socket()
+    n = 2000
+    for eid in range(1, n + 1):
+        ipcwire._pending[eid] = [None, 1, 0, False]
+    import time
+    t0 = time.time()
+    for eid in range(1, n + 1):
+        ipcwire._acknowledge(4242, ipcwire._sock_addr, eid)
+    assert time.time() - t0 < 5.0
+    assert len(ipcwire._ack_backlog[4242]) > 0                     # the queue was full at some point
+    for _ in range(50):
+        ipcwire.drain()                                            # collects, then flushes the backlog into the freed queue
+        if not ipcwire._pending:
+            break
+    assert not ipcwire._pending and not ipcwire._ack_backlog[4242] and ipcwire.stats['released'] == n
