@@ -91,6 +91,7 @@ def install():
         return array
 
     finfields.arrayGF = arrayGF
+    gth.SHAKE_PRF_TYPES.add(thresha.PRF)          # the runtime's PRF objects: same algorithm, expanded by the engine's host threads
     finfields.DeviceFieldArray = DeviceFieldArray
     done = ['finfields.arrayGF']
 

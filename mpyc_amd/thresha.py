@@ -287,6 +287,12 @@ class PRF:
         return x[0] if n is None else x
 
 
+# PRF classes whose draws ARE shake_128(key + s) chopped into byte_length-sized chunks: their streams may be expanded by
+# libffgpu's host threads instead of by calling the object.  install() adds the reference's own class (the runtime makes
+# its PRFs with mpyc.thresha.PRF); anything else -- a subclass, a user's PRF -- is called as it is.
+SHAKE_PRF_TYPES = {PRF}
+
+
 @functools.lru_cache(maxsize=None)
 def _f_S_i(field, m, i, S):
     """f_S(i+1) for the polynomial with f_S(0) = 1 and f_S(j+1) = 0 for all parties j outside S
@@ -298,7 +304,10 @@ def _f_S_i(field, m, i, S):
 
 from . import ipcwire as _ipcwire  # noqa: E402
 
-PRSS_STREAM_MIN = 16 << 20       # XOF bytes per subset key above which a PRSS call is squeezed and combined in slices
+PRSS_STREAM_MIN = 1 << 30        # XOF bytes of a call (all subset keys together) above which it is squeezed, uploaded and
+#                                  combined in slices (bounded pinned memory, host and device overlap).  Below it the keys are
+#                                  expanded in one piece each, in parallel, by libcrypto when it can be loaded -- its sponge
+#                                  squeezes 0.9-1.2 GB/s per stream against 0.75 of the library's resumable one.
 
 
 def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
@@ -345,8 +354,8 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
     first_launch = True
     for k0 in range(0, len(items), per):
         chunk = items[k0:k0 + per]
-        if all(type(prf) is PRF for _, prf in chunk):
-            if n * d * l > PRSS_STREAM_MIN and hasattr(ctx, 'prss_streamed'):
+        if all(type(prf) in SHAKE_PRF_TYPES for _, prf in chunk):
+            if len(chunk) * n * d * l > PRSS_STREAM_MIN and hasattr(ctx, 'prss_streamed'):
                 # long streams: squeeze, upload and combine slice by slice (bounded pinned memory, host and device overlap)
                 ctx.prss_streamed([prf.key + uci for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits,
                                   out, not first_launch)
