@@ -696,6 +696,7 @@ class FieldContext:
         """SHAKE128(msg).digest(out_len) for every msg, expanded in parallel on host threads into pinned
         buffers (libffgpu's ffgpu_shake128_expand) and uploaded: the XOF streams of a PRSS call
         (thresha.py:255, one per subset key).  Returns uint8 device tensors."""
+        msgs = [bytes(mg) for mg in msgs]
         k = len(msgs)
         if k == 0 or out_len == 0:
             return [torch.empty(0, dtype=torch.uint8, device=self.torch_device) for _ in msgs]
@@ -722,6 +723,7 @@ class FieldContext:
         (ffgpu_shake128_open / _squeeze): every stream is squeezed a slice (~slice_bytes) at a time on host threads into
         one half of a pinned staging buffer; the slice is uploaded and combined into its range of `out` on the device
         while the host squeezes the next slice into the other half.  Pinned memory: 2 * len(msgs) * slice_bytes."""
+        msgs = [bytes(mg) for mg in msgs]
         k = len(msgs)
         slice_bytes = slice_bytes or self.PRSS_SLICE_BYTES
         per = d * l                                                  # XOF bytes per output element and stream

@@ -357,11 +357,12 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
         if all(type(prf) in SHAKE_PRF_TYPES for _, prf in chunk):
             if len(chunk) * n * d * l > PRSS_STREAM_MIN and hasattr(ctx, 'prss_streamed'):
                 # long streams: squeeze, upload and combine slice by slice (bounded pinned memory, host and device overlap)
-                ctx.prss_streamed([prf.key + uci for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n, mask_bits,
-                                  out, not first_launch)
+                ctx.prss_streamed([bytes(prf.key) + bytes(uci) for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n,
+                                  mask_bits, out, not first_launch)
                 first_launch = False
                 continue
-            streams = ctx.shake128_streams([prf.key + uci for _, prf in chunk], n * d * l)
+            # (bytes(...): the runtime stores the PRSS keys it RECEIVED as bytearray slices, runtime.py:139)
+            streams = ctx.shake128_streams([bytes(prf.key) + bytes(uci) for _, prf in chunk], n * d * l)
         else:                                   # foreign PRF objects (e.g. the reference's own class)
             streams = [prf.raw(uci, n * d) if hasattr(prf, 'raw') else shake_128(prf.key + uci).digest(n * d * l)
                        for _, prf in chunk]

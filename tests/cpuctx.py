@@ -222,6 +222,7 @@ class CpuFieldContext(engine.FieldContext):
         return torch.frombuffer(bytearray(data), dtype=torch.uint8).view(dtype).reshape(shape)
 
     def shake128_streams(self, msgs, out_len, threads=0):
+        assert all(type(mg) is bytes for mg in msgs), 'the C entry point takes bytes (ctypes refuses a bytearray)'
         return [torch.frombuffer(bytearray(hashlib.shake_128(mg).digest(out_len)), dtype=torch.uint8) if out_len
                 else torch.empty(0, dtype=torch.uint8) for mg in msgs]
 
