@@ -52,3 +52,45 @@ def test_prf_reference_kats():
     assert po.prf_values(key, 1, b'test', 1) == [0]
     y = po.prf_values(key, 100, b'', 1)
     assert 0 <= y[0] < 100 and y == po.prf_values(key, 100, b'', 1)
+
+
+def test_mirror_prss_takes_bytearray_keys_and_foreign_prf_classes(monkeypatch):
+    """Host logic of mpyc_amd.thresha._prss_device on the CPU context: the runtime keeps the PRSS keys it RECEIVED as
+    bytearray slices (runtime.py:139) and builds its PRFs with mpyc.thresha.PRF, a different class with the same
+    algorithm.  Both must give the shares of the golden vectors through the engine's expansion path (whose C entry point
+    takes bytes only -- the CPU context asserts that), and a PRF class that is NOT registered is called as it is."""
+    from cpuctx import use_cpu_contexts
+    import mpyc_amd.finfields as gff
+    import mpyc_amd.thresha as gth
+    use_cpu_contexts(monkeypatch)
+    monkeypatch.setattr(gff, '_ctx_cache', {})
+    gff._pGF.cache_clear()
+
+    class RefPRF:                                 # stands for mpyc.thresha.PRF: same fields, same draws
+        def __init__(self, key, bound):
+            self.key, self.max = key, bound
+            self.byte_length = ((bound - 1).bit_length() + 7) // 8 + (len(key) if bound & (bound - 1) else 0)
+
+    class OtherPRF(RefPRF):                       # not registered: must be CALLED (here: it counts the calls)
+        calls = 0
+
+        def raw(self, s, n):
+            OtherPRF.calls += 1
+            import hashlib
+            return hashlib.shake_128(bytes(self.key) + s).digest(n * self.byte_length)
+    monkeypatch.setattr(gth, 'SHAKE_PRF_TYPES', {gth.PRF, RefPRF})
+    try:
+        case = load()['P61']
+        F = gff.GF(int(case['modulus'], 16))
+        uci, n = bytes.fromhex(case['uci']), case['n']
+        for st in case['settings']:
+            m, bound = st['m'], int(st['bound'], 16)
+            keys = {tuple(int(x) for x in k.split(',')): bytes.fromhex(v) for k, v in st['keys'].items()}
+            for i, party in enumerate(st['parties']):
+                for cls in (gth.PRF, RefPRF, OtherPRF):
+                    prfs = {S: cls(bytearray(k), bound) for S, k in keys.items() if i in S}
+                    got = gth.np_pseudorandom_share(F, m, i, prfs, bytearray(uci), n)
+                    assert [int(v) for v in got.value] == unhex(party['share']), (m, i, cls.__name__)
+        assert OtherPRF.calls > 0
+    finally:
+        gff._pGF.cache_clear()
