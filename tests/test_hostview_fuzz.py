@@ -119,12 +119,3 @@ def test_random_expression_chains_host_logic(p, monkeypatch):
             _chain(F, 1000 * (p % 97) + seed)
     finally:
         gff._pGF.cache_clear()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('p', PRIMES)
-def test_random_expression_chains_on_gpu(p):
-    import mpyc_amd.finfields as gff
-    F = gff.GF(p)
-    for seed in range(25):
-        _chain(F, 7000 + seed)
