@@ -60,22 +60,24 @@ def install():
         made -- mpyc.runtime has parsed the party index by then."""
         if picked:
             return
-        picked.append(True)
         import os
         import sys
         import torch
-        if not torch.cuda.is_available():
-            return
         want = os.environ.get('MPYC_AMD_DEVICE', 'party')
-        if want == 'current':
+        if not torch.cuda.is_available() or want == 'current':
+            picked.append(True)
             return
         if want.isdigit():
+            picked.append(True)
             torch.cuda.set_device(int(want))
             return
         rt = sys.modules.get('mpyc.runtime')
         mpc = getattr(rt, 'mpc', None)
+        if mpc is None:
+            return                      # (a field made while mpyc.runtime is still being imported: decide at the next one)
+        picked.append(True)
         count = torch.cuda.device_count()
-        if mpc is not None and count > 1 and len(getattr(mpc, 'parties', ())) > 1:
+        if count > 1 and len(getattr(mpc, 'parties', ())) > 1:
             torch.cuda.set_device(mpc.pid % count)
 
     @functools.cache
