@@ -113,6 +113,110 @@ def roof_mfma(field_macs, digits, ms):
             'field_GMAC_per_s': round(field_macs / (ms * 1e-3) / 1e9, 1)}
 
 
+COMPACT_LIMIT = 8000      # the driver's stdout tail holds ~8 KB: the FINAL line must fit it whole
+
+
+def _pick(d, keys):
+    return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d}
+
+
+def compact_line(out):
+    """The ONE JSON line the driver parses (last line of stdout): the contract keys, `roofline`, `cpu_baseline` and short
+    summaries of the API / multi-GPU sections.  Every per-kernel row, the full `api`, `configs2` and `multi_gpu` objects
+    travel in bench_detail.json (and in an earlier, `# detail `-prefixed stdout line), never here: the final line stays
+    far below COMPACT_LIMIT characters whatever the run measured (tests/test_bench_line.py)."""
+    line = _pick(out, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                       'vs_baseline', 'dtype', 'data'))
+    cfg = out.get('config', {})
+    line['config'] = _pick(cfg, ('workload', 'n_per_gpu', 'prime', 'm', 't', 'k', 'field_ops_per_step', 'buffer_sets',
+                                 'parallelism'))
+    if len(line['config'].get('workload', '')) > 400:
+        line['config']['workload'] = line['config']['workload'][:400]
+    if 'roofline' in out:
+        line['roofline'] = _pick(out['roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'name',
+                                                   'ms_per_launch', 'bytes_per_launch', 'frac_of_measured_copy'))
+    cb = out.get('cpu_baseline')
+    if isinstance(cb, dict):
+        line['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind', 'procs', 'host_cores', 'value_1core', 'port_value',
+                                          'port_cores', 'error'))
+        if 'sample' in cb:
+            line['cpu_baseline']['sample'] = cb['sample'][:360]
+    if 'unfused' in out:
+        line['unfused'] = _pick(out['unfused'], ('value', 'ms_per_step'))
+    if 'mulmod_per_s_1gpu' in out:
+        line['mulmod_per_s_1gpu'] = out['mulmod_per_s_1gpu']
+    c2 = out.get('configs2')
+    if isinstance(c2, dict):
+        line['configs2'] = {'workload': 'configs[2]: GF(2^64-189), 10^7 secrets, split m=7,t=3 + recombine k',
+                            'k4_secrets_per_s': c2.get('k4', {}).get('secrets_per_s'),
+                            'k7_secrets_per_s': c2.get('k7', {}).get('secrets_per_s'),
+                            'roofline': _pick(c2.get('roofline', {}), ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                                                        'name', 'ms_per_launch'))}
+    api = out.get('api')
+    if isinstance(api, dict):
+        line['api'] = _pick(api, ('elements_per_s', 'gpu_busy_frac', 'gpu_busy_frac_1e8', 'vs_reference_m1',
+                                  'gpu_busy_frac_m3_1e7_ipc', 'error'))
+        if isinstance(api.get('m3_1e7_ipc'), dict):
+            line['api']['m3_1e7_ipc'] = _pick(api['m3_1e7_ipc'], ('ms_per_rep', 'elements_per_s'))
+        if isinstance(api.get('m1_1e7'), dict):
+            line['api']['m1_1e7'] = _pick(api['m1_1e7'], ('ms_per_rep', 'elements_per_s'))
+    dd = out.get('distributed', {})
+    line['distributed'] = _pick(dd, ('backend', 'world_size', 'collective_library', 'rccl_version', 'distinct_devices'))
+    ranks = dd.get('ranks') or []
+    line['distributed']['ranks'] = [_pick(r_, ('rank', 'local_rank', 'device', 'pci_bus_id')) for r_ in ranks[:16]]
+    mg = out.get('multi_gpu')
+    if isinstance(mg, dict):
+        mgl = _pick(mg, ('error',))
+        if isinstance(mg.get('config'), dict):
+            mgl['workload'] = str(mg['config'].get('workload', ''))[:160]
+            mgl['backend'] = mg['config'].get('backend')
+        for leg in ('gate_sharded', 'party_major_all_to_all', 'party_major_all_to_all_pipelined', 'party_major_allgather'):
+            if isinstance(mg.get(leg), dict):
+                mgl[leg] = _pick(mg[leg], ('ms_per_step', 'gates_per_s', 'secrets_per_s', 'frac_of_hbm_peak', 'exchange_share',
+                                           'rank0_exchange_GBps', 'exchange_GBps_per_rank', 'error'))
+        line['multi_gpu'] = mgl
+    for key_ in ('extras_error', 'detail_file'):
+        if key_ in out:
+            line[key_] = str(out[key_])[:300]
+    kern = out.get('kernels')
+    if isinstance(kern, dict):
+        # a one-number-per-kernel digest (fraction of the row's own bound), as much as fits
+        digest = {}
+        for q, row in kern.items():
+            if isinstance(row, dict) and 'frac' in row:
+                digest[q] = row.get('valu_frac', row['frac']) if row.get('bound') == 'valu' else row['frac']
+        line['kernel_fracs'] = digest
+        if len(json.dumps(line)) > COMPACT_LIMIT - 500:
+            line.pop('kernel_fracs')
+    text = json.dumps(line)
+    for drop in ('multi_gpu', 'configs2', 'api', 'unfused'):       # never reached in practice; the cap is unconditional
+        if len(text) <= COMPACT_LIMIT - 200:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line)
+    return text
+
+
+def emit(out, detail_path=None):
+    """stdout protocol: `# detail {...}` (everything measured; not a bare JSON line), then the compact line LAST."""
+    paths = [detail_path] if detail_path else [os.path.join(ROOT, 'bench_detail.json'),
+                                                os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')]
+    written = []
+    for path in paths:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as fh:
+                json.dump(out, fh, indent=1)
+            written.append(os.path.relpath(path, ROOT))
+        except OSError:
+            pass
+    if written:
+        out['detail_file'] = written[0]
+    sys.stdout.write('# detail ' + json.dumps(out) + '\n')
+    sys.stdout.write(compact_line(out) + '\n')
+    sys.stdout.flush()
+
+
 def cpu_baseline(n_full, t, m, lam, seed=20260925):
     """The reference's own CPU path on this host (kind "reference": mpyc's FiniteFieldArray.__mul__,
     thresha.np_random_split with live secrets.randbelow draws, thresha.np_recombine -- oracle/refbaseline.py -- on 1
@@ -148,15 +252,17 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
     coracle.set_threads(1)
     port_sample = (f'full workload: n={n} P61 elements x (modmul + split m={m},t={t} + recombine k={2*t+1}), '
                    f'oracle/fforacle.c with OpenMP ({cores} threads), best of 2')
-    out = {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'kind': 'port', 'sample': port_sample,
-           'value_1core': round(res['1core'], 1)}
+    host_cores = os.cpu_count() or cores
+    out = {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
+           'sample': port_sample, 'value_1core': round(res['1core'], 1)}
     if refbaseline.available([os.path.join(ROOT, '_refstage'), '/root/reference']):
         procs = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         n_one, n_each = 2_000_000, 400_000
         r = refbaseline.measure(P61, t, m, n_one, n_each, procs, seed)
         allc = r.get('all_cores') or {'field_ops_per_s': r['one_core']['field_ops_per_s'], 'n_total': n_one, 'wall_s': 0.0}
         procs = r.get('procs', procs)
-        out = {'value': round(allc['field_ops_per_s'], 1), 'unit': 'field-ops/s', 'cores': procs, 'kind': 'reference',
+        out = {'value': round(allc['field_ops_per_s'], 1), 'unit': 'field-ops/s', 'cores': procs, 'procs': procs,
+               'host_cores': host_cores, 'kind': 'reference',
                'sample': f'lschoe/mpyc itself (FiniteFieldArray.__mul__ + thresha.np_random_split m={m},t={t} with live '
                          f'secrets.randbelow + thresha.np_recombine k={2*t+1}) over GF(2^61-1): {procs} processes x '
                          f'{n_each} elements = {allc["n_total"]} elements in {allc["wall_s"]:.2f} s wall; 1 core: '
@@ -504,6 +610,9 @@ def main():
     ap.add_argument('--no-api-leg', action='store_true', help='skip the API-level section (party processes under install())')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-multi-gpu-leg', action='store_true', help='skip the configs[3] / party-major section')
+    ap.add_argument('--parties-on-gpus', action='store_true',
+                    default=os.environ.get('FFGPU_BENCH_PARTIES_ON_GPUS', '0') == '1',
+                    help='N >= 3: also run three MPyC parties on three GPUs over the device-side wire (opt-in; never run on >1 GPU)')
     ap.add_argument('--layout', choices=('element', 'party-major'), default='element',
                     help="'party-major': only the configs[3] section (gate sharded + party-major exchange), more steps")
     args = ap.parse_args()
@@ -523,7 +632,8 @@ def main():
         fwd = ['--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup), '--sets', str(args.sets),
                '--layout', args.layout]
         fwd += [f_ for f_, on in (('--no-cpu-baseline', args.no_cpu_baseline), ('--no-extras', args.no_extras),
-                                  ('--no-api-leg', args.no_api_leg), ('--no-multi-gpu-leg', args.no_multi_gpu_leg)) if on]
+                                  ('--no-api-leg', args.no_api_leg), ('--no-multi-gpu-leg', args.no_multi_gpu_leg),
+                                  ('--parties-on-gpus', args.parties_on_gpus)) if on]
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + fwd
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, FFGPU_BENCH_N=str(args.n))))
@@ -630,11 +740,16 @@ def main():
         elapsed_unfused = float(tt.item())
 
     devinfo = f'cuda:{local_rank} ({torch.cuda.get_device_name(local_rank)})'
+    me = {'rank': rank, 'local_rank': local_rank, 'device': devinfo, 'pci_bus_id': ctx.pci_bus_id()}
     if dist is not None:
         gathered = [None] * world
-        dist.all_gather_object(gathered, {'rank': rank, 'device': devinfo})
+        dist.all_gather_object(gathered, me)
     else:
-        gathered = [{'rank': 0, 'device': devinfo}]
+        gathered = [me]
+    try:
+        rccl_version = '.'.join(str(v_) for v_ in torch.cuda.nccl.version())
+    except Exception:          # noqa: BLE001 -- informational only
+        rccl_version = None
     ops_total = 3.0 * n * world * args.steps
     value = ops_total / elapsed
     out = {
@@ -650,6 +765,8 @@ def main():
                    'buffer_sets': args.sets, 'parallelism': f'element-sharded x{world}, no collective'},
         'distributed': {'backend': (backend if dist is not None else None), 'world_size': world,
                         'collective_library': 'RCCL (torch.distributed nccl backend)' if dist is not None and backend == 'nccl' else None,
+                        'rccl_version': rccl_version,
+                        'distinct_devices': len({r_['pci_bus_id'] for r_ in gathered}),
                         'ranks': gathered},
     }
 
@@ -1134,11 +1251,7 @@ def main():
                                                                        'units_per_s': round(nblk / (ms * 1e-3), 1)}
                 del Ks, ps, pools, kpub, ppub
                 torch.cuda.empty_cache()
-            # dominant kernel of the timed step = the one with the largest share of step time
-        try:
-            optional_measurements()
-        except Exception as exc:          # noqa: BLE001 -- report, keep the main result
-            out['extras_error'] = f'{type(exc).__name__}: {exc}'
+        # dominant kernel of the timed step = the one with the largest share of step time
         step_kernels = ['mul_split_fused_p61_m3t1', 'recombine_p61_k3']
         dom = max(step_kernels, key=lambda q: kern[q]['ms_per_launch'])
         out['roofline'] = dict({kk_: vv for kk_, vv in kern[dom].items()
@@ -1148,66 +1261,85 @@ def main():
                                frac_of_measured_copy=round(kern[dom]['achieved'] / kern['device_copy']['achieved'], 4))
         # HBM traffic per launch from PMC counters (collected separately with rocprofv3 --pmc, see
         # profiles/r03_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
-        try:
-            pmc_file = next(f_ for f_ in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
-                            if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
-            with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
-                pmc = json.load(fh)
-            names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, false, false>',
-                     'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
-                     'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, false, false>',
-                     'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
-                     'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
-                     'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, false, false>',
-                     'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
-                     'mul_p128': 'k_ew2<PM128<true>, 2, true>',
-                     'split_p128_m7t3': 'k_split<PM128<true>, 3, false, true, false, false>',
-                     'recombine_p128_k7': 'k_recombine<PM128<true>, 7, true>',
-                     'device_copy': 'k_copy16'}
-            for q, kn in names.items():
-                if q in kern and kn in pmc and n == 10_000_000:
-                    kern[q]['traffic'] = pmc[kn]['traffic_bytes']
-            if n == 10_000_000 and names.get(dom) in pmc:
-                out['roofline']['traffic'] = pmc[names[dom]]['traffic_bytes']
-                out['roofline']['traffic_source'] = f'profiles/{pmc_file[:-5]}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-        except (OSError, ValueError, StopIteration):
-            pass
-        if 'configs2' in out and 'split_p64_m7t3' in kern:
-            out['configs2']['roofline']['traffic'] = kern['split_p64_m7t3'].get('traffic')
+        def annotate_traffic():
+            try:
+                pmc_file = next(f_ for f_ in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                                if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
+                with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
+                    pmc = json.load(fh)
+                names = {'mul_split_fused_p61_m3t1': 'k_split<PM64<false, true>, 1, true, true, false, false>',
+                         'mul_p61': 'k_ew2<PM64<false, true>, 2, true>',
+                         'split_p61_m3t1': 'k_split<PM64<false, true>, 1, false, true, false, false>',
+                         'recombine_p61_k3': 'k_recombine<PM64<false, true>, 3, true>',
+                         'mul_p64': 'k_ew2<PM64<true, false>, 2, true>',
+                         'split_p64_m7t3': 'k_split<PM64<true, false>, 3, false, true, false, false>',
+                         'recombine_p64_k7': 'k_recombine<PM64<true, false>, 7, true>',
+                         'mul_p128': 'k_ew2<PM128<true>, 2, true>',
+                         'split_p128_m7t3': 'k_split<PM128<true>, 3, false, true, false, false>',
+                         'recombine_p128_k7': 'k_recombine<PM128<true>, 7, true>',
+                         'device_copy': 'k_copy16'}
+                for q, kn in names.items():
+                    if q in kern and kn in pmc and n == 10_000_000:
+                        kern[q]['traffic'] = pmc[kn]['traffic_bytes']
+                if n == 10_000_000 and names.get(dom) in pmc:
+                    out['roofline']['traffic'] = pmc[names[dom]]['traffic_bytes']
+                    out['roofline']['traffic_source'] = f'profiles/{pmc_file[:-5]}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+            except (OSError, ValueError, StopIteration):
+                pass
+        annotate_traffic()
         out['roofline']['bytes_per_launch'] = kern[dom]['bytes_per_launch']
         out['kernels'] = kern
         out['mulmod_per_s_1gpu'] = kern['mul_p61']['units_per_s']
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
-    if rank == 0 and world == 1 and not args.no_api_leg and not args.no_extras:
-        torch.cuda.empty_cache()
-        try:
-            out['api'] = api_leg(n)
-        except Exception as exc:          # noqa: BLE001 -- report, keep the main result
-            out['api'] = {'error': f'{type(exc).__name__}: {exc}'}
+    def after_the_collectives():
+        """Rank 0 alone, N = 1 only (the contract's `cpu_baseline` rule; at N > 1 the other ranks have left and the driver's
+        N = 1 run already holds these sections): every measurement beyond the step's own kernels, the reference CPU path
+        and the API-level section.  A failure here never costs the headline line."""
+        if rank != 0 or world != 1:
+            return
+        if not args.no_extras:
+            try:
+                optional_measurements()
+                annotate_traffic()
+            except Exception as exc:          # noqa: BLE001 -- report, keep the main result
+                out['extras_error'] = f'{type(exc).__name__}: {exc}'
+            if 'configs2' in out and 'split_p64_m7t3' in kern:
+                out['configs2']['roofline']['traffic'] = kern['split_p64_m7t3'].get('traffic')
+        if not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
+            except Exception as exc:          # noqa: BLE001
+                out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
+        if not args.no_api_leg and not args.no_extras:
+            torch.cuda.empty_cache()
+            try:
+                out['api'] = api_leg(n)
+            except Exception as exc:          # noqa: BLE001 -- report, keep the main result
+                out['api'] = {'error': f'{type(exc).__name__}: {exc}'}
 
     # configs[3] on all N ranks: element-sharded P128 gate and the party-major exchange (the one collective).
     # It runs LAST and under a watchdog: whatever happens in the collectives (a rank failing, a transport that
     # hangs), rank 0 still prints the line with everything measured above.
     def finish(code=None):
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         if code is not None:
             sys.stdout.flush()
             os._exit(code)
 
-    if not args.no_multi_gpu_leg:
-        import threading
-        full = args.layout == 'party-major'
-        leg_done = threading.Event()
-        limit = float(os.environ.get('FFGPU_BENCH_LEG_TIMEOUT', '300'))
+    import threading
+    collectives_done = threading.Event()
+    # N > 1: a leg that has never met this node's transport must not cost minutes of the scaling run -- 60 s, then the line
+    # goes out with what was measured (headline + roofline are complete before the first collective of the leg)
+    limit = float(os.environ.get('FFGPU_BENCH_LEG_TIMEOUT', '60' if world > 1 else '300'))
 
-        def watchdog():
-            if not leg_done.wait(limit):
-                out['multi_gpu'] = {'error': f'multi-GPU leg did not finish within {limit:.0f} s (rank {rank})'}
-                finish(0)
-        threading.Thread(target=watchdog, daemon=True).start()
+    def watchdog():
+        if not collectives_done.wait(limit):
+            out.setdefault('multi_gpu', {'error': f'multi-GPU section did not finish within {limit:.0f} s (rank {rank})'})
+            finish(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    if not args.no_multi_gpu_leg:
+        full = args.layout == 'party-major'
         try:
             leg = multi_gpu_leg(dist, rank, world, local_rank, backend, n,
                                 args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else 2, lagrange)
@@ -1215,20 +1347,21 @@ def main():
             leg = {'error': f'OutOfMemoryError: {exc}'}
         except Exception as exc:          # noqa: BLE001 -- the other ranks may now be waiting in a collective: end here
             out['multi_gpu'] = {'error': f'{type(exc).__name__}: {exc}'}
-            leg_done.set()
+            collectives_done.set()
             finish(0)
-        leg_done.set()
         out['multi_gpu'] = leg
         torch.cuda.empty_cache()
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    # N >= 3 GPUs: the m-party protocol itself with ONE PARTY PER GPU -- three MPyC party processes under install() on GPUs
-    # 0, 1, 2 (MPYC_AMD_DEVICE=party), share rows crossing between the GPUs as interprocess handles (device-side wire:
-    # xGMI peer copies).  Runs after every collective is done (the other ranks are idle or gone), as subprocesses with
-    # their own timeouts; an error is reported in the object, never raised.
-    if rank == 0 and world >= 3 and not args.no_api_leg and not args.no_extras:
+    collectives_done.set()
+    after_the_collectives()
+    # OPT-IN (--parties-on-gpus / FFGPU_BENCH_PARTIES_ON_GPUS=1; N >= 3 GPUs): the m-party protocol itself with ONE PARTY PER
+    # GPU -- three MPyC party processes under install() on GPUs 0, 1, 2 (MPYC_AMD_DEVICE=party), share rows crossing between
+    # the GPUs as interprocess handles.  It has never run on more than one GPU, so it is not part of a default run; as
+    # subprocesses with their own timeouts, after every collective is done; an error is reported in the object, never raised.
+    if rank == 0 and world >= 3 and args.parties_on_gpus and not args.no_api_leg:
         torch.cuda.empty_cache()
         try:
             out['api_parties_on_gpus'] = api_leg(n, parties_on_gpus=True)

@@ -76,6 +76,9 @@ int         ffgpu_abi_version(void);
 const char* ffgpu_strerror(int status);
 const char* ffgpu_last_hip_error(void);          /* text of the last failing HIP call */
 int         ffgpu_device_count(int* count);
+/* PCI bus id ("0000:05:00.0") of a device into buf (len >= 16): lets a multi-process run show that its ranks sit on
+ * distinct GPUs.  No reference counterpart (the reference has no device).                                          */
+int         ffgpu_device_pci_bus_id(int device, char* buf, int len);
 
 /* ---- field context ---------------------------------------------------- */
 /* modulus: little-endian uint64 limbs.  FFGPU_PRIME: the prime p, nlimbs 1..3: primes of 129..192 bits are stored

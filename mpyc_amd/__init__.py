@@ -93,7 +93,8 @@ def install():
         return array
 
     finfields.arrayGF = arrayGF
-    gth.SHAKE_PRF_TYPES.add(thresha.PRF)          # the runtime's PRF objects: same algorithm, expanded by the engine's host threads
+    gth.register_shake_prf(thresha.PRF)           # the runtime's PRF objects: expanded by the engine's host threads IF a
+    #                                               known-answer check shows this mpyc's PRF is the shake_128 one
     finfields.DeviceFieldArray = DeviceFieldArray
     done = ['finfields.arrayGF']
 

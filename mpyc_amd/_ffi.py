@@ -33,6 +33,7 @@ _SIGS = {
     'ffgpu_strerror': [_int],
     'ffgpu_last_hip_error': [],
     'ffgpu_device_count': [ctypes.POINTER(_int)],
+    'ffgpu_device_pci_bus_id': [_int, ctypes.c_char_p, _int],
     'ffgpu_ctx_create': [_int, _u64p, _int, _int, ctypes.POINTER(_vp)],
     'ffgpu_ctx_destroy': [_vp],
     'ffgpu_ctx_set_timing': [_vp, _int],

@@ -251,6 +251,14 @@ int ffgpu_device_count(int* count) {
     return FFGPU_OK;
 }
 
+int ffgpu_device_pci_bus_id(int device, char* buf, int len) {
+    if (!buf || len < 16 || device < 0) return FFGPU_EINVAL;
+    buf[0] = 0;
+    hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
+    if (e != hipSuccess) return hip_fail(e, "hipDeviceGetPCIBusId");
+    return FFGPU_OK;
+}
+
 int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, ffgpu_ctx** out) {
     if (!modulus || !out || nlimbs < 1 || nlimbs > 3 || device < 0) return FFGPU_EINVAL;
     ffgpu_ctx* c = (ffgpu_ctx*)calloc(1, sizeof(ffgpu_ctx));

@@ -273,6 +273,12 @@ class FieldContext:
     def torch_device(self):
         return torch.device('cuda', self.device)
 
+    def pci_bus_id(self) -> str:
+        """PCI bus id of this context's GPU (multi-process runs report it per rank)."""
+        buf = ctypes.create_string_buffer(32)
+        _ffi.check(self._L.ffgpu_device_pci_bus_id(self.device, buf, 32), "device_pci_bus_id")
+        return buf.value.decode()
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 

@@ -503,7 +503,7 @@ def _src_dev(src) -> DevArray:
 
 
 _POISON = np.array(None, dtype=object)
-_HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_operand', '_binop', '_shift_left',
+_HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exact', '_thunk', '_true', '_derive', '_dev_ok', '_cmp_on_device', '_operand', '_binop', '_shift_left',
                      '_bits_and', '_outer_src', '_outer_T', '_shift_src', '_lift', 'T', 'transpose', 'shape', 'ndim', 'size', 'dtype', 'reshape', '__class__', '__dict__', '__reduce__',
                      '__reduce_ex__', '__setitem__', '__array_function__', '__array_ufunc__', '__array_finalize__',
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
@@ -670,7 +670,9 @@ class HostView(np.ndarray):
         return getattr(object.__getattribute__(self, '_real')(), name)
 
     def _dev_ok(self) -> bool:
-        if not self._is_lazy:
+        if not self._is_lazy or self._outer_src is not None:
+            # (a symbolic np.right_shift.outer view: _fa is the UN-shifted source, only `& 1` and `.T` may use it --
+            # both test _outer_src before they come here; everything else materialises)
             return False
         if self._fa_value is None:
             return True                       # deferred views are only ever created on the prime-field device path
@@ -856,13 +858,19 @@ class HostView(np.ndarray):
     __rand__ = __and__
     __iand__ = __and__
 
+    def _cmp_on_device(self, other) -> bool:
+        # integers in [0, p) only: FieldArray comparison reduces its scalar, the reference compares integers (x == -1 and
+        # x == p are False for every residue)
+        return self._dev_ok() and self._exact and isinstance(other, (int, np.integer)) and \
+            0 <= int(other) < type(self._fa).field.modulus
+
     def __ne__(self, other):
-        if self._dev_ok() and self._exact and isinstance(other, (int, np.integer)):
+        if self._cmp_on_device(other):
             return self._fa != int(other)
         return self._real() != _hv_unwrap(other)
 
     def __eq__(self, other):
-        if self._dev_ok() and self._exact and isinstance(other, (int, np.integer)):
+        if self._cmp_on_device(other):
             return self._fa == int(other)
         return self._real() == _hv_unwrap(other)
 

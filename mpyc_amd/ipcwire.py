@@ -8,8 +8,8 @@ party is a process on the SAME node -- one per GPU, or several on one GPU -- the
 
   exporter   FieldArray.__reduce__ (finfields.py), when called from the runtime's own marshalling, returns a
              descriptor instead of the limb bytes: (pid, export id, 64-byte hipIpc handle of the allocation, offset,
-             size) -- a few hundred bytes on the TCP mesh.  The device buffer is parked in `_pending` so that the
-             allocator cannot recycle it.
+             size) -- a few hundred bytes on the TCP mesh.  A device clone of the row is parked in `_pending` so that
+             neither the allocator can recycle it nor the caller write to it.
   receiver   `_array_from_ipc` (the unpickle hook) opens the handle (ffgpu_ipc_open; opened allocations are cached),
              copies the row device-to-device into its own memory (ffgpu_ipc_read; over xGMI between GPUs),
              synchronises, and ACKNOWLEDGES with an 8-byte datagram to the exporter's abstract UNIX socket (its address ends
@@ -24,9 +24,11 @@ party is a process on the SAME node -- one per GPU, or several on one GPU -- the
 
 Scope of the switch: descriptors are only produced while the RUNTIME marshals (`mpyc.runtime.pickle` is replaced by a
 shim that raises a flag around `dumps`); `pickle.dumps(array)` anywhere else keeps producing the limb bytes.
-MPYC_AMD_IPC_WIRE=1 switches the wire on, =0 off; unset, it is on exactly when the runtime's party list puts every party
-on this host (`-M<m>`: all 'localhost').  A descriptor is meaningless on another host; receiving one there fails loudly
-in ffgpu_ipc_open (set MPYC_AMD_IPC_WIRE=0 on every party, e.g. for containers that share a loopback but not the GPUs).
+MPYC_AMD_IPC_WIRE=1 switches the wire on, =0 off; unset, it is on exactly when the runtime itself launched every party
+on this machine (`-M<m>` without `-P`/`-C`).  A descriptor is meaningless on another host; receiving one there fails
+loudly in ffgpu_ipc_open.  What is parked is a device CLONE of the row taken at marshal time (the semantics of
+pickle.dumps); a descriptor is recognised as this process's own by the random tag of its acknowledgement address, never
+by the pid.
 """
 import atexit
 import ctypes
@@ -56,8 +58,8 @@ _hooked = False
 _pending = {}             # export id -> [tensor, times sent, acknowledgements, resolved locally]
 _next_id = 0
 _sock = None              # this process's acknowledgement socket (abstract namespace: no file to clean up)
-_ack_socks = {}           # exporter pid -> connected datagram socket
-_opened = OrderedDict()   # (exporter pid, handle bytes) -> (base pointer, ctx)
+_ack_socks = {}           # exporter's tagged address -> connected datagram socket
+_opened = OrderedDict()   # (exporter's tagged address, handle bytes) -> (base pointer, ctx)
 stats = {'exported': 0, 'imported': 0, 'local': 0, 'released': 0, 'inline': 0}
 
 
@@ -68,9 +70,11 @@ def enable(on=True):
 
 
 def resolve_auto():
-    """MPYC_AMD_IPC_WIRE unset: the wire is switched on when the runtime's party list says that every party runs on
-    this host (`-M<m>` local parties: runtime.py:5193 gives them 'localhost' addresses) and there is more than one.
-    Called once the runtime has been imported (mpyc_amd.install -> arrayGF); explicit '0' / '1' always win."""
+    """MPYC_AMD_IPC_WIRE unset: the wire is switched on only when the runtime itself started every party as a process on
+    THIS machine -- `-M<m>` without `-P`/`-C` (runtime.py:5154-5190: party 0 spawns parties m-1..1 with the same command
+    line).  Loopback addresses given with `-P localhost:...` say nothing about where the peer runs (containers sharing a
+    loopback, SSH-forwarded ports): such runs keep the reference's byte wire unless MPYC_AMD_IPC_WIRE=1 is set on every
+    party.  Called once the runtime has been imported (mpyc_amd.install -> arrayGF); explicit '0' / '1' always win."""
     global ENABLED, _auto
     if not _auto:
         return ENABLED
@@ -80,8 +84,11 @@ def resolve_auto():
     if parties is None:
         return ENABLED
     _auto = False
+    opts = getattr(mpc, 'options', None)
+    launched_here = bool(getattr(opts, 'M', None)) and not getattr(opts, 'parties', None) and not getattr(opts, 'config', None)
     hosts = [getattr(pty, 'host', None) for pty in parties]
-    ENABLED = len(parties) > 1 and all(h is None or h in _LOOPBACK for h in hosts) and torch.cuda.is_available()
+    ENABLED = (launched_here and len(parties) > 1 and all(h is None or h in _LOOPBACK for h in hosts)
+               and torch.cuda.is_available())
     return ENABLED
 
 
@@ -162,10 +169,15 @@ def ensure_runtime_hooks():
     orig_send = rt.Runtime._send_message
 
     def _send_message(self, peer_pid, data):
-        if len(data) < 4096:
+        if _pending:
+            # every descriptor in the payload, whatever else travels with it (mpc.transfer pickles arbitrary objects);
+            # bytes.find runs at memchr speed, and with the wire on the large rows are descriptors, not bytes
             at = data.find(TOKEN)
             while at >= 0:
-                ent = _pending.get(int(data[at + len(TOKEN):at + len(TOKEN) + 16], 16))
+                try:
+                    ent = _pending.get(int(data[at + len(TOKEN):at + len(TOKEN) + 16], 16))
+                except ValueError:
+                    ent = None
                 if ent is not None:
                     ent[1] += 1
                 at = data.find(TOKEN, at + 1)
@@ -185,10 +197,14 @@ def want_descriptor(ctx, nbytes):
 
 
 def export(ctx, t):
-    """Park the device tensor t and return its descriptor (plain picklable values)."""
+    """Park a SNAPSHOT of the device tensor t and return its descriptor (plain picklable values).  pickle.dumps copies
+    the bytes at marshal time (runtime.py:484,571,655); a peer reads the parked buffer later, so what is parked must not
+    be storage the caller can still write to (`mpc.output(a)` followed by `np_update(a, ...)`): one device-to-device
+    copy, on the stream the export waits for."""
     global _next_id
     _ack_socket()
     drain()
+    t = t.clone(memory_format=torch.contiguous_format)          # on torch's current stream = ctx._stream() below
     handle = ctypes.create_string_buffer(HANDLE_BYTES)
     canary = ctypes.create_string_buffer(32)
     offset = ctypes.c_ulonglong()
@@ -214,16 +230,20 @@ def fetch(ctx, desc, reduce_n=None):
     of ctx's field -- they are reduced to canonical form on the way (one pass instead of copy + reduce)."""
     pid, token, handle, offset, nbytes, dtype, shape, ack_addr, canary = desc
     eid = int(token[len(TOKEN):], 16)
-    if pid == os.getpid():
+    if _sock_addr is not None and ack_addr == _sock_addr:
+        # this process's own descriptor (the address ends in a 64-bit random tag: a peer with the same pid and export
+        # counter -- another container, a forwarded port -- never matches).  An interprocess handle cannot be opened by
+        # the process that made it: the parked snapshot itself is the row.
         ent = _pending.get(eid)
         if ent is None:
             raise RuntimeError('device-side wire: this process no longer holds the buffer of its own descriptor')
+        t = ent[0] if not ent[3] else ent[0].clone()          # a second local resolve must not alias the first
         ent[3] = True
         stats['local'] += 1
-        t = ent[0]
         drain()
         return t
-    key = (pid, handle)
+    pid = ack_addr                    # peers are told apart by their tagged address from here on
+    key = (ack_addr, handle)
     t = torch.empty(shape, dtype=getattr(torch, dtype), device=ctx.torch_device)
     for attempt in (0, 1):
         got = _opened.get(key)
@@ -233,8 +253,9 @@ def fetch(ctx, desc, reduce_n=None):
             rc = ctx._L.ffgpu_ipc_open(ctx._h, handle, ctypes.byref(base))
             if rc != 0:
                 raise RuntimeError('MPYC_AMD_IPC_WIRE: cannot open the device buffer of party process %d (%s) -- the '
-                                   'device-side wire needs every party on the same node with its GPUs visible to the others'
-                                   % (pid, ctx._L.ffgpu_last_hip_error().decode() or ctx._L.ffgpu_strerror(rc).decode()))
+                                   'device-side wire needs every party on the same node with its GPUs visible to the others; '
+                                   'set MPYC_AMD_IPC_WIRE=0 on every party to use the byte wire'
+                                   % (desc[0], ctx._L.ffgpu_last_hip_error().decode() or ctx._L.ffgpu_strerror(rc).decode()))
             got = _opened[key] = (base.value, ctx)
             stats['opened'] = stats.get('opened', 0) + 1
             while len(_opened) > OPEN_CACHE:
@@ -260,7 +281,7 @@ def fetch(ctx, desc, reduce_n=None):
     return t
 
 
-_ack_backlog = {}         # exporter pid -> [acknowledgements its socket would not take yet]
+_ack_backlog = {}         # exporter's tagged address -> [acknowledgements its socket would not take yet]
 
 
 def _acknowledge(pid, ack_addr, eid):

@@ -293,6 +293,25 @@ class PRF:
 SHAKE_PRF_TYPES = {PRF}
 
 
+def register_shake_prf(cls) -> bool:
+    """Admit a foreign PRF class (the installed mpyc's thresha.PRF) to the engine's own XOF expansion -- only after a
+    known-answer check that ITS draws are shake_128(key + s) chopped by the same byte_length rule (thresha.py:220-266):
+    another mpyc version with a different PRF keeps being called as the object it is."""
+    if cls in SHAKE_PRF_TYPES:
+        return True
+    key, s = bytes(range(16)), b'\x07\x00\x01'
+    try:
+        for bound in (2**61 - 1, 1 << 64, 256, 2**127 - 1, 3):
+            theirs, ours = cls(key, bound), PRF(key, bound)
+            if getattr(theirs, 'byte_length', None) != ours.byte_length or getattr(theirs, 'max', None) != bound or \
+                    bytes(theirs.key) != key or list(theirs(s, 5)) != ours(s, 5) or theirs(s) != ours(s):
+                return False
+    except Exception:          # noqa: BLE001 -- a class with another constructor or call signature is simply not admitted
+        return False
+    SHAKE_PRF_TYPES.add(cls)
+    return True
+
+
 @functools.lru_cache(maxsize=None)
 def _f_S_i(field, m, i, S):
     """f_S(i+1) for the polynomial with f_S(0) = 1 and f_S(j+1) = 0 for all parties j outside S

@@ -62,3 +62,50 @@ def test_party_major_under_rccl():
 def test_party_major_two_ranks_one_gpu_gloo_staged():
     out = _run_worker('gloo', 2, 29542)
     assert 'DIST_GPU_OK gloo 2' in out
+
+
+def _bench_lines(args, env_extra, timeout=900):
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    bare = [ln for ln in lines if ln.startswith('{')]
+    assert len(bare) == 1 and lines[-1] is not None and lines[-1] == bare[0], [ln[:80] for ln in lines]
+    assert len(bare[0]) < 8000
+    detail = [ln for ln in lines if ln.startswith('# detail ')]
+    assert len(detail) == 1
+    return json.loads(bare[0]), json.loads(detail[0][len('# detail '):])
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_control_flow_on_one_gpu():
+    """The command the driver runs for the scaling record, with the 8 ranks forced onto GPU 0 (gloo, since RCCL refuses
+    two ranks on one device): self-launch under torch.distributed.run, headline + roofline before the first collective
+    of the configs[3] section, the section itself on 8 ranks, one compact line that parses."""
+    line, detail = _bench_lines(['--gpus', '8', '--steps', '5', '--warmup', '2'],
+                                {'FFGPU_BENCH_DEVICE': '0', 'FFGPU_BENCH_LEG_TIMEOUT': '600'})
+    assert line['n_gpus'] == 8 and line['distributed']['world_size'] == 8 and line['distributed']['backend'] == 'gloo'
+    assert len(line['distributed']['ranks']) == 8 and line['distributed']['distinct_devices'] == 1
+    assert all(r['pci_bus_id'] for r in line['distributed']['ranks'])
+    assert line['config']['workload'].startswith('configs[1]') and line['config']['n_per_gpu'] == 10_000_000
+    assert line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 5
+    assert line['roofline']['bound'] == 'hbm' and 0 < line['roofline']['frac'] < 1
+    assert 'cpu_baseline' not in line                      # rank 0 at N = 1 only
+    assert 'error' not in line['multi_gpu'], line['multi_gpu']
+    assert detail['multi_gpu']['config']['n_gpus'] == 8
+    for leg in ('gate_sharded', 'party_major_all_to_all', 'party_major_allgather'):
+        assert line['multi_gpu'][leg]['ms_per_step'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_every_required_object():
+    line, detail = _bench_lines(['--steps', '5', '--warmup', '2', '--no-api-leg'], {})
+    assert line['n_gpus'] == 1 and line['dtype'] == 'u64' and line['unit'] == 'field-ops/s'
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'ms_per_launch', 'bytes_per_launch'):
+        assert key in line['roofline'], key
+    cb = line['cpu_baseline']
+    assert cb['kind'] in ('reference', 'port') and cb['value'] > 0 and cb['host_cores'] >= cb['cores'] >= 1
+    assert 'extras_error' not in line, line.get('extras_error')
+    assert len(detail['kernels']) > 40

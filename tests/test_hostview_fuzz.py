@@ -9,7 +9,7 @@ import random
 import numpy as np
 import pytest
 
-PRIMES = [2**61 - 1, 2**64 - 59, 2**80 - 65, 2**127 - 1, 2**31 - 1]
+PRIMES = [2**61 - 1, 2**64 - 59, 2**80 - 65, 2**127 - 1, 2**31 - 1, 2**128 - 173]
 
 
 def _chain(F, seed, steps=14):
@@ -39,7 +39,7 @@ def _chain(F, seed, steps=14):
     v, t = fresh()
     for step in range(steps):
         op = rng.choice(['add_view', 'sub_view', 'mul_view', 'add_int', 'rsub_int', 'mul_int', 'shl', 'shl_vec', 'sq', 'modp', 'and',
-                         'sum', 'reshape', 'T', 'slice', 'where', 'vstack', 'cumsum', 'neq', 'mod2'])
+                         'sum', 'reshape', 'T', 'slice', 'where', 'vstack', 'cumsum', 'neq', 'mod2', 'eq_int', 'rshift_outer'])
         if not isinstance(v, HostView):
             v, t = fresh(np.shape(t) if np.ndim(t) else shape)           # a fallback ended the chain: start a new one
         big = max(int(abs(x)).bit_length() for x in np.asarray(t, dtype=object).reshape(-1)) if np.size(t) else 0
@@ -94,6 +94,21 @@ def _chain(F, seed, steps=14):
         elif op == 'cumsum' and np.ndim(t) >= 1:
             ax = rng.randrange(np.ndim(t))
             v, t = np.cumsum(v, axis=ax), np.cumsum(t, axis=ax)
+        elif op == 'eq_int':
+            c = rng.choice([-1, p, p + 1, 0, int(np.asarray(t, dtype=object).reshape(-1)[0])])
+            assert (np.asarray(v == c) == (t == c)).all() and (np.asarray(v != c) == (t != c)).all(), ('eq_int', c, seed)
+            continue
+        elif op == 'rshift_outer' and np.ndim(t) == 1:
+            u = t % p
+            w = v % p
+            sh = np.arange(rng.randrange(1, 6))
+            ov, ot = np.right_shift.outer(w, sh), np.right_shift.outer(u, sh)
+            kind = rng.choice(['and1', 'and3', 'T_and1', 'add', 'index', 'eq'])
+            got, want = {'and1': lambda: (ov & 1, ot & 1), 'and3': lambda: (ov & 3, ot & 3), 'T_and1': lambda: (ov.T & 1, ot.T & 1),
+                         'add': lambda: (ov + 5, ot + 5), 'index': lambda: (ov[1:], ot[1:]), 'eq': lambda: (ov == 0, ot == 0)}[kind]()
+            got = got._real() if isinstance(got, HostView) and got._is_lazy else np.asarray(got)
+            assert np.shape(got) == np.shape(want) and (np.asarray(got, dtype=object) == want).all(), ('rshift_outer', kind, seed)
+            continue
         elif op == 'neq':
             got, want = (v != 0), (t != 0)
             assert (np.asarray(got) == want).all(), ('neq', seed)
@@ -119,3 +134,14 @@ def test_random_expression_chains_host_logic(p, monkeypatch):
             _chain(F, 1000 * (p % 97) + seed)
     finally:
         gff._pGF.cache_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', PRIMES)
+def test_random_expression_chains_on_gpu(p):
+    """The same random chains with the views backed by device arrays: every device-resident branch of HostView (the
+    code behind np_trunc / np_to_bits / np_random_bits / np_sgn / np_lsb of the runtime) against NumPy on Python ints."""
+    import mpyc_amd.finfields as gff
+    F = gff.GF(p)
+    for seed in range(25):
+        _chain(F, 7000 + seed)

@@ -102,12 +102,12 @@ def test_release_after_as_many_acknowledgements_as_sends(wire):
     assert len(ids) == 3 and all(ent[1] == 0 for ent in ipcwire._pending.values())
     r._send_message(1, blobs[1])                                             # _distribute: row j to party j ...
     r._send_message(2, blobs[2])
-    r._send_message(1, b'x' * 10000 + blobs[0])                              # (large payloads are not scanned)
-    assert [ipcwire._pending[i][1] for i in ids] == [0, 1, 1] and len(sent) == 3
+    assert [ipcwire._pending[i][1] for i in ids] == [0, 1, 1] and len(sent) == 2
     ipcwire.drain()
     assert len(ipcwire._pending) == 3                                        # nothing acknowledged yet, row 0 unresolved
+    rows[0].t.fill_(77)                                                      # the caller writes to its array after marshalling ...
     own = ipcwire.fetch(FakeCtx(), pickle.loads(blobs[0]))                   # ... and the own row is unmarshalled locally
-    assert own is rows[0].t and ipcwire.stats['local'] == 1
+    assert own is not rows[0].t and bool((own == 0).all()) and ipcwire.stats['local'] == 1     # the snapshot of marshal time
     assert ids[0] not in ipcwire._pending and len(ipcwire._pending) == 2     # released: nobody else holds its descriptor
     ack(ipcwire, ids[1])
     ipcwire.drain()
@@ -126,6 +126,14 @@ def test_release_after_as_many_acknowledgements_as_sends(wire):
     assert not ipcwire._pending and ipcwire.stats['released'] == 4
     with pytest.raises(RuntimeError):
         ipcwire.fetch(FakeCtx(), pickle.loads(blobs[0]))                     # a second local resolution: the buffer is gone
+    # a descriptor inside a LARGE payload (mpc.transfer of an object holding an array and other data) is counted too
+    big = rt.pickle.dumps(Row(torch.ones(20000, dtype=torch.int64)))
+    bid = max(ipcwire._pending)
+    r._send_message(1, b'x' * 100000 + big + b'y' * 100000)
+    assert ipcwire._pending[bid][1] == 1
+    ack(ipcwire, bid)
+    ipcwire.drain()
+    assert not ipcwire._pending
 
 
 def test_wire_stays_off_without_the_runtime_hooks(wire, monkeypatch):
@@ -136,7 +144,8 @@ def test_wire_stays_off_without_the_runtime_hooks(wire, monkeypatch):
 
 
 def test_auto_mode_follows_the_party_list(wire, monkeypatch):
-    """MPYC_AMD_IPC_WIRE unset: on exactly when the runtime lists more than one party and all of them on this host."""
+    """MPYC_AMD_IPC_WIRE unset: on exactly when the runtime launched more than one party on this machine itself (-M<m>
+    without -P / -C): loopback addresses alone (containers, forwarded ports) do not switch it on."""
     ipcwire, rt, sent = wire
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
 
@@ -147,8 +156,14 @@ def test_auto_mode_follows_the_party_list(wire, monkeypatch):
                         ([None, None], True), (['127.0.0.1', ''], True)):
         monkeypatch.setattr(ipcwire, '_auto', True)
         monkeypatch.setattr(ipcwire, 'ENABLED', False)
-        rt.mpc = types.SimpleNamespace(parties=[P(h) for h in hosts])
+        rt.mpc = types.SimpleNamespace(parties=[P(h) for h in hosts], options=types.SimpleNamespace(M=len(hosts), parties=None, config=None))
         assert ipcwire.resolve_auto() is want, hosts
+    for opts in (types.SimpleNamespace(M=None, parties=['localhost:11365', 'localhost:11366'], config=None),
+                 types.SimpleNamespace(M=None, parties=None, config='run.ini'), None):
+        monkeypatch.setattr(ipcwire, '_auto', True)
+        monkeypatch.setattr(ipcwire, 'ENABLED', False)
+        rt.mpc = types.SimpleNamespace(parties=[P('localhost'), P('localhost')], options=opts)
+        assert ipcwire.resolve_auto() is False, opts
     monkeypatch.setattr(ipcwire, '_auto', False)                  # an explicit setting is not re-evaluated
     monkeypatch.setattr(ipcwire, 'ENABLED', False)
     rt.mpc = types.SimpleNamespace(parties=[P('localhost')] * 3)
@@ -188,7 +203,8 @@ class RemoteLib(FakeLib):
 
 
 def test_remote_fetch_acknowledges_and_survives_a_stale_mapping(wire, monkeypatch):
-    """The receiver's side with a peer simulated in this process (the descriptor carries another pid): the handle is opened
+    """The receiver's side with a peer simulated in this process (while it fetches, this process answers to another tagged
+    address -- the pid in the descriptor is the receiver's OWN, as for a peer in another container): the handle is opened
     once and cached, every fetch is acknowledged to the exporter's socket, a cached mapping that fails the canary check is
     unmapped, reopened and read again, and the exporter releases the buffer after the acknowledgement."""
     ipcwire, rt, sent = wire
@@ -207,11 +223,16 @@ def test_remote_fetch_acknowledges_and_survives_a_stale_mapping(wire, monkeypatc
         blob = rt.pickle.dumps(row)
         r._send_message(1, blob)
         desc = list(pickle.loads(blob))
-        desc[0] = os.getpid() + 1                                          # "another process" exported it ...
-        desc[2], desc[3] = base_handle, 8 * 20000 * j                      # ... as (handle of the allocation, offset of the row)
+        assert desc[0] == os.getpid()                                      # same pid, same export counter as a peer could have
+        desc[2], desc[3] = base_handle, 8 * 20000 * j                      # (handle of the allocation, offset of the row)
         if j == 2:
             lib.stale_next = True                                          # the cached mapping fails the canary check once
-        t = ipcwire.fetch(Ctx(), tuple(desc), reduce_n=20000 if j == 1 else None)
+        mine = ipcwire._sock_addr
+        ipcwire._sock_addr = mine[:-4] + b'beef'                           # "another process": identity is the tagged address
+        try:
+            t = ipcwire.fetch(Ctx(), tuple(desc), reduce_n=20000 if j == 1 else None)
+        finally:
+            ipcwire._sock_addr = mine
         assert torch.equal(t, row.t), j
     assert lib.opens == 2 and lib.closes == 1                              # opened once, cached, reopened after the stale read
     assert ipcwire.stats.get('stale') == 1

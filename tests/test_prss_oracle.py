@@ -94,3 +94,52 @@ def test_mirror_prss_takes_bytearray_keys_and_foreign_prf_classes(monkeypatch):
         assert OtherPRF.calls > 0
     finally:
         gff._pGF.cache_clear()
+
+
+def test_foreign_prf_class_is_admitted_only_after_a_known_answer_check(monkeypatch):
+    """install() hands mpyc.thresha.PRF to register_shake_prf: a class whose draws are shake_128(key + s) chopped by the
+    reference's byte_length rule is admitted to the engine's expansion; one with another XOF, another length rule or
+    another constructor is not (it keeps being called as the object it is)."""
+    import hashlib
+    import mpyc_amd.thresha as gth
+    monkeypatch.setattr(gth, 'SHAKE_PRF_TYPES', {gth.PRF})
+
+    class Same:
+        def __init__(self, key, bound):
+            self.key, self.max = key, bound
+            self.byte_length = ((bound - 1).bit_length() + 7) // 8 + (len(key) if bound & (bound - 1) else 0)
+
+        def __call__(self, s, n=None):
+            n_ = 1 if n is None else n
+            dk = hashlib.shake_128(self.key + s).digest(n_ * self.byte_length)
+            x = [int.from_bytes(dk[i:i + self.byte_length], 'little') % self.max for i in range(0, len(dk), self.byte_length)]
+            return x[0] if n is None else x
+
+    class OtherXof(Same):
+        def __call__(self, s, n=None):
+            n_ = 1 if n is None else n
+            dk = hashlib.shake_256(self.key + s).digest(n_ * self.byte_length)
+            x = [int.from_bytes(dk[i:i + self.byte_length], 'little') % self.max for i in range(0, len(dk), self.byte_length)]
+            return x[0] if n is None else x
+
+    class OtherLength(Same):
+        def __init__(self, key, bound):
+            super().__init__(key, bound)
+            self.byte_length += 1
+
+    class OtherCtor:
+        def __init__(self, key):
+            self.key = key
+
+    assert gth.register_shake_prf(Same) and Same in gth.SHAKE_PRF_TYPES
+    for cls in (OtherXof, OtherLength, OtherCtor):
+        assert gth.register_shake_prf(cls) is False and cls not in gth.SHAKE_PRF_TYPES
+    import os
+    import sys
+    for root in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '_refstage'), '/root/reference'):
+        if os.path.isdir(os.path.join(root, 'mpyc')):
+            monkeypatch.syspath_prepend(root)
+            sys.modules.pop('mpyc.thresha', None) if 'mpyc' not in sys.modules else None
+            from mpyc import thresha as ref
+            assert gth.register_shake_prf(ref.PRF)            # the reference's own class passes
+            break
