@@ -1038,8 +1038,8 @@ __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __re
 // LDS, ONE wave per workgroup raising the pooled total -- replaces 3/4 of the exponentiations by 15 products per thread,
 // but the three waves that wait at the barrier leave their SIMDs with one runnable wave: 61.3 us against 56.0 us at
 // n = 10^7 over 2^61 - 1.)
-template <class F, int CH, int G, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
+template <class F, int CH, int G, bool NT, int WIN = 0>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIN > 0 ? 3 : 1, 8))) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
                                                       int* __restrict__ flag) {
     typedef Pack<typename F::word> P;
@@ -1105,26 +1105,57 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
             }
         }
         const bool wave_has_zero = __any(zbits != 0);
+        // Back-substitution in reverse order of the prefix pass.  The operands are read a second time (cache hits); with
+        // every one of the CH * G second reads hoisted to the top of this phase the kernel held prefixes AND operands
+        // (10 registers per pack, 215-255 VGPRs, two waves per SIMD).  WIN > 0 keeps exactly WIN packs in flight: the
+        // read of step s + WIN is issued when step s is consumed, and a scheduling barrier per step keeps the compiler
+        // from hoisting it further.
+        constexpr int NP = CH * G;
+        auto pack_of = [&](int s_, int& g_, int& c_) { c_ = CH - 1 - s_ / G; g_ = s_ % G; };
+        // the pack addresses are formed AGAIN from an opaque copy of the stride: left to itself the compiler keeps the
+        // 2 x CH x G address registers of the prefix pass alive across the exponentiation
+        size_t gsz3 = gsz;
+        if constexpr (WIN > 0) asm volatile("" : "+s"(gsz3));
+        P win[WIN > 0 ? WIN : 1];
+        if constexpr (WIN > 0) {
 #pragma unroll
-        for (int c = CH - 1; c >= 0; --c) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const size_t j = i0 + (size_t)(g * CH + c) * gsz;
-                P t_, r;
-                if (j < nvec) t_ = ldg<NT>(av + j);         // second read of the operands (cache hit)
-#pragma unroll
-                for (int q = P::N - 1; q >= 0; --q) {
-                    W v = (j < nvec) ? t_.w[q] : ff_one(f);
-                    r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
-                    if (wave_has_zero) {                     // scalar branch: rare
-                        uint32_t zq;
-                        v = ff_zero_fix(f, v, zq);
-                        r.w[q] = ff_zero_apply(f, r.w[q], zq);
-                    }
-                    ginv[g] = ff_mul_lazy(f, ginv[g], v);
-                }
-                if (j < nvec) stg<NT>(ov + j, r);
+            for (int s_ = 0; s_ < WIN && s_ < NP; ++s_) {
+                int g, c;
+                pack_of(s_, g, c);
+                const size_t j = i0 + (size_t)(g * CH + c) * gsz3;
+                if (j < nvec) win[s_ % WIN] = ldg<NT>(av + j);
             }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NP; ++s_) {
+            int g, c;
+            pack_of(s_, g, c);
+            const size_t j = i0 + (size_t)(g * CH + c) * gsz3;
+            P t_, r;
+            if constexpr (WIN > 0) {
+                t_ = win[s_ % WIN];
+                if (s_ + WIN < NP) {
+                    int g2, c2;
+                    pack_of(s_ + WIN, g2, c2);
+                    const size_t j2 = i0 + (size_t)(g2 * CH + c2) * gsz3;
+                    if (j2 < nvec) win[s_ % WIN] = ldg<NT>(av + j2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (j < nvec) t_ = ldg<NT>(av + j);         // second read of the operands (cache hit)
+            }
+#pragma unroll
+            for (int q = P::N - 1; q >= 0; --q) {
+                W v = (j < nvec) ? t_.w[q] : ff_one(f);
+                r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
+                if (wave_has_zero) {                     // scalar branch: rare
+                    uint32_t zq;
+                    v = ff_zero_fix(f, v, zq);
+                    r.w[q] = ff_zero_apply(f, r.w[q], zq);
+                }
+                ginv[g] = ff_mul_lazy(f, ginv[g], v);
+            }
+            if (j < nvec) stg<NT>(ov + j, r);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);

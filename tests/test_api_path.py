@@ -88,6 +88,32 @@ def test_api_path_matches_reference_on_gpu_1e6(tmp_path, parties, t):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(STAGE, 'mpyc')), reason='no staged reference copy (_refstage/)')
+def test_api_path_matches_reference_on_gpu_at_the_north_star_size(tmp_path):
+    """north_star: "bit-exact vs mpyc.thresha on 10^7-element SecFld arrays" -- through the API, against the reference
+    itself run beside it: n = 10^7 over 2^61 - 1, one party (mpc.input / a * b / mpc.output = np_multiply + output,
+    runtime.py:1096-1141, 513-600), every digest equal."""
+    n = 10_000_000
+    ref = run_program(STAGE, 'ref', n, 1, str(tmp_path), reps=1)
+    dev = run_program(STAGE, 'gpu', n, 1, str(tmp_path), reps=1)
+    assert dev[0]['gpu_calls'] and dev[0]['gpu_busy_ms'] > 0
+    compare(ref, dev, 1, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(STAGE, 'mpyc')), reason='no staged reference copy (_refstage/)')
+def test_api_path_three_parties_at_the_north_star_size(tmp_path):
+    """The same at n = 10^7 for three parties (t = 1: np_random_split by every party, np_recombine of 2t+1 rows,
+    runtime.py:603-689) with the engine's parties exchanging rows over the device-side wire; the reference's three
+    parties run the identical program over its TCP mesh beside it."""
+    n = 10_000_000
+    ref = run_program(STAGE, 'ref', n, 3, str(tmp_path), reps=1, timeout=900)
+    dev = run_program(STAGE, 'gpu', n, 3, str(tmp_path), reps=1, ipc_wire=True)
+    assert dev[0]['ipc_wire'] is True and dev[0]['gpu_calls']
+    compare(ref, dev, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(STAGE, 'mpyc')), reason='no staged reference copy (_refstage/)')
 def test_api_path_chain_wide_prime_on_gpu(tmp_path):
     n = 100_000
     ref = run_program(STAGE, 'ref', n, 3, str(tmp_path), prime=2**128 - 173, chain=3, reps=1)

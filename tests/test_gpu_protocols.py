@@ -451,6 +451,42 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n', [10**6, 4 * 10**6, 10**6 + 3])
+def test_sbox_layer_at_the_configured_size(mods, n):
+    """BASELINE configs[4] at its stated size: the S-box layer of demos/np_aes.py:37-43 over 10^6 secure bytes (and 4x
+    that, and a length that is not a multiple of 4), m=3, t=1, one-kernel path; every byte, opened from two different
+    sets of t+1 parties, against the FIPS-197 table of golden/sbox.json."""
+    engine, finfields, gfpx, protocols = mods
+    g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    t, m = 1, 3
+    gen = torch.Generator(device='cuda:0')
+    gen.manual_seed(1000 + n % 97)
+    x = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda:0', generator=gen)
+    x[:256] = torch.arange(256, dtype=torch.uint8, device='cuda:0')            # every byte value is present
+    table = torch.tensor(g['table'], dtype=torch.uint8, device='cuda:0')
+    want = table[x.long()]
+    xs = protocols.share(ctx, engine.DevArray(ctx, x, n), t, m)
+    rb = torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0', generator=gen)
+    rbits = protocols.share(ctx, engine.DevArray(ctx, rb, 8 * n), t, m)
+    out = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, fused=True)
+    shares = [out.row(i) for i in range(m)]
+    rv = __import__('mpyc_amd.thresha', fromlist=['x'])._recombination_vector
+    for parties in ((1, 2), (2, 3), (1, 3)):
+        lam = [int(v) for v in rv(F, tuple(parties), 0)]
+        got = ctx.recombine([shares[i - 1] for i in parties], lam)
+        assert torch.equal(got.t[:n], want), parties
+    assert not torch.equal(shares[0].t[:n], want)                               # a share is not the value
+    # the 13-launch composition gives the same opened bytes
+    out13 = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, fused=False)
+    lam = [int(v) for v in rv(F, (1, 2), 0)]
+    assert torch.equal(ctx.recombine([out13.row(0), out13.row(1)], lam).t[:n], want)
+
+
+@pytest.mark.gpu
 def test_batched_chain_gate_opens_to_products(mods):
     """ffgpu_gate_rng_batch over a prime field: k senders in one launch, operands as plain share matrices and as
     pending blocks; every party's recombined share opens to a*b (and the senders drew different randomness)."""
