@@ -217,6 +217,29 @@ def emit(out, detail_path=None):
     sys.stdout.flush()
 
 
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9      # lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 instruction per 4 cycles)
+
+
+def annotate_valu(kern, n):
+    """Rows whose limiter is the VALU (in-kernel ChaCha, carry-less products, exponentiations, LDS-table recombination):
+    `bound: "valu"` and `valu_frac` = VALU lane-operations per element (rocprofv3 --pmc SQ_INSTS_VALU of tools/valu_probe.py,
+    profiles/r04_valu.json) x elements/s / the chip's issue rate.  `frac` stays the fraction of the HBM peak for the row's
+    algorithmic bytes.  (v_mad_u64_u32 counts once although it occupies two slots: valu_frac understates multiply-heavy rows.)"""
+    path = os.path.join(ROOT, 'profiles', 'r04_valu.json')
+    if not os.path.exists(path):
+        return
+    with open(path) as fh:
+        data = json.load(fh)
+    for row, info in data.items():
+        r = kern.get(row)
+        if not isinstance(r, dict) or not r.get('ms_per_launch'):
+            continue
+        ops = float(info['valu_lane_ops_per_unit'])
+        r.update(bound='valu', valu_lane_ops_per_unit=ops,
+                 valu_frac=round(ops * n / (r['ms_per_launch'] * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                 valu_source='profiles/r04_valu.md (SQ_INSTS_VALU x 64 / n)')
+
+
 def cpu_baseline(n_full, t, m, lam, seed=20260925):
     """The reference's own CPU path on this host (kind "reference": mpyc's FiniteFieldArray.__mul__,
     thresha.np_random_split with live secrets.randbelow draws, thresha.np_recombine -- oracle/refbaseline.py -- on 1
@@ -1301,6 +1324,7 @@ def main():
             try:
                 optional_measurements()
                 annotate_traffic()
+                annotate_valu(kern, n)
             except Exception as exc:          # noqa: BLE001 -- report, keep the main result
                 out['extras_error'] = f'{type(exc).__name__}: {exc}'
             if 'configs2' in out and 'split_p64_m7t3' in kern:

@@ -52,6 +52,8 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
                                  unsigned char* out);
 int ffgpu_launch_gf2w_mul_win(const void* policy, int limbs, const void* rtable, int device, const void* a,
                               const void* b, void* out, size_t n, hipStream_t st);
+size_t ffgpu_launch_gf2w64_mul_bitsliced(const void* policy, int device, const void* a, const void* b, void* out, size_t n,
+                                         hipStream_t st);
 int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, const void* b, void* out, size_t n,
                              hipStream_t st);
 
@@ -552,6 +554,18 @@ int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
         LaunchTimer lt(ctx, (hipStream_t)stream);
         return launch_status(ffgpu_launch_gf2w_mul_win(ctx->policy, ctx->gf2w_limbs, ctx->gf2w_rtable, ctx->device,
                                                        a, b, out, n, (hipStream_t)stream));
+    }
+    if (ctx && ctx->policy_kind == POL_GF2W64 && a && b && out && n >= ((size_t)1 << 21)) {
+        // GF(2^64) with the default modulus: bit-sliced product for the whole slabs, the element-wise kernel for the rest
+        size_t done;
+        {
+            DeviceGuard g(ctx->device);
+            LaunchTimer lt(ctx, (hipStream_t)stream);
+            done = ffgpu_launch_gf2w64_mul_bitsliced(ctx->policy, ctx->device, a, b, out, n, (hipStream_t)stream);
+            if (done && hipGetLastError() != hipSuccess) return FFGPU_EHIP;
+        }
+        if (done == n) return FFGPU_OK;
+        if (done) return do_ew2(ctx, OP_MUL, (const char*)a + 8 * done, (const char*)b + 8 * done, (char*)out + 8 * done, n - done, stream);
     }
     return do_ew2(ctx, OP_MUL, a, b, out, n, stream);
 }

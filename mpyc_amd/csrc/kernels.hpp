@@ -925,7 +925,10 @@ struct ExpArgs {
 //    left-to-right SLIDING WINDOWS of up to 4 bits over the odd powers a, a^3, ..., a^15 (one squaring + 7 products
 //    to build them; the table lives in registers and is selected by a uniform switch -- no dynamic register
 //    indexing, no scratch).
-template <class F>
+//  * WINDOWS = false leaves the window table out (square-and-multiply for whatever follows the leading run): the
+//    batched inverse holds its prefix products across the exponentiation and the eight odd powers cost it 16 registers
+//    plus their live ranges; the host picks this form when the exponent's tail is short (ff_pow_lean_ok).
+template <class F, bool WINDOWS = true>
 __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
     typedef typename F::word W;
     auto bit = [&](int i) -> uint32_t { return (uint32_t)(ex.e[i >> 6] >> (i & 63)) & 1u; };
@@ -961,7 +964,7 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
         if (hi >= 63) ones += __builtin_popcountll(ex.e[q]);
         else if (hi >= 0) ones += __builtin_popcountll(ex.e[q] & ((2ull << hi) - 1));
     }
-    if (i < 4 || ones <= 8 + (i + 1) / 8) {
+    if (!WINDOWS || i < 4 || ones <= 8 + (i + 1) / 8) {
         for (; i >= 0; --i) {
             r = ff_sqr_lazy(f, r);
             if (bit(i)) r = ff_mul_lazy(f, r, a);
@@ -1038,8 +1041,8 @@ __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __re
 // LDS, ONE wave per workgroup raising the pooled total -- replaces 3/4 of the exponentiations by 15 products per thread,
 // but the three waves that wait at the barrier leave their SIMDs with one runnable wave: 61.3 us against 56.0 us at
 // n = 10^7 over 2^61 - 1.)
-template <class F, int CH, int G, bool NT, int WIN = 0>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIN > 0 ? 3 : 1, 8))) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
+template <class F, int CH, int G, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
                                                       int* __restrict__ flag) {
     typedef Pack<typename F::word> P;
@@ -1105,57 +1108,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIN > 0 ?
             }
         }
         const bool wave_has_zero = __any(zbits != 0);
-        // Back-substitution in reverse order of the prefix pass.  The operands are read a second time (cache hits); with
-        // every one of the CH * G second reads hoisted to the top of this phase the kernel held prefixes AND operands
-        // (10 registers per pack, 215-255 VGPRs, two waves per SIMD).  WIN > 0 keeps exactly WIN packs in flight: the
-        // read of step s + WIN is issued when step s is consumed, and a scheduling barrier per step keeps the compiler
-        // from hoisting it further.
-        constexpr int NP = CH * G;
-        auto pack_of = [&](int s_, int& g_, int& c_) { c_ = CH - 1 - s_ / G; g_ = s_ % G; };
-        // the pack addresses are formed AGAIN from an opaque copy of the stride: left to itself the compiler keeps the
-        // 2 x CH x G address registers of the prefix pass alive across the exponentiation
-        size_t gsz3 = gsz;
-        if constexpr (WIN > 0) asm volatile("" : "+s"(gsz3));
-        P win[WIN > 0 ? WIN : 1];
-        if constexpr (WIN > 0) {
 #pragma unroll
-            for (int s_ = 0; s_ < WIN && s_ < NP; ++s_) {
-                int g, c;
-                pack_of(s_, g, c);
-                const size_t j = i0 + (size_t)(g * CH + c) * gsz3;
-                if (j < nvec) win[s_ % WIN] = ldg<NT>(av + j);
-            }
-        }
+        for (int c = CH - 1; c >= 0; --c) {
 #pragma unroll
-        for (int s_ = 0; s_ < NP; ++s_) {
-            int g, c;
-            pack_of(s_, g, c);
-            const size_t j = i0 + (size_t)(g * CH + c) * gsz3;
-            P t_, r;
-            if constexpr (WIN > 0) {
-                t_ = win[s_ % WIN];
-                if (s_ + WIN < NP) {
-                    int g2, c2;
-                    pack_of(s_ + WIN, g2, c2);
-                    const size_t j2 = i0 + (size_t)(g2 * CH + c2) * gsz3;
-                    if (j2 < nvec) win[s_ % WIN] = ldg<NT>(av + j2);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
+            for (int g = 0; g < G; ++g) {
+                const size_t j = i0 + (size_t)(g * CH + c) * gsz;
+                P t_, r;
                 if (j < nvec) t_ = ldg<NT>(av + j);         // second read of the operands (cache hit)
-            }
 #pragma unroll
-            for (int q = P::N - 1; q >= 0; --q) {
-                W v = (j < nvec) ? t_.w[q] : ff_one(f);
-                r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
-                if (wave_has_zero) {                     // scalar branch: rare
-                    uint32_t zq;
-                    v = ff_zero_fix(f, v, zq);
-                    r.w[q] = ff_zero_apply(f, r.w[q], zq);
+                for (int q = P::N - 1; q >= 0; --q) {
+                    W v = (j < nvec) ? t_.w[q] : ff_one(f);
+                    r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
+                    if (wave_has_zero) {                     // scalar branch: rare
+                        uint32_t zq;
+                        v = ff_zero_fix(f, v, zq);
+                        r.w[q] = ff_zero_apply(f, r.w[q], zq);
+                    }
+                    ginv[g] = ff_mul_lazy(f, ginv[g], v);
                 }
-                ginv[g] = ff_mul_lazy(f, ginv[g], v);
+                if (j < nvec) stg<NT>(ov + j, r);
             }
-            if (j < nvec) stg<NT>(ov + j, r);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -1171,6 +1143,137 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIN > 0 ?
     if (anyzero && flag) atomicOr(flag, 1);
 }
 
+
+// ---- batched inverse, one-word fields: full batches without bounds checks ------------------------------------------
+// Same arithmetic as k_inv_batch (prefix products per group, one exponentiation per thread, back-substitution with a
+// second read of the operands).  What differs is the shape of the code around it:
+//   * blocks 0 .. nfull-1 each own BLOCK * CH * G packs and every pack exists: no `j < nvec` predicate anywhere (the
+//     predicated loads of k_inv_batch compile to one exec-mask branch per pack and a vmcnt(0) after each second read);
+//     the packs past nfull * BLOCK * CH * G (fewer than one block's worth) go to a few extra blocks, one pack per
+//     thread, each element raised on its own;
+//   * the second reads are issued WIN packs ahead of their use, a scheduling barrier per step keeps the compiler from
+//     hoisting them all to the top of the phase (where they sat beside the CH * G prefixes: 10 registers per pack);
+//   * the pack addresses of the second pass are formed again from an opaque copy of the stride -- otherwise the
+//     2 * CH * G address registers of the first pass stay alive across the exponentiation;
+//   * WAVES = the occupancy the register allocator is held to (amdgpu_waves_per_eu);
+//   * LEAN: the exponentiation without its window table (ff_pow<F, false>) -- 64 registers less across the one place
+//     where all CH * G prefixes are alive; chosen by the host when the exponent's tail is short (every 2^k - c prime).
+template <class F, int CH, int G, int WIN, int WAVES, bool LEAN, int WIN1 = 0>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
+void k_inv_fast(F f, const typename F::elem* __restrict__ a, ExpArgs ex, typename F::elem* __restrict__ o, size_t nvec,
+                size_t n, unsigned nfull, int* __restrict__ flag) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    static_assert(F::EPW == 1 && CH * G * P::N <= 64 && WIN >= 1 && G <= 2, "one-word fields, 64-bit zero mask");
+    constexpr int NP = CH * G;
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
+    uint32_t anyzero = 0;
+    auto pack_of = [&](int s_, int& g_, int& c_) { c_ = CH - 1 - s_ / G; g_ = s_ % G; };   // order of the second pass
+    if (blockIdx.x < nfull) {
+        const size_t gsz = (size_t)nfull * BLOCK;
+        const size_t i0 = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+        W pre[G][CH][P::N], tot[G];
+        uint64_t zbits = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) tot[g] = ff_one(f);
+        // first pass in the order c-major, g-minor (the G chains interleave); WIN1 packs are in flight ahead of the
+        // products (0 = all CH * G reads issued up front)
+        constexpr int W1 = WIN1 > 0 && WIN1 < NP ? WIN1 : NP;
+        P ld[W1];
+        auto pack1 = [&](int s_) { return (s_ % G) * CH + s_ / G; };          // step -> pack index g * CH + c
+#pragma unroll
+        for (int s_ = 0; s_ < W1; ++s_) ld[s_] = ldg<false>(av + i0 + (size_t)pack1(s_) * gsz);      // (cacheable: read again below)
+#pragma unroll
+        for (int s_ = 0; s_ < NP; ++s_) {
+            const int g = s_ % G, c = s_ / G;
+            const P t_ = ld[s_ % W1];
+            if (s_ + W1 < NP) {
+                ld[s_ % W1] = ldg<false>(av + i0 + (size_t)pack1(s_ + W1) * gsz);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) {
+                uint32_t zq;
+                const W v = ff_zero_fix(f, t_.w[q], zq);
+                zbits |= (uint64_t)(zq & 1u) << ((g * CH + c) * P::N + q);
+                pre[g][c][q] = tot[g];
+                tot[g] = ff_mul_lazy(f, tot[g], v);
+            }
+        }
+        anyzero |= zbits != 0;
+        W all = tot[0];
+        if constexpr (G == 2) all = ff_mul_lazy(f, all, tot[1]);
+        const W inv_all = ff_pow<F, !LEAN>(f, all, ex);
+        W ginv[G];
+        if constexpr (G == 1) {
+            ginv[0] = inv_all;
+        } else {
+            ginv[0] = ff_mul_lazy(f, inv_all, tot[1]);
+            ginv[1] = ff_mul_lazy(f, inv_all, tot[0]);
+        }
+        const bool wave_has_zero = __any(zbits != 0);
+        size_t gsz2 = gsz;
+        asm volatile("" : "+s"(gsz2));
+        P win[WIN];
+#pragma unroll
+        for (int s_ = 0; s_ < WIN && s_ < NP; ++s_) {
+            int g, c;
+            pack_of(s_, g, c);
+            win[s_ % WIN] = ldg<true>(av + i0 + (size_t)(g * CH + c) * gsz2);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NP; ++s_) {
+            int g, c;
+            pack_of(s_, g, c);
+            const P t_ = win[s_ % WIN];
+            P r;
+            if (s_ + WIN < NP) {
+                int g2, c2;
+                pack_of(s_ + WIN, g2, c2);
+                win[s_ % WIN] = ldg<true>(av + i0 + (size_t)(g2 * CH + c2) * gsz2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = P::N - 1; q >= 0; --q) {
+                W v = t_.w[q];
+                r.w[q] = ff_canon(f, ff_mul_lazy(f, ginv[g], pre[g][c][q]));
+                if (wave_has_zero) {                     // scalar branch: rare
+                    uint32_t zq;
+                    v = ff_zero_fix(f, v, zq);
+                    r.w[q] = ff_zero_apply(f, r.w[q], zq);
+                }
+                ginv[g] = ff_mul_lazy(f, ginv[g], v);
+            }
+            stg<true>(ov + i0 + (size_t)(g * CH + c) * gsz2, r);
+        }
+    } else {
+        // the packs no full block covers (fewer than BLOCK * NP): one pack per thread of the extra blocks, each element
+        // raised on its own -- a few microseconds that run beside the full blocks, and no second set of prefix registers
+        const size_t j = (size_t)nfull * BLOCK * NP + (size_t)(blockIdx.x - nfull) * BLOCK + threadIdx.x;
+        if (j < nvec) {
+            const P t_ = ldg<true>(av + j);
+            P r;
+#pragma unroll
+            for (int q = 0; q < P::N; ++q) {
+                uint32_t zq;
+                const W v = ff_zero_fix(f, t_.w[q], zq);
+                anyzero |= zq & 1u;
+                r.w[q] = ff_zero_apply(f, ff_pow(f, v, ex), zq);
+            }
+            stg<true>(ov + j, r);
+        }
+        const size_t e = nvec * (size_t)P::N + (size_t)(blockIdx.x - nfull) * BLOCK + threadIdx.x;   // past the last whole pack
+        if (e < n) {
+            uint32_t z;
+            const W v = ff_zero_fix(f, ld_elem<F>(a, e), z);
+            anyzero |= z & 1u;
+            st_elem<F>(o, e, ff_zero_apply(f, ff_pow(f, v, ex), z));
+        }
+    }
+    if (anyzero && flag) atomicOr(flag, 1);
+}
 
 // ---- PRSS combination (thresha.py:163-173, 201-217) ---------------------------------------------
 // out[h] (+)= sum_{s<ks} sum_{j<d} draw_s[h*d + j] * W[s][j]
@@ -2992,6 +3095,18 @@ struct Launchers {
         // packs per thread: ONE exponentiation (70 products for 2^61 - 1) is shared by G x CH packs, and the
         // G x CH x N prefix words stay in registers (two waves per SIMD at CH = 8..12 for one-word fields)
         if constexpr (F::EPW == 1 && sizeof(W) == 8) {
+            // One exponentiation (70 products for 2^61 - 1) is shared by the CH x G packs of a thread.  Round 4: k_inv_fast
+            // (full batches without predicates, second reads in a window, exponentiation without its window table when the
+            // exponent allows it) at 8 x 2 packs = 32 elements per thread and three waves per SIMD: 41.6 us against 51.6 us
+            // for the round-3 kernel at n = 10^7 over 2^61 - 1 (profiles/r04_alu.md: thirteen shapes measured; more packs
+            // per thread spill or fall to two waves, fewer pay more exponentiations).  FFGPU_INV_VARIANT=0 runs the round-3
+            // kernel (A/B measurements).
+            const char* e = getenv("FFGPU_INV_VARIANT");
+            const int variant = e ? atoi(e) : 1;
+            if (variant > 0 && nvec >= (size_t)BLOCK * 64) {
+                if (pow_lean_ok(*ex)) return launch_inv_fast<8, 2, 6, 3, true>(f, a, ex, out, nvec, n, flag, st);
+                return launch_inv_fast<8, 2, 3, 1, false>(f, a, ex, out, nvec, n, flag, st);
+            }
             // All waves of the launch take the same time and two fit on a SIMD, so the launch runs in ROUNDS of
             // 2 x 4 x num_cu waves: 10^7 elements at CH = 8 are 4883 waves = 2.4 rounds -- three rounds of time for
             // 2.4 of work (measured: 56 us).  More packs per thread amortise the exponentiation better AND change the
@@ -3014,6 +3129,31 @@ struct Launchers {
             constexpr int CH = F::EPW > 1 ? 2 : 8;          // packed bytes: 8 words per batch (zero mask)
             return launch_inv<CH, 1>(f, lc, a, ex, out, nvec, n, flag, st);
         }
+    }
+    // square-and-multiply after the leading run costs popcount(tail) products, the window table 8 up front and one per
+    // window: lean when the tail holds few set bits (q - 2 of every 2^k - c prime: a run of ones and a short tail)
+    static bool pow_lean_ok(const ExpArgs& ex) {
+        int i = ex.nbits - 1;
+        auto bit = [&](int b) { return (int)((ex.e[b >> 6] >> (b & 63)) & 1u); };
+        while (i >= 0 && bit(i)) --i;                 // the leading run
+        if (ex.nbits - 1 - i < 12) i = ex.nbits - 2;  // (short runs are not raised by doubling: everything is tail)
+        int ones = 0;
+        for (int b = i; b >= 0; --b) ones += bit(b);
+        return ones <= 6;
+    }
+    template <int CH, int G, int WIN, int WAVES, bool LEAN, int WIN1 = 0>
+    static int launch_inv_fast(const F& f, const void* a, const ExpArgs* ex, void* out, size_t nvec, size_t n, int* flag,
+                               hipStream_t st) {
+        if constexpr (F::EPW == 1 && sizeof(W) == 8) {
+            const size_t per_block = (size_t)BLOCK * CH * G;
+            const size_t nfull = nvec / per_block;
+            const size_t rest = nvec % per_block;
+            const unsigned grid = (unsigned)nfull + (unsigned)((rest + BLOCK - 1) / BLOCK) + ((rest == 0 && n > nvec * EPV) ? 1u : 0u);
+            hipLaunchKernelGGL((k_inv_fast<F, CH, G, WIN, WAVES, LEAN, WIN1>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out,
+                               nvec, n, (unsigned)nfull, flag);
+            FFGPU_CHECK_LAUNCH();
+        }
+        return 0;
     }
     template <int CH, int G>
     static int launch_inv(const F& f, const LaunchCfg& lc, const void* a, const ExpArgs* ex, void* out, size_t nvec, size_t n,

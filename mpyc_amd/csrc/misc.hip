@@ -541,25 +541,99 @@ struct Gf8SboxLayerArgs {
     const uint8_t* tables;  // device: Gf8Tables (log / antilog), then Gf8ByteTables of np_from_bits, then of the affine fold
     uint32_t lam[7];        // Lagrange coefficients at 0 of the senders 1..2t+1
     uint32_t mu[4];         // ... of the opening parties 1..t+1
+    int burst;              // A/B switch (FFGPU_SBL_BURST=1): ChaCha20 blocks as bursts instead of interleaved
 };
 enum { SBL_TABLE_BYTES = 1536 + 2304 + 2304 };
 
-template <int M, int T>
-__global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nwords) {
+// The keystream of the layer, two ways (same words in the same order: block b of word i has counter i * NBLK + b):
+//   DR == 0  any round count: a block is computed when the previous one is used up -- a burst of ~1000 VALU
+//            instructions between phases that wait on LDS look-ups;
+//   DR  > 0  DR double rounds, known at compile time (10 = ChaCha20): block b + 1 advances by DR / 2 quarter rounds for
+//            every word taken from block b, i.e. its arithmetic sits BETWEEN the table look-ups of the gates that
+//            consume block b and fills their latency.  At 10^6 bytes every SIMD holds four waves that all start
+//            together: without this they run their ChaCha bursts and their look-up phases in step (43 us against
+//            24 us per 10^6 bytes in a long run, profiles/r04_sbox_layer.md).
+template <int DR>
+struct SblKeystream {
+    uint32_t ks[16];        // block being consumed
+    uint32_t x[16];         // DR > 0: the next block, in progress
+    int kpos, kblk, qpos;
+    uint64_t base;
+    const RngKey* rk;
+
+    __device__ __forceinline__ void start_block(uint64_t ctr) {
+        x[0] = 0x61707865u; x[1] = 0x3320646eu; x[2] = 0x79622d32u; x[3] = 0x6b206574u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[4 + q] = rk->key[q];
+        x[12] = (uint32_t)ctr; x[13] = (uint32_t)(ctr >> 32); x[14] = rk->nonce[0]; x[15] = rk->nonce[1];
+    }
+    __device__ __forceinline__ void finish_block(uint64_t ctr) {       // ks = x + the block's input words
+        ks[0] = x[0] + 0x61707865u; ks[1] = x[1] + 0x3320646eu; ks[2] = x[2] + 0x79622d32u; ks[3] = x[3] + 0x6b206574u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ks[4 + q] = x[4 + q] + rk->key[q];
+        ks[12] = x[12] + (uint32_t)ctr; ks[13] = x[13] + (uint32_t)(ctr >> 32);
+        ks[14] = x[14] + rk->nonce[0]; ks[15] = x[15] + rk->nonce[1];
+    }
+    __device__ __forceinline__ void quarter(int q) {                    // q = index within a double round (constant-folded)
+        switch (q & 7) {
+            case 0: { FF_QR(x[0], x[4], x[8], x[12]) } break;
+            case 1: { FF_QR(x[1], x[5], x[9], x[13]) } break;
+            case 2: { FF_QR(x[2], x[6], x[10], x[14]) } break;
+            case 3: { FF_QR(x[3], x[7], x[11], x[15]) } break;
+            case 4: { FF_QR(x[0], x[5], x[10], x[15]) } break;
+            case 5: { FF_QR(x[1], x[6], x[11], x[12]) } break;
+            case 6: { FF_QR(x[2], x[7], x[8], x[13]) } break;
+            default: { FF_QR(x[3], x[4], x[9], x[14]) } break;
+        }
+    }
+    __device__ __forceinline__ void begin(const RngKey* key, uint64_t first_ctr) {
+        rk = key;
+        base = first_ctr;
+        kblk = 0;
+        if (DR == 0) {
+            kpos = 16;
+        } else {
+            start_block(base);
+#pragma unroll
+            for (int q = 0; q < 8 * DR; ++q) quarter(q);
+            finish_block(base);
+            start_block(base + 1);
+            kpos = 0;
+            qpos = 0;
+        }
+    }
+    __device__ __forceinline__ uint32_t next_word() {
+        if (DR == 0) {
+            if (kpos == 16) {
+                const uint64_t ctr = base + (uint64_t)kblk;
+                chacha_block(rk->key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk->nonce[0], rk->nonce[1], (int)rk->rounds, ks);
+                ++kblk;
+                kpos = 0;
+            }
+            return ks[kpos++];
+        }
+        if (kpos == 16) {                      // block kblk used up: kblk + 1 has had 16 x DR / 2 = 8 DR quarter rounds
+            ++kblk;
+            finish_block(base + (uint64_t)kblk);
+            start_block(base + (uint64_t)kblk + 1);
+            kpos = 0;
+            qpos = 0;
+        }
+        const uint32_t w = ks[kpos++];
+#pragma unroll
+        for (int q = 0; q < DR / 2; ++q) quarter(qpos++);
+        return w;
+    }
+};
+
+// one SWAR word (four secure bytes; `valid` < 4 of them in the last word of a ragged row) through the whole layer
+template <int M, int T, int DR>
+__device__ __forceinline__ void sbl_word(const GF2P8& f, const Gf8SboxLayerArgs& a, const RngArgs& ra, const uint16_t* lg,
+                                         const uint8_t* ex, const uint8_t* tbits, const uint8_t* tfold, size_t i, int valid) {
     constexpr int K = 2 * T + 1;
     constexpr int NWORDS_RNG = 11 * K * T;                    // keystream words per thread
     constexpr int NBLK = (NWORDS_RNG + 15) / 16;
-    __shared__ uint32_t lds32[SBL_TABLE_BYTES / 4];
-    for (int i = threadIdx.x; i < SBL_TABLE_BYTES / 4; i += BLOCK) lds32[i] = reinterpret_cast<const uint32_t*>(a.tables)[i];
-    __syncthreads();
-    const uint16_t* lg = reinterpret_cast<const uint16_t*>(lds32);
-    const uint8_t* ex = reinterpret_cast<const uint8_t*>(lds32) + 512;
-    const uint8_t* tbits = reinterpret_cast<const uint8_t*>(lds32) + 1536;
-    const uint8_t* tfold = tbits + 2304;
-    rng_load_state(ra);
-    const int rounds = (int)ra.rk.rounds;
-    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    static_assert(DR % 2 == 0, "DR / 2 quarter rounds per keystream word");
     // constant product lam * w (lam wave-uniform): Horner over the bits of lam, scalar branches
     auto cmul = [&](uint32_t lam, uint32_t w) -> uint32_t {
         GF2P8::acc acc;
@@ -576,9 +650,9 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
         }
         return acc;
     };
-    for (size_t i = gid; i < nwords; i += gsz) {
-        uint32_t d[M], c[M], e[M];
-        uint4 rb[M][2];
+    uint32_t d[M], c[M], e[M];
+    uint4 rb[M][2];
+    if (valid == 4) {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             d[j] = reinterpret_cast<const uint32_t*>(a.x + (size_t)j * a.xs)[i];
@@ -586,84 +660,122 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
             rb[j][0] = ldg<true>(rv + 2 * i);
             rb[j][1] = ldg<true>(rv + 2 * i + 1);
         }
-        uint32_t ks[16];
-        int kpos = 16, kblk = 0;
-        auto next_word = [&]() -> uint32_t {
-            if (kpos == 16) {
-                const uint64_t ctr = (uint64_t)i * NBLK + (uint64_t)kblk;
-                chacha_block(ra.rk.key, (uint32_t)ctr, (uint32_t)(ctr >> 32), ra.rk.nonce[0], ra.rk.nonce[1], rounds, ks);
-                ++kblk;
-                kpos = 0;
-            }
-            return ks[kpos++];
-        };
-        // one secure multiplication for all parties: o <- shares of u * v
-        auto gate = [&](const uint32_t (&u)[M], const uint32_t (&v)[M], uint32_t (&o)[M]) {
-            uint32_t P = 0, C[T];
-#pragma unroll
-            for (int q = 0; q < T; ++q) C[q] = 0;
-#pragma unroll
-            for (int s_ = 0; s_ < K; ++s_) {
-                P ^= cmul(a.lam[s_], tabmul(u[s_], v[s_]));
-#pragma unroll
-                for (int q = 0; q < T; ++q) C[q] ^= cmul(a.lam[s_], next_word() & f.emask);
-            }
-            uint32_t res[M];
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                uint32_t h = C[T - 1];
-#pragma unroll
-                for (int q = T - 2; q >= 0; --q) h = f.muladd_small(h, (uint32_t)(j + 1), C[q]);
-                res[j] = f.muladd_small(h, (uint32_t)(j + 1), P);
-            }
-#pragma unroll
-            for (int j = 0; j < M; ++j) o[j] = res[j];
-        };
-        gate(d, d, c);          // x^2
-        gate(c, c, c);          // x^4
-        gate(c, c, c);          // x^8
-        gate(c, d, c);          // x^9
-        gate(c, c, c);          // x^18
-        gate(c, d, e);          // x^19   (c, d = c*c, c*d: both from the old c)
-        gate(c, c, c);          // x^36
-#pragma unroll
-        for (int j = 0; j < M; ++j) d[j] = e[j];
-        gate(c, d, e);          // x^55
-        gate(c, c, c);          // x^72
-#pragma unroll
-        for (int j = 0; j < M; ++j) d[j] = e[j];
-        gate(c, d, c);          // x^127
-        gate(c, c, c);          // x^254
-        // np_to_bits: open c + r_modl from the first t+1 parties
-        uint32_t opened = 0;
-#pragma unroll
-        for (int p_ = 0; p_ <= T; ++p_) {
-            const uint32_t rmod = gf8_tab_group(tbits, rb[p_][0].x, rb[p_][0].y) | (gf8_tab_group(tbits, rb[p_][0].z, rb[p_][0].w) << 8) |
-                                  (gf8_tab_group(tbits, rb[p_][1].x, rb[p_][1].y) << 16) |
-                                  (gf8_tab_group(tbits, rb[p_][1].z, rb[p_][1].w) << 24);
-            opened ^= cmul(a.mu[p_], c[p_] ^ rmod);
-        }
-        // bits(opened) + r_bits -> affine map -> np_from_bits, per party
+    } else {
+        // the last, partial word of rows whose length is not a multiple of 4: byte loads, nothing past the row's end
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            const uint32_t b0 = tfold[2048 + (opened & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].x, rb[j][0].y);
-            const uint32_t b1 = tfold[2048 + ((opened >> 8) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].z, rb[j][0].w);
-            const uint32_t b2 = tfold[2048 + ((opened >> 16) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][1].x, rb[j][1].y);
-            const uint32_t b3 = tfold[2048 + (opened >> 24)] ^ gf8_tab_group(tfold, rb[j][1].z, rb[j][1].w);
-            reinterpret_cast<uint32_t*>(a.out + (size_t)j * a.os)[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            const uint8_t* xr = a.x + (size_t)j * a.xs + 4 * i;
+            const uint8_t* rr = a.r + (size_t)j * a.rs + 32 * i;
+            uint32_t w = 0, rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {                      // (fully unrolled: rw[] stays in registers)
+                if (b < valid) {
+                    w |= (uint32_t)xr[b] << (8 * b);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rw[2 * b + (q >> 2)] |= (uint32_t)rr[8 * b + q] << (8 * (q & 3));
+                }
+            }
+            d[j] = w;
+            rb[j][0] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+            rb[j][1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
         }
     }
+    SblKeystream<DR> stream;
+    stream.begin(&ra.rk, (uint64_t)i * NBLK);
+    // one secure multiplication for all parties: o <- shares of u * v
+    auto gate = [&](const uint32_t (&u)[M], const uint32_t (&v)[M], uint32_t (&o)[M]) {
+        uint32_t P = 0, C[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) C[q] = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+            P ^= cmul(a.lam[s_], tabmul(u[s_], v[s_]));
+#pragma unroll
+            for (int q = 0; q < T; ++q) C[q] ^= cmul(a.lam[s_], stream.next_word() & f.emask);
+        }
+        uint32_t res[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            uint32_t h = C[T - 1];
+#pragma unroll
+            for (int q = T - 2; q >= 0; --q) h = f.muladd_small(h, (uint32_t)(j + 1), C[q]);
+            res[j] = f.muladd_small(h, (uint32_t)(j + 1), P);
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) o[j] = res[j];
+    };
+    gate(d, d, c);          // x^2
+    gate(c, c, c);          // x^4
+    gate(c, c, c);          // x^8
+    gate(c, d, c);          // x^9
+    gate(c, c, c);          // x^18
+    gate(c, d, e);          // x^19   (c, d = c*c, c*d: both from the old c)
+    gate(c, c, c);          // x^36
+#pragma unroll
+    for (int j = 0; j < M; ++j) d[j] = e[j];
+    gate(c, d, e);          // x^55
+    gate(c, c, c);          // x^72
+#pragma unroll
+    for (int j = 0; j < M; ++j) d[j] = e[j];
+    gate(c, d, c);          // x^127
+    gate(c, c, c);          // x^254
+    // np_to_bits: open c + r_modl from the first t+1 parties
+    uint32_t opened = 0;
+#pragma unroll
+    for (int p_ = 0; p_ <= T; ++p_) {
+        const uint32_t rmod = gf8_tab_group(tbits, rb[p_][0].x, rb[p_][0].y) | (gf8_tab_group(tbits, rb[p_][0].z, rb[p_][0].w) << 8) |
+                              (gf8_tab_group(tbits, rb[p_][1].x, rb[p_][1].y) << 16) |
+                              (gf8_tab_group(tbits, rb[p_][1].z, rb[p_][1].w) << 24);
+        opened ^= cmul(a.mu[p_], c[p_] ^ rmod);
+    }
+    // bits(opened) + r_bits -> affine map -> np_from_bits, per party
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const uint32_t b0 = tfold[2048 + (opened & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].x, rb[j][0].y);
+        const uint32_t b1 = tfold[2048 + ((opened >> 8) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].z, rb[j][0].w);
+        const uint32_t b2 = tfold[2048 + ((opened >> 16) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][1].x, rb[j][1].y);
+        const uint32_t b3 = tfold[2048 + (opened >> 24)] ^ gf8_tab_group(tfold, rb[j][1].z, rb[j][1].w);
+        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        uint8_t* orow = a.out + (size_t)j * a.os;
+        if (valid == 4) {
+            reinterpret_cast<uint32_t*>(orow)[i] = word;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                if (b < valid) orow[4 * i + b] = (uint8_t)(word >> (8 * b));
+        }
+    }
+}
+
+template <int M, int T>
+__global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nwords, int tail) {
+    __shared__ uint32_t lds32[SBL_TABLE_BYTES / 4];
+    for (int i = threadIdx.x; i < SBL_TABLE_BYTES / 4; i += BLOCK) lds32[i] = reinterpret_cast<const uint32_t*>(a.tables)[i];
+    __syncthreads();
+    const uint16_t* lg = reinterpret_cast<const uint16_t*>(lds32);
+    const uint8_t* ex = reinterpret_cast<const uint8_t*>(lds32) + 512;
+    const uint8_t* tbits = reinterpret_cast<const uint8_t*>(lds32) + 1536;
+    const uint8_t* tfold = tbits + 2304;
+    rng_load_state(ra);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    if (ra.rk.rounds == 20 && !a.burst) {
+        for (size_t i = gid; i < nwords; i += gsz) sbl_word<M, T, 10>(f, a, ra, lg, ex, tbits, tfold, i, 4);
+    } else {
+        for (size_t i = gid; i < nwords; i += gsz) sbl_word<M, T, 0>(f, a, ra, lg, ex, tbits, tfold, i, 4);
+    }
+    if (tail && gid == 0) sbl_word<M, T, 0>(f, a, ra, lg, ex, tbits, tfold, nwords, tail);      // n % 4 bytes of every row
     rng_state_release(ra);
 }
 
 // tables_dev: SBL_TABLE_BYTES of device memory (the caller caches it per matrix); returns 2 when the shape is not
-// covered (m, t combination, n not a multiple of 4, rows not 4- / 16-byte aligned): the caller composes the layer
-// from the per-step kernels then.
+// covered (rows not 4- / 16-byte aligned, m > 7 or t > 3): the caller composes the layer from the per-step kernels
+// then.  Any n: the n % 4 bytes after the last whole word of each row are handled by one thread with byte accesses.
 int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, size_t xs, const void* r, size_t rs, void* out,
                                 size_t os, const void* tables_dev, const uint64_t* lam2, const uint64_t* mu2, int t, int m,
                                 size_t n, hipStream_t st, const RngArgs* rng) {
     const GF2P8& f = *reinterpret_cast<const GF2P8*>(policy);
-    if (f.n != 8 || (n & 3) || (((uintptr_t)x | (uintptr_t)out | xs | os) & 3) || (((uintptr_t)r | rs) & 15)) return 2;
+    if (f.n != 8 || (((uintptr_t)x | (uintptr_t)out | xs | os) & 3) || (((uintptr_t)r | rs) & 15)) return 2;
     Gf8SboxLayerArgs a;
     memset(&a, 0, sizeof(a));
     a.x = (const uint8_t*)x; a.r = (const uint8_t*)r; a.out = (uint8_t*)out;
@@ -673,6 +785,13 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     for (int i = 0; i <= t; ++i) a.mu[i] = (uint32_t)(mu2[2 * i] & 0xffu);
     RngArgs ra = *rng;
     const size_t nwords = n / 4;
+    const int tail = (int)(n & 3);
+    static int burst = -1;
+    if (burst < 0) {
+        const char* e = getenv("FFGPU_SBL_BURST");
+        burst = e ? atoi(e) : 0;
+    }
+    a.burst = burst;
     size_t want = (nwords + BLOCK - 1) / BLOCK;
     if (want < 1) want = 1;
     if (want > 0x7fffffff) want = 0x7fffffff;
@@ -680,13 +799,14 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     ra.release = (ra.dev_key && !ra.no_advance && grid <= (unsigned)RNG_RELEASE_MAX_GRID) ? 1 : 0;
 #define SBL_CASE(MM, TT)                                                                                      \
     if (m == MM && t == TT) {                                                                                 \
-        hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nwords);     \
+        hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nwords, tail); \
         FFGPU_CHECK_LAUNCH();                                                                                 \
         if (ra.dev_key && !ra.release && !ra.no_advance)                                                      \
             hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u); \
         return 0;                                                                                             \
     }
-    SBL_CASE(3, 1) SBL_CASE(4, 1) SBL_CASE(5, 1) SBL_CASE(5, 2) SBL_CASE(7, 2) SBL_CASE(7, 3)
+    SBL_CASE(3, 1) SBL_CASE(4, 1) SBL_CASE(5, 1) SBL_CASE(5, 2) SBL_CASE(6, 1) SBL_CASE(6, 2) SBL_CASE(7, 1) SBL_CASE(7, 2)
+    SBL_CASE(7, 3)
 #undef SBL_CASE
     (void)device;
     return 2;
@@ -702,6 +822,155 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
     memcpy(out + 1536, &tb, 2304);
     gf8_byte_tables(f, m2, bias2, tb);
     memcpy(out + 1536 + 2304, &tb, 2304);
+}
+
+// ---- GF(2^64), x^64 + x^4 + x^3 + x + 1: element-wise product, BIT-SLICED ------------------------------------------
+// (gfpx.py:988-1045 + finfields.py:537-541.)  The multiplier route (ff_clmul64: 48 v_mad_u64_u32 + masks, 280 VALU
+// instructions per element, profiles/r04_valu.md) is issue-bound at 0.36 of the HBM rate.  Here a lane holds 32 elements
+// as 64 bit-planes of uint32 (two 32 x 32 bit transposes per operand: v_perm_b32 for the 16- and 8-bit stages, shift +
+// v_bitop3 select for the rest), a partial-product MAC of all 32 elements is ONE v_bitop3_b32 (acc ^ (a & b)), Karatsuba
+// runs down to 8 x 8 leaves (27 x 64 MACs), the fold is four XORs per high plane, and two transposes return the packed
+// result: 153 instructions per element including the register traffic below.  The price is the register file: 64 + 64
+// operand planes, 127 product planes and the Karatsuba temporaries need ~320 registers, so a wave takes a SIMD for itself
+// (256 VGPRs + AGPRs) -- the kernel is PERSISTENT, one wave per SIMD, and the next slab's 32 loads are in flight while
+// the current slab is multiplied (455 registers in all).  64 us against 83 us at n = 10^7 (0.47 against 0.36 of the HBM
+// peak; tools/bitslice_probe.hip is the stand-alone probe with the variants that were measured, profiles/r04_gf2w.md).
+// The same layout for GF(2^128) needs 256 + 255 planes per lane: it does not fit any register budget (ibid.).
+namespace bs64 {
+__device__ __forceinline__ uint32_t mac(uint32_t acc, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(acc, a, b, 0x78); }
+template <int S>
+__device__ __forceinline__ void tr_stage(uint32_t (&A)[32]) {
+    constexpr uint32_t M = S == 4 ? 0x0f0f0f0fu : S == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k & S) continue;
+        const uint32_t x = A[k], y = A[k + S];
+        if constexpr (S == 16) {
+            A[k] = __builtin_amdgcn_perm(y, x, 0x05040100u);          // lo16(x) | lo16(y) << 16
+            A[k + S] = __builtin_amdgcn_perm(y, x, 0x07060302u);      // hi16(x) | hi16(y) << 16
+        } else if constexpr (S == 8) {
+            A[k] = __builtin_amdgcn_perm(y, x, 0x06020400u);          // bytes x0, y0, x2, y2
+            A[k + S] = __builtin_amdgcn_perm(y, x, 0x07030501u);      // bytes x1, y1, x3, y3
+        } else {
+            A[k] = ff_bsel(M, x, y << S);
+            A[k + S] = ff_bsel(M, x >> S, y);
+        }
+    }
+}
+// 32 x 32 bit-matrix transpose in registers: out word i, bit e = in word e, bit i
+__device__ __forceinline__ void transpose32(uint32_t (&A)[32]) {
+    tr_stage<16>(A); tr_stage<8>(A); tr_stage<4>(A); tr_stage<2>(A); tr_stage<1>(A);
+}
+// c (2N - 1 planes) = a (N planes) x b (N planes) over GF(2)[x]
+template <int N>
+struct Mul {
+    static __device__ __forceinline__ void run(const uint32_t* a, const uint32_t* b, uint32_t* c) {
+        constexpr int H = N / 2;
+        uint32_t z0[N - 1], z2[N - 1], zm[N - 1], am[H], bm[H];
+        Mul<H>::run(a, b, z0);
+        Mul<H>::run(a + H, b + H, z2);
+#pragma unroll
+        for (int i = 0; i < H; ++i) { am[i] = a[i] ^ a[i + H]; bm[i] = b[i] ^ b[i + H]; }
+        Mul<H>::run(am, bm, zm);
+#pragma unroll
+        for (int k = 0; k < 2 * N - 1; ++k) {
+            uint32_t v = k < N - 1 ? z0[k] : (k >= N ? z2[k - N] : 0u);
+            const int q = k - H;
+            if (q >= 0 && q < N - 1) {
+                const uint32_t mid = ff_xor3(zm[q], z0[q], z2[q]);
+                v = (k == N - 1) ? mid : (v ^ mid);
+            }
+            c[k] = v;
+        }
+    }
+};
+template <>
+struct Mul<8> {
+    static __device__ __forceinline__ void run(const uint32_t* a, const uint32_t* b, uint32_t* c) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            uint32_t acc = 0;
+            bool first = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = k - i;
+                if (j < 0 || j > 7) continue;
+                acc = first ? (a[i] & b[j]) : mac(acc, a[i], b[j]);
+                first = false;
+            }
+            c[k] = acc;
+        }
+    }
+};
+}  // namespace bs64
+
+// a slab = 2048 consecutive elements = 1024 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
+// (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..15
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ o, size_t nslab) {
+    const size_t wave0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * BLOCK) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave0 >= nslab) return;
+    uint4 na[16], nb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        na[r] = ldg<true>(a + wave0 * 1024 + lane + (size_t)r * 64);
+        nb[r] = ldg<true>(b + wave0 * 1024 + lane + (size_t)r * 64);
+    }
+    for (size_t wave = wave0; wave < nslab; wave += nwaves) {
+        const size_t base = wave * 1024 + lane;
+        uint32_t pa[64], pb[64];
+        {
+            uint32_t lo[32], hi[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { lo[2 * r] = na[r].x; hi[2 * r] = na[r].y; lo[2 * r + 1] = na[r].z; hi[2 * r + 1] = na[r].w; }
+            bs64::transpose32(lo); bs64::transpose32(hi);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { pa[i] = lo[i]; pa[32 + i] = hi[i]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { lo[2 * r] = nb[r].x; hi[2 * r] = nb[r].y; lo[2 * r + 1] = nb[r].z; hi[2 * r + 1] = nb[r].w; }
+            bs64::transpose32(lo); bs64::transpose32(hi);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { pb[i] = lo[i]; pb[32 + i] = hi[i]; }
+        }
+        const size_t nxt = wave + nwaves;
+        if (nxt < nslab) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                na[r] = ldg<true>(a + nxt * 1024 + lane + (size_t)r * 64);
+                nb[r] = ldg<true>(b + nxt * 1024 + lane + (size_t)r * 64);
+            }
+        }
+        uint32_t c[127];
+        bs64::Mul<64>::run(pa, pb, c);
+#pragma unroll
+        for (int k = 126; k >= 64; --k) {                 // x^64 = x^4 + x^3 + x + 1
+            const uint32_t h = c[k];
+            c[k - 64] ^= h; c[k - 63] ^= h; c[k - 61] ^= h; c[k - 60] ^= h;
+        }
+        uint32_t lo[32], hi[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { lo[i] = c[i]; hi[i] = c[32 + i]; }
+        bs64::transpose32(lo); bs64::transpose32(hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
+    }
+}
+
+// returns the number of leading elements it has multiplied (a multiple of 2048; 0 = not applicable): the caller sends
+// the rest through the element-wise kernel
+size_t ffgpu_launch_gf2w64_mul_bitsliced(const void* policy, int device, const void* a, const void* b, void* out, size_t n,
+                                         hipStream_t st) {
+    const GF2W64& f = *reinterpret_cast<const GF2W64*>(policy);
+    const char* e = getenv("FFGPU_GF2W_BITSLICED");             // =0: the multiplier kernel (A/B measurements, tests)
+    const bool off = e && atoi(e) == 0;
+    if (off || f.n != 64 || f.red != 0x1bull || n < ((size_t)1 << 21) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return 0;
+    const size_t nslab = n / 2048;
+    LaunchCfg lc = launch_cfg(device);
+    const unsigned grid = (unsigned)(lc.num_cu > 0 ? lc.num_cu : 256);       // one workgroup of four waves per CU: a wave per SIMD
+    hipLaunchKernelGGL(k_gf2w64_mul_bitsliced, dim3(grid), dim3(BLOCK), 0, st, (const uint4*)a, (const uint4*)b, (uint4*)out, nslab);
+    return nslab * 2048;
 }
 
 // ---- GF(2^n), n <= 8: multiplication through log / antilog tables in LDS ---------------------

@@ -282,6 +282,43 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
         assert unpack(ctx.mul(ctx.inv(va), va).to_numpy(), eb) == [1] * (n - 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('modulus', [P61, P64, 2**40 - 87, 2**63 - 25, 8123557937065977257, 2**33 - 9])
+def test_batched_inverse_full_batch_kernel(eng, modulus, monkeypatch):
+    """k_inv_fast (kernels.hpp; one-word fields, n >= 32768): full blocks without bounds checks + the extra blocks for
+    the leftover packs and the odd last element; the lean exponentiation (run of ones + short tail: every 2^k - c prime)
+    and the window-table one (8123557937065977257: a prime whose q - 2 has 38 set bits); zeros anywhere give zero and
+    raise; against Python's pow on a sample and a * a^-1 == 1 on every element.  FFGPU_INV_VARIANT=0 (the round-3 kernel,
+    read per call) must give the same array."""
+    import torch
+    ctx = ctx_for(eng, modulus, False)
+    if ctx.elem_bytes != 8:
+        pytest.skip('one-word fields only')
+    r = random.Random(modulus % 1009)
+    for n in (32768 * 2, 200_003, 1_000_000, 8192 * 32 + 5119 * 2 + 1):
+        vals = [r.randrange(modulus) for _ in range(n)]
+        for i in (0, 1, 2, 777, n // 2, n - 2, n - 1):
+            vals[i] = 0
+        vals[3], vals[4] = 1, modulus - 1
+        dA = ctx.from_numpy(pack(vals, 8))
+        with pytest.raises(ZeroDivisionError):
+            ctx.inv(dA)
+        inv = ctx.inv(dA, check_zero=False)
+        got = inv.to_numpy().view(np.uint64)
+        for i in list(range(0, 64)) + list(range(n - 64, n)) + [r.randrange(n) for _ in range(300)]:
+            assert int(got[i]) == (pow(vals[i], modulus - 2, modulus) if vals[i] else 0), (hex(modulus), n, i)
+        nz = dA.t != 0
+        one = ctx.mul(dA, inv).t
+        assert bool((one[nz] == 1).all()) and bool((inv.t[~nz] == 0).all())
+        monkeypatch.setenv('FFGPU_INV_VARIANT', '0')
+        old = ctx.inv(dA, check_zero=False)
+        monkeypatch.delenv('FFGPU_INV_VARIANT')
+        assert torch.equal(old.t, inv.t), (hex(modulus), n)
+        vals2 = [v or 1 for v in vals]
+        dN = ctx.from_numpy(pack(vals2, 8))
+        ctx.inv(dN)                                      # no zeros: no exception
+
+
 def test_binary_fields_dense_and_small(eng, coracle):
     """GF(2^n) multiplication paths: in-register carry-less product + fold (sparse moduli), 4-bit
     window LDS kernel (dense moduli), long division (n <= 32) -- all against the oracle; plus the
@@ -332,6 +369,33 @@ def test_wide_binary_products_all_degrees(eng, coracle):
         assert (ctx.mul(dA, dB).to_numpy() == want).all(), (deg, hex(mod))
         ctx.mul(dA, dB, out=dA)                                    # in place
         assert (dA.to_numpy() == want).all(), deg
+
+
+def test_gf2_64_bitsliced_product(eng, coracle, monkeypatch):
+    """GF(2^64) with the default modulus x^64 + x^4 + x^3 + x + 1, n >= 2^21: the bit-sliced kernel
+    (k_gf2w64_mul_bitsliced, misc.hip) multiplies the whole 2048-element slabs, the element-wise kernel the rest.
+    Every element against the C oracle (gfpx.py:988-1045 restated), extreme operands in the first and the last slab and
+    across the seam, in place, and equal to the multiplier kernel (FFGPU_GF2W_BITSLICED=0)."""
+    mod = (1 << 64) | 0x1b
+    F = po.Field(mod, True)
+    ctx = ctx_for(eng, mod, True)
+    cf = coracle.CField(mod, True)
+    for n in ((1 << 21), (1 << 21) + 2048 * 3 + 5, 5_000_011):
+        A, B = rand_np(F, 8, n, 41 + n % 7), rand_np(F, 8, n, 43 + n % 7)
+        top = pack([F.order - 1, F.order >> 1, (F.order >> 1) | 1, 7 << 61, 5 << 61, 1 << 63, 0, 1, 2, 0x1b], 8)
+        seam = n // 2048 * 2048
+        for at in (0, 2048 * 7 + 100, seam - len(top) - 3, max(0, min(seam - 2, n - len(top))), n - len(top)):
+            A[at:at + len(top)] = top
+            B[at:at + len(top)] = top[::-1] if at % 2 else top
+        dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+        want = cf.ew(coracle.MUL, A, B)
+        got = ctx.mul(dA, dB)
+        assert (got.to_numpy() == want).all(), n
+        monkeypatch.setenv('FFGPU_GF2W_BITSLICED', '0')
+        assert torch.equal(ctx.mul(dA, dB).t, got.t)
+        monkeypatch.delenv('FFGPU_GF2W_BITSLICED')
+        ctx.mul(dA, dB, out=dA)                                    # in place
+        assert (dA.to_numpy() == want).all(), n
 
 
 def test_wide_binary_recombination_tables(eng, coracle):

@@ -408,12 +408,12 @@ def test_gf256_mask_open_and_bits_affine_fold_match_the_step_by_step_kernels(mod
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('fused', [True, False])
-@pytest.mark.parametrize('t,m', [(1, 3), (2, 5), (1, 4), (3, 7), (1, 5), (2, 7), (2, 6)])
+@pytest.mark.parametrize('t,m', [(1, 3), (2, 5), (1, 4), (3, 7), (1, 5), (2, 7), (2, 6), (1, 6), (1, 7)])
 def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
-    """protocols.sbox_layer_all -- fused: the whole layer as ONE kernel (ffgpu_gf256_sbox_layer; shapes it does not
-    cover, here n not a multiple of 4 and (m, t) = (6, 2), fall back); not fused: 13 launches (11 batched chain gates +
-    2 bit-decomposition kernels) -- opens to the FIPS-197 S-box of every byte value, like the per-party layer, from
-    any t+1 parties."""
+    """protocols.sbox_layer_all -- fused: the whole layer as ONE kernel (ffgpu_gf256_sbox_layer; any length -- the
+    n % 4 bytes after the last whole word of each row are one thread's byte accesses -- and every (m, t) with
+    m <= 7, t <= 3); not fused: 13 launches (11 batched chain gates + 2 bit-decomposition kernels) -- opens to the
+    FIPS-197 S-box of every byte value, like the per-party layer, from any t+1 parties."""
     engine, finfields, gfpx, protocols = mods
     g = json.load(open(os.path.join(GOLDEN, 'sbox.json')))
     F = finfields.GF(gfpx.GFpX(2)(0x11b))
@@ -431,9 +431,10 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
         out = protocols.sbox_layer_all(ctx, F, xs, rbits, t, A, B, fused=fused)
         shares = [out.row(i) for i in range(m)]
         want = [g['table'][v] for v in x]
-        if fused and n % 4 == 0 and (m, t) != (6, 2):
-            # the one-kernel path really ran: a second call re-shares with fresh randomness inside the chain, but the
-            # OUTPUT shares depend only on the opened masked value and the bit shares -> identical; and the direct call works
+        if fused:
+            # the one-kernel path really ran (for every shape here, ragged lengths and (6, 2) included): a second call
+            # re-shares with fresh randomness inside the chain, but the OUTPUT shares depend only on the opened masked
+            # value and the bit shares -> identical; and the direct call works
             direct = ctx.gf256_sbox_layer(X, protocols.as_matrix(ctx, rbits), t, protocols._lagrange(F, range(1, 2 * t + 2)),
                                           protocols._lagrange(F, range(1, t + 2)), A, B)
             assert torch.equal(direct.t[:, :n], out.t[:, :n])
@@ -448,6 +449,42 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
     lone = [ctx.from_numpy(np.array([1, 2, 3], dtype=np.uint8)) for _ in range(m)]
     M = protocols.as_matrix(ctx, lone)
     assert M.rows == m and unpack(M.row(m - 1).to_numpy(), 1) == [1, 2, 3]
+
+
+@pytest.mark.gpu
+def test_sbox_layer_interleaved_keystream_equals_burst_keystream(tmp_path):
+    """The ChaCha20 blocks of the one-kernel layer advance between the table look-ups (SblKeystream<10>); with
+    FFGPU_SBL_BURST=1 they are computed as whole blocks when needed, as in round 3.  Same key, nonce and inputs:
+    the output shares must be identical byte for byte (same keystream words in the same order), ragged tail included."""
+    import subprocess
+    import sys
+    prog = r'''
+import sys, json, os, hashlib
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch
+from mpyc_amd import engine, finfields, gfpx, protocols
+g = json.load(open(os.path.join(os.environ["REPO"], "tests", "golden", "sbox.json")))
+F = finfields.GF(gfpx.GFpX(2)(0x11b))
+ctx = engine.FieldContext(0x11b, True, device=0)
+A = [[(g["rows8"][r] >> c) & 1 for c in range(8)] for r in range(8)]
+B = [(g["b"] >> r) & 1 for r in range(8)]
+out = []
+for (m, t, n) in ((3, 1, 100003), (7, 3, 5001), (6, 2, 4096)):
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    X = ctx.empty_matrix(m, n); X.t[:, :n].copy_(torch.randint(0, 256, (m, n), dtype=torch.uint8, device="cuda:0", generator=gen))
+    R = ctx.empty_matrix(m, 8 * n); R.t[:, :8 * n].copy_(torch.randint(0, 2, (m, 8 * n), dtype=torch.uint8, device="cuda:0", generator=gen))
+    o = ctx.gf256_sbox_layer(X, R, t, protocols._lagrange(F, range(1, 2 * t + 2)), protocols._lagrange(F, range(1, t + 2)), A, B,
+                             key=bytes(range(32)), nonce=9)
+    out.append(hashlib.sha256(o.t[:, :n].contiguous().cpu().numpy().tobytes()).hexdigest())
+print("DIGESTS", json.dumps(out))
+'''
+    res = []
+    for burst in ('0', '1'):
+        r = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FFGPU_SBL_BURST=burst, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        assert r.returncode == 0 and 'DIGESTS' in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+        res.append(r.stdout.split('DIGESTS', 1)[1].strip())
+    assert res[0] == res[1]
 
 
 @pytest.mark.gpu
