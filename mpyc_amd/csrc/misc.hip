@@ -626,12 +626,17 @@ struct SblKeystream {
     }
 };
 
-// one SWAR word (four secure bytes; `valid` < 4 of them in the last word of a ragged row) through the whole layer
-template <int M, int T, int DR>
-__device__ __forceinline__ void sbl_word(const GF2P8& f, const Gf8SboxLayerArgs& a, const RngArgs& ra, const uint16_t* lg,
-                                         const uint8_t* ex, const uint8_t* tbits, const uint8_t* tfold, size_t i, int valid) {
+// W SWAR words (four secure bytes each) of one thread through the whole layer.  The words share ONE keystream: W x 33
+// coefficient words (m = 3, t = 1) are 4.125 ChaCha blocks for W = 2 -- five blocks for eight bytes instead of six --
+// and the 2 W K table products of a gate are independent of each other (twice the look-ups in flight per wave).
+// full: every word of the thread holds four bytes of every row (aligned dword / 16-byte accesses); otherwise word w holds
+// valid[w] in 0..4 bytes (the ragged end of the rows): byte accesses, nothing past a row's end.
+template <int M, int T, int DR, int W>
+__device__ __forceinline__ void sbl_words(const GF2P8& f, const Gf8SboxLayerArgs& a, const RngArgs& ra, const uint16_t* lg,
+                                          const uint8_t* ex, const uint8_t* tbits, const uint8_t* tfold, size_t i, bool full,
+                                          const int (&valid)[W]) {
     constexpr int K = 2 * T + 1;
-    constexpr int NWORDS_RNG = 11 * K * T;                    // keystream words per thread
+    constexpr int NWORDS_RNG = 11 * K * T * W;                // keystream words per thread
     constexpr int NBLK = (NWORDS_RNG + 15) / 16;
     static_assert(DR % 2 == 0, "DR / 2 quarter rounds per keystream word");
     // constant product lam * w (lam wave-uniform): Horner over the bits of lam, scalar branches
@@ -650,59 +655,78 @@ __device__ __forceinline__ void sbl_word(const GF2P8& f, const Gf8SboxLayerArgs&
         }
         return acc;
     };
-    uint32_t d[M], c[M], e[M];
-    uint4 rb[M][2];
-    if (valid == 4) {
+    uint32_t d[W][M], c[W][M], e[W][M];
+    uint4 rb[W][M][2];
+    if (full) {
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            d[j] = reinterpret_cast<const uint32_t*>(a.x + (size_t)j * a.xs)[i];
-            const uint4* rv = reinterpret_cast<const uint4*>(a.r + (size_t)j * a.rs);
-            rb[j][0] = ldg<true>(rv + 2 * i);
-            rb[j][1] = ldg<true>(rv + 2 * i + 1);
-        }
-    } else {
-        // the last, partial word of rows whose length is not a multiple of 4: byte loads, nothing past the row's end
+        for (int w = 0; w < W; ++w)
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const uint8_t* xr = a.x + (size_t)j * a.xs + 4 * i;
-            const uint8_t* rr = a.r + (size_t)j * a.rs + 32 * i;
-            uint32_t w = 0, rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {                      // (fully unrolled: rw[] stays in registers)
-                if (b < valid) {
-                    w |= (uint32_t)xr[b] << (8 * b);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rw[2 * b + (q >> 2)] |= (uint32_t)rr[8 * b + q] << (8 * (q & 3));
-                }
+            for (int j = 0; j < M; ++j) {
+                d[w][j] = reinterpret_cast<const uint32_t*>(a.x + (size_t)j * a.xs)[i * W + w];
+                const uint4* rv = reinterpret_cast<const uint4*>(a.r + (size_t)j * a.rs);
+                rb[w][j][0] = ldg<true>(rv + 2 * (i * W + w));
+                rb[w][j][1] = ldg<true>(rv + 2 * (i * W + w) + 1);
             }
-            d[j] = w;
-            rb[j][0] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
-            rb[j][1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
-        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const uint8_t* xr = a.x + (size_t)j * a.xs + 4 * (i * W + w);
+                const uint8_t* rr = a.r + (size_t)j * a.rs + 32 * (i * W + w);
+                uint32_t xw = 0, rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {                  // (fully unrolled: rw[] stays in registers)
+                    if (b < valid[w]) {
+                        xw |= (uint32_t)xr[b] << (8 * b);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rw[2 * b + (q >> 2)] |= (uint32_t)rr[8 * b + q] << (8 * (q & 3));
+                    }
+                }
+                d[w][j] = xw;
+                rb[w][j][0] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+                rb[w][j][1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+            }
     }
     SblKeystream<DR> stream;
     stream.begin(&ra.rk, (uint64_t)i * NBLK);
-    // one secure multiplication for all parties: o <- shares of u * v
-    auto gate = [&](const uint32_t (&u)[M], const uint32_t (&v)[M], uint32_t (&o)[M]) {
-        uint32_t P = 0, C[T];
+    // one secure multiplication for all parties and all W words: o <- shares of u * v
+    auto gate = [&](const uint32_t (&u)[W][M], const uint32_t (&v)[W][M], uint32_t (&o)[W][M]) {
+        uint32_t P[W], C[W][T];
 #pragma unroll
-        for (int q = 0; q < T; ++q) C[q] = 0;
+        for (int w = 0; w < W; ++w) {
+            P[w] = 0;
 #pragma unroll
-        for (int s_ = 0; s_ < K; ++s_) {
-            P ^= cmul(a.lam[s_], tabmul(u[s_], v[s_]));
-#pragma unroll
-            for (int q = 0; q < T; ++q) C[q] ^= cmul(a.lam[s_], stream.next_word() & f.emask);
-        }
-        uint32_t res[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            uint32_t h = C[T - 1];
-#pragma unroll
-            for (int q = T - 2; q >= 0; --q) h = f.muladd_small(h, (uint32_t)(j + 1), C[q]);
-            res[j] = f.muladd_small(h, (uint32_t)(j + 1), P);
+            for (int q = 0; q < T; ++q) C[w][q] = 0;
         }
 #pragma unroll
-        for (int j = 0; j < M; ++j) o[j] = res[j];
+        for (int s_ = 0; s_ < K; ++s_)
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                P[w] ^= cmul(a.lam[s_], tabmul(u[w][s_], v[w][s_]));
+#pragma unroll
+                for (int q = 0; q < T; ++q) C[w][q] ^= cmul(a.lam[s_], stream.next_word() & f.emask);
+            }
+        uint32_t res[W][M];
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                uint32_t h = C[w][T - 1];
+#pragma unroll
+                for (int q = T - 2; q >= 0; --q) h = f.muladd_small(h, (uint32_t)(j + 1), C[w][q]);
+                res[w][j] = f.muladd_small(h, (uint32_t)(j + 1), P[w]);
+            }
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int j = 0; j < M; ++j) o[w][j] = res[w][j];
+    };
+    auto copy = [&](uint32_t (&dst)[W][M], const uint32_t (&src)[W][M]) {
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int j = 0; j < M; ++j) dst[w][j] = src[w][j];
     };
     gate(d, d, c);          // x^2
     gate(c, c, c);          // x^4
@@ -711,44 +735,48 @@ __device__ __forceinline__ void sbl_word(const GF2P8& f, const Gf8SboxLayerArgs&
     gate(c, c, c);          // x^18
     gate(c, d, e);          // x^19   (c, d = c*c, c*d: both from the old c)
     gate(c, c, c);          // x^36
-#pragma unroll
-    for (int j = 0; j < M; ++j) d[j] = e[j];
+    copy(d, e);
     gate(c, d, e);          // x^55
     gate(c, c, c);          // x^72
-#pragma unroll
-    for (int j = 0; j < M; ++j) d[j] = e[j];
+    copy(d, e);
     gate(c, d, c);          // x^127
     gate(c, c, c);          // x^254
-    // np_to_bits: open c + r_modl from the first t+1 parties
-    uint32_t opened = 0;
 #pragma unroll
-    for (int p_ = 0; p_ <= T; ++p_) {
-        const uint32_t rmod = gf8_tab_group(tbits, rb[p_][0].x, rb[p_][0].y) | (gf8_tab_group(tbits, rb[p_][0].z, rb[p_][0].w) << 8) |
-                              (gf8_tab_group(tbits, rb[p_][1].x, rb[p_][1].y) << 16) |
-                              (gf8_tab_group(tbits, rb[p_][1].z, rb[p_][1].w) << 24);
-        opened ^= cmul(a.mu[p_], c[p_] ^ rmod);
-    }
-    // bits(opened) + r_bits -> affine map -> np_from_bits, per party
+    for (int w = 0; w < W; ++w) {
+        // np_to_bits: open c + r_modl from the first t+1 parties
+        uint32_t opened = 0;
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const uint32_t b0 = tfold[2048 + (opened & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].x, rb[j][0].y);
-        const uint32_t b1 = tfold[2048 + ((opened >> 8) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][0].z, rb[j][0].w);
-        const uint32_t b2 = tfold[2048 + ((opened >> 16) & 0xffu)] ^ gf8_tab_group(tfold, rb[j][1].x, rb[j][1].y);
-        const uint32_t b3 = tfold[2048 + (opened >> 24)] ^ gf8_tab_group(tfold, rb[j][1].z, rb[j][1].w);
-        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        uint8_t* orow = a.out + (size_t)j * a.os;
-        if (valid == 4) {
-            reinterpret_cast<uint32_t*>(orow)[i] = word;
-        } else {
+        for (int p_ = 0; p_ <= T; ++p_) {
+            const uint32_t rmod = gf8_tab_group(tbits, rb[w][p_][0].x, rb[w][p_][0].y) | (gf8_tab_group(tbits, rb[w][p_][0].z, rb[w][p_][0].w) << 8) |
+                                  (gf8_tab_group(tbits, rb[w][p_][1].x, rb[w][p_][1].y) << 16) |
+                                  (gf8_tab_group(tbits, rb[w][p_][1].z, rb[w][p_][1].w) << 24);
+            opened ^= cmul(a.mu[p_], c[w][p_] ^ rmod);
+        }
+        // bits(opened) + r_bits -> affine map -> np_from_bits, per party
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-                if (b < valid) orow[4 * i + b] = (uint8_t)(word >> (8 * b));
+        for (int j = 0; j < M; ++j) {
+            const uint32_t b0 = tfold[2048 + (opened & 0xffu)] ^ gf8_tab_group(tfold, rb[w][j][0].x, rb[w][j][0].y);
+            const uint32_t b1 = tfold[2048 + ((opened >> 8) & 0xffu)] ^ gf8_tab_group(tfold, rb[w][j][0].z, rb[w][j][0].w);
+            const uint32_t b2 = tfold[2048 + ((opened >> 16) & 0xffu)] ^ gf8_tab_group(tfold, rb[w][j][1].x, rb[w][j][1].y);
+            const uint32_t b3 = tfold[2048 + (opened >> 24)] ^ gf8_tab_group(tfold, rb[w][j][1].z, rb[w][j][1].w);
+            const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            uint8_t* orow = a.out + (size_t)j * a.os;
+            if (full) {
+                reinterpret_cast<uint32_t*>(orow)[i * W + w] = word;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b < valid[w]) orow[4 * (i * W + w) + b] = (uint8_t)(word >> (8 * b));
+            }
         }
     }
 }
 
-template <int M, int T>
-__global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nwords, int tail) {
+// nthreads_full threads own W whole words each; one more thread (the first of the next block slot) owns what is left:
+// up to W - 1 whole words and the n % 4 bytes after them
+template <int M, int T, int W>
+__global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nthreads_full,
+                                                          int rest_bytes) {
     __shared__ uint32_t lds32[SBL_TABLE_BYTES / 4];
     for (int i = threadIdx.x; i < SBL_TABLE_BYTES / 4; i += BLOCK) lds32[i] = reinterpret_cast<const uint32_t*>(a.tables)[i];
     __syncthreads();
@@ -757,15 +785,37 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
     const uint8_t* tbits = reinterpret_cast<const uint8_t*>(lds32) + 1536;
     const uint8_t* tfold = tbits + 2304;
     rng_load_state(ra);
+    // Device-resident generator state: this long kernel counts its workgroups as they START (each has read the state by
+    // then; the ticket is consumed at the end, so the ~25 ns per same-address atomic are spread over the dispatch ramp
+    // instead of piling up where all workgroups finish together).  The group that drew the last ticket advances the nonce
+    // before it exits -- every other group has loaded the state, the next launch on the stream starts after this one ends.
+    uint32_t ticket = 0;
+    if (ra.dev_key && ra.release && threadIdx.x == 0) ticket = atomicAdd(&const_cast<RngKey*>(ra.dev_key)->pad_, 1u);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
+    int all4[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) all4[w] = 4;
     if (ra.rk.rounds == 20 && !a.burst) {
-        for (size_t i = gid; i < nwords; i += gsz) sbl_word<M, T, 10>(f, a, ra, lg, ex, tbits, tfold, i, 4);
+        for (size_t i = gid; i < nthreads_full; i += gsz) sbl_words<M, T, 10, W>(f, a, ra, lg, ex, tbits, tfold, i, true, all4);
     } else {
-        for (size_t i = gid; i < nwords; i += gsz) sbl_word<M, T, 0>(f, a, ra, lg, ex, tbits, tfold, i, 4);
+        for (size_t i = gid; i < nthreads_full; i += gsz) sbl_words<M, T, 0, W>(f, a, ra, lg, ex, tbits, tfold, i, true, all4);
     }
-    if (tail && gid == 0) sbl_word<M, T, 0>(f, a, ra, lg, ex, tbits, tfold, nwords, tail);      // n % 4 bytes of every row
-    rng_state_release(ra);
+    if (rest_bytes && gid == 0) {                                // the ragged end of every row
+        int valid[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int left = rest_bytes - 4 * w;
+            valid[w] = left >= 4 ? 4 : (left > 0 ? left : 0);
+        }
+        sbl_words<M, T, 0, W>(f, a, ra, lg, ex, tbits, tfold, nthreads_full, false, valid);
+    }
+    if (ra.dev_key && ra.release && threadIdx.x == 0 && ticket == gridDim.x - 1) {
+        RngKey* st = const_cast<RngKey*>(ra.dev_key);
+        st->pad_ = 0;
+        if (++st->nonce[0] == 0) st->nonce[1] += 65536u;
+        __threadfence();
+    }
 }
 
 // tables_dev: SBL_TABLE_BYTES of device memory (the caller caches it per matrix); returns 2 when the shape is not
@@ -784,30 +834,45 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     for (int i = 0; i < 2 * t + 1; ++i) a.lam[i] = (uint32_t)(lam2[2 * i] & 0xffu);
     for (int i = 0; i <= t; ++i) a.mu[i] = (uint32_t)(mu2[2 * i] & 0xffu);
     RngArgs ra = *rng;
-    const size_t nwords = n / 4;
-    const int tail = (int)(n & 3);
-    static int burst = -1;
+    static int burst = -1, wpt = -1;
     if (burst < 0) {
         const char* e = getenv("FFGPU_SBL_BURST");
         burst = e ? atoi(e) : 0;
+        e = getenv("FFGPU_SBL_WPT");
+        wpt = e ? atoi(e) : 2;
     }
     a.burst = burst;
-    size_t want = (nwords + BLOCK - 1) / BLOCK;
+    // two words (eight bytes) per thread for t = 1 and large n (five ChaCha blocks instead of six, twice the look-ups in
+    // flight); t >= 2 keeps one word per thread (174 VGPRs at m = 7, t = 3 as it is)
+    // (measured, profiles/r04_sbox_layer.md: two words per thread need >= 3 x 10^6 bytes to fill the SIMDs -- at 10^6 the
+    // 1954 double-work waves take 45 us against 38 us for 3908 single-word waves; at 4 x 10^6: 28.3 against 31.4 us per 10^6)
+    const int W = (t == 1 && wpt == 2 && n >= 3000000) ? 2 : 1;
+    const size_t nthreads_full = n / (4 * (size_t)W);
+    const int rest_bytes = (int)(n - nthreads_full * 4 * W);
+    size_t want = (nthreads_full + BLOCK - 1) / BLOCK;
     if (want < 1) want = 1;
     if (want > 0x7fffffff) want = 0x7fffffff;
     const unsigned grid = (unsigned)want;
-    ra.release = (ra.dev_key && !ra.no_advance && grid <= (unsigned)RNG_RELEASE_MAX_GRID) ? 1 : 0;
-#define SBL_CASE(MM, TT)                                                                                      \
-    if (m == MM && t == TT) {                                                                                 \
-        hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nwords, tail); \
-        FFGPU_CHECK_LAUNCH();                                                                                 \
-        if (ra.dev_key && !ra.release && !ra.no_advance)                                                      \
-            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u); \
-        return 0;                                                                                             \
+    // up to 1024 workgroups (10^6 bytes: 977) advance the state themselves: the tickets are drawn at workgroup START
+    ra.release = (ra.dev_key && !ra.no_advance && grid <= 1024u) ? 1 : 0;
+#define SBL_LAUNCH(MM, TT, WW)                                                                                        \
+    {                                                                                                                 \
+        hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT, WW>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nthreads_full,   \
+                           rest_bytes);                                                                               \
+        FFGPU_CHECK_LAUNCH();                                                                                         \
+        if (ra.dev_key && !ra.release && !ra.no_advance)                                                              \
+            hipLaunchKernelGGL((k_rng_advance<0>), dim3(1), dim3(1), 0, st, const_cast<RngKey*>(ra.dev_key), 1u);     \
+        return 0;                                                                                                     \
+    }
+#define SBL_CASE(MM, TT)                                 \
+    if (m == MM && t == TT) {                            \
+        if (TT == 1 && W == 2) SBL_LAUNCH(MM, TT, (TT == 1 ? 2 : 1)) \
+        SBL_LAUNCH(MM, TT, 1)                            \
     }
     SBL_CASE(3, 1) SBL_CASE(4, 1) SBL_CASE(5, 1) SBL_CASE(5, 2) SBL_CASE(6, 1) SBL_CASE(6, 2) SBL_CASE(7, 1) SBL_CASE(7, 2)
     SBL_CASE(7, 3)
 #undef SBL_CASE
+#undef SBL_LAUNCH
     (void)device;
     return 2;
 }
@@ -905,19 +970,36 @@ struct Mul<8> {
 }  // namespace bs64
 
 // a slab = 2048 consecutive elements = 1024 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
-// (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..15
+// (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..15.  The last slab may be partial: its
+// accesses are guarded per uint4 (nvec4 = n / 2 of them exist), missing operands are zero.
+__device__ __forceinline__ void bs64_load(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t slab, int lane, size_t nvec4,
+                                          uint4 (&na)[16], uint4 (&nb)[16]) {
+    const size_t base = slab * 1024 + lane;
+    if ((slab + 1) * 1024 <= nvec4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            na[r] = ldg<true>(a + base + (size_t)r * 64);
+            nb[r] = ldg<true>(b + base + (size_t)r * 64);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool in = base + (size_t)r * 64 < nvec4;
+            na[r] = in ? ldg<true>(a + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
+            nb[r] = in ? ldg<true>(b + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ o, size_t nslab) {
+void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ o, size_t nslab,
+                            size_t nvec4) {
     const size_t wave0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * BLOCK) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave0 >= nslab) return;
     uint4 na[16], nb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        na[r] = ldg<true>(a + wave0 * 1024 + lane + (size_t)r * 64);
-        nb[r] = ldg<true>(b + wave0 * 1024 + lane + (size_t)r * 64);
-    }
+    bs64_load(a, b, wave0, lane, nvec4, na, nb);
     for (size_t wave = wave0; wave < nslab; wave += nwaves) {
         const size_t base = wave * 1024 + lane;
         uint32_t pa[64], pb[64];
@@ -934,14 +1016,7 @@ void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict
 #pragma unroll
             for (int i = 0; i < 32; ++i) { pb[i] = lo[i]; pb[32 + i] = hi[i]; }
         }
-        const size_t nxt = wave + nwaves;
-        if (nxt < nslab) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                na[r] = ldg<true>(a + nxt * 1024 + lane + (size_t)r * 64);
-                nb[r] = ldg<true>(b + nxt * 1024 + lane + (size_t)r * 64);
-            }
-        }
+        if (wave + nwaves < nslab) bs64_load(a, b, wave + nwaves, lane, nvec4, na, nb);     // in flight during the product below
         uint32_t c[127];
         bs64::Mul<64>::run(pa, pb, c);
 #pragma unroll
@@ -953,24 +1028,32 @@ void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict
 #pragma unroll
         for (int i = 0; i < 32; ++i) { lo[i] = c[i]; hi[i] = c[32 + i]; }
         bs64::transpose32(lo); bs64::transpose32(hi);
+        if ((wave + 1) * 1024 <= nvec4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
+            for (int r = 0; r < 16; ++r) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (base + (size_t)r * 64 < nvec4) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
+        }
     }
 }
 
-// returns the number of leading elements it has multiplied (a multiple of 2048; 0 = not applicable): the caller sends
-// the rest through the element-wise kernel
+// returns the number of leading elements it has multiplied (all of them but the last one of an odd n; 0 = not applicable):
+// the caller sends the rest through the element-wise kernel
 size_t ffgpu_launch_gf2w64_mul_bitsliced(const void* policy, int device, const void* a, const void* b, void* out, size_t n,
                                          hipStream_t st) {
     const GF2W64& f = *reinterpret_cast<const GF2W64*>(policy);
     const char* e = getenv("FFGPU_GF2W_BITSLICED");             // =0: the multiplier kernel (A/B measurements, tests)
     const bool off = e && atoi(e) == 0;
     if (off || f.n != 64 || f.red != 0x1bull || n < ((size_t)1 << 21) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return 0;
-    const size_t nslab = n / 2048;
+    const size_t nvec4 = n / 2;
+    const size_t nslab = (nvec4 + 1023) / 1024;
     LaunchCfg lc = launch_cfg(device);
     const unsigned grid = (unsigned)(lc.num_cu > 0 ? lc.num_cu : 256);       // one workgroup of four waves per CU: a wave per SIMD
-    hipLaunchKernelGGL(k_gf2w64_mul_bitsliced, dim3(grid), dim3(BLOCK), 0, st, (const uint4*)a, (const uint4*)b, (uint4*)out, nslab);
-    return nslab * 2048;
+    hipLaunchKernelGGL(k_gf2w64_mul_bitsliced, dim3(grid), dim3(BLOCK), 0, st, (const uint4*)a, (const uint4*)b, (uint4*)out, nslab,
+                       nvec4);
+    return nvec4 * 2;
 }
 
 // ---- GF(2^n), n <= 8: multiplication through log / antilog tables in LDS ---------------------

@@ -869,7 +869,11 @@ class FieldContext:
             key = _secrets.token_bytes(32)
         defer = 0
         if state is not None:
-            nonce, defer = state.take_offset(), 1
+            if state.pending:
+                nonce, defer = state.take_offset(), 1          # inside a sequence of deferred launches: commit() follows
+            else:
+                nonce = 0          # the layer is ONE launch: it advances the device nonce itself (the last workgroup of the
+                #                    kernel for grids of up to 512 workgroups -- 10^6 bytes --, a one-thread kernel above that)
         _ffi.check(self._L.ffgpu_gf256_sbox_layer(self._h, mm, bb, self._scalars(lam), self._scalars(mu), t, m, X.ptr, X.stride,
                                                   R.ptr, R.stride, out.ptr, out.stride, n, key, nonce, rounds,
                                                   state.ptr if state is not None else None, defer, self._stream()),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 passes on the GPU box.  STAGES="tests bench prof pmc valu newtests probe"
+# Round-4 passes on the GPU box.  STAGES="tests bench prof pmc valu micro newtests probe"
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 T=${TAG:-r04}
 STAGES=${STAGES:-"tests bench prof"}
@@ -28,6 +28,15 @@ if has pmc; then
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${T}_$C -o $C -- python $R/tools/pmc_probe.py) > $O/pmc_${T}_$C.log 2>&1
     echo "pmc $C rc=$?"
   done
+fi
+if has valu; then
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/valu_$T -o valu -- python $R/tools/valu_probe.py) > $O/valu_$T.log 2>&1
+  F=$(find $O/valu_$T -name '*counter_collection.csv' | head -1)
+  python tools/valu_summary.py $F $O/valu_order.json $O/${T}_valu.json $O/${T}_valu.md | tail -20
+fi
+if has micro; then
+  (timeout 300 python tools/sbox_clock_probe.py; PROBE_P61_ONLY= timeout 300 python tools/inv_probe.py; timeout 200 python tools/gf2w_probe.py) 2>&1 | grep -v amdgpu.ids > $O/micro_$T.log
+  cat $O/micro_$T.log
 fi
 if has probe; then
   (timeout ${PROBE_TIMEOUT:-600} bash -c "$PROBE") > $O/probe_$T.log 2>&1; echo "probe rc=$?" >> $O/probe_$T.log
