@@ -235,8 +235,10 @@ def annotate_valu(kern, n):
         if not isinstance(r, dict) or not r.get('ms_per_launch'):
             continue
         ops = float(info['valu_lane_ops_per_unit'])
+        # rows that state their issue SLOTS (double-slot multiplies counted twice: mul_gf2_128) are priced on those
+        slots = float(r.get('valu_issue_slots_per_unit', ops))
         r.update(bound='valu', valu_lane_ops_per_unit=ops,
-                 valu_frac=round(ops * n / (r['ms_per_launch'] * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                 valu_frac=round(max(slots, ops) * n / (r['ms_per_launch'] * 1e-3) / VALU_PEAK_LANE_OPS, 4),
                  valu_source='profiles/r04_valu.md (SQ_INSTS_VALU x 64 / n)')
 
 
@@ -1286,7 +1288,7 @@ def main():
         # profiles/r03_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
         def annotate_traffic():
             try:
-                pmc_file = next(f_ for f_ in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                pmc_file = next(f_ for f_ in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                                 if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
                 with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                     pmc = json.load(fh)

@@ -785,12 +785,6 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
     const uint8_t* tbits = reinterpret_cast<const uint8_t*>(lds32) + 1536;
     const uint8_t* tfold = tbits + 2304;
     rng_load_state(ra);
-    // Device-resident generator state: this long kernel counts its workgroups as they START (each has read the state by
-    // then; the ticket is consumed at the end, so the ~25 ns per same-address atomic are spread over the dispatch ramp
-    // instead of piling up where all workgroups finish together).  The group that drew the last ticket advances the nonce
-    // before it exits -- every other group has loaded the state, the next launch on the stream starts after this one ends.
-    uint32_t ticket = 0;
-    if (ra.dev_key && ra.release && threadIdx.x == 0) ticket = atomicAdd(&const_cast<RngKey*>(ra.dev_key)->pad_, 1u);
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     int all4[W];
@@ -810,12 +804,7 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
         }
         sbl_words<M, T, 0, W>(f, a, ra, lg, ex, tbits, tfold, nthreads_full, false, valid);
     }
-    if (ra.dev_key && ra.release && threadIdx.x == 0 && ticket == gridDim.x - 1) {
-        RngKey* st = const_cast<RngKey*>(ra.dev_key);
-        st->pad_ = 0;
-        if (++st->nonce[0] == 0) st->nonce[1] += 65536u;
-        __threadfence();
-    }
+    rng_state_release(ra);
 }
 
 // tables_dev: SBL_TABLE_BYTES of device memory (the caller caches it per matrix); returns 2 when the shape is not
@@ -853,8 +842,10 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     if (want < 1) want = 1;
     if (want > 0x7fffffff) want = 0x7fffffff;
     const unsigned grid = (unsigned)want;
-    // up to 1024 workgroups (10^6 bytes: 977) advance the state themselves: the tickets are drawn at workgroup START
-    ra.release = (ra.dev_key && !ra.no_advance && grid <= 1024u) ? 1 : 0;
+    // (measured and NOT kept, round 4: letting up to 1024 workgroups advance the state themselves with a ticket drawn at
+    // workgroup START -- the returning atomic sits in front of the wave's first loads in the in-order vmcnt queue, and 977
+    // same-address atomics at ~25 ns each delay those waves: 43.7 us against 38.4 us with the one-thread kernel after it)
+    ra.release = (ra.dev_key && !ra.no_advance && grid <= (unsigned)RNG_RELEASE_MAX_GRID) ? 1 : 0;
 #define SBL_LAUNCH(MM, TT, WW)                                                                                        \
     {                                                                                                                 \
         hipLaunchKernelGGL((k_gf8_sbox_layer<MM, TT, WW>), dim3(grid), dim3(BLOCK), 0, st, f, a, ra, nthreads_full,   \
