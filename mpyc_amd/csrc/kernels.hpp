@@ -2148,6 +2148,168 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_lds(F f, const int8_t* __re
     }
 }
 
+// ---- the same product with the operand tiles streamed STRAIGHT into LDS, three stages deep (round 4) ------------
+// k_limb_gemm_lds holds one tile ahead in registers: its fetch is issued one k-step (64 MFMAs = ~1 us) before the
+// data is needed, which does not cover the HBM / L2 latency at one wave per SIMD (the accumulators take the register
+// file: 512 of 512) -- measured: the operand fetch cost 37 % of the 4096^3 product, and the 64-row shape ran at 110 us
+// against 31 us of MFMA work.  Here the digit-plane tiles (byte for byte their LDS image: limb_off) and, for BRAW, the
+// raw rows of B go global -> LDS without passing through registers (global_load_lds_dwordx4: LDS address = wave-uniform
+// base + lane * 16), TWO tiles ahead in a ring of three stages; the waves wait with a COUNTED vmcnt (the tile issued
+// last stays in flight across the barrier) and synchronise with raw s_barrier (a __syncthreads would drain vmcnt to
+// 0).  BRAW: the raw 64-bit elements of tile s + 1 are converted to digit bytes LDS -> LDS (same arithmetic as the
+// register variant) while the MFMAs of tile s run.  No staging registers (32 fewer).  Requires K padded to 32 (planes:
+// always) and, for BRAW, K % 32 == 0, N % 64 == 0 and 16-byte aligned rows of B; the launcher falls back to
+// k_limb_gemm_lds otherwise.  FFGPU_MM_GLDS=0 selects the register-staged kernel (A/B measurements, parity tests).
+template <class F>
+__device__ __forceinline__ void limb_epilogue8(const F& f, const ff_v16i (&acc)[15], typename F::elem* __restrict__ C, size_t ldc,
+                                               int M, int N, int bm0, int bn0, int wm, int wn, int lane, int accumulate) {
+    typedef typename F::word W;
+    const W t32 = f.reduce_raw((W)(1ull << 32));
+    const W r64 = f.mul(t32, t32);                 // 2^64 mod p
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int dq[15];
+#pragma unroll
+        for (int d = 0; d < 15; ++d) dq[d] = acc[d][q];
+        W v = limb_combine15(f, dq, r64);
+        const int col = bn0 + wn + (lane & 31), row = bm0 + wm + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+            if (accumulate) v = f.add(v, ld_elem<F>(C, (size_t)row * ldc + col));
+            st_elem<F>(C, (size_t)row * ldc + col, v);
+        }
+    }
+}
+
+enum { GLDS_TILE = 8 * 2 * 64 * 16 };              // bytes of one operand tile per k-step (L = 8): 16 KiB
+template <class F, bool BRAW>
+__global__ __launch_bounds__(BLOCK) void k_limb_gemm_glds(F f, const int8_t* __restrict__ Ap, const int8_t* __restrict__ Bp,
+                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int N, int Kp,
+                                                           int kb, int ke, int accumulate, int kslice, size_t zstride,
+                                                           const typename F::elem* __restrict__ Braw, size_t ldb, uint64_t pmod) {
+    static_assert(sizeof(typename F::elem) == 8, "eight digits, 64-bit storage");
+    constexpr int L = 8;
+    // LDS: A stages [3][16 KiB]; planes of B: stages [3][16 KiB]; BRAW: raw stages [3][32 k][64 columns] uint64 + digit tiles [2][16 KiB]
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+    unsigned char* sA = glds_smem;
+    unsigned char* sBst = glds_smem + 3 * GLDS_TILE;                   // planes of B, or the raw stages
+    unsigned char* sBd = glds_smem + 6 * GLDS_TILE;                    // BRAW only: converted digit tiles [2]
+    if (kslice > 0) {                                  // split-K: slice blockIdx.z -> its own slab of C
+        kb += blockIdx.z * kslice;
+        ke = kb + kslice < ke ? kb + kslice : ke;
+        C += (size_t)blockIdx.z * zstride;
+        if (kb >= ke) { kb = 0; ke = 0; }              // empty slice: writes zeros
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int bm0 = blockIdx.y * 64, bn0 = blockIdx.x * 64;
+    const int r = lane & 31, h = lane >> 5;
+    ff_v16i acc[15];
+#pragma unroll
+    for (int d = 0; d < 15; ++d) acc[d] = (ff_v16i){0};
+    const int nsteps = (ke - kb) >> 5;
+    typedef __attribute__((address_space(3))) void lds_void;
+    // tile `s` -> stage s % 3: four 1 KiB pieces per wave and operand
+    auto issue = [&](int s_) {
+        const int k0 = kb + 32 * s_, st = s_ % 3;
+        const int8_t* at = Ap + limb_off<L>(0, bm0, k0, Kp);           // 16 KiB contiguous, already in LDS order
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int piece = wave * 4 + u;                            // 1 KiB pieces 0..15
+            __builtin_amdgcn_global_load_lds(at + piece * 1024 + lane * 16, (lds_void*)(sA + st * GLDS_TILE + piece * 1024), 16, 0, 0);
+        }
+        if constexpr (!BRAW) {
+            const int8_t* bt = Bp + limb_off<L>(0, bn0, k0, Kp);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int piece = wave * 4 + u;
+                __builtin_amdgcn_global_load_lds(bt + piece * 1024 + lane * 16, (lds_void*)(sBst + st * GLDS_TILE + piece * 1024), 16, 0, 0);
+            }
+        } else {
+            // raw rows k0 .. k0 + 31, 64 columns of 8 bytes: one instruction = two k rows (lanes 0..31 / 32..63, two columns each)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kr = (wave * 4 + u) * 2;
+                const int8_t* src = reinterpret_cast<const int8_t*>(Braw + (size_t)(k0 + kr + (lane >> 5)) * ldb + bn0 + (lane & 31) * 2);
+                __builtin_amdgcn_global_load_lds(src, (lds_void*)(sBst + st * GLDS_TILE + kr * 512), 16, 0, 0);
+            }
+        }
+    };
+    // BRAW: raw stage of tile s -> digit tile s & 1 (thread: column bcol, eight consecutive k)
+    const int bcol = threadIdx.x & 63, bkg = threadIdx.x >> 6;
+    auto convert = [&](int s_) {
+        const uint64_t* raw = reinterpret_cast<const uint64_t*>(sBst + (s_ % 3) * GLDS_TILE);
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t d = limb_digits_packed<8>(raw[(bkg * 8 + i) * 64 + bcol], pmod);      // byte l = digit l of element k
+            lo[i] = (uint32_t)d;
+            hi[i] = (uint32_t)(d >> 32);
+        }
+        uint32_t w[4][4];
+        transpose4x4_bytes(lo[0], lo[1], lo[2], lo[3], w[0]);
+        transpose4x4_bytes(lo[4], lo[5], lo[6], lo[7], w[1]);
+        transpose4x4_bytes(hi[0], hi[1], hi[2], hi[3], w[2]);
+        transpose4x4_bytes(hi[4], hi[5], hi[6], hi[7], w[3]);
+        uint64_t* sb8 = reinterpret_cast<uint64_t*>(sBd + (s_ & 1) * GLDS_TILE);
+        const int hh = bkg >> 1, half = bkg & 1;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const uint64_t run = (uint64_t)w[(l >> 2) * 2][l & 3] | ((uint64_t)w[(l >> 2) * 2 + 1][l & 3] << 32);
+            sb8[(((l * 2 + hh) * 64 + bcol) << 1) + half] = run;
+        }
+    };
+    auto barrier = [&]() {                             // LDS traffic of this wave done, then the workgroup meets (vmcnt untouched)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    constexpr int PER_TILE = 8;                        // global_load_lds instructions per wave and tile (4 for A + 4 for B)
+    if (nsteps > 0) {
+        issue(0);
+        if (nsteps > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        barrier();                                     // tile 0 is in LDS for every wave
+        if constexpr (BRAW) {
+            convert(0);
+            barrier();
+        }
+    }
+    static_assert(PER_TILE == 8, "the counted waits below leave exactly one tile (8 instructions) in flight");
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+        // stage (s + 2) % 3 held tile s - 1: its last readers (the MFMAs of step s - 1, the conversion in step s - 2)
+        // finished before the barrier that ended step s - 1
+        if (s_ + 2 < nsteps) issue(s_ + 2);
+        const ff_v4i* a4 = reinterpret_cast<const ff_v4i*>(sA + (s_ % 3) * GLDS_TILE);
+        const ff_v4i* b4 = reinterpret_cast<const ff_v4i*>(BRAW ? sBd + (s_ & 1) * GLDS_TILE : sBst + (s_ % 3) * GLDS_TILE);
+        ff_v4i a[L], b[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            a[l] = a4[(l * 2 + h) * 64 + wm + r];
+            b[l] = b4[(l * 2 + h) * 64 + wn + r];
+        }
+#pragma unroll
+        for (int la = 0; la < L; ++la)
+#pragma unroll
+            for (int lb = 0; lb < L; ++lb)
+                acc[la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la], b[lb], acc[la + lb], 0, 0, 0);
+        if (s_ + 1 < nsteps) {
+            // tile s + 1 (issued a whole step ago) must have landed; tile s + 2 stays in flight
+            if (s_ + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier();
+            if constexpr (BRAW) {
+                convert(s_ + 1);
+                barrier();
+            }
+        }
+    }
+    limb_epilogue8(f, acc, C, ldc, M, N, bm0, bn0, wm, wn, lane, accumulate);
+}
+
 // ---- the matrix-core product for primes of 65..128 bits ---------------------------------------------------------
 // L = 12 digits (96-bit storage) or 16: 2L-1 = 23 / 31 diagonals do not fit the register file at once, so the
 // product runs in PASSES over ranges of diagonals [D0, D0+NDP): a pass issues only the MFMAs whose digit pair lies
@@ -2775,6 +2937,27 @@ struct Launchers {
     // dwordx3 needs dword alignment only; three-limb elements go as three dwordx2
     enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : sizeof(E) == 24 ? 8 : 16 };
     static bool al(const void* p) { return ((uintptr_t)p & (PACK_ALIGN - 1)) == 0; }
+    // (a member function, not a lambda inside `matmul`: clang does not emit the host stub of a kernel specialisation
+    // that is only named inside a generic lambda's discarded-branch neighbourhood)
+    template <bool BRAW>
+    static void launch_glds(const F& f, dim3 grid, hipStream_t st, const int8_t* Ap, const int8_t* Bp, E* out, size_t out_ld, int M, int N,
+                            int Kp, int kb, int ke, int acc_, int kslice, size_t zs, const E* Braw, size_t ldb, uint64_t pmod) {
+        if constexpr (F::EPW == 1 && !F::BINARY && sizeof(E) == 8) {
+            const size_t lds = (size_t)(BRAW ? 8 : 6) * GLDS_TILE;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_limb_gemm_glds<F, BRAW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((k_limb_gemm_glds<F, BRAW>), grid, dim3(BLOCK), lds, st, f, Ap, Bp, out, out_ld, M, N, Kp, kb, ke, acc_,
+                               kslice, zs, Braw, ldb, pmod);
+        }
+    }
+    static bool limb_glds() {                       // FFGPU_MM_GLDS=0: the register-staged product kernel (read per call)
+        const char* e = getenv("FFGPU_MM_GLDS");
+        return !(e && atoi(e) == 0);
+    }
     static bool limb_braw() {                       // FFGPU_MM_BRAW=0: always go through digit planes of B (A/B measurements)
         static int v = -1;
         if (v < 0) {
@@ -3279,6 +3462,14 @@ struct Launchers {
                         hipLaunchKernelGGL((k_limb_split_bt<F, LL>), gb, dim3(BLOCK), 0, st, (const E*)B, ldb, pmod, Bp, K, N, Np, Kp);
                     auto product = [&](dim3 grid, E* out, size_t out_ld, int kb, int ke, int acc_, int kslice, size_t zs) {
                         if constexpr (CAN_RAW) {
+                            // operand tiles straight into LDS, two k-steps ahead (k_limb_gemm_glds); raw B needs whole
+                            // tiles and 16-byte aligned rows
+                            const bool raw_ok = K % 32 == 0 && N % 64 == 0 && ldb % 2 == 0 && (((uintptr_t)B) & 15) == 0;
+                            if (limb_glds() && (!braw || raw_ok)) {
+                                if (braw) launch_glds<true>(f, grid, st, Ap, (const int8_t*)nullptr, out, out_ld, M, N, Kp, kb, ke, acc_, kslice, zs, (const E*)B, ldb, pmod);
+                                else launch_glds<false>(f, grid, st, Ap, Bp, out, out_ld, M, N, Kp, kb, ke, acc_, kslice, zs, (const E*)nullptr, (size_t)0, (uint64_t)0);
+                                return;
+                            }
                             if (braw) {
                                 hipLaunchKernelGGL((k_limb_gemm_lds<F, LL, true>), grid, dim3(BLOCK), 0, st, f, (const int8_t*)Ap,
                                                    (const int8_t*)nullptr, out, out_ld, M, N, Mp, Np, Kp, kb, ke, acc_, kslice, zs,
@@ -3295,7 +3486,15 @@ struct Launchers {
                     const size_t tiles = (size_t)gg.x * gg.y;
                     int ks = 1;
                     if (use_mfma != 2 && tiles <= 128 && Kp >= 512) {
-                        ks = (int)((768 + tiles - 1) / tiles);
+                        // ONE round of workgroups (a workgroup holds a CU: 512 registers per lane): tiles x slabs ~ CUs.
+                        // Measured (tools/mm_ks.py, 64 x 4096 x 4096): 256 workgroups 94 us, 384: 127, 512: 107, 768 (the
+                        // round-2 choice): 117, 1536: 121 -- every extra slab repeats the epilogue and the pipeline fill.
+                        const int ncu = launch_cfg(device).num_cu;
+                        int target = ncu > 0 ? ncu : 256;
+                        if (const char* e = getenv("FFGPU_MM_KS")) {          // workgroups aimed at (A/B measurements)
+                            if (atoi(e) > 0) target = atoi(e);
+                        }
+                        ks = (int)((target + tiles - 1) / tiles);
                         if (ks > Kp / 256) ks = Kp / 256;
                         while (ks > 1 && need + 256 + (size_t)ks * M * N * sizeof(E) > workspace_bytes) --ks;
                     }

@@ -371,6 +371,33 @@ def test_wide_binary_products_all_degrees(eng, coracle):
         assert (dA.to_numpy() == want).all(), deg
 
 
+@pytest.mark.parametrize('modulus', [(1 << 64) | 0x1b, (1 << 40) | 0x39, (1 << 63) | 0x3])
+def test_batched_inverse_full_batch_kernel_binary(eng, modulus, monkeypatch):
+    """The same kernel over GF(2^n), 33 <= n <= 64 (one-word elements): q - 2 = 2^n - 3 is a run of ones and '01'."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    if not BinaryPolynomial.is_irreducible(modulus):
+        modulus = int(BinaryPolynomial.next_irreducible(modulus))
+    F = po.Field(modulus, True)
+    ctx = ctx_for(eng, modulus, True)
+    assert ctx.elem_bytes == 8
+    n = 300_007
+    A = rand_np(F, 8, n, 91)
+    A[[0, 5, n // 2, n - 1]] = 0
+    A[1], A[2] = 1, F.order - 1
+    dA = ctx.from_numpy(A)
+    with pytest.raises(ZeroDivisionError):
+        ctx.inv(dA)
+    inv = ctx.inv(dA, check_zero=False)
+    nz = dA.t != 0
+    assert bool((ctx.mul(dA, inv).t[nz] == 1).all()) and bool((inv.t[~nz] == 0).all())
+    got = inv.to_numpy()
+    for i in [1, 2, 3, 4, n - 2] + list(range(100, 140)):
+        if int(A[i]):
+            assert po.mul(F, int(got[i]), int(A[i])) == 1, (hex(modulus), i)
+    monkeypatch.setenv('FFGPU_INV_VARIANT', '0')
+    assert torch.equal(ctx.inv(dA, check_zero=False).t, inv.t)
+
+
 def test_gf2_64_bitsliced_product(eng, coracle, monkeypatch):
     """GF(2^64) with the default modulus x^64 + x^4 + x^3 + x + 1, n >= 2^21: the bit-sliced kernel
     (k_gf2w64_mul_bitsliced, misc.hip) multiplies the whole 2048-element slabs, the element-wise kernel the rest.
@@ -769,6 +796,26 @@ def test_matrix_core_product(eng, coracle):
     ones = pack([P64 - 1] * (M * K), 8)
     got = unpack(ctx.matmul(ctx.from_numpy(ones), ctx.from_numpy(ones), M, K, N).to_numpy(), 8)
     assert set(got) == {K * (P64 - 1) * (P64 - 1) % P64}
+
+
+def test_matrix_core_product_lds_direct_equals_register_staged(eng, monkeypatch):
+    """k_limb_gemm_glds (operand tiles streamed straight into LDS, two k-steps ahead, counted waits) against the
+    register-staged k_limb_gemm_lds (FFGPU_MM_GLDS=0, read per call): identical arrays for digit planes of both operands,
+    for the raw right operand of the 64-row shapes (whole tiles and the fallback for ragged ones), split-K slabs, K beyond
+    one 8192 chunk (accumulating launches) and one, two and three k-steps (the prologue / drain of the three-stage ring)."""
+    for modulus in (P61, P64, 2**63 - 25):
+        F = po.Field(modulus, False)
+        ctx = ctx_for(eng, modulus, False)
+        # (tests/conftest.py lowers the matrix-core threshold to 1.6e7 multiply-accumulates)
+        for (M, K, N) in ((256, 256, 256), (64, 1024, 256), (64, 4096, 512), (1024, 64, 512), (512, 96, 512), (128, 128, 1024),
+                          (65, 8300, 70), (64, 1030, 300), (300, 9000, 130), (64, 8192 + 64, 128), (128, 8192 + 96, 64)):
+            A, B = rand_np(F, 8, M * K, 5 + M), rand_np(F, 8, K * N, 7 + N)
+            dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+            got = ctx.matmul(dA, dB, M, K, N)
+            monkeypatch.setenv('FFGPU_MM_GLDS', '0')
+            want = ctx.matmul(dA, dB, M, K, N)
+            monkeypatch.delenv('FFGPU_MM_GLDS')
+            assert torch.equal(got.t, want.t), (hex(modulus), M, K, N)
 
 
 def test_matrix_core_product_two_limb_primes(eng, coracle):
