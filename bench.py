@@ -237,7 +237,8 @@ def annotate_valu(kern, n):
         ops = float(info['valu_lane_ops_per_unit'])
         # rows that state their issue SLOTS (double-slot multiplies counted twice: mul_gf2_128) are priced on those
         slots = float(r.get('valu_issue_slots_per_unit', ops))
-        r.update(bound='valu', valu_lane_ops_per_unit=ops,
+        # (the dense GF(2^n) recombination waits on its LDS look-ups as much as on the VALU: both are named)
+        r.update(bound='lds+valu' if row.endswith('_dense') else 'valu', valu_lane_ops_per_unit=ops,
                  valu_frac=round(max(slots, ops) * n / (r['ms_per_launch'] * 1e-3) / VALU_PEAK_LANE_OPS, 4),
                  valu_source='profiles/r04_valu.md (SQ_INSTS_VALU x 64 / n)')
 

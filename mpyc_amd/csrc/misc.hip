@@ -557,8 +557,8 @@ template <int DR>
 struct SblKeystream {
     uint32_t ks[16];        // block being consumed
     uint32_t x[16];         // DR > 0: the next block, in progress
-    int kpos, kblk, qpos;
-    uint64_t base;
+    int kpos, qpos;
+    uint64_t next_ctr;      // counter of the block in x (DR > 0) / of the next block to compute (DR == 0)
     const RngKey* rk;
 
     __device__ __forceinline__ void start_block(uint64_t ctr) {
@@ -586,36 +586,36 @@ struct SblKeystream {
             default: { FF_QR(x[3], x[4], x[9], x[14]) } break;
         }
     }
+    // begin(): x holds block `first_ctr` complete (DR > 0) / nothing is computed yet (DR == 0); step_begin() marks the
+    // consumed block as used up.  All positions (kpos, qpos) are compile-time constants once the caller is unrolled:
+    // a step that takes a multiple of 16 words from the stream leaves it in the state step_begin() describes.
+    __device__ __forceinline__ void step_begin() {
+        kpos = 16;
+        qpos = 8 * DR;
+    }
     __device__ __forceinline__ void begin(const RngKey* key, uint64_t first_ctr) {
         rk = key;
-        base = first_ctr;
-        kblk = 0;
-        if (DR == 0) {
-            kpos = 16;
-        } else {
-            start_block(base);
+        next_ctr = first_ctr;
+        if (DR > 0) {
+            start_block(next_ctr);
 #pragma unroll
             for (int q = 0; q < 8 * DR; ++q) quarter(q);
-            finish_block(base);
-            start_block(base + 1);
-            kpos = 0;
-            qpos = 0;
         }
+        step_begin();
     }
     __device__ __forceinline__ uint32_t next_word() {
         if (DR == 0) {
             if (kpos == 16) {
-                const uint64_t ctr = base + (uint64_t)kblk;
-                chacha_block(rk->key, (uint32_t)ctr, (uint32_t)(ctr >> 32), rk->nonce[0], rk->nonce[1], (int)rk->rounds, ks);
-                ++kblk;
+                chacha_block(rk->key, (uint32_t)next_ctr, (uint32_t)(next_ctr >> 32), rk->nonce[0], rk->nonce[1], (int)rk->rounds, ks);
+                ++next_ctr;
                 kpos = 0;
             }
             return ks[kpos++];
         }
-        if (kpos == 16) {                      // block kblk used up: kblk + 1 has had 16 x DR / 2 = 8 DR quarter rounds
-            ++kblk;
-            finish_block(base + (uint64_t)kblk);
-            start_block(base + (uint64_t)kblk + 1);
+        if (kpos == 16) {                      // the block in x has had its 16 x DR / 2 = 8 DR quarter rounds: it becomes ks
+            finish_block(next_ctr);
+            ++next_ctr;
+            start_block(next_ctr);
             kpos = 0;
             qpos = 0;
         }
@@ -631,14 +631,27 @@ struct SblKeystream {
 // and the 2 W K table products of a gate are independent of each other (twice the look-ups in flight per wave).
 // full: every word of the thread holds four bytes of every row (aligned dword / 16-byte accesses); otherwise word w holds
 // valid[w] in 0..4 bytes (the ragged end of the rows): byte accesses, nothing past a row's end.
-template <int M, int T, int DR, int W>
+template <int M, int T, int DR, int W, bool CONT>
 __device__ __forceinline__ void sbl_words(const GF2P8& f, const Gf8SboxLayerArgs& a, const RngArgs& ra, const uint16_t* lg,
                                           const uint8_t* ex, const uint8_t* tbits, const uint8_t* tfold, size_t i, bool full,
-                                          const int (&valid)[W]) {
+                                          const int (&valid)[W], SblKeystream<DR>& stream, uint64_t step_ctr, uint32_t spare_word) {
     constexpr int K = 2 * T + 1;
-    constexpr int NWORDS_RNG = 11 * K * T * W;                // keystream words per thread
-    constexpr int NBLK = (NWORDS_RNG + 15) / 16;
+    constexpr int NWORDS_RNG = 11 * K * T * W;                // keystream words per step
     static_assert(DR % 2 == 0, "DR / 2 quarter rounds per keystream word");
+    static_assert(!CONT || NWORDS_RNG == 33, "continued keystream: two whole blocks + one spare word per step");
+    // CONT: the thread's keystream continues from step to step -- 32 words = two whole blocks from the stream, the 33rd
+    // from a spare block that serves 16 steps (spare_word).  Otherwise the step starts a stream of its own at step_ctr.
+    if (CONT) stream.step_begin();
+    else stream.begin(&ra.rk, step_ctr);
+    int ndraw = 0;
+    auto draw = [&]() -> uint32_t {
+        if (CONT && ndraw == 32) {
+            ++ndraw;
+            return spare_word;
+        }
+        ++ndraw;
+        return stream.next_word();
+    };
     // constant product lam * w (lam wave-uniform): Horner over the bits of lam, scalar branches
     auto cmul = [&](uint32_t lam, uint32_t w) -> uint32_t {
         GF2P8::acc acc;
@@ -688,8 +701,6 @@ __device__ __forceinline__ void sbl_words(const GF2P8& f, const Gf8SboxLayerArgs
                 rb[w][j][1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
             }
     }
-    SblKeystream<DR> stream;
-    stream.begin(&ra.rk, (uint64_t)i * NBLK);
     // one secure multiplication for all parties and all W words: o <- shares of u * v
     auto gate = [&](const uint32_t (&u)[W][M], const uint32_t (&v)[W][M], uint32_t (&o)[W][M]) {
         uint32_t P[W], C[W][T];
@@ -705,7 +716,7 @@ __device__ __forceinline__ void sbl_words(const GF2P8& f, const Gf8SboxLayerArgs
             for (int w = 0; w < W; ++w) {
                 P[w] ^= cmul(a.lam[s_], tabmul(u[w][s_], v[w][s_]));
 #pragma unroll
-                for (int q = 0; q < T; ++q) C[w][q] ^= cmul(a.lam[s_], stream.next_word() & f.emask);
+                for (int q = 0; q < T; ++q) C[w][q] ^= cmul(a.lam[s_], draw() & f.emask);
             }
         uint32_t res[W][M];
 #pragma unroll
@@ -778,6 +789,7 @@ template <int M, int T, int W>
 __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerArgs a, RngArgs ra, size_t nthreads_full,
                                                           int rest_bytes) {
     __shared__ uint32_t lds32[SBL_TABLE_BYTES / 4];
+    __shared__ uint32_t spare_lds[(T == 1 && W == 1) ? 16 * BLOCK : 1];      // the continued keystream's spare blocks
     for (int i = threadIdx.x; i < SBL_TABLE_BYTES / 4; i += BLOCK) lds32[i] = reinterpret_cast<const uint32_t*>(a.tables)[i];
     __syncthreads();
     const uint16_t* lg = reinterpret_cast<const uint16_t*>(lds32);
@@ -790,10 +802,53 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
     int all4[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) all4[w] = 4;
-    if (ra.rk.rounds == 20 && !a.burst) {
-        for (size_t i = gid; i < nthreads_full; i += gsz) sbl_words<M, T, 10, W>(f, a, ra, lg, ex, tbits, tfold, i, true, all4);
-    } else {
-        for (size_t i = gid; i < nthreads_full; i += gsz) sbl_words<M, T, 0, W>(f, a, ra, lg, ex, tbits, tfold, i, true, all4);
+    // ONE keystream per thread, continued from step to step (t = 1, one word per thread): 11 K T = 33 coefficient words per
+    // step do not fill whole 16-word blocks, and a thread that starts a fresh block for every step discards 15 of every
+    // 48 words -- 31 % of the layer's ChaCha work, which is ~90 % of its VALU instructions.  Here a step takes two whole
+    // blocks from the thread's stream (compile-time positions) and its 33rd word from a spare block that serves 16
+    // steps; the launcher caps the grid at the resident workgroups, so at 10^8 bytes a thread walks through ~95 steps
+    // on 2.06 blocks each.  Counters: thread g streams blocks [g * bpt, (g + 1) * bpt), its spare blocks are
+    // 2^62 + g * spt + (step / 16), the ragged end of the rows draws from 2^61.
+    constexpr bool CAN_CONT = (T == 1 && W == 1);
+    constexpr int NBLK = (11 * (2 * T + 1) * T * W + 15) / 16;
+    const uint64_t steps = (nthreads_full + gsz - 1) / gsz;
+    const uint64_t bpt = 2 * steps + 2, spt = steps / 16 + 1;
+    auto run = [&](auto dr_, auto cont_) {
+        constexpr int DRV = decltype(dr_)::value;
+        constexpr bool CONT = decltype(cont_)::value;
+        SblKeystream<DRV> stream;
+        if (CONT && gid < nthreads_full) stream.begin(&ra.rk, (uint64_t)gid * bpt);
+        uint64_t j = 0;
+        for (size_t i = gid; i < nthreads_full; i += gsz, ++j) {
+            uint32_t sw = 0;
+            if constexpr (CONT) {
+                // the spare block lives in LDS ([word][thread]: conflict-free), not in 16 registers: the kernel stays at
+                // four waves per SIMD
+                if ((j & 15) == 0) {
+                    const uint64_t c = (1ull << 62) + (uint64_t)gid * spt + (j >> 4);
+                    uint32_t blk[16];
+                    chacha_block(ra.rk.key, (uint32_t)c, (uint32_t)(c >> 32), ra.rk.nonce[0], ra.rk.nonce[1], (int)ra.rk.rounds, blk);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) spare_lds[q * BLOCK + threadIdx.x] = blk[q];
+                }
+                sw = spare_lds[(int)(j & 15) * BLOCK + threadIdx.x];
+            }
+            sbl_words<M, T, DRV, W, CONT>(f, a, ra, lg, ex, tbits, tfold, i, true, all4, stream, (uint64_t)i * NBLK, sw);
+        }
+    };
+    // (a thread with one or two steps gains nothing from the continued stream and would compute its spare block as a
+    // burst: 45.6 us against 38.5 us at 10^6 bytes, measured -- those launches take a fresh stream per step)
+    const bool cont = CAN_CONT && steps >= 4;
+    const bool dr10 = ra.rk.rounds == 20 && !a.burst;
+    if constexpr (CAN_CONT) {
+        if (cont) {
+            if (dr10) run(std::integral_constant<int, 10>(), std::true_type());
+            else run(std::integral_constant<int, 0>(), std::true_type());
+        }
+    }
+    if (!cont) {
+        if (dr10) run(std::integral_constant<int, 10>(), std::false_type());
+        else run(std::integral_constant<int, 0>(), std::false_type());
     }
     if (rest_bytes && gid == 0) {                                // the ragged end of every row
         int valid[W];
@@ -802,7 +857,8 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
             const int left = rest_bytes - 4 * w;
             valid[w] = left >= 4 ? 4 : (left > 0 ? left : 0);
         }
-        sbl_words<M, T, 0, W>(f, a, ra, lg, ex, tbits, tfold, nthreads_full, false, valid);
+        SblKeystream<0> stream;
+        sbl_words<M, T, 0, W, false>(f, a, ra, lg, ex, tbits, tfold, nthreads_full, false, valid, stream, 1ull << 61, 0u);
     }
     rng_state_release(ra);
 }
@@ -828,19 +884,24 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
         const char* e = getenv("FFGPU_SBL_BURST");
         burst = e ? atoi(e) : 0;
         e = getenv("FFGPU_SBL_WPT");
-        wpt = e ? atoi(e) : 2;
+        wpt = e ? atoi(e) : 1;
     }
     a.burst = burst;
     // two words (eight bytes) per thread for t = 1 and large n (five ChaCha blocks instead of six, twice the look-ups in
     // flight); t >= 2 keeps one word per thread (174 VGPRs at m = 7, t = 3 as it is)
     // (measured, profiles/r04_sbox_layer.md: two words per thread need >= 3 x 10^6 bytes to fill the SIMDs -- at 10^6 the
     // 1954 double-work waves take 45 us against 38 us for 3908 single-word waves; at 4 x 10^6: 28.3 against 31.4 us per 10^6)
-    const int W = (t == 1 && wpt == 2 && n >= 3000000) ? 2 : 1;
+    const int W = (t == 1 && wpt == 2) ? 2 : 1;                // (FFGPU_SBL_WPT=2: two words per thread, A/B only)
     const size_t nthreads_full = n / (4 * (size_t)W);
     const int rest_bytes = (int)(n - nthreads_full * 4 * W);
     size_t want = (nthreads_full + BLOCK - 1) / BLOCK;
     if (want < 1) want = 1;
-    if (want > 0x7fffffff) want = 0x7fffffff;
+    // persistent above one round of resident workgroups (4 per CU at t = 1, m <= 4: 119-128 VGPRs; 3 for m >= 5; 2-3 per CU
+    // for t >= 2): the threads of the t = 1 kernels then carry their keystream from step to step instead of discarding 15
+    // of every 48 words
+    LaunchCfg lc = launch_cfg(device);
+    const size_t resident = (size_t)(lc.num_cu > 0 ? lc.num_cu : 256) * (t == 1 ? (m <= 4 ? 4 : 3) : (t == 2 ? 3 : 2));
+    if (want > resident) want = resident;
     const unsigned grid = (unsigned)want;
     // (measured and NOT kept, round 4: letting up to 1024 workgroups advance the state themselves with a ticket drawn at
     // workgroup START -- the returning atomic sits in front of the wave's first loads in the in-order vmcnt queue, and 977
@@ -864,7 +925,6 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     SBL_CASE(7, 3)
 #undef SBL_CASE
 #undef SBL_LAUNCH
-    (void)device;
     return 2;
 }
 
