@@ -232,14 +232,14 @@ def annotate_valu(kern, n):
         data = json.load(fh)
     for row, info in data.items():
         r = kern.get(row)
-        if not isinstance(r, dict) or not r.get('ms_per_launch'):
+        if not isinstance(r, dict) or not r.get('ms_per_launch') or not r.get('units_per_s'):
             continue
         ops = float(info['valu_lane_ops_per_unit'])
         # rows that state their issue SLOTS (double-slot multiplies counted twice: mul_gf2_128) are priced on those
         slots = float(r.get('valu_issue_slots_per_unit', ops))
         # (the dense GF(2^n) recombination waits on its LDS look-ups as much as on the VALU: both are named)
         r.update(bound='lds+valu' if row.endswith('_dense') else 'valu', valu_lane_ops_per_unit=ops,
-                 valu_frac=round(max(slots, ops) * n / (r['ms_per_launch'] * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                 valu_frac=round(max(slots, ops) * r['units_per_s'] / VALU_PEAK_LANE_OPS, 4),
                  valu_source='profiles/r04_valu.md (SQ_INSTS_VALU x 64 / n)')
 
 
@@ -1214,9 +1214,16 @@ def main():
                 # (a) ONE kernel for the whole layer (ffgpu_gf256_sbox_layer): the parties' shares of four bytes travel
                 # through the 11 gates, the opening and the affine fold in registers.  HBM traffic 10 m = 30 B per secure
                 # byte; the kernel is bound by VALU work (ChaCha20 for 33 coefficient words + 33 GF(2^8) products per 4
-                # bytes, 808 lane-operations per secure byte measured, profiles/r03_sbox_layer.md), so both fractions are given
+                # bytes; lane-operations per secure byte measured, profiles/r04_valu.md), so both fractions are given
                 ms = time_launches(lambda s_: protocols.sbox_layer_all(ctx8, F8, xs, rbits, 1, A8, B8), [0], 5 if n8 < 10**8 else 2)
-                ops_per_byte = 808.0      # SQ_INSTS_VALU x 64 lanes / n, profiles/r03_sbox_layer.md
+                # SQ_INSTS_VALU x 64 lanes / n of this kernel at this size (profiles/r04_valu.json: 1005 at 10^6 -- a fresh,
+                # interleaved keystream per step -- and 773 at 10^8, continued keystream); 808 was the round-3 kernel
+                ops_per_byte = 808.0
+                try:
+                    with open(os.path.join(ROOT, 'profiles', 'r04_valu.json')) as fh_:
+                        ops_per_byte = float(json.load(fh_)[f'secure_sbox_layer_m3t1_{tag}']['valu_lane_ops_per_unit'])
+                except (OSError, KeyError, ValueError):
+                    pass
                 kern[f'secure_sbox_layer_m3t1_{tag}'] = dict(
                     roof(30 * n8, ms), algorithmic_bytes_per_unit=30, units_per_s=round(n8 / (ms * 1e-3), 1), kernels_per_layer=1,
                     bound='valu', valu_lane_ops_per_unit=ops_per_byte,
@@ -1369,7 +1376,7 @@ def main():
         full = args.layout == 'party-major'
         try:
             leg = multi_gpu_leg(dist, rank, world, local_rank, backend, n,
-                                args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else 2, lagrange)
+                                args.steps if full else max(2, min(args.steps, 10)), args.warmup if full else max(1, min(args.warmup, 2)), lagrange)
         except torch.OutOfMemoryError as exc:
             leg = {'error': f'OutOfMemoryError: {exc}'}
         except Exception as exc:          # noqa: BLE001 -- the other ranks may now be waiting in a collective: end here

@@ -838,8 +838,13 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
     };
     // (a thread with one or two steps gains nothing from the continued stream and would compute its spare block as a
     // burst: 45.6 us against 38.5 us at 10^6 bytes, measured -- those launches take a fresh stream per step)
+#if defined(SBL_PROBE_PATH)      // static instruction counts of ONE path (tools: hipcc -DSBL_PROBE_PATH=n -save-temps)
+    const bool cont = CAN_CONT && (SBL_PROBE_PATH & 1);
+    const bool dr10 = (SBL_PROBE_PATH & 2) != 0;
+#else
     const bool cont = CAN_CONT && steps >= 4;
     const bool dr10 = ra.rk.rounds == 20 && !a.burst;
+#endif
     if constexpr (CAN_CONT) {
         if (cont) {
             if (dr10) run(std::integral_constant<int, 10>(), std::true_type());

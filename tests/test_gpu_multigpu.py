@@ -84,13 +84,13 @@ def test_bench_eight_ranks_control_flow_on_one_gpu():
     """The command the driver runs for the scaling record, with the 8 ranks forced onto GPU 0 (gloo, since RCCL refuses
     two ranks on one device): self-launch under torch.distributed.run, headline + roofline before the first collective
     of the configs[3] section, the section itself on 8 ranks, one compact line that parses."""
-    line, detail = _bench_lines(['--gpus', '8', '--steps', '5', '--warmup', '2'],
+    line, detail = _bench_lines(['--gpus', '8', '--steps', '2', '--warmup', '1'],
                                 {'FFGPU_BENCH_DEVICE': '0', 'FFGPU_BENCH_LEG_TIMEOUT': '600'})
     assert line['n_gpus'] == 8 and line['distributed']['world_size'] == 8 and line['distributed']['backend'] == 'gloo'
     assert len(line['distributed']['ranks']) == 8 and line['distributed']['distinct_devices'] == 1
     assert all(r['pci_bus_id'] for r in line['distributed']['ranks'])
     assert line['config']['workload'].startswith('configs[1]') and line['config']['n_per_gpu'] == 10_000_000
-    assert line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 5
+    assert line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
     assert line['roofline']['bound'] == 'hbm' and 0 < line['roofline']['frac'] < 1
     assert 'cpu_baseline' not in line                      # rank 0 at N = 1 only
     assert 'error' not in line['multi_gpu'], line['multi_gpu']

@@ -67,6 +67,22 @@ for label, modulus, tail, ebg in (('gf2_64', (1 << 64) | 0x1b, (), 8), ('gf2_128
         plan = cb.recombine_plan([shb.row(j) for j in range(kk)], lamd, bufs[2])
         rows.append((f'recombine_{label}_k{kk}_dense', plan))
     keep.append((cb, bufs, shb))
+# ---- the one-kernel secure S-box layer (three parties, t = 1): per secure BYTE, 10^6 (fresh keystream per step) and 10^8 (continued)
+from mpyc_amd import protocols
+ctx8 = FieldContext(0x11b, binary=True, device=0)
+F8 = gff.GF(ggx.GFpX(2)(0x11b))
+r_ = [1, 0, 0, 0, 1, 1, 1, 1]
+rows8 = [sum(r_[(c_ - j_) % 8] << c_ for c_ in range(8)) for j_ in range(8)]
+A8 = [[(rows8[r] >> c) & 1 for c in range(8)] for r in range(8)]
+B8 = [(0x63 >> r) & 1 for r in range(8)]
+units = {}
+for tag, n8 in (('1e6', 10**6), ('1e8', 10**8)):
+    xs8 = ctx8.empty_matrix(3, n8); xs8.t[:, :n8].copy_(torch.randint(0, 256, (3, n8), dtype=torch.uint8, device='cuda:0', generator=gen))
+    rb8 = ctx8.empty_matrix(3, 8 * n8); rb8.t[:, :8 * n8].copy_(torch.randint(0, 2, (3, 8 * n8), dtype=torch.uint8, device='cuda:0', generator=gen))
+    st8 = ctx8.rng_state()
+    keep.append((xs8, rb8, st8))
+    rows.append((f'secure_sbox_layer_m3t1_{tag}', lambda xs8=xs8, rb8=rb8, st8=st8: protocols.sbox_layer_all(ctx8, F8, xs8, rb8, 1, A8, B8, rng=st8, fused=True)))
+    units[f'secure_sbox_layer_m3t1_{tag}'] = n8
 torch.cuda.synchronize()
 # ---- the measured sequence: a marker copy (k_copy16) opens every row
 order = []
@@ -78,5 +94,5 @@ for name, fn in rows:
 torch.cuda.synchronize()
 out = os.environ.get('VALU_ORDER', os.path.join(ROOT, 'gpurun_out', 'valu_order.json'))
 os.makedirs(os.path.dirname(out), exist_ok=True)
-json.dump({'n': n, 'launches_per_row': 3, 'rows': order}, open(out, 'w'))
+json.dump({'n': n, 'launches_per_row': 3, 'rows': order, 'units': units}, open(out, 'w'))
 print('valu probe done:', len(order), 'rows')

@@ -8,7 +8,8 @@ as well (one wave instruction occupies its SIMD for 4 cycles x 16 lanes)."""
 import collections, csv, json, re, sys
 
 rows = json.load(open(sys.argv[2]))
-n, per = rows['n'], rows['launches_per_row']
+n_default, per = rows['n'], rows['launches_per_row']
+units = rows.get('units', {})
 disp = collections.OrderedDict()          # dispatch id -> {name, counters}
 for r in csv.DictReader(open(sys.argv[1])):
     name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ffgpu::', '').replace('void ', '')
@@ -31,6 +32,7 @@ for name, g in zip(rows['rows'], groups):
         continue
     insts = sum(d.get('SQ_INSTS_VALU', 0.0) for d in main) / per
     kern = main[0]['name']
+    n = units.get(name, n_default)
     out[name] = {'kernel': kern, 'sq_insts_valu_per_launch': round(insts, 1), 'valu_lane_ops_per_unit': round(insts * 64 / n, 2),
                  'sq_waves': main[0].get('SQ_WAVES'), 'n': n}
     lines.append(f"| `{name}` | `{kern}` | {insts:.4g} | {insts * 64 / n:.1f} | {main[0].get('SQ_WAVES', 0):.0f} |")
