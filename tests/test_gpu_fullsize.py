@@ -101,3 +101,32 @@ def test_configs2_p64_m7_t3_vs_oracle_1e7(eng, threads):
 def test_configs3_p128_gate_m7_t3_vs_oracle_1e7(eng, threads):
     run_config(eng, threads, P128, N_FULL, 3, 7, 3001)
     torch.cuda.empty_cache()
+
+
+def test_round4_kernels_at_1e7(eng, threads):
+    """The kernels that changed in round 4, at n = 10^7: the bit-sliced GF(2^64) product element by element against the C
+    oracle (gfpx.py:988-1045 restated), and the full-batch inverse over 2^61 - 1 and 2^64 - 189 (finfields.py:1416-1422):
+    a * a^-1 == 1 on every non-zero element (the product kernel is itself checked against the oracle above), zeros give
+    zero, a sample against Python's pow."""
+    co = threads
+    mod = (1 << 64) | 0x1b
+    F = po.Field(mod, True)
+    ctx = eng.FieldContext(mod, True, device=0)
+    A, B = rand_np(F, 8, N_FULL, 401), rand_np(F, 8, N_FULL, 402)
+    got = ctx.mul(ctx.from_numpy(A), ctx.from_numpy(B)).to_numpy()
+    want = co.CField(mod, True).ew(co.MUL, A, B)
+    assert (got == want).all(), int(np.argmin(got == want))
+    for p in (2**61 - 1, P64):
+        Fp = po.Field(p)
+        cp = eng.FieldContext(p, device=0)
+        X = rand_np(Fp, 8, N_FULL, 403)
+        X[[0, 7, N_FULL // 3, N_FULL - 1]] = 0
+        dX = cp.from_numpy(X)
+        inv = cp.inv(dX, check_zero=False)
+        nz = dX.t != 0
+        assert bool((cp.mul(dX, inv).t[nz] == 1).all()) and bool((inv.t[~nz] == 0).all()), hex(p)
+        gi = inv.to_numpy()
+        for i in (1, 2, 3, 12345, N_FULL // 2, N_FULL - 2):
+            assert int(gi[i]) == pow(int(X[i]), p - 2, p), (hex(p), i)
+        with pytest.raises(ZeroDivisionError):
+            cp.inv(dX)
