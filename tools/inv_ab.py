@@ -7,10 +7,10 @@ from mpyc_amd.engine import FieldContext, DevArray
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(3)
 p = 2**61 - 1
 ctx = FieldContext(p, device=0)
-names = {0: 'round-3 kernel (CH 8/10 by rounds, window table)', 1: 'CH10 G2 win3 waves1 windows', 2: 'CH10 G2 win3 waves3 lean',
-         3: 'CH8 G2 win3 waves3 lean', 4: 'CH8 G2 win3 waves1 windows', 5: 'CH6 G2 win3 waves4 lean', 6: 'CH12 G2 win3 waves3 lean',
-         7: 'CH10 G2 win3 waves2 lean', 8: 'CH8 G2 win6 waves3 lean', 9: 'CH6 G2 win3 waves3 windows', 10: 'CH7 G2 win3 waves3 lean',
-         11: 'CH9 G2 win3 waves3 lean', 12: 'CH16 G1 win3 waves3 lean'}
+# (the thirteen shapes of profiles/r04_alu.md were instantiations of k_inv_fast selected by this variable while the round-4
+# kernel was chosen; the library keeps the winner -- CH 8, G 2, window 6, three waves, lean exponentiation -- and variant 0)
+names = {1: 'k_inv_fast (round 4: CH8 G2 win6 waves3, lean exponentiation when the exponent allows it)',
+         0: 'k_inv_batch (round 3: CH 8/10 by rounds, window table)'}
 variants = [int(v) for v in os.environ.get('INV_VARIANTS', ','.join(str(k) for k in names)).split(',')]
 for n in (10_000_000, 10_000_000 + 7, 4_000_003):
     sets = [(DevArray(ctx, bench.uniform_field(gen, n, p, 'cuda:0'), n), ctx.empty(n)) for _ in range(3)]
