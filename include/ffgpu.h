@@ -392,10 +392,15 @@ int ffgpu_gf256_bits_affine_fold(ffgpu_ctx* ctx, const uint64_t* host_matrix, co
  * shares and np_from_bits.  Everything is element-wise, so a thread carries the m shares of four bytes through the
  * whole protocol in registers: 10 m bytes of HBM traffic per secure byte instead of the 269 of the per-step kernels.
  * x / out: m rows of n bytes (row strides in bytes, multiples of 4); rbits: m rows of 8 n bit shares (stride a
- * multiple of 16).  GF(2^8) only; (m, t) in {(3,1), (4,1), (5,1), (5,2), (7,2), (7,3)}, n a multiple of 4 --
- * FFGPU_ENOTSUP otherwise (compose the layer from ffgpu_gate_rng_batch / ffgpu_gf256_mask_open /
- * ffgpu_gf256_bits_affine_fold then).  Randomness: as ffgpu_gate_rng_batch (host key + nonce + rounds, or dev_state
- * with `nonce` as offset and defer_advance).  Scalars: canonical 2-limb host scalars.                              */
+ * multiple of 16).  GF(2^8) only; any n (the n % 4 bytes after the last whole word of each row are handled with byte
+ * accesses), every (m, t) with 2t+1 <= m <= 7, t <= 3 that the reference's defaults and t = 1 produce: (3,1), (4,1),
+ * (5,1), (5,2), (6,1), (6,2), (7,1), (7,2), (7,3) -- FFGPU_ENOTSUP otherwise, and for unaligned rows (compose the
+ * layer from ffgpu_gate_rng_batch / ffgpu_gf256_mask_open / ffgpu_gf256_bits_affine_fold then).  Randomness: as
+ * ffgpu_gate_rng_batch (host key + nonce + rounds, or dev_state with `nonce` as offset and defer_advance; with
+ * defer_advance = 0 the launch advances the device-resident nonce itself).  For t = 1 and more than three words per
+ * thread of the (capped) grid, a thread's keystream continues from word to word: the coefficient a given position
+ * receives then depends on n and on the number of compute units -- as with every device-CSPRNG entry point, the
+ * randomness is not part of the parity contract (the opened values are).  Scalars: canonical 2-limb host scalars.  */
 int ffgpu_gf256_sbox_layer(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, const uint64_t* host_lambda,
                            const uint64_t* host_mu, int t, int m, const void* x, size_t x_stride, const void* rbits,
                            size_t rbits_stride, void* out, size_t out_stride, size_t n, const uint8_t* host_key32, uint64_t nonce,
