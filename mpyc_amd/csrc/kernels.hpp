@@ -3286,7 +3286,9 @@ struct Launchers {
             // kernel (A/B measurements).
             const char* e = getenv("FFGPU_INV_VARIANT");
             const int variant = e ? atoi(e) : 1;
-            if (variant > 0 && nvec >= (size_t)BLOCK * 64) {
+            // (prime fields only: the GF(2^n) product has run-time loops, its prefix array lives in scratch memory either way,
+            // and the round-3 kernel needs less of it -- 272-336 B against 528-624 B per thread)
+            if (variant > 0 && !F::BINARY && nvec >= (size_t)BLOCK * 64) {
                 if (pow_lean_ok(*ex)) return launch_inv_fast<8, 2, 6, 3, true>(f, a, ex, out, nvec, n, flag, st);
                 return launch_inv_fast<8, 2, 3, 1, false>(f, a, ex, out, nvec, n, flag, st);
             }

@@ -373,7 +373,8 @@ def test_wide_binary_products_all_degrees(eng, coracle):
 
 @pytest.mark.parametrize('modulus', [(1 << 64) | 0x1b, (1 << 40) | 0x39, (1 << 63) | 0x3])
 def test_batched_inverse_full_batch_kernel_binary(eng, modulus, monkeypatch):
-    """The same kernel over GF(2^n), 33 <= n <= 64 (one-word elements): q - 2 = 2^n - 3 is a run of ones and '01'."""
+    """Large arrays over GF(2^n), 33 <= n <= 64 (one-word elements, q - 2 = 2^n - 3): these keep the round-3 kernel
+    (k_inv_batch; the full-batch kernel is for prime fields) -- inverse property, zeros, a sample against the oracle."""
     from mpyc_amd.gfpx import BinaryPolynomial
     if not BinaryPolynomial.is_irreducible(modulus):
         modulus = int(BinaryPolynomial.next_irreducible(modulus))
