@@ -7,6 +7,7 @@
 //   * the streaming copy used as the achievable-HBM-bandwidth yardstick.
 #include <stdlib.h>
 #include "kernels.hpp"
+#include "bitslice.hpp"
 
 using namespace ffgpu;
 
@@ -957,73 +958,8 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
 // the current slab is multiplied (455 registers in all).  64 us against 83 us at n = 10^7 (0.47 against 0.36 of the HBM
 // peak; tools/bitslice_probe.hip is the stand-alone probe with the variants that were measured, profiles/r04_gf2w.md).
 // The same layout for GF(2^128) needs 256 + 255 planes per lane: it does not fit any register budget (ibid.).
-namespace bs64 {
-__device__ __forceinline__ uint32_t mac(uint32_t acc, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(acc, a, b, 0x78); }
-template <int S>
-__device__ __forceinline__ void tr_stage(uint32_t (&A)[32]) {
-    constexpr uint32_t M = S == 4 ? 0x0f0f0f0fu : S == 2 ? 0x33333333u : 0x55555555u;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        if (k & S) continue;
-        const uint32_t x = A[k], y = A[k + S];
-        if constexpr (S == 16) {
-            A[k] = __builtin_amdgcn_perm(y, x, 0x05040100u);          // lo16(x) | lo16(y) << 16
-            A[k + S] = __builtin_amdgcn_perm(y, x, 0x07060302u);      // hi16(x) | hi16(y) << 16
-        } else if constexpr (S == 8) {
-            A[k] = __builtin_amdgcn_perm(y, x, 0x06020400u);          // bytes x0, y0, x2, y2
-            A[k + S] = __builtin_amdgcn_perm(y, x, 0x07030501u);      // bytes x1, y1, x3, y3
-        } else {
-            A[k] = ff_bsel(M, x, y << S);
-            A[k + S] = ff_bsel(M, x >> S, y);
-        }
-    }
-}
-// 32 x 32 bit-matrix transpose in registers: out word i, bit e = in word e, bit i
-__device__ __forceinline__ void transpose32(uint32_t (&A)[32]) {
-    tr_stage<16>(A); tr_stage<8>(A); tr_stage<4>(A); tr_stage<2>(A); tr_stage<1>(A);
-}
-// c (2N - 1 planes) = a (N planes) x b (N planes) over GF(2)[x]
-template <int N>
-struct Mul {
-    static __device__ __forceinline__ void run(const uint32_t* a, const uint32_t* b, uint32_t* c) {
-        constexpr int H = N / 2;
-        uint32_t z0[N - 1], z2[N - 1], zm[N - 1], am[H], bm[H];
-        Mul<H>::run(a, b, z0);
-        Mul<H>::run(a + H, b + H, z2);
-#pragma unroll
-        for (int i = 0; i < H; ++i) { am[i] = a[i] ^ a[i + H]; bm[i] = b[i] ^ b[i + H]; }
-        Mul<H>::run(am, bm, zm);
-#pragma unroll
-        for (int k = 0; k < 2 * N - 1; ++k) {
-            uint32_t v = k < N - 1 ? z0[k] : (k >= N ? z2[k - N] : 0u);
-            const int q = k - H;
-            if (q >= 0 && q < N - 1) {
-                const uint32_t mid = ff_xor3(zm[q], z0[q], z2[q]);
-                v = (k == N - 1) ? mid : (v ^ mid);
-            }
-            c[k] = v;
-        }
-    }
-};
-template <>
-struct Mul<8> {
-    static __device__ __forceinline__ void run(const uint32_t* a, const uint32_t* b, uint32_t* c) {
-#pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            uint32_t acc = 0;
-            bool first = true;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = k - i;
-                if (j < 0 || j > 7) continue;
-                acc = first ? (a[i] & b[j]) : mac(acc, a[i], b[j]);
-                first = false;
-            }
-            c[k] = acc;
-        }
-    }
-};
-}  // namespace bs64
+// (namespace bs64 -- transposes, Karatsuba on bit-planes, the fold -- lives in bitslice.hpp: the same header compiles
+// with g++ for tests/test_hostcheck.py)
 
 // a slab = 2048 consecutive elements = 1024 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
 // (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..15.  The last slab may be partial: its
@@ -1075,11 +1011,7 @@ void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict
         if (wave + nwaves < nslab) bs64_load(a, b, wave + nwaves, lane, nvec4, na, nb);     // in flight during the product below
         uint32_t c[127];
         bs64::Mul<64>::run(pa, pb, c);
-#pragma unroll
-        for (int k = 126; k >= 64; --k) {                 // x^64 = x^4 + x^3 + x + 1
-            const uint32_t h = c[k];
-            c[k - 64] ^= h; c[k - 63] ^= h; c[k - 61] ^= h; c[k - 60] ^= h;
-        }
+        bs64::fold_1b(c);                                 // x^64 = x^4 + x^3 + x + 1
         uint32_t lo[32], hi[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) { lo[i] = c[i]; hi[i] = c[32 + i]; }

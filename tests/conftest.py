@@ -31,7 +31,7 @@ def hostcheck():
     dst = os.path.join(ROOT, 'tests', '_hostcheck.so')
     deps = [src, os.path.join(ROOT, 'mpyc_amd', 'csrc', 'fields.hpp'),
             os.path.join(ROOT, "mpyc_amd", "csrc", "policy_build.hpp"),
-            os.path.join(ROOT, "mpyc_amd", "csrc", "rng.hpp")]
+            os.path.join(ROOT, "mpyc_amd", "csrc", "rng.hpp"), os.path.join(ROOT, "mpyc_amd", "csrc", "bitslice.hpp")]
     if any(_newer(d, dst) for d in deps):
         subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-o', dst, src], check=True)
     return ctypes.CDLL(dst)

@@ -8,6 +8,7 @@
 #include <type_traits>
 #include "../mpyc_amd/csrc/policy_build.hpp"
 #include "../mpyc_amd/csrc/rng.hpp"
+#include "../mpyc_amd/csrc/bitslice.hpp"
 
 using namespace ffgpu;
 
@@ -279,3 +280,24 @@ extern "C" int hc_limb_digits_wide(const uint64_t* x2, const uint64_t* p2, int L
     return 0;
 }
 
+
+// the bit-sliced GF(2^64) product of k_gf2w64_mul_bitsliced on 32 elements (bitslice.hpp: transposes, Karatsuba on
+// bit-planes, fold modulo x^64 + x^4 + x^3 + x + 1, transposes back); a, b, out: 32 uint64 each
+extern "C" int hc_bs64_mul32(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    uint32_t alo[32], ahi[32], blo[32], bhi[32], olo[32], ohi[32];
+    for (int e = 0; e < 32; ++e) {
+        alo[e] = (uint32_t)a[e]; ahi[e] = (uint32_t)(a[e] >> 32);
+        blo[e] = (uint32_t)b[e]; bhi[e] = (uint32_t)(b[e] >> 32);
+    }
+    bs64::mul32(alo, ahi, blo, bhi, olo, ohi);
+    for (int e = 0; e < 32; ++e) out[e] = (uint64_t)olo[e] | ((uint64_t)ohi[e] << 32);
+    return 0;
+}
+// one 32 x 32 bit transpose (out word i, bit e = in word e, bit i)
+extern "C" int hc_bs64_transpose32(const uint32_t* in, uint32_t* out) {
+    uint32_t A[32];
+    for (int i = 0; i < 32; ++i) A[i] = in[i];
+    bs64::transpose32(A);
+    for (int i = 0; i < 32; ++i) out[i] = A[i];
+    return 0;
+}

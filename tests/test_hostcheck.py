@@ -422,3 +422,32 @@ def test_pm64_general_policy_all_widths(hostcheck):
             lam = [rng.randrange(p) for _ in range(7)]
             got, _ = run(hostcheck, F, HC_DOT, [v for row in rows for v in row], lam=lam, k=7, n=64)
             assert got == [sum(l * rows[j][i] for j, l in enumerate(lam)) % p for i in range(64)], (k, c)
+
+
+def test_bitsliced_gf2_64_product(hostcheck):
+    """mpyc_amd/csrc/bitslice.hpp (the arithmetic of k_gf2w64_mul_bitsliced) compiled for the host: the 32 x 32 bit
+    transpose against its definition, and the product of 32 elements at a time -- transposes in, Karatsuba on 64 bit-planes
+    down to 8 x 8 leaves, fold modulo x^64 + x^4 + x^3 + x + 1, transposes out -- against the oracle's GF(2^64) product
+    (gfpx.py:988-1045 restated) for random and extreme operands."""
+    import random
+    from oracle import pyoracle as po
+    rng = random.Random(64)
+    for _ in range(5):
+        words = [rng.getrandbits(32) for _ in range(32)]
+        out = (ctypes.c_uint32 * 32)()
+        assert hostcheck.hc_bs64_transpose32((ctypes.c_uint32 * 32)(*words), out) == 0
+        assert list(out) == [sum(((words[e] >> i) & 1) << e for e in range(32)) for i in range(32)]
+    F = po.Field((1 << 64) | 0x1b, True)
+    full = (1 << 64) - 1
+    extreme = [0, 1, 2, 3, full, full - 1, 1 << 63, (1 << 63) | 1, 0x1b, 1 << 32, (1 << 32) - 1, 0x8000000080000000, 0x5555555555555555,
+               0xAAAAAAAAAAAAAAAA, 7 << 61, 0xFFFFFFFF00000000]
+    for rnd in range(20):
+        a = [rng.getrandbits(64) for _ in range(32)]
+        b = [rng.getrandbits(64) for _ in range(32)]
+        if rnd < 4:
+            a[:16] = extreme
+            b[:16] = extreme[::-1] if rnd % 2 else extreme
+            b[16:32] = extreme[rnd:] + extreme[:rnd]
+        out = (ctypes.c_uint64 * 32)()
+        assert hostcheck.hc_bs64_mul32((ctypes.c_uint64 * 32)(*a), (ctypes.c_uint64 * 32)(*b), out) == 0
+        assert list(out) == [po.mul(F, x, y) for x, y in zip(a, b)], rnd
