@@ -893,11 +893,11 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
         wpt = e ? atoi(e) : 1;
     }
     a.burst = burst;
-    // two words (eight bytes) per thread for t = 1 and large n (five ChaCha blocks instead of six, twice the look-ups in
-    // flight); t >= 2 keeps one word per thread (174 VGPRs at m = 7, t = 3 as it is)
-    // (measured, profiles/r04_sbox_layer.md: two words per thread need >= 3 x 10^6 bytes to fill the SIMDs -- at 10^6 the
-    // 1954 double-work waves take 45 us against 38 us for 3908 single-word waves; at 4 x 10^6: 28.3 against 31.4 us per 10^6)
-    const int W = (t == 1 && wpt == 2) ? 2 : 1;                // (FFGPU_SBL_WPT=2: two words per thread, A/B only)
+    // One word (four bytes) per thread.  FFGPU_SBL_WPT=2 (A/B only, t = 1): two words per thread sharing a keystream -- five
+    // ChaCha blocks for eight bytes instead of six and twice the look-ups in flight, but 131 VGPRs and half the waves: 45 us
+    // against 38 us at 10^6 bytes, 28.3 against 31.4 us per 10^6 at 4 x 10^6 (profiles/r04_sbox_layer.md); the continued
+    // keystream below gets the same saving and more without the registers.
+    const int W = (t == 1 && wpt == 2) ? 2 : 1;
     const size_t nthreads_full = n / (4 * (size_t)W);
     const int rest_bytes = (int)(n - nthreads_full * 4 * W);
     size_t want = (nthreads_full + BLOCK - 1) / BLOCK;
