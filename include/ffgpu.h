@@ -351,6 +351,22 @@ void ffgpu_shake128_close(void* handle);
 int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, int d, int l, int mask_bits,
                        const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream);
 
+/* PRODUCTION mode of the same combination: the draws come from a COUNTER-MODE PRF expanded on the device instead of the
+ * reference's SHAKE128 stream (a sponge is sequential per key: in parity mode the host squeezes and the device idles).
+ * host_keys: ks x 40 bytes, per subset key the 32-byte ChaCha key followed by the 8-byte nonce, both derived by the caller
+ * from (PRF key, common input) -- the mirror uses shake_128(b"mpyc_amd prss chacha v1\0" + len(key) + key + input).digest(40).
+ * A draw is l little-endian KEYSTREAM bytes reduced into range(bound) by the reference's own rule (`% bound`,
+ * l = byte_length + len(key), thresha.py:234-236, or a mask for bound = 2^mask_bits), so a draw depends on (key, input,
+ * index, bound) only -- not on the field (runtime.py:758-761 evaluates one set of PRFs over two fields).  rounds: 20, 12 or 8.
+ * Layout of the keystream: ffgpu_prss_chacha_layout (tb blocks per tile of dpt draws, ceil(l/4) words per draw; draw j of
+ * element h sits in tile h / dpt, slot h % dpt, block counters (tile * d + j) * tb + b).  Every party must use the same
+ * mode; there is no reference counterpart for the PRF itself (pinned to RFC 8439 and to oracle/fforacle.c
+ * orc_prss_chacha, not to reference outputs), the combination is the reference's.  ks <= 32, ks * d <= 64 per call.
+ * replaces: thresha.py:163-173, 201-217 (np_pseudorandom_share, np_pseudorandom_share_0) with PRF := ChaCha.      */
+int ffgpu_prss_chacha(ffgpu_ctx* ctx, const uint8_t* host_keys, int ks, int d, int l, int mask_bits, int rounds,
+                      const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream);
+int ffgpu_prss_chacha_layout(int l, int* tb, int* dpt);
+
 /* ---- GF(2^8) S-box layer (local / public values) ----------------------- */
 /* GF(2^n<=8), the linear layer of the AES S-box on BIT SHARES: for every group of 8 elements (the shares of the
  * 8 bits of one byte, 8-byte aligned): y = M x + bias with a public 8x8 matrix M (row-major canonical scalars);

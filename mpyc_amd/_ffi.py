@@ -87,6 +87,8 @@ _SIGS = {
     'ffgpu_shake128_squeeze': [_vp, ctypes.POINTER(ctypes.c_void_p), _sz, _int],
     'ffgpu_shake128_close': [_vp],
     'ffgpu_prss_combine': [_vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _u64p, _int, _vp, _sz, _vp],
+    'ffgpu_prss_chacha': [_vp, ctypes.POINTER(ctypes.c_uint8), _int, _int, _int, _int, _int, _u64p, _int, _vp, _sz, _vp],
+    'ffgpu_prss_chacha_layout': [_int, ctypes.POINTER(_int), ctypes.POINTER(_int)],
     'ffgpu_gf256_bit_affine': [_vp, _u64p, _u64p, _int, _vp, _vp, _sz, _vp],
     'ffgpu_gf256_to_bits': [_vp, _vp, _vp, _vp, _sz, _vp],
     'ffgpu_gf256_mask_open': [_vp, ctypes.POINTER(_vp), _u64p, _int, ctypes.POINTER(_vp), _u64p, _int, _vp, _sz, _vp],

@@ -1093,6 +1093,25 @@ int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, 
                                         r2, accumulate, out, n, (hipStream_t)stream));
 }
 
+int ffgpu_prss_chacha(ffgpu_ctx* ctx, const uint8_t* host_keys, int ks, int d, int l, int mask_bits, int rounds,
+                      const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream) {
+    ARGCHK(ctx);
+    ARGCHK(ks >= 1 && d >= 1 && l >= 1 && l <= 64 && mask_bits >= 0 && mask_bits <= 192);
+    ARGCHK(rounds == 20 || rounds == 12 || rounds == 8);
+    if (n == 0) return FFGPU_OK;
+    ARGCHK(host_keys && host_weights && out);
+    uint64_t r2[2] = {ctx->rng_r[0], ctx->rng_r[1]};
+    DeviceGuard g(ctx->device);
+    LaunchTimer lt(ctx, (hipStream_t)stream);
+    return launch_status(ctx->ops->prss_chacha(ctx->policy, ctx->device, host_keys, ks, d, l, mask_bits, rounds, host_weights,
+                                               r2, accumulate, out, n, (hipStream_t)stream));
+}
+int ffgpu_prss_chacha_layout(int l, int* tb, int* dpt) {
+    ARGCHK(l >= 1 && l <= 64 && tb && dpt);
+    ffgpu::prss_cc_layout(l, tb, dpt);
+    return FFGPU_OK;
+}
+
 int ffgpu_gf256_to_bits(ffgpu_ctx* ctx, const void* in, const void* addend, void* out, size_t n, void* stream) {
     ARGCHK(ctx);
     if (ctx->kind != FFGPU_BINARY || ctx->elem_bytes != 1) return FFGPU_ENOTSUP;

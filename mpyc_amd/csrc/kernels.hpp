@@ -1388,6 +1388,143 @@ __global__ __launch_bounds__(BLOCK) void k_prss(F f, PrssArgs<F> pa, typename F:
 }
 
 
+// ---- PRSS with a COUNTER-MODE PRF (production mode; thresha.py:163-173, 201-217 with PRF := ChaCha) ----------------
+// The reference's PRF is one SHAKE128 stream per subset key (thresha.py:238-266): sequential by construction, so in
+// parity mode (k_prss above) the host squeezes it and the device idles.  Here every subset key has a ChaCha stream
+// (RFC 8439 block function; 256-bit key + 64-bit nonce derived on the host from (PRF key, common input)), addressed by
+// block counter, so each lane expands the draws of its own elements.  Sampling rule = the reference's: a draw is l
+// little-endian keystream bytes, taken `% bound` (l = byte_length + len(key) for a bound that is not a power of two,
+// thresha.py:234-236) or masked for a power-of-two bound -- the value depends on (key, input, index, bound) only, never on
+// the field, like the reference's (runtime.py:758-761 evaluates the same PRFs over two fields).
+// Public layout (restated in oracle/fforacle.c, oracle/pyoracle.py): LW = ceil(l / 4) keystream words per draw; a TILE
+// is TB consecutive blocks holding DPT = min(8, 16 TB / LW) draws, TB in {1,2,3} chosen to waste the least keystream
+// (prss_cc_layout).  Draw j of element h (j < d) of a stream: tile = h / DPT, slot = h % DPT, block counters
+// (tile * d + j) * TB + b for b < TB, words [slot * LW, slot * LW + LW) of those 16 TB words.
+// out[h] (+)= sum_s sum_j W[s][j] * draw_s(h, j).
+enum { PRSS_CC_MAXS = 32, PRSS_CC_MAXW = 64, PRSS_CC_MAXDPT = 8, PRSS_CC_MAXTB = 3 };
+inline void prss_cc_layout(int l, int* tb, int* dpt) {
+    const int lw = (l + 3) / 4;
+    int best_tb = 1, best_dpt = 16 / lw < PRSS_CC_MAXDPT ? 16 / lw : PRSS_CC_MAXDPT;
+    for (int t = 2; t <= PRSS_CC_MAXTB; ++t) {
+        int dp = 16 * t / lw < PRSS_CC_MAXDPT ? 16 * t / lw : PRSS_CC_MAXDPT;
+        if (dp * best_tb > best_dpt * t) { best_tb = t; best_dpt = dp; }     // more draws per block: less waste
+    }
+    *tb = best_tb;
+    *dpt = best_dpt;
+}
+template <class F>
+struct PrssCcArgs {
+    uint32_t key[PRSS_CC_MAXS][8];
+    uint32_t nonce[PRSS_CC_MAXS][2];
+    typename F::word w[PRSS_CC_MAXW];   // (ks, d) prepared weights
+    uint64_t r0, r1;                    // 2^(limb bits) mod p
+    int ks, d, l, mask_bits, accumulate, rounds, tb, dpt;
+};
+
+// draw = the l bytes starting at keystream word w0 of this thread's LDS column (word q at col[q * BLOCK]) -> field element
+template <class F>
+__device__ __forceinline__ typename F::word prss_draw_words(const F& f, const PrssCcArgs<F>& pa, const uint32_t* col, int w0) {
+    typedef typename F::word W;
+    constexpr int LWD = F::EPW > 1 ? 1 : (int)sizeof(W) / 4;      // keystream words per limb
+    const int l = pa.l;
+    const int lw = (l + 3) >> 2;
+    const uint32_t lastmask = (l & 3) ? ((1u << (8 * (l & 3))) - 1u) : 0xffffffffu;
+    auto word32 = [&](int k) -> uint32_t {                          // k-th word of the draw; zero beyond its l bytes
+        uint32_t v = k < lw ? col[(size_t)(w0 + k) * BLOCK] : 0u;
+        return k == lw - 1 ? (v & lastmask) : v;
+    };
+    auto word64 = [&](int k) -> uint64_t { return (uint64_t)word32(k) | ((uint64_t)word32(k + 1) << 32); };
+    auto limb = [&](int wk) -> W {
+        if constexpr (sizeof(W) == 24) {
+            W w;
+            w.lo = word64(wk);
+            w.mid = word64(wk + 2);
+            w.hi = word64(wk + 4);
+            return w;
+        } else if constexpr (sizeof(W) == 16) {
+            W w;
+            w.lo = word64(wk);
+            w.hi = word64(wk + 2);
+            return w;
+        } else if constexpr (sizeof(W) == 8) {
+            return (W)word64(wk);
+        } else {
+            return (W)word32(wk);
+        }
+    };
+    if (pa.mask_bits > 0 || lw <= LWD) {
+        W v = limb(0);
+        if (pa.mask_bits > 0) {
+            const int mb = pa.mask_bits;
+            if constexpr (sizeof(W) == 24) {
+                if (mb < 64) { v.lo &= (1ull << mb) - 1; v.mid = v.hi = 0; }
+                else if (mb < 128) { v.mid &= (1ull << (mb - 64)) - 1; v.hi = 0; }
+                else if (mb < 192) v.hi &= (1ull << (mb - 128)) - 1;
+            } else if constexpr (sizeof(W) == 16) {
+                if (mb < 64) { v.lo &= (1ull << mb) - 1; v.hi = 0; }
+                else if (mb < 128) v.hi &= (1ull << (mb - 64)) - 1;
+            } else {
+                if (mb < 8 * (int)sizeof(W)) v = (W)((uint64_t)v & ((1ull << mb) - 1));
+            }
+            return v;            // < bound <= order: canonical
+        }
+        return f.reduce_raw(v);
+    }
+    W R;
+    if constexpr (sizeof(W) == 24) {
+        W t96;
+        t96.lo = 0;
+        t96.mid = 1ull << 32;
+        t96.hi = 0;
+        t96 = f.reduce_raw(t96);
+        R = f.mul(t96, t96);
+    } else if constexpr (sizeof(W) == 16) { R.lo = pa.r0; R.hi = pa.r1; } else { R = (W)pa.r0; }
+    const int topw = (lw - 1) / LWD * LWD;
+    W r = f.reduce_raw(limb(topw));
+    for (int wk = topw - LWD; wk >= 0; wk -= LWD) r = f.add(f.mul(r, R), f.reduce_raw(limb(wk)));
+    return r;
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_prss_chacha(F f, PrssCcArgs<F> pa, typename F::elem* __restrict__ out, size_t n) {
+    typedef typename F::word W;
+    // the keystream of a tile goes through LDS because LW is a run-time value: a draw's words sit at run-time (wave-uniform)
+    // offsets; one column per thread (word q of thread t at [q * BLOCK + t]: conflict-free), no barrier anywhere
+    __shared__ uint32_t ksm[PRSS_CC_MAXTB * 16 * BLOCK];
+    uint32_t* col = ksm + threadIdx.x;
+    const size_t tile = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t h0 = tile * (size_t)pa.dpt;
+    if (h0 >= n) return;
+    const int lw = (pa.l + 3) >> 2;
+    typename F::acc acc[PRSS_CC_MAXDPT];
+#pragma unroll
+    for (int i = 0; i < PRSS_CC_MAXDPT; ++i) f.acc_zero(acc[i]);
+    for (int s = 0; s < pa.ks; ++s) {
+        for (int j = 0; j < pa.d; ++j) {
+            const uint64_t c0 = ((uint64_t)tile * (uint64_t)pa.d + (uint64_t)j) * (uint64_t)pa.tb;
+            for (int b = 0; b < pa.tb; ++b) {
+                uint32_t blk[16];
+                const uint64_t ctr = c0 + (uint64_t)b;
+                chacha_block(pa.key[s], (uint32_t)ctr, (uint32_t)(ctr >> 32), pa.nonce[s][0], pa.nonce[s][1], pa.rounds, blk);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) col[(size_t)(b * 16 + q) * BLOCK] = blk[q];
+            }
+            const W wt = pa.w[s * pa.d + j];
+#pragma unroll
+            for (int i = 0; i < PRSS_CC_MAXDPT; ++i)
+                if (i < pa.dpt) f.acc_mac(acc[i], wt, prss_draw_words(f, pa, col, i * lw));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PRSS_CC_MAXDPT; ++i)
+        if (i < pa.dpt && h0 + (size_t)i < n) {
+            W r = f.acc_reduce(acc[i]);
+            if (pa.accumulate) r = f.add(r, ld_elem<F>(out, h0 + (size_t)i));
+            st_elem<F>(out, h0 + (size_t)i, r);
+        }
+}
+
+
 // ---- dense matrix product C = A @ B over the field (finfields.py:1126-1135, runtime.py:2531) -----
 // Classic LDS-tiled product, but the inner operation is the field's lazily reduced multiply-
 // accumulate (acc_mac: 128/256-bit products summed unreduced, one reduction per FLUSH products), so
@@ -2872,6 +3009,9 @@ struct FieldOps {
                   void* out, int add_de, size_t n, hipStream_t st);
     int (*prss)(const void* F, int device, const void* const* streams, int ks, int d, int l, int mask_bits,
                 const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
+    // keys40: ks x (32-byte ChaCha key + 8-byte nonce)
+    int (*prss_chacha)(const void* F, int device, const uint8_t* keys40, int ks, int d, int l, int mask_bits, int rounds,
+                       const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st);
 };
 
 // Host scalars (Lagrange coefficients, constants, matrix entries) cross the C ABI as little-endian 64-bit limbs:
@@ -3752,8 +3892,30 @@ struct Launchers {
         return 0;
     }
 
+    static int prss_chacha(const void* Fp, int device, const uint8_t* keys40, int ks, int d, int l, int mask_bits, int rounds,
+                           const uint64_t* weights2, const uint64_t* r2, int accumulate, void* out, size_t n, hipStream_t st) {
+        const F& f = *reinterpret_cast<const F*>(Fp);
+        if (ks < 1 || d < 1 || l < 1 || l > 64 || ks > PRSS_CC_MAXS || ks * d > PRSS_CC_MAXW) return 2;
+        PrssCcArgs<F> pa;
+        memset(&pa, 0, sizeof(pa));
+        for (int s = 0; s < ks; ++s) {
+            memcpy(pa.key[s], keys40 + 40 * s, 32);
+            memcpy(pa.nonce[s], keys40 + 40 * s + 32, 8);
+        }
+        for (int i = 0; i < ks * d; ++i) pa.w[i] = f.prep(word_at<F>(f, weights2, i));
+        pa.r0 = r2[0];
+        pa.r1 = r2[1];
+        pa.ks = ks; pa.d = d; pa.l = l; pa.mask_bits = mask_bits; pa.accumulate = accumulate; pa.rounds = rounds;
+        prss_cc_layout(l, &pa.tb, &pa.dpt);
+        const size_t tiles = (n + (size_t)pa.dpt - 1) / (size_t)pa.dpt;
+        const unsigned grid = (unsigned)((tiles + BLOCK - 1) / BLOCK);
+        hipLaunchKernelGGL((k_prss_chacha<F>), dim3(grid), dim3(BLOCK), 0, st, f, pa, (E*)out, n);
+        FFGPU_CHECK_LAUNCH();
+        return 0;
+    }
+
     static const FieldOps* table() {
-        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &gate, &sqrt_cl, &gauss, &group_matvec, &beaver, &prss};
+        static const FieldOps ops = {&ew2, &ew1, &muladd, &split, &rng_coeffs, &recombine, &pow, &inv, &matmul, &dot, &gate, &sqrt_cl, &gauss, &group_matvec, &beaver, &prss, &prss_chacha};
         return &ops;
     }
 };

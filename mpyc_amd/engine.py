@@ -790,6 +790,21 @@ class FieldContext:
                                               self._stream()), 'prss_combine')
         return out
 
+    def prss_chacha(self, keys40: Sequence[bytes], d: int, l: int, weights: Sequence[int], n: int, mask_bits: int = 0,
+                    rounds: int = 20, out: Optional[DevArray] = None, accumulate: bool = False) -> DevArray:
+        """The same combination with the draws expanded ON THE DEVICE from one ChaCha stream per subset key (production
+        mode, ffgpu_prss_chacha): keys40[s] = 32-byte key + 8-byte nonce of stream s; a draw = l keystream bytes reduced
+        by the reference's rule (thresha.py:234-266).  At most 32 streams and 64 weights per call."""
+        ks = len(keys40)
+        if len(weights) != ks * d or any(len(k_) != 40 for k_ in keys40):
+            raise ValueError('need ks 40-byte stream keys and ks*d weights')
+        out = out or self.empty(n)
+        w = self._scalars(weights)
+        kb = ctypes.create_string_buffer(b''.join(bytes(k_) for k_ in keys40), 40 * ks)
+        _ffi.check(self._L.ffgpu_prss_chacha(self._h, ctypes.cast(kb, ctypes.POINTER(ctypes.c_uint8)), ks, d, l, mask_bits,
+                                             rounds, w, int(accumulate), out.ptr, n, self._stream()), 'prss_chacha')
+        return out
+
     def bit_affine(self, bits: DevArray, matrix: Sequence[Sequence[int]], bias: Optional[Sequence[int]] = None,
                    from_bits: bool = False, out: Optional[DevArray] = None) -> DevArray:
         """GF(2^n<=8): y = M bits + bias per group of 8 bit shares (np_aes.py:40-41); from_bits: also

@@ -253,7 +253,26 @@ def recombine(field, points, x_rs=0):
 # runs on the host (hashlib); its raw output is uploaded and everything per element -- wide
 # reduction of each l-byte draw, multiplication by f_S(i) (and the powers of i+1 for zero
 # sharings), summation over the subsets -- is one kernel (ffgpu_prss_combine).
+#
+# Production mode (opt-in: prss_prf = 'chacha', or MPYC_AMD_PRSS_PRF=chacha in the environment of EVERY party): the subset
+# keys' draws come from ChaCha streams expanded by the lanes that consume them (ffgpu_prss_chacha) -- same subsets, same
+# f_S(i) weights, same l-byte-then-`% bound` sampling rule (thresha.py:234-266), another PRF: the values differ from the
+# reference's, the distribution and the sharing structure do not.  SHAKE128 stays the default and the parity mode.
 # --------------------------------------------------------------------------------------------
+import os as _os
+
+prss_prf = _os.environ.get('MPYC_AMD_PRSS_PRF', 'shake')         # 'shake' (reference PRF, bit-exact) | 'chacha' (device PRF)
+prss_rounds = int(_os.environ.get('MPYC_AMD_PRSS_ROUNDS', '20'))   # ChaCha rounds of the device PRF: 20, 12 or 8
+PRSS_CHACHA_DOMAIN = b'mpyc_amd prss chacha v1\0'
+
+
+def prss_chacha_stream_key(key: bytes, s: bytes) -> bytes:
+    """32-byte ChaCha key + 8-byte nonce of the stream that replaces shake_128(key + s) (thresha.py:255) in production
+    mode: a KDF call per (PRF key, common input), microseconds on the host; the expansion runs on the device."""
+    key = bytes(key)
+    return shake_128(PRSS_CHACHA_DOMAIN + len(key).to_bytes(2, 'little') + key + bytes(s)).digest(40)
+
+
 class PRF:
     """A pseudorandom function determined by a key and a public bound (thresha.py:220-266)."""
 
@@ -367,6 +386,18 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
                 for _ in range(power):
                     w = ops.mul(w, i1)
                 weights.append(w)
+    if prss_prf == 'chacha' and all(hasattr(prf, 'key') for _, prf in items):
+        # production mode: one ChaCha stream per subset key, expanded on the device (32 streams / 64 weights per launch)
+        per = max(1, min(32, 64 // d))
+        if d > 64:
+            raise NotImplementedError('zero sharing of degree > 64')
+        for k0 in range(0, len(items), per):
+            chunk = items[k0:k0 + per]
+            ctx.prss_chacha([prss_chacha_stream_key(prf.key, uci) for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n,
+                            mask_bits=mask_bits, rounds=prss_rounds, out=out, accumulate=k0 > 0)
+        return out
+    if prss_prf not in ('shake', 'chacha'):
+        raise ValueError(f"prss_prf must be 'shake' or 'chacha', not {prss_prf!r}")
     # kernel argument limits: 48 streams / 96 weights per launch.  The XOF streams of a chunk (one per subset
     # key; each is inherently sequential) are expanded in parallel on host threads into pinned buffers.
     per = max(1, min(48, 96 // d))

@@ -113,6 +113,27 @@ def rng_coeffs(cf: 'CField', key32: bytes, nonce: int, rounds: int, t: int, n: i
     return out
 
 
+def prss_chacha(cf: 'CField', keys40, d: int, l: int, mask_bits: int, rounds: int, weights, n: int, out: np.ndarray = None,
+                accumulate: bool = False) -> np.ndarray:
+    """PRSS combination over ChaCha streams exactly as ffgpu_prss_chacha computes it (fields of up to 128 bits)."""
+    eb = cf.eb
+    dt = {1: np.uint8, 4: np.uint32, 8: np.uint64, 12: np.uint32, 16: np.uint64}[eb]
+    shape = (n, 2) if eb == 16 else (n, 3) if eb == 12 else (n,)
+    if out is None:
+        out = np.zeros(shape, dtype=dt)
+    ks = len(keys40)
+    kb = b''.join(bytes(k) for k in keys40)
+    w = (ctypes.c_uint64 * (2 * ks * d))()
+    for i, v in enumerate(weights):
+        w[2 * i] = int(v) & (2**64 - 1)
+        w[2 * i + 1] = int(v) >> 64
+    rc = lib().orc_prss_chacha(cf._buf, kb, ks, d, l, mask_bits, rounds, w, int(accumulate), out.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.c_size_t(n))
+    if rc:
+        raise ValueError('orc_prss_chacha: unsupported parameters')
+    return out
+
+
 def matmul(cf: 'CField', A: np.ndarray, B: np.ndarray, M: int, K: int, N: int) -> np.ndarray:
     A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
     shape = (M * N, 2) if cf.eb == 16 else (M * N, 3) if cf.eb == 12 else (M * N,)

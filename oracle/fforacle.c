@@ -457,4 +457,73 @@ int orc_rng_coeffs(const orc_field* f, const uint8_t key32[32], uint64_t nonce, 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * PRSS in PRODUCTION mode (ffgpu_prss_chacha, mpyc_amd/csrc/kernels.hpp k_prss_chacha): the combination is the
+ * reference's (thresha.py:163-173, 201-217: out[h] = sum_S sum_j W[S][j] * draw_S(h, j)), the PRF is a ChaCha stream
+ * per subset key instead of SHAKE128 -- no reference counterpart, pinned to RFC 8439 + the layout below:
+ *   LW = ceil(l / 4) words per draw; tile = TB consecutive blocks holding DPT = min(8, 16 TB / LW) draws, TB in
+ *   {1, 2, 3} = the value with the most draws per block (smallest on ties); draw j of element h: tile h / DPT, slot
+ *   h % DPT, block counters (tile * d + j) * TB + b; value = the l little-endian bytes at word slot * LW of the tile's
+ *   keystream, `% p` (mask_bits == 0) or masked to mask_bits bits -- the reference's sampling rule (thresha.py:234-266).
+ * keys40: ks x (32-byte key, 8-byte nonce); weights: ks * d scalars, two 64-bit limbs each.  Fields of up to 128 bits,
+ * l <= 32 (wider ones: oracle/pyoracle.py).
+ * ------------------------------------------------------------------------------------------ */
+void orc_prss_chacha_layout(int l, int* tb, int* dpt) {
+    const int lw = (l + 3) / 4;
+    int best_tb = 0, best_dpt = 0;
+    for (int t = 1; t <= 3; ++t) {
+        int dp = 16 * t / lw;
+        if (dp > 8) dp = 8;
+        if (best_tb == 0 || dp * best_tb > best_dpt * t) { best_tb = t; best_dpt = dp; }
+    }
+    *tb = best_tb;
+    *dpt = best_dpt;
+}
+
+int orc_prss_chacha(const orc_field* f, const uint8_t* keys40, int ks, int d, int l, int mask_bits, int rounds,
+                    const uint64_t* weights, int accumulate, unsigned char* out, size_t n) {
+    if (l < 1 || l > 32 || f->eb > 16) return 1;
+    int tb, dpt;
+    orc_prss_chacha_layout(l, &tb, &dpt);
+    const int lw = (l + 3) / 4, eb = f->eb;
+    const u128 r128 = f->binary ? 0 : ((~(u128)0) % f->p + 1) % f->p;      /* 2^128 mod p */
+    long long h_;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (h_ = 0; h_ < (long long)n; ++h_) {
+        const size_t h = (size_t)h_;
+        const uint64_t tile = h / (size_t)dpt;
+        const int slot = (int)(h % (size_t)dpt);
+        u128 acc = accumulate ? ld(out, h, eb) : 0;
+        for (int s = 0; s < ks; ++s) {
+            uint32_t key[8], nn[2];
+            memcpy(key, keys40 + 40 * s, 32);
+            memcpy(nn, keys40 + 40 * s + 32, 8);
+            for (int j = 0; j < d; ++j) {
+                uint32_t ksw[16 * 3];
+                for (int b = 0; b < tb; ++b) {
+                    uint64_t ctr = (tile * (uint64_t)d + (uint64_t)j) * (uint64_t)tb + (uint64_t)b;
+                    uint32_t w[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), nn[0], nn[1]};
+                    orc_chacha_block(key, w, rounds, ksw + 16 * b);
+                }
+                unsigned char bytes[32];
+                memset(bytes, 0, sizeof(bytes));
+                memcpy(bytes, ksw + slot * lw, (size_t)l);        /* little-endian host: words -> bytes in keystream order */
+                u128 lo, hi;
+                memcpy(&lo, bytes, 16);
+                memcpy(&hi, bytes + 16, 16);
+                u128 v;
+                if (mask_bits > 0) {
+                    v = mask_bits >= 128 ? lo : (lo & ((((u128)1) << mask_bits) - 1));
+                } else {                                           /* (hi 2^128 + lo) mod p, any p of up to 128 bits */
+                    v = addmod(mulmod(hi % f->p, r128, f->p), lo % f->p, f->p);
+                }
+                u128 wt = ((u128)weights[2 * (s * d + j) + 1] << 64) | weights[2 * (s * d + j)];
+                acc = f_add(f, acc, f_mul(f, wt, f_red(f, v)));
+            }
+        }
+        st(out, h, eb, acc);
+    }
+    return 0;
+}
+
 size_t orc_field_sizeof(void) { return sizeof(orc_field); }

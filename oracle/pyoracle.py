@@ -430,6 +430,107 @@ def np_pseudorandom_share_0(F: Field, m: int, i: int, keys: dict, bound: int, uc
 
 
 # --------------------------------------------------------------------------
+# PRSS in production mode: the reference's combination (thresha.py:163-173, 201-217) over a COUNTER-MODE PRF -- one
+# ChaCha stream per subset key (mpyc_amd/csrc/kernels.hpp k_prss_chacha).  No reference counterpart for the PRF: pinned
+# to RFC 8439 (test vector 2.3.2 in tests/test_prss_chacha.py) and to the layout restated here and in fforacle.c.
+# --------------------------------------------------------------------------
+def chacha_block(key32: bytes, counter: int, nonce8: bytes, rounds: int = 20) -> bytes:
+    """RFC 8439 section 2.3 block function; state words 12, 13 = 64-bit block counter, 14, 15 = nonce."""
+    M = 0xffffffff
+    init = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574]
+    init += [int.from_bytes(key32[4 * i:4 * i + 4], 'little') for i in range(8)]
+    init += [counter & M, (counter >> 32) & M, int.from_bytes(nonce8[:4], 'little'), int.from_bytes(nonce8[4:8], 'little')]
+    x = list(init)
+
+    def rot(v, c):
+        return ((v << c) & M) | (v >> (32 - c))
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 7)
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return b''.join(((a + b) & M).to_bytes(4, 'little') for a, b in zip(x, init))
+
+
+def prss_chacha_layout(l: int) -> Tuple[int, int]:
+    """(TB, DPT): blocks per tile and draws per tile for l-byte draws (LW = ceil(l/4) words each): TB in {1,2,3} with
+    the most draws per block, DPT = min(8, 16 TB // LW)."""
+    lw = (l + 3) // 4
+    best = None
+    for tb in (1, 2, 3):
+        dpt = min(8, 16 * tb // lw)
+        if best is None or dpt * best[0] > best[1] * tb:
+            best = (tb, dpt)
+    return best
+
+
+def prss_chacha_stream_key(key: bytes, s: bytes) -> bytes:
+    """key (32) + nonce (8) of the stream of PRF key `key` on common input `s` (mpyc_amd/thresha.py)."""
+    from hashlib import shake_128
+    return shake_128(b'mpyc_amd prss chacha v1\0' + len(key).to_bytes(2, 'little') + key + s).digest(40)
+
+
+def prf_values_chacha(key: bytes, bound: int, s: bytes, n: int, d: int = 1, rounds: int = 20) -> List[int]:
+    """The n*d draws (h, j) -> index h*d + j of one subset key in production mode: l bytes of keystream `% bound`, l as in
+    thresha.py:232-236."""
+    l = ((bound - 1).bit_length() + 7) // 8
+    if bound & (bound - 1):
+        l += len(key)
+    if l == 0:
+        return [0] * (n * d)
+    k40 = prss_chacha_stream_key(key, s)
+    tb, dpt = prss_chacha_layout(l)
+    lw = (l + 3) // 4
+    out = []
+    cache = {}
+    for h in range(n):
+        tile, slot = divmod(h, dpt)
+        for j in range(d):
+            if (tile, j) not in cache:
+                cache = {kk: vv for kk, vv in cache.items() if kk[0] == tile}
+                cache[(tile, j)] = b''.join(chacha_block(k40[:32], (tile * d + j) * tb + b, k40[32:], rounds) for b in range(tb))
+            ksb = cache[(tile, j)]
+            out.append(int.from_bytes(ksb[4 * slot * lw:4 * slot * lw + l], 'little') % bound)
+    return out
+
+
+def np_pseudorandom_share_chacha(F: Field, m: int, i: int, keys: dict, bound: int, uci: bytes, n: int, rounds: int = 20):
+    """thresha.py:163-173 with the production PRF."""
+    out = [0] * n
+    for S, key in keys.items():
+        f = f_S_i(F, m, i, S)
+        prl = prf_values_chacha(key, bound, uci, n, 1, rounds)
+        for h in range(n):
+            out[h] = add(F, out[h], mul(F, reduce(F, prl[h]), f))
+    return out
+
+
+def np_pseudorandom_share_0_chacha(F: Field, m: int, i: int, keys: dict, bound: int, uci: bytes, n: int, rounds: int = 20,
+                                   list_convention: bool = False):
+    """thresha.py:201-217 with the production PRF (draw j of secret h multiplies (i+1)^(j+1))."""
+    d = m - len(next(iter(keys)))
+    i1 = reduce(F, i + 1)
+    out = [0] * n
+    for S, key in keys.items():
+        f = f_S_i(F, m, i, S)
+        prl = prf_values_chacha(key, bound, uci, n, d, rounds)
+        for h in range(n):
+            acc = 0
+            for j in range(d):
+                power = d - j if list_convention else j + 1
+                w = 1
+                for _ in range(power):
+                    w = mul(F, w, i1)
+                acc = add(F, acc, mul(F, reduce(F, prl[h * d + j]), w))
+            out[h] = add(F, out[h], mul(F, acc, f))
+    return out
+
+
+# --------------------------------------------------------------------------
 # AES-128 (FIPS-197), as demos/np_aes.py:55-86 computes it on public values
 # --------------------------------------------------------------------------
 def aes128_encrypt(key: Sequence[int], block: Sequence[int]) -> List[int]:

@@ -239,6 +239,21 @@ class CpuFieldContext(engine.FieldContext):
                     acc[h] = po.add(self.F, acc[h], po.mul(self.F, x, weights[s * d + j]))
         return self._put(out, acc)
 
+    def prss_chacha(self, keys40, d, l, weights, n, mask_bits=0, rounds=20, out=None, accumulate=False):
+        out = out or self.empty(n)
+        acc = out.to_ints() if accumulate else [0] * n
+        bound = (1 << mask_bits) if mask_bits else self.order
+        tb, dpt = po.prss_chacha_layout(l)
+        lw = (l + 3) // 4
+        for s, k40 in enumerate(keys40):
+            for h in range(n):
+                tile, slot = divmod(h, dpt)
+                for j in range(d):
+                    ksb = b''.join(po.chacha_block(k40[:32], (tile * d + j) * tb + b, k40[32:], rounds) for b in range(tb))
+                    x = po.reduce(self.F, int.from_bytes(ksb[4 * slot * lw:4 * slot * lw + l], 'little') % bound)
+                    acc[h] = po.add(self.F, acc[h], po.mul(self.F, x, weights[s * d + j]))
+        return self._put(out, acc)
+
     def bit_affine(self, bits, matrix, bias=None, from_bits=False, out=None):
         y = self.group_matvec(bits, matrix, bias)
         if not from_bits:
