@@ -41,6 +41,8 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* lane_ops_per_s,
+                            double* clock_mhz, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
 int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
@@ -1285,6 +1287,14 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
     DeviceGuard g(ctx->device);
     LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_copy(ctx->device, src, dst, bytes, (hipStream_t)stream));
+}
+int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* lane_ops_per_s,
+                     double* clock_mhz, void* stream) {
+    ARGCHK(ctx && scratch32 && lane_ops_per_s && clock_mhz);
+    ARGCHK(op >= 0 && op <= 2 && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8);
+    DeviceGuard g(ctx->device);
+    return launch_status(ffgpu_launch_valu_probe(ctx->device, op, iters, waves_per_simd, scratch32, lane_ops_per_s, clock_mhz,
+                                                 (hipStream_t)stream));
 }
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, int reps, void* stream,
                     float* ms) {

@@ -1605,3 +1605,78 @@ int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipS
     FFGPU_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- VALU issue-rate yardstick (the compute-side counterpart of k_copy16) --------------------------------------------
+// What the integer VALU of THIS chip sustains at THIS moment, measured instead of assumed: every wave runs `iters` passes
+// over 8 independent chains x 16 dependent instructions of one kind (inline asm: nothing is folded), the launch fills
+// every SIMD with `waves_per_simd` waves.  One thread per launch also brackets its loop with s_memtime (shader cycles) and
+// the constant 100 MHz counter, which gives the shader clock UNDER this load.  bench.py prices its VALU-bound rows
+// (`valu_frac`) against these rates.
+//   op 0: v_bitop3_b32 (the 3-input logic op of the GF(2^n) kernels)      op 1: v_add_u32
+//   op 2: v_mad_u64_u32 (the 32 x 32 + 64 multiply-add every prime-field product is made of)
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sink, uint64_t* __restrict__ clk, int iters) {
+    uint32_t a[8], b = threadIdx.x * 2654435761u + 1u, c = blockIdx.x * 40503u + 7u;
+    uint64_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = b * (uint32_t)(k + 3);
+        q[k] = ((uint64_t)a[k] << 32) | c;
+    }
+    const uint64_t t0 = __builtin_readcyclecounter();
+    const uint64_t w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (OP == 0) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[k]) : "v"(b), "v"(c));
+                else if constexpr (OP == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(b), "v"(c) : "vcc");
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    const uint64_t w1 = wall_clock64();
+    uint32_t x = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x ^= a[k] ^ (uint32_t)q[k] ^ (uint32_t)(q[k] >> 32);
+    if (x == 0x5a17c0deu) sink[0] = x;                         // keeps the chains alive; practically never true
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = t1 - t0;
+        clk[1] = w1 - w0;
+    }
+}
+
+// lane-operations per second of instruction kind `op` and the shader clock (MHz) while it ran; 0 on success
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* lane_ops_per_s,
+                            double* clock_mhz, hipStream_t st) {
+    LaunchCfg lc = launch_cfg(device);
+    if (op < 0 || op > 2 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
+    const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
+    uint32_t* sink = (uint32_t*)scratch16;
+    uint64_t* clk = (uint64_t*)((char*)scratch16 + 16);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    auto launch = [&](int n_it) {
+        if (op == 0) hipLaunchKernelGGL(k_valu_probe<0>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
+        else if (op == 1) hipLaunchKernelGGL(k_valu_probe<1>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
+        else hipLaunchKernelGGL(k_valu_probe<2>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
+    };
+    launch(iters / 4 + 1);                                                    // warm-up: clocks ramp
+    hipEventRecord(e0, st);
+    launch(iters);
+    hipEventRecord(e1, st);
+    hipError_t err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    uint64_t host_clk[2] = {0, 0};
+    if (err == hipSuccess) err = hipMemcpy(host_clk, clk, 16, hipMemcpyDeviceToHost);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (err != hipSuccess || ms <= 0.f) return 1;
+    const double wave_instr = (double)grid * 4.0 * (double)iters * 128.0;
+    *lane_ops_per_s = wave_instr * 64.0 / ((double)ms * 1e-3);
+    *clock_mhz = host_clk[1] ? (double)host_clk[0] / (double)host_clk[1] * 100.0 : 0.0;
+    return 0;
+}

@@ -26,6 +26,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = os.path.join(ROOT, '_refstage')
 PROG = os.path.join(ROOT, 'tests', 'fxp_program.py')
+OUTLIER_SEED = 4      # FXP_SEED for which the reference itself (one party, n = 10^5) produces ONE short-mask outlier (found by
+#                       running the reference over seeds 1..10 in the build container: seeds 4 and 9 have one, the others none)
 
 
 def run_program(ref, mode, n, parties, tmp, seed=3, timeout=1500, prf=None):
@@ -89,9 +91,14 @@ def test_fxp_product_production_prf_host_logic(tmp_path):
 @pytest.mark.parametrize('parties', [1, 3])
 def test_fxp_product_matches_reference_on_gpu_1e5(tmp_path, parties):
     n = 100_000
-    ref = run_program(STAGE, 'ref', n, parties, str(tmp_path))
-    dev = run_program(STAGE, 'gpu', n, parties, str(tmp_path))
+    seed = OUTLIER_SEED if parties == 1 else 3
+    ref = run_program(STAGE, 'ref', n, parties, str(tmp_path), seed=seed)
+    dev = run_program(STAGE, 'gpu', n, parties, str(tmp_path), seed=seed)
     compare(ref, dev, parties)
+    if parties == 1:
+        # the REFERENCE's own run has one element off by 2^48 with these keys -- and so has the engine's, same element
+        assert ref[0]['outliers_reference_trunc_mask'] == dev[0]['outliers_reference_trunc_mask'] == 1
+        assert ref[0]['max_abs_error'] == 2.0**48 and dev[0]['max_abs_error_without_outliers'] < 0.01
 
 
 @pytest.mark.gpu

@@ -216,6 +216,7 @@ def test_device_equals_c_oracle_all_policies(api, monkeypatch):
                 want0 = unpack(co.prss_chacha(cf, k40, t, l, mb, rounds, weights_zero(OF, m, i, keys, t), n), cf.eb)
                 assert dev_ints(thresha.np_pseudorandom_share_0(F, m, i, prfs, b'pc7', n)) == want0, (name, m, bound, 'zero')
     # n = 0 and n = 1
+    monkeypatch.setattr(thresha, 'prss_rounds', 20)
     F = gpu_field(api, 2**61 - 1, False)
     prfs = {S: thresha.PRF(k, F.order) for S, k in keys_for(3, 1, 0).items()}
     assert dev_ints(thresha.np_pseudorandom_share(F, 3, 0, prfs, b'x', 0)) == []

@@ -1,0 +1,45 @@
+#!/bin/bash
+# The ONE script for passes on the GPU box (replaces the per-round gpu_r0*.sh).  STAGES (any subset, in this order):
+#   newtests  pytest -m gpu on $NEWTESTS (files / node ids)          tests   the whole -m gpu suite
+#   bench     bench.py --steps 20 --warmup 5 (the driver's line)      prof    rocprofv3 --kernel-trace --stats of the bench
+#   pmc       FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py    valu    SQ_INSTS_VALU pass of tools/valu_probe.py
+#   probe     bash -c "$PROBE" (timeout $PROBE_TIMEOUT, default 600)
+# TAG names the outputs (default r05): gpurun_out/{pytest_gpu,bench,rocprof_$TAG,...}.
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
+T=${TAG:-r05}
+STAGES=${STAGES:-"tests bench prof"}
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+export TMPDIR=/tmp
+if has newtests; then
+  (time timeout ${NEWTESTS_TIMEOUT:-1500} python -m pytest -m gpu -x -q --durations=8 ${NEWTESTS}) > $O/pytest_new.log 2>&1; echo "pytest rc=$?" >> $O/pytest_new.log
+  tail -${NEWTESTS_TAIL:-25} $O/pytest_new.log
+fi
+if has tests; then
+  (time timeout 2400 python -m pytest tests -m gpu -x -q --durations=15) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  tail -25 $O/pytest_gpu.log
+fi
+if has bench; then
+  SECONDS=0
+  (timeout 1500 python bench.py --steps 20 --warmup 5) > $O/bench.log 2> $O/bench.err; echo "bench rc=$? wall=${SECONDS}s" | tee -a $O/bench.err
+  tail -n 1 $O/bench.log | wc -c
+  tail -n 1 $O/bench.log | cut -c1-2500
+fi
+if has prof; then
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o $T -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-leg) > $O/rocprof_$T.log 2>&1
+  echo "rocprof rc=$?"
+fi
+if has pmc; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${T}_$C -o $C -- python $R/tools/pmc_probe.py) > $O/pmc_${T}_$C.log 2>&1
+    echo "pmc $C rc=$?"
+  done
+fi
+if has valu; then
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/valu_$T -o valu -- python $R/tools/valu_probe.py) > $O/valu_$T.log 2>&1
+  F=$(find $O/valu_$T -name '*counter_collection.csv' | head -1)
+  python tools/valu_summary.py $F $O/valu_order.json $O/${T}_valu.json $O/${T}_valu.md | tail -20
+fi
+if has probe; then
+  (timeout ${PROBE_TIMEOUT:-600} bash -c "$PROBE") > $O/probe_$T.log 2>&1; echo "probe rc=$?" >> $O/probe_$T.log
+  tail -${PROBE_TAIL:-60} $O/probe_$T.log
+fi
