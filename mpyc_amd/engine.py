@@ -888,7 +888,8 @@ class FieldContext:
                 nonce, defer = state.take_offset(), 1          # inside a sequence of deferred launches: commit() follows
             else:
                 nonce = 0          # the layer is ONE launch: it advances the device nonce itself (the last workgroup of the
-                #                    kernel for grids of up to 512 workgroups -- 10^6 bytes --, a one-thread kernel above that)
+                #                    kernel for grids of up to RNG_RELEASE_MAX_GRID = 512 workgroups -- up to ~5.2 * 10^5 bytes;
+                #                    10^6 bytes are 977 workgroups --, a one-thread kernel, k_rng_advance, above that)
         _ffi.check(self._L.ffgpu_gf256_sbox_layer(self._h, mm, bb, self._scalars(lam), self._scalars(mu), t, m, X.ptr, X.stride,
                                                   R.ptr, R.stride, out.ptr, out.stride, n, key, nonce, rounds,
                                                   state.ptr if state is not None else None, defer, self._stream()),

@@ -237,7 +237,10 @@ def fetch(ctx, desc, reduce_n=None):
         ent = _pending.get(eid)
         if ent is None:
             raise RuntimeError('device-side wire: this process no longer holds the buffer of its own descriptor')
-        t = ent[0] if not ent[3] else ent[0].clone()          # a second local resolve must not alias the first
+        # ALWAYS a copy: peers that were (or are about to be) sent the same descriptor read the parked snapshot later, and the
+        # local caller may write to what it gets here in place (runtime.py:384-396 loads the one marshalled row locally too);
+        # the parked buffer itself is never handed out.  One device copy of a row: microseconds.
+        t = ent[0].clone()
         ent[3] = True
         stats['local'] += 1
         drain()

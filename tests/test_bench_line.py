@@ -20,6 +20,10 @@ def canned(n_kernels=120, n_ranks=8, fat=400):
            'algorithmic_bytes_per_unit': 48, 'units_per_s': 1.2e11, 'note': 'x' * fat}
     kern = {f'kernel_row_number_{i}_with_a_long_name': dict(row) for i in range(n_kernels)}
     kern['inv_p61'] = dict(row, bound='valu', valu_frac=0.9, frac=0.4)
+    kern['recombine_gf2_128_k7_dense'] = dict(row, bound='lds+valu', valu_frac=0.5, frac=0.45)
+    kern['prss_share_p61_m7t3'] = {'ms_per_launch': 98.9, 'bound': 'host', 'unit': 'GB/s', 'achieved': 11.3, 'frac': None}
+    kern['mul_p61_pcie_inclusive'] = {'ms_per_launch': 4.4, 'bound': 'pcie', 'unit': 'GB/s', 'achieved': 54.0, 'frac': None}
+    kern['secure_aes128_encrypt_m3t1_62500_blocks'] = {'ms_per_launch': 3.2, 'bound': 'hbm/alu', 'unit': 'blocks/s', 'frac': None}
     leg = {'n': 10**7, 'parties': 3, 'ms_per_rep': 1.17, 'elements_per_s': 6.6e9, 'note': 'y' * fat}
     return {
         'metric': 'field-ops/sec (modmul + share+recombine) on 10^7-elt SecFld array', 'value': 226585726170.5,
@@ -34,8 +38,11 @@ def canned(n_kernels=120, n_ranks=8, fat=400):
         'unfused': {'value': 1.9e11, 'unit': 'field-ops/s', 'ms_per_step': 0.157, 'note': 'z' * fat},
         'roofline': dict(row, name='mul_split_fused_p61_m3t1', frac_of_measured_copy=1.01, traffic_source='s' * fat),
         'kernels': kern, 'mulmod_per_s_1gpu': 2.55e11,
-        'configs2': {'k4': {'secrets_per_s': 1e10, 'frac': 0.7}, 'k7': {'secrets_per_s': 9e9}, 'roofline': dict(row, name='split_p64_m7t3'),
+        'configs2': {'k4': {'value': 1e10, 'frac': 0.7, 'ms_per_pass': 0.21}, 'k7': {'value': 9e9}, 'roofline': dict(row, name='split_p64_m7t3'),
                      'note': 'c' * 3000},
+        'configs0': {'workload': 'configs[0]: list path', 'mirror_secrets_per_s': 5e5, 'reference_secrets_per_s': 4e5, 'parity': 'p' * 90},
+        'valu_peak': {'lane_ops_per_s': 3.6e13, 'mad_u64_u32_lane_ops_per_s': 1.8e13, 'shader_clock_mhz': 2250.0,
+                      'source': 'ffgpu_valu_probe in this run', 'x': 'v' * fat},
         'cpu_baseline': {'value': 28694617.3, 'unit': 'field-ops/s', 'cores': 32, 'procs': 32, 'host_cores': 128,
                          'kind': 'reference', 'sample': 's' * 2000, 'value_1core': 2491105.2, 'port_value': 3.5e8,
                          'port_cores': 128, 'process_count_probe': [{'procs': p, 'field_ops_per_s': 1.0} for p in range(64)]},
@@ -72,7 +79,21 @@ def test_compact_line_fits_the_driver_tail_and_parses():
             assert key in line['cpu_baseline'], key
         assert line['distributed']['world_size'] == out['n_gpus'] == len(line['distributed']['ranks'])
         assert line['api']['m3_1e7_ipc']['ms_per_rep'] == 1.17
-        assert 'kernels' not in line
+        assert 'kernels' not in line and 'kernel_fracs' not in line
+        # no null where a number was measured ...
+        assert line['configs2']['k4_secrets_per_s'] == 1e10 and line['configs2']['k7_secrets_per_s'] == 9e9
+        assert line['roofline']['traffic_source']
+        assert line['configs0']['mirror_secrets_per_s'] == 5e5 and line['valu_peak']['shader_clock_mhz'] == 2250.0
+        # ... and no key that mixes two kinds of fraction (weak 5a): a row is in exactly one of the two maps, rows without a
+        # roofline meaning (host / PCIe / whole-protocol rows) in neither, and no 0.0 placeholders
+        if kw.get('n_kernels', 120) <= 120:
+            hb, va = line['hbm_fracs'], line['valu_fracs']
+            assert (len(hb) == 3) if kw.get('n_kernels') == 3 else (0 < len(hb) < 120 and line['hbm_fracs_rows_cut'] == 120 - len(hb))
+            assert not set(hb) & set(va)
+            assert va == {'inv_p61': 0.9, 'recombine_gf2_128_k7_dense': 0.5}
+            assert 'inv_p61' not in hb and all(v == 0.7729 for v in hb.values())
+            for name in ('prss_share_p61_m7t3', 'mul_p61_pcie_inclusive', 'secure_aes128_encrypt_m3t1_62500_blocks'):
+                assert name not in hb and name not in va
 
 
 def test_compact_line_without_optional_sections():

@@ -97,6 +97,38 @@ def test_bench_eight_ranks_control_flow_on_one_gpu():
     assert detail['multi_gpu']['config']['n_gpus'] == 8
     for leg in ('gate_sharded', 'party_major_all_to_all', 'party_major_allgather'):
         assert line['multi_gpu'][leg]['ms_per_step'] > 0
+    # every rank's parity checks of the section, all-reduced (MIN) into one flag
+    assert line['multi_gpu']['parity_passed_on_every_rank'] is True and detail['multi_gpu']['parity']['failures_on_rank_0'] == []
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_party_major_layout_on_one_gpu():
+    """`--layout party-major` (only the configs[3] section, full step count) with two ranks on GPU 0 over gloo: the
+    exchange + recombination legs run, their parity checks pass on both ranks and the flag says so."""
+    line, detail = _bench_lines(['--gpus', '2', '--steps', '3', '--warmup', '1', '--layout', 'party-major'],
+                                {'FFGPU_BENCH_DEVICE': '0', 'FFGPU_BENCH_LEG_TIMEOUT': '600', 'FFGPU_BENCH_N': '2000000'})
+    assert line['n_gpus'] == 2 and line['distributed']['backend'] == 'gloo' and line['scaling'] == 'weak'
+    mg = line['multi_gpu']
+    assert 'error' not in mg and mg['parity_passed_on_every_rank'] is True
+    for leg in ('gate_sharded', 'party_major_all_to_all', 'party_major_all_to_all_pipelined', 'party_major_allgather'):
+        assert mg[leg]['ms_per_step'] > 0
+    assert detail['multi_gpu']['config']['steps'] == 3 and detail['multi_gpu']['config']['n_gpus'] == 2
+    assert 'kernels' not in detail                          # party-major layout: no extras
+
+
+@pytest.mark.gpu
+def test_bench_refuses_two_rccl_ranks_on_one_device():
+    """Two NCCL ranks that land on ONE device must not produce a scaling number: the run ends with a non-zero status and
+    a line that says `invalid` (RCCL itself refuses the communicator on current versions -- either way rc != 0)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', FFGPU_BENCH_DEVICE='0', FFGPU_BENCH_BACKEND='nccl',
+               FFGPU_BENCH_N='1000000', FFGPU_BENCH_LEG_TIMEOUT='60')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-multi-gpu-leg'], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    bare = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if bare:                                                # the communicator came up: the line must carry the verdict
+        import json
+        assert json.loads(bare[-1])['scaling'].startswith('invalid: ranks share a device')
 
 
 @pytest.mark.gpu

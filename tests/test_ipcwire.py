@@ -106,7 +106,9 @@ def test_release_after_as_many_acknowledgements_as_sends(wire):
     ipcwire.drain()
     assert len(ipcwire._pending) == 3                                        # nothing acknowledged yet, row 0 unresolved
     rows[0].t.fill_(77)                                                      # the caller writes to its array after marshalling ...
+    parked = ipcwire._pending[ids[0]][0]
     own = ipcwire.fetch(FakeCtx(), pickle.loads(blobs[0]))                   # ... and the own row is unmarshalled locally
+    assert own.data_ptr() != parked.data_ptr()       # never the parked snapshot itself: peers holding the descriptor read it later
     assert own is not rows[0].t and bool((own == 0).all()) and ipcwire.stats['local'] == 1     # the snapshot of marshal time
     assert ids[0] not in ipcwire._pending and len(ipcwire._pending) == 2     # released: nobody else holds its descriptor
     ack(ipcwire, ids[1])

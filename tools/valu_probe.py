@@ -3,7 +3,7 @@
 three launches each, at n = 10^7.  Run under
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d DIR -o valu -- python tools/valu_probe.py
 and feed the counter CSV to tools/valu_summary.py: library dispatches are consumed in order, three per row -> VALU
-instructions per element for every row (profiles/r04_valu.json, read by bench.py for `valu_frac`)."""
+instructions per element for every row (profiles/r05_valu.json, read by bench.py for `valu_frac`)."""
 import json, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,6 +40,18 @@ for rounds in (20, 8):
     rows.append((f'chain_gate_p61_m3t1_chacha{rounds}', lambda st=st: ctx.gate([s.shares.row(j) for j in range(k)], lam, None, None, t, m, state=st, out=out_chain)))
 rows.append(('inv_p61', lambda: ctx.inv(s.a, out=s.c, check_zero=False)))
 rows.append(('sqrt_p61', lambda: ctx.pow(s.a, (P61 + 1) // 4, out=s.c)))
+# ---- PRSS shares in production mode (ChaCha streams expanded in k_prss_chacha), one party of m = 7, t = 3 / m = 3, t = 1
+import itertools
+F61 = gff.GF(P61)
+for (mm_, ii_), rr_ in itertools.product(((7, 2), (3, 0)), (20, 8)):
+    keys_ = {S: bytes([sum(S) % 256]) * 16 for S in itertools.combinations(range(mm_), mm_ - (mm_ - 1) // 2) if ii_ in S}
+    prfs_ = {S: gth.PRF(kk_, F61.order) for S, kk_ in keys_.items()}
+
+    def prss_row(mm_=mm_, ii_=ii_, rr_=rr_, prfs_=prfs_):
+        gth.prss_prf, gth.prss_rounds = 'chacha', rr_
+        gth.np_pseudorandom_share(F61, mm_, ii_, prfs_, b'uci', n)
+        gth.prss_prf, gth.prss_rounds = 'shake', 20
+    rows.append((f'prss_share_p61_m{mm_}t{(mm_ - 1) // 2}_chacha{rr_}', prss_row))
 # ---- 2^64 - 189, m = 7, t = 3
 ctx64 = FieldContext(P64, device=0)
 t2, m2 = 3, 7

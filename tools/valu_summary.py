@@ -36,6 +36,8 @@ for name, g in zip(rows['rows'], groups):
     out[name] = {'kernel': kern, 'sq_insts_valu_per_launch': round(insts, 1), 'valu_lane_ops_per_unit': round(insts * 64 / n, 2),
                  'sq_waves': main[0].get('SQ_WAVES'), 'n': n}
     lines.append(f"| `{name}` | `{kern}` | {insts:.4g} | {insts * 64 / n:.1f} | {main[0].get('SQ_WAVES', 0):.0f} |")
+import os
+out['_meta'] = {'commit': os.environ.get('VALU_COMMIT'), 'counter': 'SQ_INSTS_VALU (wave instructions) x 64 / units'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 open(sys.argv[4], 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))
