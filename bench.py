@@ -189,7 +189,8 @@ def compact_line(out):
     if isinstance(c0, dict):
         line['configs0'] = _pick(c0, ('workload', 'mirror_secrets_per_s', 'reference_secrets_per_s', 'parity', 'error', 'skipped'))
     if isinstance(out.get('valu_peak'), dict):
-        line['valu_peak'] = _pick(out['valu_peak'], ('lane_ops_per_s', 'mad_u64_u32_lane_ops_per_s', 'shader_clock_mhz', 'source'))
+        line['valu_peak'] = _pick(out['valu_peak'], ('lane_ops_per_s', 'mad_u64_u32_lane_ops_per_s', 'mad_slots', 'shader_clock_mhz',
+                                                     'shader_clock_mhz_under_full_valu_load', 'source'))
     kern = out.get('kernels')
     if isinstance(kern, dict):
         # one number per kernel row, in TWO maps that never mix: hbm_fracs = algorithmic bytes / time / 8 TB/s for the rows
@@ -250,20 +251,27 @@ VALU_COUNTS_FILES = ('r05_valu.json', 'r04_valu.json')     # SQ_INSTS_VALU per u
 
 
 def measure_valu_peak(ctx):
-    """The chip's integer-VALU issue rate, MEASURED in this run (ffgpu_valu_probe: 8 independent dependent-chains per wave, four
-    waves per SIMD): lane-operations/s of single-slot instructions (v_bitop3_b32 / v_add_u32: the lower of the two) and of
-    v_mad_u64_u32, and the shader clock under that load.  `valu_frac` of every VALU-bound row is priced against THESE numbers,
-    so no clock is assumed anywhere and a fraction above 1 would mean the instruction counts are wrong."""
-    r_bit, mhz = ctx.valu_probe(0)
-    r_add, mhz2 = ctx.valu_probe(1)
-    r_mad, mhz3 = ctx.valu_probe(2)
-    single = min(r_bit, r_add)
-    return {'lane_ops_per_s': round(single, 1), 'bitop3_lane_ops_per_s': round(r_bit, 1), 'add_u32_lane_ops_per_s': round(r_add, 1),
-            'mad_u64_u32_lane_ops_per_s': round(r_mad, 1), 'mad_slots': round(single / r_mad, 3),
-            'shader_clock_mhz': round(min(mhz, mhz2, mhz3), 1), 'shader_clock_mhz_per_probe': [round(mhz, 1), round(mhz2, 1), round(mhz3, 1)],
-            'lanes_per_cycle_per_simd': round(single / (min(mhz, mhz2) * 1e6) /
-                                              (torch.cuda.get_device_properties(ctx.torch_device).multi_processor_count * 4), 2),
-            'source': 'ffgpu_valu_probe in this run'}
+    """The chip's integer-VALU issue rate, MEASURED in this run (ffgpu_valu_probe: 8 independent dependent-chains per wave).
+    Under a pure-VALU load at four waves per SIMD the chip clocks to its power budget (lowest clock); a kernel with stalls runs
+    at a higher one.  So the PEAK a row is priced against is the per-cycle issue rate measured at full occupancy times the
+    HIGHEST shader clock any probe of this run reached (one wave per SIMD: light load) -- the rate no kernel of this run could
+    exceed; `valu_frac` of a row above 1 would mean its instruction count is wrong.  No clock is assumed anywhere."""
+    simds = torch.cuda.get_device_properties(ctx.torch_device).multi_processor_count * 4
+    probes = {}
+    for name, op in (('bitop3_b32', 0), ('add_u32', 1), ('mad_u64_u32', 2)):
+        for waves in (4, 1):
+            rate, mhz, cyc = ctx.valu_probe(op, waves_per_simd=waves)
+            probes[f'{name}_w{waves}'] = {'lane_ops_per_s': round(rate, 1), 'shader_clock_mhz': round(mhz, 1),
+                                          'cycles_per_wave_instruction': round(cyc, 3),
+                                          'lanes_per_cycle_per_simd': round(rate / (mhz * 1e6) / simds, 2) if mhz else None}
+    clock_max = max(p_['shader_clock_mhz'] for p_ in probes.values())
+    full = min(probes['bitop3_b32_w4'], probes['add_u32_w4'], key=lambda p_: p_['lane_ops_per_s'])
+    single = full['lane_ops_per_s'] * clock_max / full['shader_clock_mhz']
+    mad = probes['mad_u64_u32_w4']
+    mad_rate = mad['lane_ops_per_s'] * clock_max / mad['shader_clock_mhz']
+    return {'lane_ops_per_s': round(single, 1), 'mad_u64_u32_lane_ops_per_s': round(mad_rate, 1), 'mad_slots': round(single / mad_rate, 3),
+            'shader_clock_mhz': clock_max, 'shader_clock_mhz_under_full_valu_load': full['shader_clock_mhz'],
+            'probes': probes, 'source': 'ffgpu_valu_probe in this run: per-cycle rate at 4 waves per SIMD x the highest clock seen'}
 
 
 def annotate_valu(kern, out):

@@ -443,13 +443,13 @@ int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uin
 /* device-to-device copy of `bytes` (multiple of 16, 16-byte aligned) with the library's own
  * streaming kernel: the achievable-bandwidth yardstick reported next to the 8 TB/s nominal peak. */
 int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
-/* VALU issue-rate yardstick (the compute-side counterpart of ffgpu_time_copy): lane-operations per second the chip
- * sustains for one instruction kind -- op 0: v_bitop3_b32, 1: v_add_u32, 2: v_mad_u64_u32 -- with `waves_per_simd` waves
- * on every SIMD, `iters` x 128 dependent-chain instructions per wave, and the shader clock (MHz, s_memtime against the
- * 100 MHz counter) under that load.  scratch32: 32 bytes of device memory.  bench.py prices its VALU-bound rows with it.
+/* VALU issue-rate yardstick (the compute-side counterpart of ffgpu_time_copy): what the chip sustains for one instruction
+ * kind -- op 0: v_bitop3_b32, 1: v_add_u32, 2: v_mad_u64_u32 -- with `waves_per_simd` waves on every SIMD and `iters` x 128
+ * instructions in 8 independent dependent-chains per wave.  out3[0] = lane-operations per second (events around the launch),
+ * out3[1] = shader clock in MHz under that load (s_memtime against the 100 MHz counter), out3[2] = shader cycles per wave
+ * instruction and SIMD.  scratch32: 32 bytes of device memory.  bench.py prices its VALU-bound rows with it.
  * replaces: nothing in the reference (measurement aid, like the ffgpu_time_* entry points).                            */
-int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* lane_ops_per_s,
-                     double* clock_mhz, void* stream);
+int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* out3, void* stream);
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,
                     int reps, void* stream, float* ms_per_launch);
 

@@ -100,7 +100,7 @@ _SIGS = {
     'ffgpu_time_split': [_vp, _vp, _vp, _sz, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],
     'ffgpu_time_recombine': [_vp, ctypes.POINTER(_vp), _u64p, _int, _int, _vp, _sz, _sz, _int, _vp, _fp],
     'ffgpu_time_copy': [_vp, _vp, _vp, _sz, _int, _vp, _fp],
-    'ffgpu_valu_probe': [_vp, _int, _int, _int, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp],
+    'ffgpu_valu_probe': [_vp, _int, _int, _int, _vp, ctypes.POINTER(ctypes.c_double), _vp],
     'ffgpu_copy': [_vp, _vp, _vp, _sz, _vp],
     'ffgpu_ipc_export': [_vp, _vp, _sz, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_char_p, _vp],
     'ffgpu_ipc_open': [_vp, ctypes.c_char_p, ctypes.POINTER(_vp)],

@@ -41,8 +41,7 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
-int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* lane_ops_per_s,
-                            double* clock_mhz, hipStream_t st);
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* out, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
 int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,
@@ -67,6 +66,7 @@ struct ffgpu_ctx {
     int policy_kind;
     const FieldOps* ops;
     uint64_t rng_r[2];  // 2^W mod p for the keystream sampler
+    ffgpu::Tuning tune; // run-time switches, read from the environment when the context is created
     int gf8_tab_min;    // GF(2^n<=8): arrays of at least this many elements multiply through LDS tables
     alignas(16) unsigned char gf8_tables[1536];
     int gf2w_limbs;     // GF(2^n), 9 <= n <= 128: 1 or 2 limbs -> windowed multiplication kernel
@@ -294,6 +294,14 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     c->elem_bytes = pb.elem_bytes;
     c->policy_kind = pb.kind;
     rng_const(pb, c->rng_r);
+    {   // the library's switches: read here, once per context -- no call path looks at the environment
+        const char* e = getenv("FFGPU_MM_MFMA");
+        c->tune.mm_mfma = e ? (atoi(e) != 0) : 1;
+        e = getenv("FFGPU_MM_MFMA_MIN");
+        c->tune.mm_mfma_min = e ? atof(e) : 8e7;
+        e = getenv("FFGPU_GF2W_BITSLICED");
+        c->tune.gf2w_bitsliced = e ? (atoi(e) != 0) : 1;
+    }
     c->gf2w_limbs = 0;
     if (pb.kind == POL_GF2W64 || pb.kind == POL_GF2W128) {
         // sparse moduli (all MPyC defaults) multiply in registers through the integer multiplier
@@ -308,7 +316,6 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
             memcpy(&f, pb.bytes, sizeof(f));
             in_regs = f.n <= 32 || (f.fast & 1) != 0;
         }
-        if (getenv("FFGPU_GF2W_WINDOW")) in_regs = false;
         if (!in_regs) {
             c->gf2w_limbs = pb.kind == POL_GF2W128 ? 2 : 1;
             ffgpu_gf2w_build_rtable(c->policy, c->gf2w_limbs, c->gf2w_rtable);
@@ -316,9 +323,7 @@ int ffgpu_ctx_create(int kind, const uint64_t* modulus, int nlimbs, int device, 
     }
     c->gf8_tab_min = 0;
     if (pb.kind == POL_GF2P8 && ffgpu_gf8_build_tables(c->policy, c->gf8_tables) == 0) {
-        const char* e = getenv("FFGPU_GF8_TABLE_MIN");
-        c->gf8_tab_min = e ? atoi(e) : (1 << 18);   // below this the shift-xor kernel has lower latency
-        if (c->gf8_tab_min <= 0) c->gf8_tab_min = 0x7fffffff;
+        c->gf8_tab_min = 1 << 18;   // below this the shift-xor kernel has lower latency
     }
     *out = c;
     return FFGPU_OK;
@@ -557,7 +562,7 @@ int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
         return launch_status(ffgpu_launch_gf2w_mul_win(ctx->policy, ctx->gf2w_limbs, ctx->gf2w_rtable, ctx->device,
                                                        a, b, out, n, (hipStream_t)stream));
     }
-    if (ctx && ctx->policy_kind == POL_GF2W64 && a && b && out && n >= ((size_t)1 << 21)) {
+    if (ctx && ctx->policy_kind == POL_GF2W64 && ctx->tune.gf2w_bitsliced && a && b && out && n >= ((size_t)1 << 21)) {
         // GF(2^64) with the default modulus: bit-sliced product for the whole slabs, the element-wise kernel for the rest
         size_t done;
         {
@@ -950,7 +955,7 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
     // GF(2^n), 9 <= n <= 128 with a sparse modulus: shared nibble tables of the (uniform) Lagrange
     // coefficients in LDS instead of one full field multiplication per row and element
     if ((ctx->policy_kind == POL_GF2W64 || ctx->policy_kind == POL_GF2W128) && !ctx->gf2w_limbs && k <= 9 &&
-        n >= 65536 && !getenv("FFGPU_GF2W_REC_PLAIN")) {
+        n >= 65536) {
         const int limbs = ctx->policy_kind == POL_GF2W128 ? 2 : 1;
         int rc = 0;
         for (int r = 0; r < w && rc == 0; ++r)
@@ -973,14 +978,12 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
     LaunchTimer lt(ctx, (hipStream_t)stream);
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    int mod_bits = 128;
-    if (ctx->kind == FFGPU_PRIME) mod_bits = ctx->modulus[2] ? 192 : ctx->modulus[1] ? 128 : 64 - __builtin_clzll(ctx->modulus[0] | 1);
     {
         // scratch: int8 limb planes for the matrix-core product (10 x (M + N) x K bytes, up to 8 GiB), else 64 MiB of
         // split-K partial sums
         size_t want = 0;
         const size_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
-        if (ctx->kind == FFGPU_PRIME && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= ffgpu::mfma_min_macs()) {
+        if (ctx->kind == FFGPU_PRIME && M >= 64 && N >= 64 && K >= 64 && ctx->tune.mm_mfma && (double)M * N * K >= ctx->tune.mm_mfma_min) {
             want = (size_t)(ctx->elem_bytes <= 8 ? 8 : 16) * (Mp + Np) * Kp + ((size_t)64 << 20);   // digit planes per operand + split-K slabs
             if (want > ((size_t)8 << 30)) want = 0;
         }
@@ -1018,7 +1021,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
         }
     }
     return launch_status(ctx->ops->matmul(ctx->policy, ctx->device, A, lda, B, ldb, C, ldc, (int)M, (int)K, (int)N, ws,
-                                          ws_bytes, mod_bits, (hipStream_t)stream));
+                                          ws_bytes, &ctx->tune, (hipStream_t)stream));
 }
 
 int ffgpu_group_matvec(ffgpu_ctx* ctx, const uint64_t* host_matrix, const uint64_t* host_bias, int r, int g,
@@ -1288,13 +1291,11 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
     LaunchTimer lt(ctx, (hipStream_t)stream);
     return launch_status(ffgpu_launch_copy(ctx->device, src, dst, bytes, (hipStream_t)stream));
 }
-int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* lane_ops_per_s,
-                     double* clock_mhz, void* stream) {
-    ARGCHK(ctx && scratch32 && lane_ops_per_s && clock_mhz);
+int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* out3, void* stream) {
+    ARGCHK(ctx && scratch32 && out3);
     ARGCHK(op >= 0 && op <= 2 && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8);
     DeviceGuard g(ctx->device);
-    return launch_status(ffgpu_launch_valu_probe(ctx->device, op, iters, waves_per_simd, scratch32, lane_ops_per_s, clock_mhz,
-                                                 (hipStream_t)stream));
+    return launch_status(ffgpu_launch_valu_probe(ctx->device, op, iters, waves_per_simd, scratch32, out3, (hipStream_t)stream));
 }
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, int reps, void* stream,
                     float* ms) {

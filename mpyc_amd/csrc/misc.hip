@@ -31,15 +31,6 @@ FF_HD uint32_t gf_pow254(const GF2P8& f, uint32_t a) {
     return f.mul(c, c);        // a^254
 }
 
-static int table_blocks_per_cu() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FFGPU_TABLE_BPC");
-        v = e ? atoi(e) : 0;  // 0 = uncapped: the per-workgroup table copy is cheap (measured best)
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_sbox(SboxLut tab, const uint8_t* __restrict__ in,
                                                  uint8_t* __restrict__ out, size_t nvec, size_t n) {
     __shared__ uint8_t lut[256];
@@ -83,9 +74,7 @@ int ffgpu_launch_sbox(const uint8_t* lut256, int device, const void* in, void* o
     LaunchCfg lc = launch_cfg(device);
     bool vec = aligned16(in) && aligned16(out);
     size_t nvec = vec ? n / 16 : 0;
-    LaunchCfg capped = lc;
-    if (capped.blocks_per_cu <= 0) capped.blocks_per_cu = table_blocks_per_cu();
-    unsigned grid = grid_for(nvec ? nvec : n, capped);
+    unsigned grid = grid_for(nvec ? nvec : n, lc);      // uncapped: the per-workgroup table copy is cheap (measured best)
     hipLaunchKernelGGL(k_sbox, dim3(grid), dim3(BLOCK), 0, st, tab, (const uint8_t*)in, (uint8_t*)out, nvec, n);
     FFGPU_CHECK_LAUNCH();
     return 0;
@@ -495,7 +484,6 @@ int ffgpu_launch_gf8_mask_open(const void* policy, int device, const void* const
     }
     const size_t npair = vec ? n / 2 : 0;
     LaunchCfg lc = launch_cfg(device);
-    if (lc.blocks_per_cu <= 0) lc.blocks_per_cu = table_blocks_per_cu();      // every workgroup copies 2.3 KiB of tables
     unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
     hipLaunchKernelGGL(k_gf8_mask_open, dim3(grid), dim3(BLOCK), 0, st, f, tb, a, (uint8_t*)out, npair, n);
     FFGPU_CHECK_LAUNCH();
@@ -512,7 +500,6 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
     if (nbatch > 1) vec = vec && (ybr % 16 == 0) && (ybo % 2 == 0);
     const size_t npair = vec ? n / 2 : 0;
     LaunchCfg lc = launch_cfg(device);
-    if (lc.blocks_per_cu <= 0) lc.blocks_per_cu = table_blocks_per_cu();
     unsigned grid = grid_for(npair ? (npair + 1) / 2 : n, lc);
     hipLaunchKernelGGL(k_gf8_bits_affine_fold, dim3(grid, (unsigned)nbatch), dim3(BLOCK), 0, st, tb,
                        (const uint8_t*)c, (const uint8_t*)rbits, ybr, (uint8_t*)out, ybo, npair, n);
@@ -542,7 +529,6 @@ struct Gf8SboxLayerArgs {
     const uint8_t* tables;  // device: Gf8Tables (log / antilog), then Gf8ByteTables of np_from_bits, then of the affine fold
     uint32_t lam[7];        // Lagrange coefficients at 0 of the senders 1..2t+1
     uint32_t mu[4];         // ... of the opening parties 1..t+1
-    int burst;              // A/B switch (FFGPU_SBL_BURST=1): ChaCha20 blocks as bursts instead of interleaved
 };
 enum { SBL_TABLE_BYTES = 1536 + 2304 + 2304 };
 
@@ -844,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void k_gf8_sbox_layer(GF2P8 f, Gf8SboxLayerA
     const bool dr10 = (SBL_PROBE_PATH & 2) != 0;
 #else
     const bool cont = CAN_CONT && steps >= 4;
-    const bool dr10 = ra.rk.rounds == 20 && !a.burst;
+    const bool dr10 = ra.rk.rounds == 20;
 #endif
     if constexpr (CAN_CONT) {
         if (cont) {
@@ -885,19 +871,10 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     for (int i = 0; i < 2 * t + 1; ++i) a.lam[i] = (uint32_t)(lam2[2 * i] & 0xffu);
     for (int i = 0; i <= t; ++i) a.mu[i] = (uint32_t)(mu2[2 * i] & 0xffu);
     RngArgs ra = *rng;
-    static int burst = -1, wpt = -1;
-    if (burst < 0) {
-        const char* e = getenv("FFGPU_SBL_BURST");
-        burst = e ? atoi(e) : 0;
-        e = getenv("FFGPU_SBL_WPT");
-        wpt = e ? atoi(e) : 1;
-    }
-    a.burst = burst;
-    // One word (four bytes) per thread.  FFGPU_SBL_WPT=2 (A/B only, t = 1): two words per thread sharing a keystream -- five
-    // ChaCha blocks for eight bytes instead of six and twice the look-ups in flight, but 131 VGPRs and half the waves: 45 us
-    // against 38 us at 10^6 bytes, 28.3 against 31.4 us per 10^6 at 4 x 10^6 (profiles/r04_sbox_layer.md); the continued
-    // keystream below gets the same saving and more without the registers.
-    const int W = (t == 1 && wpt == 2) ? 2 : 1;
+    // One word (four bytes) per thread.  (Two words per thread sharing a keystream -- five ChaCha blocks for eight bytes instead
+    // of six, but 131 VGPRs and half the waves -- measured slower at 10^6 bytes in round 4 and was removed; the continued
+    // keystream of the kernel gets the same saving without the registers: profiles/r04_sbox_layer.md.)
+    constexpr int W = 1;
     const size_t nthreads_full = n / (4 * (size_t)W);
     const int rest_bytes = (int)(n - nthreads_full * 4 * W);
     size_t want = (nthreads_full + BLOCK - 1) / BLOCK;
@@ -909,6 +886,13 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     const size_t resident = (size_t)(lc.num_cu > 0 ? lc.num_cu : 256) * (t == 1 ? (m <= 4 ? 4 : 3) : (t == 2 ? 3 : 2));
     if (want > resident) want = resident;
     const unsigned grid = (unsigned)want;
+    {   // the keystream's counter ranges never meet: threads stream blocks [g * bpt, (g + 1) * bpt) (or step i its blocks
+        // i * NBLK ...), the ragged end draws from 2^61, the spare blocks of the continued stream from 2^62 + g * spt + j / 16,
+        // re-draws elsewhere in the library from 2^63 -- refuse shapes that would leave their range (n > ~10^17 bytes)
+        const uint64_t gsz = (uint64_t)grid * BLOCK;
+        const uint64_t steps = (nthreads_full + gsz - 1) / gsz;
+        if (gsz * (2 * steps + 2) >= (1ull << 61) || gsz * (steps / 16 + 1) >= (1ull << 61) || nthreads_full * 16ull >= (1ull << 61)) return 2;
+    }
     // (measured and NOT kept, round 4: letting up to 1024 workgroups advance the state themselves with a ticket drawn at
     // workgroup START -- the returning atomic sits in front of the wave's first loads in the in-order vmcnt queue, and 977
     // same-address atomics at ~25 ns each delay those waves: 43.7 us against 38.4 us with the one-thread kernel after it)
@@ -924,7 +908,6 @@ int ffgpu_launch_gf8_sbox_layer(const void* policy, int device, const void* x, s
     }
 #define SBL_CASE(MM, TT)                                 \
     if (m == MM && t == TT) {                            \
-        if (TT == 1 && W == 2) SBL_LAUNCH(MM, TT, (TT == 1 ? 2 : 1)) \
         SBL_LAUNCH(MM, TT, 1)                            \
     }
     SBL_CASE(3, 1) SBL_CASE(4, 1) SBL_CASE(5, 1) SBL_CASE(5, 2) SBL_CASE(6, 1) SBL_CASE(6, 2) SBL_CASE(7, 1) SBL_CASE(7, 2)
@@ -1032,9 +1015,7 @@ void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict
 size_t ffgpu_launch_gf2w64_mul_bitsliced(const void* policy, int device, const void* a, const void* b, void* out, size_t n,
                                          hipStream_t st) {
     const GF2W64& f = *reinterpret_cast<const GF2W64*>(policy);
-    const char* e = getenv("FFGPU_GF2W_BITSLICED");             // =0: the multiplier kernel (A/B measurements, tests)
-    const bool off = e && atoi(e) == 0;
-    if (off || f.n != 64 || f.red != 0x1bull || n < ((size_t)1 << 21) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return 0;
+    if (f.n != 64 || f.red != 0x1bull || n < ((size_t)1 << 21) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return 0;
     const size_t nvec4 = n / 2;
     const size_t nslab = (nvec4 + 1023) / 1024;
     LaunchCfg lc = launch_cfg(device);
@@ -1130,9 +1111,7 @@ int ffgpu_launch_gf8_mul_tab(const void* tables, int device, const void* a, cons
     LaunchCfg lc = launch_cfg(device);
     bool vec = aligned16(a) && aligned16(b) && aligned16(out);
     size_t nvec = vec ? n / 16 : 0;
-    LaunchCfg capped = lc;
-    if (capped.blocks_per_cu <= 0) capped.blocks_per_cu = table_blocks_per_cu();
-    unsigned grid = grid_for(nvec ? nvec : n, capped);
+    unsigned grid = grid_for(nvec ? nvec : n, lc);      // uncapped: the per-workgroup table copy is cheap (measured best)
     hipLaunchKernelGGL(k_gf8_mul_tab, dim3(grid), dim3(BLOCK), 0, st, tb, (const uint8_t*)a, (const uint8_t*)b,
                        (uint8_t*)out, nvec, n);
     FFGPU_CHECK_LAUNCH();
@@ -1565,11 +1544,10 @@ static int dispatch_gf2w_rec(const void* policy, int device, const void* const* 
             }
         ++kt;
     }
-    static const bool deep = !(getenv("FFGPU_GF2W_REC_DEEP") && atoi(getenv("FFGPU_GF2W_REC_DEEP")) == 0);
+    // (DEEP = 16 look-ups per batch in flight for every table count > 0: the round-3 measurement; kt = 0 is a plain XOR)
 #define GF2W_REC_CASE(KK)                                                                         \
     case KK:                                                                                      \
-        return deep && KK > 0 ? launch_gf2w_rec<LIMBS, KK, true>(policy, device, ra, out, n, st)  \
-                              : launch_gf2w_rec<LIMBS, KK, false>(policy, device, ra, out, n, st);
+        return launch_gf2w_rec<LIMBS, KK, (KK > 0)>(policy, device, ra, out, n, st);
     switch (kt) {
         GF2W_REC_CASE(0) GF2W_REC_CASE(1) GF2W_REC_CASE(2) GF2W_REC_CASE(3) GF2W_REC_CASE(4) GF2W_REC_CASE(5)
         GF2W_REC_CASE(6) GF2W_REC_CASE(7) GF2W_REC_CASE(8) GF2W_REC_CASE(9)
@@ -1648,9 +1626,8 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
     }
 }
 
-// lane-operations per second of instruction kind `op` and the shader clock (MHz) while it ran; 0 on success
-int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* lane_ops_per_s,
-                            double* clock_mhz, hipStream_t st) {
+// out[0] = lane-operations per second, out[1] = shader clock in MHz, out[2] = shader cycles per wave instruction and SIMD
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* out, hipStream_t st) {
     LaunchCfg lc = launch_cfg(device);
     if (op < 0 || op > 2 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
     const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
@@ -1676,7 +1653,8 @@ int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, v
     hipEventDestroy(e1);
     if (err != hipSuccess || ms <= 0.f) return 1;
     const double wave_instr = (double)grid * 4.0 * (double)iters * 128.0;
-    *lane_ops_per_s = wave_instr * 64.0 / ((double)ms * 1e-3);
-    *clock_mhz = host_clk[1] ? (double)host_clk[0] / (double)host_clk[1] * 100.0 : 0.0;
+    out[0] = wave_instr * 64.0 / ((double)ms * 1e-3);
+    out[1] = host_clk[1] ? (double)host_clk[0] / (double)host_clk[1] * 100.0 : 0.0;
+    out[2] = (double)host_clk[0] / ((double)iters * 128.0 * (double)waves_per_simd);     // the timed wave shared its SIMD with the others
     return 0;
 }

@@ -959,13 +959,13 @@ class FieldContext:
         _ffi.check(self._L.ffgpu_copy(self._h, src.data_ptr(), dst.data_ptr(), nbytes, self._stream()), 'copy')
 
     def valu_probe(self, op: int = 0, iters: int = 2000, waves_per_simd: int = 4):
-        """(lane-operations per second, shader clock in MHz) the integer VALU sustains right now for one instruction kind
-        (0: v_bitop3_b32, 1: v_add_u32, 2: v_mad_u64_u32): the compute-side yardstick beside `copy` (ffgpu_valu_probe)."""
+        """(lane-operations per second, shader clock in MHz, shader cycles per wave instruction and SIMD) the integer VALU
+        sustains right now for one instruction kind (0: v_bitop3_b32, 1: v_add_u32, 2: v_mad_u64_u32): the compute-side
+        yardstick beside `copy` (ffgpu_valu_probe)."""
         scratch = torch.zeros(4, dtype=torch.int64, device=self.torch_device)
-        rate, mhz = ctypes.c_double(), ctypes.c_double()
-        _ffi.check(self._L.ffgpu_valu_probe(self._h, op, iters, waves_per_simd, scratch.data_ptr(), ctypes.byref(rate),
-                                            ctypes.byref(mhz), self._stream()), 'valu_probe')
-        return float(rate.value), float(mhz.value)
+        out = (ctypes.c_double * 3)()
+        _ffi.check(self._L.ffgpu_valu_probe(self._h, op, iters, waves_per_simd, scratch.data_ptr(), out, self._stream()), 'valu_probe')
+        return float(out[0]), float(out[1]), float(out[2])
 
     def time_copy(self, src: torch.Tensor, dst: torch.Tensor, reps: int) -> float:
         ms = ctypes.c_float()

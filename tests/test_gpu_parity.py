@@ -288,8 +288,8 @@ def test_batched_inverse_full_batch_kernel(eng, modulus, monkeypatch):
     """k_inv_fast (kernels.hpp; one-word fields, n >= 32768): full blocks without bounds checks + the extra blocks for
     the leftover packs and the odd last element; the lean exponentiation (run of ones + short tail: every 2^k - c prime)
     and the window-table one (8123557937065977257: a prime whose q - 2 has 38 set bits); zeros anywhere give zero and
-    raise; against Python's pow on a sample and a * a^-1 == 1 on every element.  FFGPU_INV_VARIANT=0 (the round-3 kernel,
-    read per call) must give the same array."""
+    raise; against Python's pow on a sample and a * a^-1 == 1 on every element; pieces of the array below the kernel's
+    threshold (k_inv_batch) must give the same elements."""
     import torch
     ctx = ctx_for(eng, modulus, False)
     if ctx.elem_bytes != 8:
@@ -310,10 +310,11 @@ def test_batched_inverse_full_batch_kernel(eng, modulus, monkeypatch):
         nz = dA.t != 0
         one = ctx.mul(dA, inv).t
         assert bool((one[nz] == 1).all()) and bool((inv.t[~nz] == 0).all())
-        monkeypatch.setenv('FFGPU_INV_VARIANT', '0')
-        old = ctx.inv(dA, check_zero=False)
-        monkeypatch.delenv('FFGPU_INV_VARIANT')
-        assert torch.equal(old.t, inv.t), (hex(modulus), n)
+        # the same array in pieces of fewer than 32768 elements takes the general kernel (k_inv_batch): same elements
+        step = 30_000
+        for lo in range(0, n, step * 7):
+            part = ctx.inv(eng.DevArray(ctx, dA.t[lo:lo + step].clone(), min(step, n - lo)), check_zero=False)
+            assert torch.equal(part.t, inv.t[lo:lo + step]), (hex(modulus), n, lo)
         vals2 = [v or 1 for v in vals]
         dN = ctx.from_numpy(pack(vals2, 8))
         ctx.inv(dN)                                      # no zeros: no exception
@@ -395,8 +396,8 @@ def test_batched_inverse_full_batch_kernel_binary(eng, modulus, monkeypatch):
     for i in [1, 2, 3, 4, n - 2] + list(range(100, 140)):
         if int(A[i]):
             assert po.mul(F, int(got[i]), int(A[i])) == 1, (hex(modulus), i)
-    monkeypatch.setenv('FFGPU_INV_VARIANT', '0')
-    assert torch.equal(ctx.inv(dA, check_zero=False).t, inv.t)
+    part = ctx.inv(eng.DevArray(ctx, dA.t[:30_000].clone(), 30_000), check_zero=False)       # below the threshold: k_inv_batch
+    assert torch.equal(part.t, inv.t[:30_000])
 
 
 def test_gf2_64_bitsliced_product(eng, coracle, monkeypatch):
@@ -419,9 +420,10 @@ def test_gf2_64_bitsliced_product(eng, coracle, monkeypatch):
         want = cf.ew(coracle.MUL, A, B)
         got = ctx.mul(dA, dB)
         assert (got.to_numpy() == want).all(), n
-        monkeypatch.setenv('FFGPU_GF2W_BITSLICED', '0')
-        assert torch.equal(ctx.mul(dA, dB).t, got.t)
+        monkeypatch.setenv('FFGPU_GF2W_BITSLICED', '0')          # (switches are read when a context is created)
+        plain = eng.FieldContext(mod, binary=True)
         monkeypatch.delenv('FFGPU_GF2W_BITSLICED')
+        assert torch.equal(plain.mul(eng.DevArray(plain, dA.t, n), eng.DevArray(plain, dB.t, n)).t, got.t)
         ctx.mul(dA, dB, out=dA)                                    # in place
         assert (dA.to_numpy() == want).all(), n
 
@@ -799,23 +801,26 @@ def test_matrix_core_product(eng, coracle):
     assert set(got) == {K * (P64 - 1) * (P64 - 1) % P64}
 
 
-def test_matrix_core_product_lds_direct_equals_register_staged(eng, monkeypatch):
-    """k_limb_gemm_glds (operand tiles streamed straight into LDS, two k-steps ahead, counted waits) against the
-    register-staged k_limb_gemm_lds (FFGPU_MM_GLDS=0, read per call): identical arrays for digit planes of both operands,
-    for the raw right operand of the 64-row shapes (whole tiles and the fallback for ragged ones), split-K slabs, K beyond
-    one 8192 chunk (accumulating launches) and one, two and three k-steps (the prologue / drain of the three-stage ring)."""
-    for modulus in (P61, P64, 2**63 - 25):
+def test_matrix_core_product_equals_valu_product(eng, monkeypatch):
+    """k_limb_gemm_glds (operand tiles streamed straight into LDS, two k-steps ahead, counted waits) against the VALU product
+    (k_matmul: a context created with FFGPU_MM_MFMA=0 -- the library's switches are read per context): identical arrays for
+    digit planes of both operands, for the raw right operand of the 64-row shapes (whole tiles, and ragged ones that go
+    through the planes), split-K slabs, K beyond one 8192 chunk (accumulating launches) and one, two and three k-steps
+    (the prologue / drain of the three-stage ring); 32-bit storage (k_limb_gemm_l4) as well."""
+    for modulus in (P61, P64, 2**63 - 25, 2**31 - 1):
         F = po.Field(modulus, False)
         ctx = ctx_for(eng, modulus, False)
+        monkeypatch.setenv('FFGPU_MM_MFMA', '0')
+        valu = eng.FieldContext(modulus)
+        monkeypatch.delenv('FFGPU_MM_MFMA')
+        eb = ctx.elem_bytes
         # (tests/conftest.py lowers the matrix-core threshold to 1.6e7 multiply-accumulates)
         for (M, K, N) in ((256, 256, 256), (64, 1024, 256), (64, 4096, 512), (1024, 64, 512), (512, 96, 512), (128, 128, 1024),
                           (65, 8300, 70), (64, 1030, 300), (300, 9000, 130), (64, 8192 + 64, 128), (128, 8192 + 96, 64)):
-            A, B = rand_np(F, 8, M * K, 5 + M), rand_np(F, 8, K * N, 7 + N)
+            A, B = rand_np(F, eb, M * K, 5 + M), rand_np(F, eb, K * N, 7 + N)
             dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
             got = ctx.matmul(dA, dB, M, K, N)
-            monkeypatch.setenv('FFGPU_MM_GLDS', '0')
-            want = ctx.matmul(dA, dB, M, K, N)
-            monkeypatch.delenv('FFGPU_MM_GLDS')
+            want = valu.matmul(eng.DevArray(valu, dA.t, M * K), eng.DevArray(valu, dB.t, K * N), M, K, N)
             assert torch.equal(got.t, want.t), (hex(modulus), M, K, N)
 
 

@@ -452,39 +452,42 @@ def test_sbox_layer_all_parties_in_one_launch(mods, t, m, fused):
 
 
 @pytest.mark.gpu
-def test_sbox_layer_interleaved_keystream_equals_burst_keystream(tmp_path):
-    """The ChaCha20 blocks of the one-kernel layer advance between the table look-ups (SblKeystream<10>); with
-    FFGPU_SBL_BURST=1 they are computed as whole blocks when needed, as in round 3.  Same key, nonce and inputs:
-    the output shares must be identical byte for byte (same keystream words in the same order), ragged tail included."""
-    import subprocess
-    import sys
-    prog = r'''
-import sys, json, os, hashlib
-sys.path.insert(0, os.environ["REPO"])
-import numpy as np, torch
-from mpyc_amd import engine, finfields, gfpx, protocols
-g = json.load(open(os.path.join(os.environ["REPO"], "tests", "golden", "sbox.json")))
-F = finfields.GF(gfpx.GFpX(2)(0x11b))
-ctx = engine.FieldContext(0x11b, True, device=0)
-A = [[(g["rows8"][r] >> c) & 1 for c in range(8)] for r in range(8)]
-B = [(g["b"] >> r) & 1 for r in range(8)]
-out = []
-for (m, t, n) in ((3, 1, 100003), (7, 3, 5001), (6, 2, 4096)):
-    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
-    X = ctx.empty_matrix(m, n); X.t[:, :n].copy_(torch.randint(0, 256, (m, n), dtype=torch.uint8, device="cuda:0", generator=gen))
-    R = ctx.empty_matrix(m, 8 * n); R.t[:, :8 * n].copy_(torch.randint(0, 2, (m, 8 * n), dtype=torch.uint8, device="cuda:0", generator=gen))
-    o = ctx.gf256_sbox_layer(X, R, t, protocols._lagrange(F, range(1, 2 * t + 2)), protocols._lagrange(F, range(1, t + 2)), A, B,
-                             key=bytes(range(32)), nonce=9)
-    out.append(hashlib.sha256(o.t[:, :n].contiguous().cpu().numpy().tobytes()).hexdigest())
-print("DIGESTS", json.dumps(out))
-'''
-    res = []
-    for burst in ('0', '1'):
-        r = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, FFGPU_SBL_BURST=burst, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-        assert r.returncode == 0 and 'DIGESTS' in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
-        res.append(r.stdout.split('DIGESTS', 1)[1].strip())
-    assert res[0] == res[1]
+def test_sbox_layer_replays_advance_the_device_nonce(mods):
+    """A captured one-kernel S-box layer with a device-resident generator state (engine.RngState) must draw from a fresh
+    nonce on EVERY replay: the kernel advances the device nonce itself -- by its last workgroup for grids of up to 512
+    workgroups (n = 4096 and 5 * 10^5 bytes), by the one-thread k_rng_advance behind it above that (10^6 bytes = 977
+    workgroups, and the persistent grid of 4.2 * 10^6 bytes whose threads continue their keystream from step to step).
+    Two replays advance it by exactly 2; the opened result is the FIPS-197 table every time.  (What the shares
+    look like does not depend on the keystream -- the re-sharing randomness cancels in every opening -- so the nonce is the
+    observable here.)"""
+    import json
+    engine, finfields, gfpx, protocols = mods
+    import torch
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'sbox.json')) as fh:
+        g = json.load(fh)
+    F = finfields.GF(gfpx.GFpX(2)(0x11b))
+    ctx = engine.FieldContext(0x11b, True, device=0)
+    A = [[(g['rows8'][r] >> c) & 1 for c in range(8)] for r in range(8)]
+    B = [(g['b'] >> r) & 1 for r in range(8)]
+    table = torch.tensor(g['table'], dtype=torch.uint8, device='cuda:0')
+    gen = torch.Generator(device='cuda:0')
+    gen.manual_seed(11)
+    for n in (4096, 500_000, 1_000_000, 4_200_000):
+        xpub = engine.DevArray(ctx, torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda:0', generator=gen), n)
+        xs = protocols.as_matrix(ctx, protocols.share(ctx, xpub, 1, 3))
+        rb = engine.DevArray(ctx, torch.randint(0, 2, (8 * n,), dtype=torch.uint8, device='cuda:0', generator=gen), 8 * n)
+        rbits = protocols.as_matrix(ctx, protocols.share(ctx, rb, 1, 3))
+        st = ctx.rng_state()
+        cg = engine.CapturedLaunches(lambda: protocols.sbox_layer_all(ctx, F, xs, rbits, 1, A, B, rng=st, fused=True))
+        torch.cuda.synchronize()
+        n0 = st.nonce()
+        want = table[xpub.t.long()]
+        for k_ in (1, 2):
+            cg.replay()
+            torch.cuda.synchronize()
+            assert st.nonce() == n0 + k_, (n, k_, st.nonce() - n0)
+            opened = protocols.open_(ctx, F, [cg.result.row(i_) for i_ in range(3)], 1).t
+            assert torch.equal(opened, want), n
 
 
 @pytest.mark.gpu
