@@ -563,16 +563,16 @@ int ffgpu_mul(ffgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
                                                        a, b, out, n, (hipStream_t)stream));
     }
     if (ctx && ctx->policy_kind == POL_GF2W64 && ctx->tune.gf2w_bitsliced && a && b && out && n >= ((size_t)1 << 21)) {
-        // GF(2^64) with the default modulus: bit-sliced product for the whole slabs, the element-wise kernel for the rest
-        size_t done;
-        {
-            DeviceGuard g(ctx->device);
-            LaunchTimer lt(ctx, (hipStream_t)stream);
-            done = ffgpu_launch_gf2w64_mul_bitsliced(ctx->policy, ctx->device, a, b, out, n, (hipStream_t)stream);
-            if (done && hipGetLastError() != hipSuccess) return FFGPU_EHIP;
-        }
+        // GF(2^64) with the default modulus: bit-sliced product for all whole pairs of elements, the element-wise kernel for
+        // the odd last one -- both launches under ONE timer scope (ffgpu_last_kernel_ms reports the call, not its tail)
+        DeviceGuard g(ctx->device);
+        LaunchTimer lt(ctx, (hipStream_t)stream);
+        const size_t done = ffgpu_launch_gf2w64_mul_bitsliced(ctx->policy, ctx->device, a, b, out, n, (hipStream_t)stream);
+        if (done && hipGetLastError() != hipSuccess) return FFGPU_EHIP;
         if (done == n) return FFGPU_OK;
-        if (done) return do_ew2(ctx, OP_MUL, (const char*)a + 8 * done, (const char*)b + 8 * done, (char*)out + 8 * done, n - done, stream);
+        if (done)
+            return launch_status(ctx->ops->ew2(ctx->policy, ctx->device, OP_MUL, (const char*)a + 8 * done, (const char*)b + 8 * done,
+                                               (char*)out + 8 * done, n - done, (hipStream_t)stream));
     }
     return do_ew2(ctx, OP_MUL, a, b, out, n, stream);
 }

@@ -931,83 +931,48 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
 
 // ---- GF(2^64), x^64 + x^4 + x^3 + x + 1: element-wise product, BIT-SLICED ------------------------------------------
 // (gfpx.py:988-1045 + finfields.py:537-541.)  The multiplier route (ff_clmul64: 48 v_mad_u64_u32 + masks, 280 VALU
-// instructions per element, profiles/r04_valu.md) is issue-bound at 0.36 of the HBM rate.  Here a lane holds 32 elements
-// as 64 bit-planes of uint32 (two 32 x 32 bit transposes per operand: v_perm_b32 for the 16- and 8-bit stages, shift +
-// v_bitop3 select for the rest), a partial-product MAC of all 32 elements is ONE v_bitop3_b32 (acc ^ (a & b)), Karatsuba
-// runs down to 8 x 8 leaves (27 x 64 MACs), the fold is four XORs per high plane, and two transposes return the packed
-// result: 153 instructions per element including the register traffic below.  The price is the register file: 64 + 64
-// operand planes, 127 product planes and the Karatsuba temporaries need ~320 registers, so a wave takes a SIMD for itself
-// (256 VGPRs + AGPRs) -- the kernel is PERSISTENT, one wave per SIMD, and the next slab's 32 loads are in flight while
-// the current slab is multiplied (455 registers in all).  64 us against 83 us at n = 10^7 (0.47 against 0.36 of the HBM
-// peak; tools/bitslice_probe.hip is the stand-alone probe with the variants that were measured, profiles/r04_gf2w.md).
-// The same layout for GF(2^128) needs 256 + 255 planes per lane: it does not fit any register budget (ibid.).
-// (namespace bs64 -- transposes, Karatsuba on bit-planes, the fold -- lives in bitslice.hpp: the same header compiles
-// with g++ for tests/test_hostcheck.py)
-
-// a slab = 2048 consecutive elements = 1024 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
-// (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..15.  The last slab may be partial: its
-// accesses are guarded per uint4 (nvec4 = n / 2 of them exist), missing operands are zero.
-__device__ __forceinline__ void bs64_load(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t slab, int lane, size_t nvec4,
-                                          uint4 (&na)[16], uint4 (&nb)[16]) {
-    const size_t base = slab * 1024 + lane;
-    if ((slab + 1) * 1024 <= nvec4) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            na[r] = ldg<true>(a + base + (size_t)r * 64);
-            nb[r] = ldg<true>(b + base + (size_t)r * 64);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool in = base + (size_t)r * 64 < nvec4;
-            na[r] = in ? ldg<true>(a + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
-            nb[r] = in ? ldg<true>(b + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_gf2w64_mul_bitsliced(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ o, size_t nslab,
-                            size_t nvec4) {
-    const size_t wave0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const size_t nwaves = ((size_t)gridDim.x * BLOCK) >> 6;
+// instructions per element) is issue-bound at 0.36 of the HBM rate.  Bit-sliced, a partial-product MAC of a whole batch of
+// elements is ONE v_bitop3_b32 (acc ^ (a & b)) and Karatsuba runs down to 8 x 8 leaves.  Round 4 held 32 elements per lane as
+// 64 full-width planes per operand: 455 registers, ONE wave per SIMD, VALU busy 0.65 (nothing covers the dependent-issue
+// latency), 66-70 us at n = 10^7.  Round 5 (bitslice.hpp, mul16_planes): 16 elements per lane with the two 32-coefficient
+// HALVES of an operand packed into the two halves of a plane register -- one 32 x 32 transpose of [lo words ; hi words] yields
+// exactly that -- so the outer Karatsuba products A0 B0 and A1 B1 come out of ONE Mul<32> on packed registers, the middle
+// product is packed the same way one level down, and nothing is ever held as 64 or 127 full-width planes: the kernel fits
+// TWO waves per SIMD (amdgpu_waves_per_eu(2, 2)), no prefetch registers needed -- the other wave's arithmetic covers this
+// wave's loads.  The same arithmetic compiles with g++ for tests/test_hostcheck.py.
+// A slab = 1024 consecutive elements = 512 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
+// (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..7.  The last slab may be partial: its accesses
+// are guarded per uint4 (nvec4 = n / 2 of them exist), missing operands are zero.  In place (o == a or o == b) is fine: a
+// wave loads its whole slab before it stores any of it, and slabs are disjoint -- hence no __restrict__ on the pointers.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gf2w64_mul_bitsliced(const uint4* a, const uint4* b, uint4* o, size_t nslab, size_t nvec4) {
     const int lane = threadIdx.x & 63;
-    if (wave0 >= nslab) return;
-    uint4 na[16], nb[16];
-    bs64_load(a, b, wave0, lane, nvec4, na, nb);
-    for (size_t wave = wave0; wave < nslab; wave += nwaves) {
-        const size_t base = wave * 1024 + lane;
-        uint32_t pa[64], pb[64];
-        {
-            uint32_t lo[32], hi[32];
+    const size_t slab = (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (slab >= nslab) return;
+    const size_t base = slab * 512 + lane;
+    const bool whole = (slab + 1) * 512 <= nvec4;
+    uint32_t pa[32], pb[32];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { lo[2 * r] = na[r].x; hi[2 * r] = na[r].y; lo[2 * r + 1] = na[r].z; hi[2 * r + 1] = na[r].w; }
-            bs64::transpose32(lo); bs64::transpose32(hi);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) { pa[i] = lo[i]; pa[32 + i] = hi[i]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { lo[2 * r] = nb[r].x; hi[2 * r] = nb[r].y; lo[2 * r + 1] = nb[r].z; hi[2 * r + 1] = nb[r].w; }
-            bs64::transpose32(lo); bs64::transpose32(hi);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) { pb[i] = lo[i]; pb[32 + i] = hi[i]; }
-        }
-        if (wave + nwaves < nslab) bs64_load(a, b, wave + nwaves, lane, nvec4, na, nb);     // in flight during the product below
-        uint32_t c[127];
-        bs64::Mul<64>::run(pa, pb, c);
-        bs64::fold_1b(c);                                 // x^64 = x^4 + x^3 + x + 1
-        uint32_t lo[32], hi[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { lo[i] = c[i]; hi[i] = c[32 + i]; }
-        bs64::transpose32(lo); bs64::transpose32(hi);
-        if ((wave + 1) * 1024 <= nvec4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (base + (size_t)r * 64 < nvec4) stg<true>(o + base + (size_t)r * 64, make_uint4(lo[2 * r], hi[2 * r], lo[2 * r + 1], hi[2 * r + 1]));
-        }
+    for (int r = 0; r < 8; ++r) {
+        const bool in = whole || base + (size_t)r * 64 < nvec4;
+        const uint4 va = in ? ldg<true>(a + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
+        const uint4 vb = in ? ldg<true>(b + base + (size_t)r * 64) : make_uint4(0, 0, 0, 0);
+        pa[2 * r] = va.x; pa[16 + 2 * r] = va.y; pa[2 * r + 1] = va.z; pa[16 + 2 * r + 1] = va.w;      // rows: lo words, then hi words
+        pb[2 * r] = vb.x; pb[16 + 2 * r] = vb.y; pb[2 * r + 1] = vb.z; pb[16 + 2 * r + 1] = vb.w;
     }
+    bs64::transpose32(pa);
+    bs64::transpose32(pb);
+    uint32_t c[127];
+    bs64::mul16_planes(pa, pb, c);
+    bs64::fold_1b(c);                                      // x^64 = x^4 + x^3 + x + 1
+    uint32_t ov[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) ov[i] = bs64::lo_pair(c[i + 32], c[i]);
+    bs64::transpose32(ov);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (whole || base + (size_t)r * 64 < nvec4)
+            stg<true>(o + base + (size_t)r * 64, make_uint4(ov[2 * r], ov[16 + 2 * r], ov[2 * r + 1], ov[16 + 2 * r + 1]));
 }
 
 // returns the number of leading elements it has multiplied (all of them but the last one of an odd n; 0 = not applicable):
@@ -1017,9 +982,8 @@ size_t ffgpu_launch_gf2w64_mul_bitsliced(const void* policy, int device, const v
     const GF2W64& f = *reinterpret_cast<const GF2W64*>(policy);
     if (f.n != 64 || f.red != 0x1bull || n < ((size_t)1 << 21) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return 0;
     const size_t nvec4 = n / 2;
-    const size_t nslab = (nvec4 + 1023) / 1024;
-    LaunchCfg lc = launch_cfg(device);
-    const unsigned grid = (unsigned)(lc.num_cu > 0 ? lc.num_cu : 256);       // one workgroup of four waves per CU: a wave per SIMD
+    const size_t nslab = (nvec4 + 511) / 512;
+    const unsigned grid = (unsigned)((nslab + BLOCK / 64 - 1) / (BLOCK / 64));
     hipLaunchKernelGGL(k_gf2w64_mul_bitsliced, dim3(grid), dim3(BLOCK), 0, st, (const uint4*)a, (const uint4*)b, (uint4*)out, nslab,
                        nvec4);
     return nvec4 * 2;

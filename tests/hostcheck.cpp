@@ -281,16 +281,16 @@ extern "C" int hc_limb_digits_wide(const uint64_t* x2, const uint64_t* p2, int L
 }
 
 
-// the bit-sliced GF(2^64) product of k_gf2w64_mul_bitsliced on 32 elements (bitslice.hpp: transposes, Karatsuba on
-// bit-planes, fold modulo x^64 + x^4 + x^3 + x + 1, transposes back); a, b, out: 32 uint64 each
-extern "C" int hc_bs64_mul32(const uint64_t* a, const uint64_t* b, uint64_t* out) {
-    uint32_t alo[32], ahi[32], blo[32], bhi[32], olo[32], ohi[32];
-    for (int e = 0; e < 32; ++e) {
+// the bit-sliced GF(2^64) product of k_gf2w64_mul_bitsliced on the 16 elements of a lane (bitslice.hpp mul16_packed: one
+// transpose per operand, packed Karatsuba on bit-planes, fold modulo x^64 + x^4 + x^3 + x + 1, transpose back)
+extern "C" int hc_bs64_mul16_packed(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    uint32_t alo[16], ahi[16], blo[16], bhi[16], olo[16], ohi[16];
+    for (int e = 0; e < 16; ++e) {
         alo[e] = (uint32_t)a[e]; ahi[e] = (uint32_t)(a[e] >> 32);
         blo[e] = (uint32_t)b[e]; bhi[e] = (uint32_t)(b[e] >> 32);
     }
-    bs64::mul32(alo, ahi, blo, bhi, olo, ohi);
-    for (int e = 0; e < 32; ++e) out[e] = (uint64_t)olo[e] | ((uint64_t)ohi[e] << 32);
+    bs64::mul16_packed(alo, ahi, blo, bhi, olo, ohi);
+    for (int e = 0; e < 16; ++e) out[e] = (uint64_t)olo[e] | ((uint64_t)ohi[e] << 32);
     return 0;
 }
 // one 32 x 32 bit transpose (out word i, bit e = in word e, bit i)

@@ -426,8 +426,9 @@ def test_pm64_general_policy_all_widths(hostcheck):
 
 def test_bitsliced_gf2_64_product(hostcheck):
     """mpyc_amd/csrc/bitslice.hpp (the arithmetic of k_gf2w64_mul_bitsliced) compiled for the host: the 32 x 32 bit
-    transpose against its definition, and the product of 32 elements at a time -- transposes in, Karatsuba on 64 bit-planes
-    down to 8 x 8 leaves, fold modulo x^64 + x^4 + x^3 + x + 1, transposes out -- against the oracle's GF(2^64) product
+    transpose against its definition, and the product of the 16 elements of a lane -- one transpose per operand (operand halves
+    in register halves), packed Karatsuba down to 8 x 8 leaves, fold modulo x^64 + x^4 + x^3 + x + 1, transpose out -- against
+    the oracle's GF(2^64) product
     (gfpx.py:988-1045 restated) for random and extreme operands."""
     import random
     from oracle import pyoracle as po
@@ -448,6 +449,7 @@ def test_bitsliced_gf2_64_product(hostcheck):
             a[:16] = extreme
             b[:16] = extreme[::-1] if rnd % 2 else extreme
             b[16:32] = extreme[rnd:] + extreme[:rnd]
-        out = (ctypes.c_uint64 * 32)()
-        assert hostcheck.hc_bs64_mul32((ctypes.c_uint64 * 32)(*a), (ctypes.c_uint64 * 32)(*b), out) == 0
-        assert list(out) == [po.mul(F, x, y) for x, y in zip(a, b)], rnd
+        for off in (0, 16):
+            o16 = (ctypes.c_uint64 * 16)()
+            assert hostcheck.hc_bs64_mul16_packed((ctypes.c_uint64 * 16)(*a[off:off + 16]), (ctypes.c_uint64 * 16)(*b[off:off + 16]), o16) == 0
+            assert list(o16) == [po.mul(F, x, y) for x, y in zip(a[off:off + 16], b[off:off + 16])], (rnd, off)
