@@ -189,8 +189,8 @@ def compact_line(out):
     if isinstance(c0, dict):
         line['configs0'] = _pick(c0, ('workload', 'mirror_secrets_per_s', 'reference_secrets_per_s', 'parity', 'error', 'skipped'))
     if isinstance(out.get('valu_peak'), dict):
-        line['valu_peak'] = _pick(out['valu_peak'], ('lane_ops_per_s', 'mad_u64_u32_lane_ops_per_s', 'mad_slots', 'shader_clock_mhz',
-                                                     'shader_clock_mhz_under_full_valu_load', 'source'))
+        line['valu_peak'] = _pick(out['valu_peak'], ('lane_ops_per_s', 'vop3_lane_ops_per_s', 'mad_u64_u32_lane_ops_per_s', 'vop3_ceiling',
+                                                     'shader_clock_mhz', 'shader_clock_mhz_under_full_valu_load', 'source'))
     kern = out.get('kernels')
     if isinstance(kern, dict):
         # one number per kernel row, in TWO maps that never mix: hbm_fracs = algorithmic bytes / time / 8 TB/s for the rows
@@ -251,36 +251,36 @@ VALU_COUNTS_FILES = ('r05_valu.json', 'r04_valu.json')     # SQ_INSTS_VALU per u
 
 
 def measure_valu_peak(ctx):
-    """The chip's integer-VALU issue rate, MEASURED in this run (ffgpu_valu_probe: 8 independent dependent-chains per wave).
-    Under a pure-VALU load at four waves per SIMD the chip clocks to its power budget (lowest clock); a kernel with stalls runs
-    at a higher one.  So the PEAK a row is priced against is the per-cycle issue rate measured at full occupancy times the
-    HIGHEST shader clock any probe of this run reached (one wave per SIMD: light load) -- the rate no kernel of this run could
-    exceed; `valu_frac` of a row above 1 would mean its instruction count is wrong.  No clock is assumed anywhere."""
-    simds = torch.cuda.get_device_properties(ctx.torch_device).multi_processor_count * 4
+    """The chip's integer-VALU issue rates, MEASURED in this run (ffgpu_valu_probe: 8 independent dependent-chains per wave, four
+    waves per SIMD; profiles/r05_valu_rates.md has the whole table).  Two-operand VOP2 instructions issue at ~2.35 cycles per
+    wave64 once a SIMD holds two or more waves, three-operand VOP3 ones and v_mad_u64_u32 at ~4.1-4.4.  The PEAK a row is priced
+    against is the two-operand rate times the HIGHEST shader clock any probe of this run reached (a pure-VALU load at full
+    occupancy clocks lowest): the rate no instruction mix can exceed, so a `valu_frac` above 1 would mean the instruction count
+    is wrong; a kernel made of three-operand instructions tops out at `vop3_ceiling` of it.  No clock is assumed anywhere."""
     probes = {}
-    for name, op in (('bitop3_b32', 0), ('add_u32', 1), ('mad_u64_u32', 2)):
+    for name, op in (('xor_b32', 3), ('add_u32', 1), ('bitop3_b32', 0), ('mad_u64_u32', 2)):
         for waves in (4, 1):
-            rate, mhz, cyc = ctx.valu_probe(op, waves_per_simd=waves)
-            probes[f'{name}_w{waves}'] = {'lane_ops_per_s': round(rate, 1), 'shader_clock_mhz': round(mhz, 1),
-                                          'cycles_per_wave_instruction': round(cyc, 3),
-                                          'lanes_per_cycle_per_simd': round(rate / (mhz * 1e6) / simds, 2) if mhz else None}
+            rate, mhz, _ = ctx.valu_probe(op, waves_per_simd=waves)
+            probes[f'{name}_w{waves}'] = {'lane_ops_per_s': round(rate, 1), 'shader_clock_mhz': round(mhz, 1)}
     clock_max = max(p_['shader_clock_mhz'] for p_ in probes.values())
-    full = min(probes['bitop3_b32_w4'], probes['add_u32_w4'], key=lambda p_: p_['lane_ops_per_s'])
-    single = full['lane_ops_per_s'] * clock_max / full['shader_clock_mhz']
-    mad = probes['mad_u64_u32_w4']
-    mad_rate = mad['lane_ops_per_s'] * clock_max / mad['shader_clock_mhz']
-    return {'lane_ops_per_s': round(single, 1), 'mad_u64_u32_lane_ops_per_s': round(mad_rate, 1), 'mad_slots': round(single / mad_rate, 3),
-            'shader_clock_mhz': clock_max, 'shader_clock_mhz_under_full_valu_load': full['shader_clock_mhz'],
-            'probes': probes, 'source': 'ffgpu_valu_probe in this run: per-cycle rate at 4 waves per SIMD x the highest clock seen'}
+
+    def at_max(key):
+        return probes[key]['lane_ops_per_s'] * clock_max / probes[key]['shader_clock_mhz']
+    fast = max(at_max('xor_b32_w4'), at_max('add_u32_w4'))
+    return {'lane_ops_per_s': round(fast, 1), 'vop3_lane_ops_per_s': round(at_max('bitop3_b32_w4'), 1),
+            'mad_u64_u32_lane_ops_per_s': round(at_max('mad_u64_u32_w4'), 1), 'vop3_ceiling': round(at_max('bitop3_b32_w4') / fast, 3),
+            'shader_clock_mhz': clock_max, 'shader_clock_mhz_under_full_valu_load': probes['bitop3_b32_w4']['shader_clock_mhz'],
+            'probes': probes,
+            'source': 'ffgpu_valu_probe in this run: two-operand (VOP2) rate at 4 waves per SIMD x the highest shader clock seen'}
 
 
 def annotate_valu(kern, out):
     """Rows whose limiter is the VALU (in-kernel ChaCha, carry-less products, exponentiations, LDS-table recombination):
-    `bound: "valu"` and `valu_frac` = issue slots per unit x units/s / the single-slot issue rate MEASURED in this run
-    (out['valu_peak']).  Slots per unit = VALU instructions per unit (rocprofv3 --pmc SQ_INSTS_VALU of tools/valu_probe.py,
-    profiles/r05_valu.json -- counted at the commit named in its `_meta`, reported as `valu_counts`) plus, for rows that state
-    their multiplies (`valu_mads_per_unit`), (mad_slots - 1) further slots per v_mad_u64_u32, mad_slots measured too.  Rows
-    without a multiply count understate multiply-heavy kernels; `frac` stays the fraction of the HBM peak for the row's bytes."""
+    `bound: "valu"` and `valu_frac` = VALU instructions per unit (rocprofv3 --pmc SQ_INSTS_VALU of tools/valu_probe.py,
+    profiles/r05_valu.json -- counted at the commit named in its `_meta`, reported as `valu_counts`) x 64 lanes x units/s / the
+    issue rate MEASURED in this run (out['valu_peak']: the two-operand rate, an upper bound for any mix -- three-operand
+    instructions and multiplies issue at `vop3_ceiling` of it, so a kernel made of those is issue-bound at that fraction).
+    `frac` stays the fraction of the HBM peak for the row's bytes."""
     peak = out.get('valu_peak')
     path = next((os.path.join(ROOT, 'profiles', f_) for f_ in VALU_COUNTS_FILES if os.path.exists(os.path.join(ROOT, 'profiles', f_))), None)
     if not isinstance(peak, dict) or path is None:
@@ -290,7 +290,7 @@ def annotate_valu(kern, out):
     meta = data.pop('_meta', {})
     out['valu_counts'] = {'file': os.path.relpath(path, ROOT), 'counted_at_commit': meta.get('commit'),
                           'note': 'instruction counts are a property of the kernels at that commit; the RATES are from this run'}
-    single, mad_slots = peak['lane_ops_per_s'], peak['mad_slots']
+    fast = peak['lane_ops_per_s']
     jobs = [(row, info) for row, info in data.items()]
     jobs += [(row, data[r_['valu_counts_of']]) for row, r_ in kern.items()
              if isinstance(r_, dict) and r_.get('valu_counts_of') in data]          # rows that run a counted kernel another way
@@ -299,10 +299,9 @@ def annotate_valu(kern, out):
         if not isinstance(r, dict) or not r.get('ms_per_launch') or not r.get('units_per_s'):
             continue
         ops = float(info['valu_lane_ops_per_unit'])
-        slots = ops + float(r.get('valu_mads_per_unit', 0.0)) * (mad_slots - 1.0)
         # (the dense GF(2^n) recombination waits on its LDS look-ups as much as on the VALU: both are named)
         r.update(bound='lds+valu' if row.endswith('_dense') else 'valu', valu_lane_ops_per_unit=ops,
-                 valu_issue_slots_per_unit=round(slots, 1), valu_frac=round(slots * r['units_per_s'] / single, 4))
+                 valu_frac=round(ops * r['units_per_s'] / fast, 4))
 
 
 def cpu_baseline(n_full, t, m, lam, seed=20260925):
@@ -1194,8 +1193,7 @@ def main():
                 kern[f'mul_{label}'] = dict(roof(3 * ebg * n, ms), algorithmic_bytes_per_unit=3 * ebg, bound_note='integer ALU (carry-less product)',
                                             units_per_s=round(n / (ms * 1e-3), 1))
                 if label == 'gf2_128':
-                    # no carry-less multiply on gfx950: 9 x 16 v_mad_u64_u32 on "every 4th bit" classes + logic; the 144 multiplies
-                    # per element occupy more than one issue slot each (mad_slots, measured): annotate_valu prices them
+                    # no carry-less multiply on gfx950: 9 x 16 v_mad_u64_u32 on "every 4th bit" classes + logic
                     kern['mul_gf2_128']['valu_mads_per_unit'] = 144.0
                 cfb = cb_.empty_matrix(t2, n)
                 for j in range(t2):

@@ -152,15 +152,27 @@ struct PM64 {
         if (!K64 && C1) return csub(fold64(presum(a, b)));
         return red128((ff_u128)a * b);
     }
+    // k == 64: ANY 64-bit word is a valid representative (x and x - p when x >= p), and the fold below keeps a product inside
+    // 64 bits without the final conditional subtraction -- chains of products (ff_pow, the batched inverse) skip the 64-bit
+    // compare + subtract + two selects per product (6 of ~40 instructions) and subtract p once at the end (`canon`)
+    FF_HD uint64_t red128_lazy(ff_u128 x) const {
+        ff_u128 t = (ff_u128)ff_hi(x) * c + ff_lo(x);  // < 2^96
+        uint64_t tl = ff_lo(t);
+        uint64_t u = tl + ff_hi(t) * (uint64_t)c;      // hi(t) <= 2^31, c < 2^31
+        if (u < tl) u += c;                            // wrapped: 2^64 == c; u < 2^62 here, no second wrap
+        return u;
+    }
     FF_HD uint64_t mul_lazy(uint64_t a, uint64_t b) const {
         if (!K64 && C1) return fold64(presum(a, b));
+        if (K64) return red128_lazy((ff_u128)a * b);
         return mul(a, b);
     }
     FF_HD uint64_t sqr_lazy(uint64_t a) const {
         if (!K64 && C1) return fold64(presum_sqr(a));
+        if (K64) return red128_lazy((ff_u128)a * a);
         return mul(a, a);
     }
-    FF_HD uint64_t canon(uint64_t x) const { return (!K64 && C1) ? csub(x) : x; }
+    FF_HD uint64_t canon(uint64_t x) const { return ((!K64 && C1) || K64) ? csub(x) : x; }
     FF_HD uint64_t reduce_raw(uint64_t x) const {
         if (K64) return csub(x);
         return red128((ff_u128)x);

@@ -938,8 +938,15 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
 // HALVES of an operand packed into the two halves of a plane register -- one 32 x 32 transpose of [lo words ; hi words] yields
 // exactly that -- so the outer Karatsuba products A0 B0 and A1 B1 come out of ONE Mul<32> on packed registers, the middle
 // product is packed the same way one level down, and nothing is ever held as 64 or 127 full-width planes: the kernel fits
-// TWO waves per SIMD (amdgpu_waves_per_eu(2, 2)), no prefetch registers needed -- the other wave's arithmetic covers this
-// wave's loads.  The same arithmetic compiles with g++ for tests/test_hostcheck.py.
+// TWO waves per SIMD (amdgpu_waves_per_eu(2, 2)): 214 VGPRs, 58.7 us at n = 10^7 (0.51 of the HBM rate; round 4: 66-70 us).
+// One slab per wave on an uncapped grid: a finished wave is replaced at once and the new wave's loads overlap its partner's
+// arithmetic.  (Measured and NOT kept: a persistent variant that streams the next slab's operands global -> LDS with
+// global_load_lds while the current one is multiplied -- 72.3 us: sixteen LDS-DMA pieces cost more issue time than the
+// latency they hide, and the capped grid loses the tail.)  What still separates the kernel from its issue bound (~42 us for
+// this instruction mix: three-operand instructions take ~4.1 cycles per wave64, two-operand ones 2.4 -- profiles/
+// r05_valu_rates.md) is the time a wave runs ALONE on its SIMD while its partner waits for memory: a lone wave issues at most
+// one instruction per 4.7 cycles.  A third wave needs <= 168 registers.  The same arithmetic compiles with g++
+// (tests/test_hostcheck.py).
 // A slab = 1024 consecutive elements = 512 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
 // (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..7.  The last slab may be partial: its accesses
 // are guarded per uint4 (nvec4 = n / 2 of them exist), missing operands are zero.  In place (o == a or o == b) is fine: a
@@ -1554,8 +1561,11 @@ int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipS
 // every SIMD with `waves_per_simd` waves.  One thread per launch also brackets its loop with s_memtime (shader cycles) and
 // the constant 100 MHz counter, which gives the shader clock UNDER this load.  bench.py prices its VALU-bound rows
 // (`valu_frac`) against these rates.
-//   op 0: v_bitop3_b32 (the 3-input logic op of the GF(2^n) kernels)      op 1: v_add_u32
-//   op 2: v_mad_u64_u32 (the 32 x 32 + 64 multiply-add every prime-field product is made of)
+//   op 0: v_bitop3_b32 (the 3-input logic op of the GF(2^n) kernels)      op 1: v_add_u32      op 3: v_xor_b32
+//   op 2: v_mad_u64_u32 (the 32 x 32 + 64 multiply-add every prime-field product is made of)     op 4: v_perm_b32
+//   op 5: v_lshrrev_b32      op 6: v_and_or_b32      op 7: v_add3_u32      op 8: v_mul_lo_u32
+// (measured, round 5: two-operand VOP2 instructions issue at ~2 cycles per wave64 once a SIMD holds two or more waves, the
+// three-operand VOP3 ones and the multiplies at ~4: profiles/r05_valu_rates.md)
 template <int OP>
 __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sink, uint64_t* __restrict__ clk, int iters) {
     uint32_t a[8], b = threadIdx.x * 2654435761u + 1u, c = blockIdx.x * 40503u + 7u;
@@ -1574,7 +1584,13 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
             for (int k = 0; k < 8; ++k) {
                 if constexpr (OP == 0) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[k]) : "v"(b), "v"(c));
                 else if constexpr (OP == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
-                else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(b), "v"(c) : "vcc");
+                else if constexpr (OP == 2) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(b), "v"(c) : "vcc");
+                else if constexpr (OP == 3) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                else if constexpr (OP == 4) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                else if constexpr (OP == 5) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[k]));
+                else if constexpr (OP == 6) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                else if constexpr (OP == 7) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+                else asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
             }
         }
     }
@@ -1593,16 +1609,17 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
 // out[0] = lane-operations per second, out[1] = shader clock in MHz, out[2] = shader cycles per wave instruction and SIMD
 int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* out, hipStream_t st) {
     LaunchCfg lc = launch_cfg(device);
-    if (op < 0 || op > 2 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
+    if (op < 0 || op > 8 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
     const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
     uint32_t* sink = (uint32_t*)scratch16;
     uint64_t* clk = (uint64_t*)((char*)scratch16 + 16);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
     auto launch = [&](int n_it) {
-        if (op == 0) hipLaunchKernelGGL(k_valu_probe<0>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
-        else if (op == 1) hipLaunchKernelGGL(k_valu_probe<1>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
-        else hipLaunchKernelGGL(k_valu_probe<2>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it);
+#define FF_PROBE_CASE(OPV) case OPV: hipLaunchKernelGGL(k_valu_probe<OPV>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); break;
+        switch (op) { FF_PROBE_CASE(0) FF_PROBE_CASE(1) FF_PROBE_CASE(2) FF_PROBE_CASE(3) FF_PROBE_CASE(4) FF_PROBE_CASE(5)
+                      FF_PROBE_CASE(6) FF_PROBE_CASE(7) default: hipLaunchKernelGGL(k_valu_probe<8>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); }
+#undef FF_PROBE_CASE
     };
     launch(iters / 4 + 1);                                                    // warm-up: clocks ramp
     hipEventRecord(e0, st);

@@ -125,6 +125,10 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                         if (u <= 2) u += f.p;
                         if (v <= 2) v += f.p;
                     }
+                    if (x && std::is_same<F, PM64<true, false> >::value) {      // p = 2^64 - c: every u < c has a second 64-bit representative
+                        if (u < f.c) u += f.p;
+                        if (v < f.c) v += f.p;
+                    }
                     r = f.mul_lazy(u, v);
                     for (int j = 0; j < 6; ++j) {
                         r = f.sqr_lazy(r);

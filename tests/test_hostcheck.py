@@ -392,6 +392,30 @@ def test_mersenne_policy_and_lazy_chains(hostcheck):
         assert got == [x * y % p for x, y in zip(ra, rb)], k
 
 
+def test_k64_lazy_chains(hostcheck):
+    """PM64<true,false> (p = 2^64 - c): the partially reduced product chains of ff_pow / the batched inverse (fields.hpp
+    red128_lazy: any 64-bit word is a representative, p is subtracted once at the end), entered with canonical operands and
+    with the second representative u + p of every u < c, for small, typical and the largest admissible c."""
+    from types import SimpleNamespace
+    rng = random.Random(64189)
+    for c in (3, 59, 189, 2**16 + 1, 2**31 - 1, 2**31 - 19):
+        p = 2**64 - c
+        F = SimpleNamespace(modulus=p, binary=False, order=p)
+        edge = [0, 1, 2, c - 1, c, c + 1, p - 1, p - 2, p - c, 2**32 - 1, 2**32, 2**63, 2**63 - 1, p >> 1, (p >> 1) + 1, p - 2**32]
+        edge = [e % p for e in edge] + [rng.randrange(p) for _ in range(10)] + [rng.randrange(c) for _ in range(4)]
+        a, b = cross(edge)
+        for noncanon in (0, 1):
+            got, pk = run(hostcheck, F, HC_LAZY, a, b, x=noncanon)
+            want = []
+            for u, v in zip(a, b):
+                r = u * v % p
+                for j in range(6):
+                    r = r * r % p
+                    r = r * (u if j & 1 else v) % p
+                want.append(r)
+            assert got == want, (c, noncanon)
+
+
 def test_pm64_general_policy_all_widths(hostcheck):
     """PM64<false,false> (p = 2^k - c, 33 <= k <= 63, 1 < c < 2^min((k-1)/2, 31)): the two folds are written on the words
     (fields.hpp fold128: `(hi << (64 - k)) | (lo >> k)`), so every k must be exercised -- edge values, values around the fold
