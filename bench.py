@@ -1421,7 +1421,7 @@ def main():
         # profiles/r03_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
         def annotate_traffic():
             try:
-                pmc_file = next(f_ for f_ in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                pmc_file = next(f_ for f_ in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                                 if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
                 with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                     pmc = json.load(fh)
