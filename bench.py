@@ -164,7 +164,7 @@ def compact_line(out):
             line['api']['m1_1e7'] = _pick(api['m1_1e7'], ('ms_per_rep', 'elements_per_s'))
         for leg in ('fxp_m1_1e6', 'fxp_m1_1e6_chacha'):
             if isinstance(api.get(leg), dict):
-                line['api'][leg] = _pick(api[leg], ('s_per_product_and_opening', 'outliers_reference_trunc_mask', 'max_abs_error', 'error'))
+                line['api'][leg] = _pick(api[leg], ('s_per_product', 's_per_product_and_opening', 'outliers_reference_trunc_mask', 'max_abs_error', 'error'))
     dd = out.get('distributed', {})
     line['distributed'] = _pick(dd, ('backend', 'world_size', 'collective_library', 'rccl_version', 'distinct_devices'))
     ranks = dd.get('ranks') or []
@@ -462,7 +462,11 @@ def api_leg(n_full, parties_on_gpus=False):
         d = json.loads(line[len('FXP_RESULT '):])
         secs = d['s_per_product_and_opening']
         return {'n': n_, 'parties': parties, 'prss_prf': d['prss_prf'], 's_per_product_and_opening': round(secs, 5),
-                'elements_per_s': round(n_ / secs, 1),
+                # the secure product alone (np_multiply + np_trunc: PRSS bits and masks, one masked opening; the share stays on the
+                # device) -- the opening after it ends in the REFERENCE's conversion of n field elements to Python floats
+                # (sectypes.py:1426-1447: np.vectorize of a Python lambda), host-bound whatever computed them
+                's_per_product': round(d.get('s_per_product', float('nan')), 5),
+                'elements_per_s': round(n_ / secs, 1), 'products_per_s': round(n_ / d['s_per_product'], 1) if d.get('s_per_product') else None,
                 # elements off by 2^48: the REFERENCE's own np_trunc mask for array types is f bits short (runtime.py:852; about
                 # one element in 10^6; reproduced bit for bit: tests/test_fxp_path.py) -- counted, and excluded from the error
                 'outliers_reference_trunc_mask': d['outliers_reference_trunc_mask'],
@@ -1019,7 +1023,9 @@ def main():
                 gth.prss_prf = 'chacha'
                 for (mm_, ii_, pr_), rr_ in itertools.product(((7, 2, prfs7), (3, 0, prfs3)), (20, 8)):
                     gth.prss_rounds = rr_
-                    ms = time_launches(lambda s_: gth.np_pseudorandom_share(F61, mm_, ii_, pr_, b'uci', n), [0], 3)
+                    for _ in range(3):          # (the host-bound parity-mode run above lets the clocks drop: ramp them up again)
+                        gth.np_pseudorandom_share(F61, mm_, ii_, pr_, b'uci', n)
+                    ms = time_launches(lambda s_: gth.np_pseudorandom_share(F61, mm_, ii_, pr_, b'uci', n), [0], 10)
                     tt_ = (mm_ - 1) // 2
                     kern[f'prss_share_p61_m{mm_}t{tt_}_chacha{rr_}'] = dict(
                         roof(eb * n, ms), algorithmic_bytes_per_unit=eb, units_per_s=round(n / (ms * 1e-3), 1), bound='valu',

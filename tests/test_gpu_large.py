@@ -106,3 +106,21 @@ def test_p61_beyond_4gib_bytes(eng):
     sa, sb, sab = (ctx.sum(v).to_ints()[0] for v in (a, b, ctx.add(a, b)))
     assert (sa + sb) % P61 == sab
     assert ctx.dot(a, b).to_ints()[0] == ctx.sum(c).to_ints()[0]
+
+
+def test_valu_probe_reports_plausible_rates():
+    """ffgpu_valu_probe (the compute-side yardstick of bench.py): every instruction kind, one and four waves per SIMD -- rates
+    and clocks in the range an MI355X can produce, two-operand instructions faster than three-operand ones at full occupancy,
+    a lone wave slower than a full SIMD."""
+    from mpyc_amd.engine import FieldContext
+    ctx = FieldContext(2**61 - 1)
+    rates = {}
+    for op in range(9):
+        for w in (1, 4):
+            rate, mhz, cyc = ctx.valu_probe(op, iters=1000, waves_per_simd=w)
+            assert 5e12 < rate < 1.5e14 and 500 < mhz < 3500 and cyc > 0, (op, w, rate, mhz, cyc)
+            rates[op, w] = rate
+    assert rates[3, 4] > 1.3 * rates[0, 4]          # v_xor_b32 (VOP2) against v_bitop3_b32 (VOP3)
+    assert rates[1, 4] > 1.5 * rates[1, 1]          # a SIMD needs two or more waves for the two-operand rate
+    with pytest.raises(ValueError):
+        ctx.valu_probe(9)

@@ -21,9 +21,16 @@ for name, mod, tail, eb in (('gf2_128', (1 << 128) | 0x87, (2,), 16), ('gf2_64',
         ms = bench.time_launches(lambda s: plan(), [0], 5)
         print(name, 'recombine k=%d xs=%s lam=%s: %.1f us %.0f GB/s' % (k, xs, [hex(v) for v in lam][:3], ms * 1e3, (k + 1) * eb * n / ms / 1e6))
     import random
-    rnd = random.Random(3)
+    # dense coefficients: the same two coefficient sets on the same two row layouts -- rows that are slices of ONE tensor
+    # (n * eb bytes apart) and rows of a share matrix (engine.empty_matrix: pitch padded to 256 B and skewed) -- to settle
+    # which of the two in-repo measurements of this shape (this probe: 413 us, bench.py: 272 us for GF(2^128), k = 7) is what
+    mtx = ctx.empty_matrix(8, n)
+    for i in range(8):
+        mtx.row(i).t.copy_(x[i])
     for k in (4, 7):
-        lam = [rnd.randrange(2, F.order) for _ in range(k)]
-        plan = ctx.recombine_plan(rows[:k], lam, out)
-        ms = bench.time_launches(lambda s: plan(), [0], 5)
-        print(name, 'recombine k=%d DENSE random coefficients: %.1f us %.0f GB/s' % (k, ms * 1e3, (k + 1) * eb * n / ms / 1e6))
+        for tag, lam in (('Random(3)', [random.Random(3).randrange(2, F.order) for _ in range(k)]),
+                         ('Random(1000+k) [bench.py]', [random.Random(1000 + k).randrange(2, 1 << (8 * eb)) for _ in range(k)])):
+            for layout, rr, oo in (('slices of one tensor', rows[:k], out), ('share-matrix rows', [mtx.row(j) for j in range(k)], mtx.row(7))):
+                plan = ctx.recombine_plan(rr, lam, oo)
+                ms = bench.time_launches(lambda s: plan(), [0], 5)
+                print(name, 'recombine k=%d DENSE %s, %s: %.1f us %.0f GB/s' % (k, tag, layout, ms * 1e3, (k + 1) * eb * n / ms / 1e6))

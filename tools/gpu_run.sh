@@ -3,6 +3,7 @@
 #   newtests  pytest -m gpu on $NEWTESTS (files / node ids)          tests   the whole -m gpu suite
 #   bench     bench.py --steps 20 --warmup 5 (the driver's line)      prof    rocprofv3 --kernel-trace --stats of the bench
 #   pmc       FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py    valu    SQ_INSTS_VALU pass of tools/valu_probe.py
+#   counters  SQ counter passes (waves, busy / wave cycles, VALU / LDS instructions and waits) of $COUNTERS_CMD
 #   probe     bash -c "$PROBE" (timeout $PROBE_TIMEOUT, default 600)
 # TAG names the outputs (default r05): gpurun_out/{pytest_gpu,bench,rocprof_$TAG,...}.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
@@ -38,6 +39,29 @@ if has valu; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/valu_$T -o valu -- python $R/tools/valu_probe.py) > $O/valu_$T.log 2>&1
   F=$(find $O/valu_$T -name '*counter_collection.csv' | head -1)
   python tools/valu_summary.py $F $O/valu_order.json $O/${T}_valu.json $O/${T}_valu.md | tail -20
+fi
+if has counters; then
+  # SQ counters (three passes of four) of the kernels run by $COUNTERS_CMD (default: the GF(2^n) products + PRSS production mode)
+  CC=${COUNTERS_CMD:-"python $R/tools/gf2w_probe.py; PRSS_N=10000000 python $R/tools/prss_chacha_time.py"}
+  i=0
+  for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
+    i=$((i+1))
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/ctr_$T/p$i -o pmc -- bash -c "$CC") > $O/ctr_${T}_p$i.log 2>&1
+    echo "counters pass $i rc=$?"
+  done
+  python - <<PY | tee $O/${T}_sq_counters.txt
+import csv, collections, glob, re
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('$O/ctr_$T/*/pmc_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ffgpu::', '').replace('void ', '')
+        if any(k in name for k in ('k_gf2w64_mul_bitsliced', 'k_ew2<GF2W128, 2', 'k_ew2<GF2W64, 2', 'k_prss_chacha', 'k_gf2w_recombine_tab')):
+            acc[name + ' grid ' + r['Grid_Size']][r['Counter_Name']].append(float(r['Counter_Value']))
+for k in sorted(acc):
+    print(k)
+    for c, v in sorted(acc[k].items()):
+        print(f'    {c:28s} {sum(v)/len(v):14.4g} per launch ({len(v)} launches)')
+PY
 fi
 if has probe; then
   (timeout ${PROBE_TIMEOUT:-600} bash -c "$PROBE") > $O/probe_$T.log 2>&1; echo "probe rc=$?" >> $O/probe_$T.log
