@@ -14,6 +14,8 @@ for name, mod, tail, eb in (('gf2_128', (1 << 128) | 0x87, (2,), 16), ('gf2_64',
     out = rows[8]
     ms = bench.time_launches(lambda s: ctx.mul(rows[0], rows[1], out=out), [0], 5)
     print(name, 'mul %.1f us %.0f GB/s' % (ms * 1e3, 3 * eb * n / ms / 1e6))
+    if os.environ.get('GF2W_MUL_ONLY'):
+        continue
     for k in (4, 5, 7):
         xs = [((3 + j) % 7) + 1 for j in range(k)] if os.environ.get('GF2W_ROT') else list(range(1, k + 1))
         lam = [int(v) for v in gth._recombination_vector(F, tuple(xs), 0)]

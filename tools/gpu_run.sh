@@ -3,7 +3,7 @@
 #   newtests  pytest -m gpu on $NEWTESTS (files / node ids)          tests   the whole -m gpu suite
 #   bench     bench.py --steps 20 --warmup 5 (the driver's line)      prof    rocprofv3 --kernel-trace --stats of the bench
 #   pmc       FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py    valu    SQ_INSTS_VALU pass of tools/valu_probe.py
-#   counters  SQ counter passes (waves, busy / wave cycles, VALU / LDS instructions and waits) of $COUNTERS_CMD
+#   counters  SQ counter passes (waves, busy / wave cycles, VALU / LDS instructions and waits) of the GF(2^n) products and PRSS
 #   probe     bash -c "$PROBE" (timeout $PROBE_TIMEOUT, default 600)
 # TAG names the outputs (default r05): gpurun_out/{pytest_gpu,bench,rocprof_$TAG,...}.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
@@ -41,12 +41,13 @@ if has valu; then
   python tools/valu_summary.py $F $O/valu_order.json $O/${T}_valu.json $O/${T}_valu.md | tail -20
 fi
 if has counters; then
-  # SQ counters (three passes of four) of the kernels run by $COUNTERS_CMD (default: the GF(2^n) products + PRSS production mode)
-  CC=${COUNTERS_CMD:-"python $R/tools/gf2w_probe.py; PRSS_N=10000000 python $R/tools/prss_chacha_time.py"}
+  # SQ counters (three passes of four) of the GF(2^n) products (tools/gf2w_probe.py) and PRSS production mode (tools/prss_chacha_time.py)
   i=0
   for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
     i=$((i+1))
-    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/ctr_$T/p$i -o pmc -- bash -c "$CC") > $O/ctr_${T}_p$i.log 2>&1
+    # (one rocprofv3 run per program: processes of one run would overwrite each other's output files)
+    (cd /tmp && GF2W_MUL_ONLY=1 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/ctr_$T/p${i}_gf -o pmc -- python $R/tools/gf2w_probe.py) > $O/ctr_${T}_p${i}_gf.log 2>&1
+    (cd /tmp && PRSS_N=10000000 PRSS_ONLY61=1 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/ctr_$T/p${i}_prss -o pmc -- python $R/tools/prss_chacha_time.py) > $O/ctr_${T}_p${i}_prss.log 2>&1
     echo "counters pass $i rc=$?"
   done
   python - <<PY | tee $O/${T}_sq_counters.txt
