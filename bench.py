@@ -1032,6 +1032,16 @@ def main():
                         subset_keys=len(pr_), keystream_bytes_per_share=len(pr_) * lb_,
                         note='PRODUCTION mode: ChaCha counter-mode PRF on the device, same sampling rule and combination as the '
                              'reference (thresha.py:163-173, 234-266); frac = HBM fraction of the 8 B written per share')
+                # in-run guard (checker only, outside every timed region): the first and last 4096 shares of the m = 7 party against
+                # the C oracle's restatement of the keystream layout
+                from oracle import coracle as _co
+                gth.prss_rounds = 20
+                shr = gth.np_pseudorandom_share(F61, 7, 2, prfs7, b'uci', 8192 * 3 + 5)
+                k40_ = [gth.prss_chacha_stream_key(pf_.key, b'uci') for pf_ in prfs7.values()]
+                w_ = [int(gth._f_S_i(F61, 7, 2, S_)) for S_ in prfs7]
+                ref_ = _co.prss_chacha(_co.CField(P61), k40_, 1, lb_, 0, 20, w_, 8192 * 3 + 5)
+                if not (shr.device_array.to_numpy() == ref_).all():
+                    raise SystemExit('bench parity check failed: production-mode PRSS shares differ from the oracle')
             finally:
                 gth.prss_prf, gth.prss_rounds = prev_mode, prev_rounds
             # boundary handed HOST buffers (pinned): h2d of both operands + mulmod + d2h of the product, end to end

@@ -130,3 +130,34 @@ def test_round4_kernels_at_1e7(eng, threads):
             assert int(gi[i]) == pow(int(X[i]), p - 2, p), (hex(p), i)
         with pytest.raises(ZeroDivisionError):
             cp.inv(dX)
+
+
+def test_prss_production_mode_vs_oracle_1e7(eng, threads):
+    """PRSS shares in production mode (ffgpu_prss_chacha, thresha.py:163-173 / 201-217 over the ChaCha counter-mode PRF) at
+    n = 10^7, EVERY element against the C oracle's independent restatement of the keystream layout (orc_prss_chacha): one
+    party of m = 7, t = 3 (20 subset keys) over GF(2^64-189) -- the share and the zero sharing (d = 3 draws per element and
+    key) -- and one party of m = 3, t = 1 over GF(2^128-173)."""
+    import itertools
+    co = threads
+    for modulus, m, t, i, zero in ((P64, 7, 3, 2, False), (P64, 7, 3, 6, True), (P128, 3, 1, 0, False)):
+        F = po.Field(modulus)
+        ctx = eng.FieldContext(modulus, device=0)
+        cf = co.CField(modulus)
+        keys = {S: bytes([(29 * sum(S) + 7 * b) % 251 for b in range(16)]) for S in itertools.combinations(range(m), m - t) if i in S}
+        k40 = [po.prss_chacha_stream_key(k, b'full-size') for k in keys.values()]
+        l = (modulus.bit_length() + 7) // 8 + 16
+        d = t if zero else 1
+        i1 = po.reduce(F, i + 1)
+        weights = []
+        for S in keys:
+            f = po.f_S_i(F, m, i, S)
+            for j in range(d):
+                w = f
+                for _ in range(j + 1 if zero else 0):
+                    w = po.mul(F, w, i1)
+                weights.append(w)
+        n = N_FULL if not zero else N_FULL // 4
+        got = ctx.prss_chacha(k40, d, l, weights, n).to_numpy()
+        want = co.prss_chacha(cf, k40, d, l, 0, 20, weights, n)
+        same = got == want
+        assert same.all(), (hex(modulus), m, zero, int(np.argmin(same.reshape(n, -1).all(axis=1))))
