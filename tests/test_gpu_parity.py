@@ -782,7 +782,7 @@ def test_matrix_core_product(eng, coracle):
         edge = sorted({v % modulus for v in (0, 1, 127, 128, 255, 256, T8 - 1, T8, T8 + 1, T8 + 2, modulus // 2, modulus // 2 + 1,
                                               modulus - 1, modulus - 2, modulus - 128, modulus - 129, 2**31, 2**63 % modulus,
                                               0x8080808080808080 % modulus, 0x80 << 24)})
-        # 256 rows: digit planes of both operands; 64 rows: the product kernel converts B itself (k_limb_gemm_lds BRAW)
+        # 256 rows: digit planes of both operands; 64 rows: the product kernel converts B itself (k_limb_gemm_glds<BRAW>)
         for (M, K, N) in ((256, 256, 256), (64, 1024, 256)):
             rng = random.Random(modulus % 1000)
             a = [edge[(i * 7 + k_ * 3) % len(edge)] if (i + k_) % 3 else rng.randrange(modulus) for i in range(M) for k_ in range(K)]

@@ -34,13 +34,14 @@ def group_of(filename):
     return None
 
 
-def profile(n, reps, tmp):
-    prof = os.path.join(tmp, f'api_{n}.prof')
+def profile(n, reps, tmp, parties=1):
+    prof = os.path.join(tmp, f'api_{n}_{parties}.prof')
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, REF]), API_MODE=os.environ.get('HOSTPROF_MODE', 'gpu'), API_N=str(n),
-               API_REPS=str(reps), API_WARMUP='3', API_CPROFILE=prof, MPYC_AMD_IPC_WIRE='0')
+               API_REPS=str(reps), API_WARMUP='3', API_CPROFILE=prof, MPYC_AMD_IPC_WIRE='1' if parties > 1 else '0')
     for k in ('API_SEED', 'API_DIGEST', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, PROG, '--no-log'], capture_output=True, text=True, cwd=tmp, env=env, timeout=900)
+    r = subprocess.run([sys.executable, PROG, '--no-log'] + ([f'-M{parties}'] if parties > 1 else []), capture_output=True, text=True,
+                       cwd=tmp, env=env, timeout=900)
     line = next((ln for ln in r.stdout.splitlines() if ln.startswith('API_RESULT ')), None)
     if r.returncode != 0 or line is None:
         raise SystemExit((r.stdout + r.stderr)[-2000:])
@@ -67,7 +68,7 @@ def profile(n, reps, tmp):
     # (profiled repetitions include the 3 warm-up ones: API_WARMUP + API_REPS)
     nrep = reps + 3
     wall = sum(res['times_s']) / len(res['times_s'])
-    return {'n': n, 'reps': reps, 'wall_ms_per_rep': wall * 1e3, 'gpu_busy_ms_per_rep': (res['gpu_busy_ms'] or 0.0) / reps,
+    return {'n': n, 'parties': parties, 'reps': reps, 'wall_ms_per_rep': wall * 1e3, 'gpu_busy_ms_per_rep': (res['gpu_busy_ms'] or 0.0) / reps,
             'own_ms_per_rep': {g: v / nrep * 1e3 for g, v in own.items()},
             'top': {g: [f'{t / nrep * 1e6:.0f} us  {name}' for t, name in sorted(v, reverse=True)[:6]] for g, v in top.items()}}
 
@@ -81,16 +82,19 @@ def main():
         sizes = [int(v) for v in os.environ.get('HOSTPROF_SIZES', '10000,100000,1000000,10000000').split(',')]
         for n, reps in [(n_, 200 if n_ <= 10**5 else 100 if n_ <= 10**6 else 30) for n_ in sizes]:
             rows.append(profile(n, reps, tmp))
-    lines = ['| n | wall per repetition (profiled run) | mirror (`mpyc_amd/`) | reference runtime (`mpyc/`, asyncio) | other | GPU busy |',
-             '|---|---|---|---|---|---|']
+        if os.environ.get('HOSTPROF_M3', '1') == '1' and os.environ.get('HOSTPROF_MODE', 'gpu') == 'gpu':
+            for n in (10**6, 10**7):              # three local parties over the device-side wire (party 0 profiled)
+                rows.append(profile(n, 30, tmp, parties=3))
+    lines = ['| parties | n | wall per repetition (profiled run) | mirror (`mpyc_amd/`) | reference runtime (`mpyc/`, asyncio) | other | GPU busy |',
+             '|---|---|---|---|---|---|---|']
     for r in rows:
         o = r['own_ms_per_rep']
         tot = sum(o.values()) or 1.0
-        lines.append(f"| {r['n']:.0e} | {r['wall_ms_per_rep']:.3f} ms | {o['mirror']:.3f} ms ({o['mirror'] / tot:.0%}) | "
+        lines.append(f"| {r['parties']} | {r['n']:.0e} | {r['wall_ms_per_rep']:.3f} ms | {o['mirror']:.3f} ms ({o['mirror'] / tot:.0%}) | "
                      f"{o['reference']:.3f} ms ({o['reference'] / tot:.0%}) | {o['other']:.3f} ms | {r['gpu_busy_ms_per_rep']:.3f} ms |")
     lines.append('')
     for r in rows:
-        lines.append(f"n = {r['n']:.0e}: largest own-time entries per repetition")
+        lines.append(f"m = {r['parties']}, n = {r['n']:.0e}: largest own-time entries per repetition")
         for g in ('mirror', 'reference'):
             lines.append(f'  {g}:')
             lines += [f'    {t}' for t in r['top'][g]]

@@ -1,5 +1,5 @@
 // mfma_rate.hip -- issue-rate microbenchmark for the int8 matrix-core instructions in the register pattern of
-// k_limb_gemm_lds: one wave per SIMD, ND resident accumulator tiles, L x L products per step, operands fixed in
+// k_limb_gemm_glds / _l4: one wave per SIMD, ND resident accumulator tiles, L x L products per step, operands fixed in
 // registers (no memory traffic).  Prints int8 TOP/s per variant.
 //   hipcc -O3 --offload-arch=gfx950 tools/mfma_rate.hip -o build/mfma_rate
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-"""One 4096^3 product over GF(2^61-1), a few times: target for rocprofv3 --pmc (MFMA utilisation of k_limb_gemm_lds)."""
+"""One 4096^3 product over GF(2^61-1), a few times: target for rocprofv3 --pmc (MFMA utilisation of k_limb_gemm_glds)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
