@@ -9,7 +9,7 @@ Layout:
     thresha.py     host-side mirror of mpyc.thresha (np_)random_split / (np_)recombine
     install()      substitution of both into an importable mpyc
 """
-__version__ = '0.2.0'
+__version__ = '0.3.0'
 
 list_path_min = 256     # install(): thresha.random_split / recombine (the per-element list path, thresha.py:23-44,
 #                         88-116) go to the device from this many secrets on; below it the reference's own
@@ -30,6 +30,8 @@ def install():
       reference's own array classes.
     * `thresha.np_random_split / np_recombine / np_pseudorandom_share(_0)` are replaced for those fields; the
       list-path functions from `list_path_min` secrets on.
+    * PRSS keeps the reference's SHAKE128 PRF (bit-exact) unless MPYC_AMD_PRSS_PRF=chacha is set for EVERY party: then the
+      draws come from a counter-mode PRF expanded on the device (mpyc_amd/thresha.py).
     """
     global _installed
     if _installed is not None:
