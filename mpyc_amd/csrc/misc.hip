@@ -945,7 +945,8 @@ void ffgpu_gf8_sbox_layer_tables(const void* policy, const void* mul_tables, con
 // latency they hide, and the capped grid loses the tail.)  What still separates the kernel from its issue bound (~42 us for
 // this instruction mix: three-operand instructions take ~4.1 cycles per wave64, two-operand ones 2.4 -- profiles/
 // r05_valu_rates.md) is the time a wave runs ALONE on its SIMD while its partner waits for memory: a lone wave issues at most
-// one instruction per 4.7 cycles.  A third wave needs <= 168 registers.  The same arithmetic compiles with g++
+// one instruction per 4.7 cycles.  A third wave needs <= 168 registers: forced with amdgpu_waves_per_eu(3, 3) the compiler
+// spills 33 registers to scratch and the kernel takes 74.5 us -- measured, not kept.  The same arithmetic compiles with g++
 // (tests/test_hostcheck.py).
 // A slab = 1024 consecutive elements = 512 uint4; lane l of the wave that owns it reads uint4 number r * 64 + l
 // (coalesced), i.e. holds elements 128 r + 2 l and 128 r + 2 l + 1, r = 0..7.  The last slab may be partial: its accesses
