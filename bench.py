@@ -911,8 +911,8 @@ def main():
                                'modmul is fused into the share-generation kernel (product never written to HBM)',
                    'n_per_gpu': n, 'prime': '2^61-1', 'm': m, 't': t, 'k': k, 'field_ops_per_step': 3 * n,
                    'buffer_sets': args.sets, 'parallelism': f'element-sharded x{world}, no collective'},
-        'distributed': {'backend': (backend if dist is not None else None), 'world_size': world,
-                        'collective_library': 'RCCL (torch.distributed nccl backend)' if dist is not None and backend == 'nccl' else None,
+        'distributed': {'backend': (backend if dist is not None else 'none (single process)'), 'world_size': world,
+                        'collective_library': 'RCCL (torch.distributed nccl backend)' if dist is not None and backend == 'nccl' else 'none',
                         'rccl_version': rccl_version,
                         'distinct_devices': len({r_['pci_bus_id'] for r_ in gathered}),
                         'ranks': gathered},
