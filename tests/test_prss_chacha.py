@@ -287,3 +287,46 @@ def test_default_mode_is_still_the_reference_prf(api):
     prfs = {S: thresha.PRF(k, F.order) for S, k in keys.items()}
     assert dev_ints(thresha.np_pseudorandom_share(F, 3, 1, prfs, b'u', 100)) == \
         po.np_pseudorandom_share(OF, 3, 1, keys, F.order, b'u', 100)
+
+
+@pytest.mark.gpu
+def test_every_draw_width_and_mask(api):
+    """The kernel takes the draw width l (1..64 bytes) and the mask width as run-time values: every l -- i.e. every tile shape
+    (1-3 blocks, 1-8 draws), every partial last word, every number of limbs in the wide reduction -- and a sweep of mask
+    widths, for one-, two- and three-limb primes and 32-bit storage, against a restatement from RFC 8439 blocks and the
+    documented layout in Python integers (ks = 2 streams, d = 2 draws per element, ragged n)."""
+    finfields, gfpx, thresha = api
+    from mpyc_amd.finfields import _context
+
+    def expected(F, k40s, d, l, mask_bits, weights, n, rounds):
+        tb, dpt = po.prss_chacha_layout(l)
+        lw = (l + 3) // 4
+        out = []
+        for h in range(n):
+            tile, slot = divmod(h, dpt)
+            acc = 0
+            for s, k40 in enumerate(k40s):
+                for j in range(d):
+                    ks = b''.join(po.chacha_block(k40[:32], (tile * d + j) * tb + b, k40[32:], rounds) for b in range(tb))
+                    v = int.from_bytes(ks[4 * slot * lw:4 * slot * lw + l], 'little')
+                    v = v & ((1 << mask_bits) - 1) if mask_bits else v % F.order
+                    acc = po.add(F, acc, po.mul(F, po.reduce(F, v), weights[s * d + j]))
+            out.append(acc)
+        return out
+
+    k40s = [bytes((7 * i + 3 * s) % 256 for i in range(40)) for s in range(2)]
+    for mod in (2**61 - 1, 2**128 - 173, 2**31 - 1, finfields.find_prime_root(160)[0], 2**96 - 17):
+        F, OF = finfields.GF(mod), po.Field(mod)
+        ctx = _context(F)
+        weights = [(mod // 3 + 11 * i) % mod for i in range(4)]
+        for l in range(1, 65):
+            tb, dpt = po.prss_chacha_layout(l)
+            n = 2 * dpt + (l % 3) + 1
+            got = ctx.prss_chacha(k40s, 2, l, weights, n, mask_bits=0, rounds=12).to_ints()
+            assert got == expected(OF, k40s, 2, l, 0, weights, n, 12), (hex(mod), l)
+        bits = mod.bit_length()
+        for mb in sorted({1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, bits - 2, bits - 1} & set(range(1, bits))):
+            l = (mb + 7) // 8
+            n = 19
+            got = ctx.prss_chacha(k40s, 2, l, weights, n, mask_bits=mb, rounds=8).to_ints()
+            assert got == expected(OF, k40s, 2, l, mb, weights, n, 8), (hex(mod), 'mask', mb)
