@@ -448,7 +448,7 @@ def api_leg(n_full, parties_on_gpus=False):
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
         for k_ in ('MPYC_GPU', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'FXP_SEED', 'FXP_DIGEST', 'MPYC_AMD_PRSS_PRF'):
             env.pop(k_, None)
-        env.update(FXP_MODE=mode, FXP_N=str(n_), FXP_REPS='2' if mode != 'ref' else '1', MPYC_AMD_IPC_WIRE='1' if ipc else '0')
+        env.update(FXP_MODE=mode, FXP_N=str(n_), FXP_REPS='3' if mode != 'ref' else '1', MPYC_AMD_IPC_WIRE='1' if ipc else '0')
         if prf:
             env['MPYC_AMD_PRSS_PRF'] = prf
         cmd = [sys.executable, os.path.join(ROOT, 'tests', 'fxp_program.py'), '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
@@ -466,6 +466,7 @@ def api_leg(n_full, parties_on_gpus=False):
                 # device) -- the opening after it ends in the REFERENCE's conversion of n field elements to Python floats
                 # (sectypes.py:1426-1447: np.vectorize of a Python lambda), host-bound whatever computed them
                 's_per_product': round(d.get('s_per_product', float('nan')), 5),
+                's_per_product_reps': [round(v, 5) for v in d.get('times_product_s', [])],       # (the value above is their minimum)
                 'elements_per_s': round(n_ / secs, 1), 'products_per_s': round(n_ / d['s_per_product'], 1) if d.get('s_per_product') else None,
                 # elements off by 2^48: the REFERENCE's own np_trunc mask for array types is f bits short (runtime.py:852; about
                 # one element in 10^6; reproduced bit for bit: tests/test_fxp_path.py) -- counted, and excluded from the error
@@ -1092,8 +1093,9 @@ def main():
                 kern[f'matmul_p61_{dim}'] = dict(roof_mfma(macs, 8, ms), kernel='k_limb_gemm<PM64,8> (8 signed base-256 digits)')
                 del Am, Bm, Cm
             # the shape the reference's author names as the np_bnnmnist bottleneck (demos/np_bnnmnist.py:10-15): a
-            # 1 x 4096 activation row times a 4096 x 4096 weight matrix, and the transposed (matrix x vector) form
-            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (64, 4096, 4096)):
+            # 1 x 4096 activation row times a 4096 x 4096 weight matrix (and batches of 4 and 8 rows: column sums of partial
+            # products, k_vecmat_partial_col), and the transposed (matrix x vector) form
+            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (64, 4096, 4096)):
                 big = [DevArray(ctx, uniform_field(gen, max(mm_, 4096) * 4096, P61, ctx.torch_device), max(mm_, 4096) * 4096) for _ in range(3)]
                 small = DevArray(ctx, uniform_field(gen, 64 * 4096, P61, ctx.torch_device), 64 * 4096)
                 outm = ctx.empty(mm_ * nn_)

@@ -1409,6 +1409,52 @@ struct GF2W128 {
     }
 };
 
+// ---- column accumulators for dot products with a SHARED operand (skinny products, matmul.hpp) ------------------
+// Prime fields on one 64-bit word (PM64<*>, RC64).  acc_mac above forms the 128-bit product and adds it to a 192-bit sum:
+// four v_mad_u64_u32 plus a chain of carries -- 32 instructions per term as the compiler writes it.  When the left
+// operand a is the same for every lane (a row of activations against a matrix of weights) it is split ONCE into three
+// limbs of 22 / 22 / 20 bits; with b = b1 2^32 + b0 the six partial products a_i b_j are below 2^54 and are summed per
+// weight 2^(22 i + 32 j) in six 64-bit columns by the multiply-add itself: six v_mad_u64_u32 per term and nothing else,
+// no carry for 2^10 terms.  gather() rebuilds the 192-bit sum for acc_reduce (its bound: at most 256 terms).
+struct ColLimbs {
+    uint32_t l0, l1, l2, pad;
+};
+FF_HD ColLimbs col_limbs(uint64_t a) {
+    ColLimbs r;
+    r.l0 = (uint32_t)a & 0x3fffffu;
+    r.l1 = (uint32_t)(a >> 22) & 0x3fffffu;
+    r.l2 = (uint32_t)(a >> 44);
+    r.pad = 0;
+    return r;
+}
+template <class ACC>
+struct ColAcc {
+    uint64_t c00, c10, c20, c01, c11, c21;                    // c_ij: sum of a_i b_j, weight 2^(22 i + 32 j)
+    FF_HD void zero() { c00 = c10 = c20 = c01 = c11 = c21 = 0; }
+    FF_HD void mac(const ColLimbs& a, uint64_t b) {
+        const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+        c00 += (uint64_t)a.l0 * b0;
+        c10 += (uint64_t)a.l1 * b0;
+        c20 += (uint64_t)a.l2 * b0;
+        c01 += (uint64_t)a.l0 * b1;
+        c11 += (uint64_t)a.l1 * b1;
+        c21 += (uint64_t)a.l2 * b1;
+    }
+    // <= 256 terms: c_ij < 2^62; the five columns below weight 2^64 sum to less than 2^117, c21 2^12 < 2^72 on top
+    FF_HD ACC gather() const {
+        const ff_u128 lo = (ff_u128)c00 + ((ff_u128)c10 << 22) + ((ff_u128)c01 << 32) + ((ff_u128)c20 << 44) + ((ff_u128)c11 << 54);
+        const ff_u128 mid = (ff_u128)ff_hi(lo) + ((ff_u128)c21 << 12);
+        ACC s;
+        s.a0 = ff_lo(lo);
+        s.a1 = ff_lo(mid);
+        s.a2 = ff_hi(mid);
+        return s;
+    }
+};
+template <class F> struct col_mac_ok { enum { value = 0 }; };
+template <bool K64, bool C1> struct col_mac_ok<PM64<K64, C1> > { enum { value = 1 }; };
+template <> struct col_mac_ok<RC64> { enum { value = 1 }; };
+
 // ---- share generation by forward differences (prime fields) -------------------------------------------------
 // The parties' points are the consecutive integers 1..m (thresha.py:55-61), so f(x) = s + c_1 x + ... + c_T x^T is
 // evaluated as f(x) = f(x-1) + D_1, D_1 += D_2, ..., D_{T-1} += D_T: T modular additions per share and no

@@ -567,10 +567,29 @@ struct Launchers {
         const bool vec = sizeof(E) != 12 && CW > 1 && al(B) && stride_ok(ldb) && N % CW == 0;
         if (vec) {
             dim3 grid((N / CW + BLOCK - 1) / BLOCK, ks);
-            hipLaunchKernelGGL((k_vecmat_partial<F, MM, true>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
+            hipLaunchKernelGGL((k_vecmat_partial<F, MM, true, (MM > 1)>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
         } else {
             dim3 grid((N + BLOCK - 1) / BLOCK, ks);
-            hipLaunchKernelGGL((k_vecmat_partial<F, MM, false>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
+            hipLaunchKernelGGL((k_vecmat_partial<F, MM, false, (MM > 1)>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, M, K, N, kchunk);
+        }
+    }
+    // one-word prime fields: column accumulators, one instantiation per M, one column per thread.  Rows of B per group (two
+    // groups in registers) and resident workgroups per CU follow the registers of the column sums, 12 per row of A (measured,
+    // 4096 x 4096 over 2^61 - 1, profiles/HISTORY.md): up to 4 rows four workgroups and groups of 8; 5..7 rows three
+    // workgroups and groups of 4; 8 rows two workgroups and groups of 16
+    template <int MM>
+    struct VecmatCol {
+        static constexpr int UNR = MM <= 4 ? 8 : MM < 8 ? 4 : 16;
+        static constexpr int MINB = MM <= 4 ? 4 : MM < 8 ? 3 : 2;
+    };
+    static int vecmat_col_per_cu(int M) { return M <= 4 ? 4 : M < 8 ? 3 : 2; }
+    template <int MM>
+    static void go_vecmat_col(const F& f, const E* A, size_t lda, const E* B, size_t ldb, W* part, int K, int N, int ks,
+                              int kchunk, hipStream_t st) {
+        if constexpr (col_mac_ok<F>::value) {
+            typedef VecmatCol<MM> C;
+            dim3 grid((N + BLOCK - 1) / BLOCK, ks);
+            hipLaunchKernelGGL((k_vecmat_partial_col<F, MM, C::UNR, C::MINB>), grid, dim3(BLOCK), 0, st, f, A, lda, B, ldb, part, K, N, kchunk);
         }
     }
     static int matmul(const void* Fp, int device, const void* A, size_t lda, const void* B, size_t ldb, void* C,
@@ -589,9 +608,16 @@ struct Launchers {
                 return 0;
             }
             if (M <= SKINNY_MAX && N >= 64 && K >= 1 && workspace) {
-                // split K so that about 2^18 threads are in flight; each chunk at least 8 rows
-                const int cols_blocks = (N / (int)Pack<W>::N + BLOCK - 1) / BLOCK;
-                int ks = (1024 + cols_blocks - 1) / cols_blocks;
+                // split K so that one round of workgroups fills the chip; each chunk at least 8 rows.  One-word primes: one
+                // column per thread, as many workgroups as are resident at once (registers of the column sums)
+                int cpt = (int)Pack<W>::N, target = 1024;        // columns per thread, workgroups
+                if constexpr (col_mac_ok<F>::value) {
+                    cpt = 1;
+                    const int ncu = launch_cfg(device).num_cu;
+                    target = (ncu > 0 ? ncu : 256) * vecmat_col_per_cu(M);
+                }
+                const int cols_blocks = (N / cpt + BLOCK - 1) / BLOCK;
+                int ks = (target + cols_blocks - 1) / cols_blocks;
                 if (ks > (K + 7) / 8) ks = (K + 7) / 8;
                 if (ks < 1) ks = 1;
                 while (ks > 1 && (size_t)ks * M * N * sizeof(W) > workspace_bytes) ks /= 2;
@@ -600,11 +626,23 @@ struct Launchers {
                     ks = (K + kchunk - 1) / kchunk;
                     W* part = (W*)workspace;
                     const E* a = (const E*)A; const E* b = (const E*)B;
-                    if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
+                    if constexpr (col_mac_ok<F>::value) {
+                        switch (M) {
+                            case 1: go_vecmat_col<1>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 2: go_vecmat_col<2>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 3: go_vecmat_col<3>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 4: go_vecmat_col<4>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 5: go_vecmat_col<5>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 6: go_vecmat_col<6>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            case 7: go_vecmat_col<7>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                            default: go_vecmat_col<8>(f, a, lda, b, ldb, part, K, N, ks, kchunk, st); break;
+                        }
+                    } else if (M == 1) go_vecmat<1>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M == 2) go_vecmat<2>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else if (M <= 4) go_vecmat<4>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
                     else go_vecmat<8>(f, a, lda, b, ldb, part, M, K, N, ks, kchunk, st);
-                    hipLaunchKernelGGL((k_vecmat_final<F>), dim3((unsigned)(((size_t)M * N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                    constexpr int CO = BLOCK / VECMAT_FINAL_G;
+                    hipLaunchKernelGGL((k_vecmat_final<F>), dim3((unsigned)(((size_t)M * N + CO - 1) / CO)), dim3(BLOCK), 0,
                                        st, f, (const W*)part, ks, M, N, (E*)C, ldc);
                     FFGPU_CHECK_LAUNCH();
                     return 0;

@@ -875,8 +875,12 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_short_rows(F f, const typename
 }
 
 // C (M x N) = A (M x K) @ B (K x N), M <= SKINNY_MAX: a pack of columns per thread, K split over blockIdx.y;
-// partial[(ks * M + m) * N + j], summed by k_vecmat_final
-template <class F, int MM, bool VEC, int UNR = 4>
+// partial[(ks * M + m) * N + j], summed by k_vecmat_final.  The entries of A are the same for every thread: with STAGE the
+// workgroup converts (prep) a tile of VECMAT_KT rows of A once into LDS and every lane reads it back as a broadcast -- without it
+// they are scalar loads in the loop, one dependent wait per row of A (measured over 2^61 - 1 at 4096 x 4096: M = 8 126 us,
+// M = 2 37.6 us against 30.5 us for M = 1), and Montgomery fields repeat the conversion in every thread.
+constexpr int VECMAT_KT = 32;
+template <class F, int MM, bool VEC, bool STAGE, int UNR = 4>
 __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F::elem* __restrict__ A, size_t lda,
                                                            const typename F::elem* __restrict__ B, size_t ldb,
                                                            typename F::word* __restrict__ partial, int M, int K, int N,
@@ -885,8 +889,11 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     constexpr int CW = VEC ? P::N : 1;                              // columns per thread
+    constexpr int KT = VECMAT_KT;
+    __shared__ W sa[STAGE ? MM : 1][STAGE ? KT : 1];
     const int j = (blockIdx.x * BLOCK + threadIdx.x) * CW;
-    if (j >= N) return;
+    const bool live = j < N;
+    if (!STAGE && !live) return;
     const int k0 = blockIdx.y * kchunk;
     const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
     typename F::acc acc[MM][CW];
@@ -918,31 +925,51 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
             b[0] = ld_elem<F>(B, (size_t)kk * ldb + j);
         }
     };
-    auto macs = [&](int kk, const W (&b)[CW]) {
-#pragma unroll
-        for (int mi = 0; mi < MM; ++mi)
-            if (mi < M) {
-                const W ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                      // wave-uniform operand
-#pragma unroll
-                for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, b[q]);
+    for (int kt0 = k0; kt0 < k1; kt0 += KT) {
+        const int kt1 = !STAGE ? k1 : (kt0 + KT < k1 ? kt0 + KT : k1);
+        if constexpr (STAGE) {
+            __syncthreads();                                        // the previous tile has been read
+            for (int e = threadIdx.x; e < MM * KT; e += BLOCK) {
+                const int mi = e / KT, kk = kt0 + e % KT;
+                W v = W();
+                if (mi < M && kk < kt1) v = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));
+                sa[mi][e % KT] = v;
             }
-    };
-    int kk = k0;
-    for (; kk + UNR <= k1; kk += UNR) {              // UNR rows of B in flight per thread
-        W b[UNR][CW];
+            __syncthreads();
+        }
+        auto macs = [&](int kk, const W (&b)[CW]) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) load_b(kk + u, b[u]);
+            for (int mi = 0; mi < MM; ++mi) {
+                if (MM == 1 || mi < M) {
+                    W ap;
+                    if constexpr (STAGE) ap = sa[mi][kk - kt0];                                 // broadcast read
+                    else ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                     // wave-uniform operand
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) macs(kk + u, b[u]);
-        cnt += UNR;
-        if (cnt >= SKINNY_FLUSH) flush();
+                    for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, b[q]);
+                }
+            }
+        };
+        if (live) {
+            int kk = kt0;
+            for (; kk + UNR <= kt1; kk += UNR) {              // UNR rows of B in flight per thread
+                W b[UNR][CW];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) load_b(kk + u, b[u]);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) macs(kk + u, b[u]);
+                cnt += UNR;
+                if (cnt >= SKINNY_FLUSH) flush();
+            }
+            for (; kk < kt1; ++kk) {
+                W b0[CW];
+                load_b(kk, b0);
+                macs(kk, b0);
+                if (++cnt >= SKINNY_FLUSH) flush();
+            }
+        }
+        if constexpr (!STAGE) break;
     }
-    for (; kk < k1; ++kk) {
-        W b0[CW];
-        load_b(kk, b0);
-        macs(kk, b0);
-        if (++cnt >= SKINNY_FLUSH) flush();
-    }
+    if (!live) return;
     flush();
 #pragma unroll
     for (int mi = 0; mi < MM; ++mi)
@@ -952,34 +979,123 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
                 if (j + q < N) partial[((size_t)blockIdx.y * M + mi) * N + j + q] = total[mi][q];
 }
 
+// The same for prime fields on one 64-bit word (col_mac_ok: PM64<*>, RC64): the staged entries of A are split into three limbs
+// and every term costs six multiply-adds into column sums (fields.hpp ColAcc) instead of a 128-bit product plus a 192-bit
+// carry chain.  One instantiation per M (no test inside the row loop), one column per thread (a wave reads 512 contiguous
+// bytes of a row of B; two columns per thread double the registers of the column sums and were never faster).  The rows of B
+// are read in groups of UNR, the NEXT group in flight while the current one is multiplied: with the loads issued and awaited
+// inside one iteration the kernel ran at the memory latency (M = 8: 55-66 us, the multiply-adds at half their issue rate).
+constexpr int VECMAT_COL_KT = 128;                                  // rows of A staged at once (16 B each per row of A)
+template <class F, int MM, int UNR, int MINB>
+__global__ __launch_bounds__(BLOCK, MINB) void k_vecmat_partial_col(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                               const typename F::elem* __restrict__ B, size_t ldb,
+                                                               typename F::word* __restrict__ partial, int K, int N, int kchunk) {
+    typedef typename F::word W;
+    constexpr int KT = VECMAT_COL_KT;
+    __shared__ ColLimbs sa[MM][KT];
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = j < N;
+    const int k0 = blockIdx.y * kchunk;
+    const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
+    ColAcc<typename F::acc> acc[MM];
+    int cnt = 0;
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi) acc[mi].zero();
+    // every SKINNY_FLUSH terms: reduce, and put the residue back as one term (1 x residue: its two words are column sums)
+    auto flush = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi) {
+            const W part = f.acc_reduce(acc[mi].gather());
+            acc[mi].zero();
+            acc[mi].c00 = (uint32_t)part;
+            acc[mi].c01 = (uint32_t)(part >> 32);
+        }
+        cnt = 1;
+    };
+    const typename F::elem* Bj = B + (live ? j : 0);
+    auto load_group = [&](int kk, W (&b)[UNR]) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) b[u] = ld_elem<F>(Bj, (size_t)(kk + u) * ldb);
+    };
+    for (int kt0 = k0; kt0 < k1; kt0 += KT) {
+        const int kt1 = kt0 + KT < k1 ? kt0 + KT : k1;
+        __syncthreads();                                            // the previous tile has been read
+        for (int e = threadIdx.x; e < MM * KT; e += BLOCK) {
+            const int mi = e / KT, kk = kt0 + e % KT;
+            if (kk < kt1) sa[mi][e % KT] = col_limbs(f.prep(ld_elem<F>(A, (size_t)mi * lda + kk)));
+        }
+        __syncthreads();
+        if (!live) continue;
+        auto mac_group = [&](int kk, const W (&b)[UNR]) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int mi = 0; mi < MM; ++mi) acc[mi].mac(sa[mi][kk + u - kt0], b[u]);        // broadcast reads
+            cnt += UNR;
+            if (cnt >= SKINNY_FLUSH) flush();
+        };
+        int kk = kt0;
+        if (kk + UNR <= kt1) {
+            W ba[UNR], bb[UNR];
+            load_group(kk, ba);
+            for (;;) {                                              // ping-pong: the group after the current one is in flight
+                const bool more = kk + 2 * UNR <= kt1;
+                if (more) load_group(kk + UNR, bb);
+                mac_group(kk, ba);
+                kk += UNR;
+                if (!more) break;
+                const bool more2 = kk + 2 * UNR <= kt1;
+                if (more2) load_group(kk + UNR, ba);
+                mac_group(kk, bb);
+                kk += UNR;
+                if (!more2) break;
+            }
+        }
+        for (; kk < kt1; ++kk) {
+            const W b0 = ld_elem<F>(Bj, (size_t)kk * ldb);
+#pragma unroll
+            for (int mi = 0; mi < MM; ++mi) acc[mi].mac(sa[mi][kk - kt0], b0);
+            if (++cnt >= SKINNY_FLUSH) flush();
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi) partial[((size_t)blockIdx.y * MM + mi) * N + j] = f.acc_reduce(acc[mi].gather());
+}
+
+// Sum of the KS partial rows.  M x N is small (4096 outputs for an activation row against 4096^2 weights) and KS ~ 128: one thread
+// per output is sixteen blocks walking a chain of loads.  Eight threads share an output instead (thread group g takes the
+// partials s = g mod 8, four loads in flight), then one pass through LDS.
+constexpr int VECMAT_FINAL_G = 8;
 template <class F>
 __global__ __launch_bounds__(BLOCK) void k_vecmat_final(F f, const typename F::word* __restrict__ partial, int KS, int M,
                                                          int N, typename F::elem* __restrict__ C, size_t ldc) {
     typedef typename F::word W;
-    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= (size_t)M * N) return;
-    const int mi = (int)(idx / N), j = (int)(idx % N);
-    // KS can be ~128: eight independent chains so that the loads overlap instead of forming one dependent sequence
-    W r[8];
+    constexpr int G = VECMAT_FINAL_G, CO = BLOCK / G;               // outputs per block
+    __shared__ W sm[G][CO];
+    const int c = threadIdx.x % CO, g = threadIdx.x / CO;
+    const size_t idx = (size_t)blockIdx.x * CO + c;
     const size_t mn = (size_t)M * N;
-    int s = 0;
-    if (KS >= 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = partial[(size_t)u * mn + idx];
-        for (s = 8; s + 8 <= KS; s += 8) {
-            W t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(s + u) * mn + idx];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = f.add(r[u], t[u]);
+    const bool live = idx < mn;
+    if (live && g < KS) {
+        int s = g;
+        W r = partial[(size_t)s * mn + idx];
+        s += G;
+        for (; s + 3 * G < KS; s += 4 * G) {
+            const W t0 = partial[(size_t)s * mn + idx], t1 = partial[(size_t)(s + G) * mn + idx];
+            const W t2 = partial[(size_t)(s + 2 * G) * mn + idx], t3 = partial[(size_t)(s + 3 * G) * mn + idx];
+            r = f.add(r, f.add(f.add(t0, t1), f.add(t2, t3)));
         }
-        r[0] = f.add(f.add(f.add(r[0], r[1]), f.add(r[2], r[3])), f.add(f.add(r[4], r[5]), f.add(r[6], r[7])));
-    } else {
-        r[0] = partial[idx];
-        s = 1;
+        for (; s < KS; s += G) r = f.add(r, partial[(size_t)s * mn + idx]);
+        sm[g][c] = r;
     }
-    for (; s < KS; ++s) r[0] = f.add(r[0], partial[(size_t)s * mn + idx]);
-    st_elem<F>(C, (size_t)mi * ldc + j, r[0]);
+    __syncthreads();
+    if (g == 0 && live) {
+        W r = sm[0][c];
+        for (int q = 1; q < G && q < KS; ++q) r = f.add(r, sm[q][c]);
+        const int mi = (int)(idx / N), j = (int)(idx % N);
+        st_elem<F>(C, (size_t)mi * ldc + j, r);
+    }
 }
 
 }  // namespace ffgpu

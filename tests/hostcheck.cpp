@@ -12,7 +12,7 @@
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9, HC_COLDOT = 10 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -88,6 +88,18 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 for (int j = 0; j < k; ++j)
                     f.acc_mac(s, f.prep(cst<F>(f, lam + (sizeof(typename F::word) == 24 ? 3 : 2) * j)), ldw<F>(a, (size_t)j * n + i));
                 r = f.acc_reduce(s);
+                break;
+            }
+            case HC_COLDOT: {
+                // the skinny products' column accumulators (fields.hpp ColAcc): lam = the shared operand, split into limbs once
+                if constexpr (col_mac_ok<F>::value) {
+                    ColAcc<typename F::acc> ca;
+                    ca.zero();
+                    for (int j = 0; j < k; ++j) ca.mac(col_limbs(f.prep(cst<F>(f, lam + 2 * j))), ldw<F>(a, (size_t)j * n + i));
+                    r = f.acc_reduce(ca.gather());
+                } else {
+                    return 2;
+                }
                 break;
             }
             case HC_SHARE: {

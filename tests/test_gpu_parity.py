@@ -713,12 +713,14 @@ def test_skinny_products(eng, coracle):
     """Matrix x few columns and few rows x matrix (the np_bnnmnist shape, demos/np_bnnmnist.py:10-15) take
     dedicated HBM-bound kernels: one output dimension <= 8, the other >= 64.  Against the oracle for every
     reduction strategy, with worst-case accumulation (all operands p-1), K beyond the 192-term accumulator
-    flush, ragged sizes, and sub-matrix views with a leading dimension larger than the row length."""
+    flush, ragged sizes, and sub-matrix views with a leading dimension larger than the row length.  Few rows x matrix over
+    one-word primes is k_vecmat_partial_col (column sums of 22 x 32-bit partial products, one instantiation per M, tiles of 128
+    staged rows, groups of rows of B in flight); other fields k_vecmat_partial."""
     cases = [(200, 333, 1), (100, 257, 3), (64, 1000, 8), (77, 5, 2), (1, 500, 300), (3, 1000, 129), (8, 2100, 64), (2, 7, 1000),
              (64, 300, 200), (40, 1000, 90), (130, 2000, 70), (9, 129, 9),      # these four: tiled kernel with split-K
              (5000, 7, 1), (3000, 32, 3),                                        # short rows: one thread per row
              (4096, 1024, 1), (4101, 1030, 2), (8192, 2050, 1),                  # several rows per workgroup (k_matvec_rows_r)
-             (1, 4096, 4096), (2, 300, 4098), (5, 1111, 640)]                    # waves of a workgroup split K (k_vecmat_slab)
+             (1, 4096, 4096), (2, 300, 4098), (5, 1111, 640), (8, 4500, 300), (7, 129, 70)]   # K split over workgroups, several staged tiles
     for modulus, binary in [(P61, False), (P64, False), (2**96 - 17, False), (P128, False), (6616326157076047771, False),
                             (2**31 - 1, False), (258797994007609146293811961253269568351, False),
                             ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]:
@@ -736,6 +738,17 @@ def test_skinny_products(eng, coracle):
             want = coracle.matmul(cf, A, B, M, K, N)
             coracle.set_threads(1)
             assert (got == want).all(), (hex(modulus), M, K, N)
+    # every operand p - 1, every M of the few-rows kernels (one instantiation each for one-word primes: column sums of
+    # 22 x 32-bit partial products, flushed every 192 terms), packed and ragged column counts
+    for modulus in (P61, P64, 6616326157076047771, 2**40 - 87):
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        for M in range(1, 9):
+            for (K, N) in ((1000 + M, 130), (389, 261)):
+                A = pack([modulus - 1] * (M * K), eb)
+                B = pack([modulus - 1] * (K * N), eb)
+                got = unpack(ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy(), eb)
+                assert got == [K * (modulus - 1) ** 2 % modulus] * (M * N), (hex(modulus), M, K, N)
     # through the mirror: 2-D @ 1-D, 1-D @ 2-D and a batch of two rows
     from mpyc_amd import finfields
     Fm = finfields.GF(P61)

@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY = range(10)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY, HC_COLDOT = range(11)
 
 
 def limbs3(x):
@@ -414,6 +414,27 @@ def test_k64_lazy_chains(hostcheck):
                     r = r * (u if j & 1 else v) % p
                 want.append(r)
             assert got == want, (c, noncanon)
+
+
+def test_column_accumulators_of_the_skinny_products(hostcheck):
+    """fields.hpp ColAcc (k_vecmat_partial_col): the shared operand in three limbs of 22 / 22 / 20 bits, six column sums of
+    partial products, rebuilt into the 192-bit sum that acc_reduce takes -- equal to the plain dot product modulo p for every
+    one-word prime policy (Mersenne, 2^64 - c, 2^k - c, reciprocal), for 1..256 terms (the bound of one flush), with all
+    operands p - 1, with limb patterns of all ones, and random."""
+    from types import SimpleNamespace
+    rng = random.Random(2264)
+    for p in (2**61 - 1, 2**64 - 189, 2**64 - 59, 2**40 - 87, 2**63 - 25, 2**33 - 9, 6616326157076047771, 18446744073709551557,
+              (1 << 62) + 135, 4294967311):
+        F = SimpleNamespace(modulus=p, binary=False, order=p)
+        for k in (1, 2, 5, 64, 192, 255, 256):
+            n = 6
+            special = [p - 1, (2**22 - 1) % p, ((2**22 - 1) << 22) % p, (2**64 - 2**44) % p, (2**32 - 1) % p, (2**64 - 2**32) % p]
+            lam = [p - 1 if k >= 192 or j % 3 == 0 else special[j % 6] if j % 3 == 1 else rng.randrange(p) for j in range(k)]
+            rows = [[p - 1] * n if k >= 192 or j % 2 == 0 else [special[(j + h) % 6] if h % 2 else rng.randrange(p) for h in range(n)]
+                    for j in range(k)]
+            got, _ = run(hostcheck, F, HC_COLDOT, [v for row in rows for v in row], lam=lam, k=k, n=n)
+            want = [sum(lam[j] * rows[j][h] for j in range(k)) % p for h in range(n)]
+            assert got == want, (hex(p), k)
 
 
 def test_pm64_general_policy_all_widths(hostcheck):
