@@ -1094,8 +1094,8 @@ def main():
                 del Am, Bm, Cm
             # the shape the reference's author names as the np_bnnmnist bottleneck (demos/np_bnnmnist.py:10-15): a
             # 1 x 4096 activation row times a 4096 x 4096 weight matrix (and batches of 4 and 8 rows: column sums of partial
-            # products, k_vecmat_partial_col), and the transposed (matrix x vector) form
-            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (64, 4096, 4096)):
+            # products, k_vecmat_partial_col), and the transposed form: matrix x vector, matrix x 4 / 8 columns (k_matvec_sub_col)
+            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (16384, 4096, 4), (16384, 4096, 8), (64, 4096, 4096)):
                 big = [DevArray(ctx, uniform_field(gen, max(mm_, 4096) * 4096, P61, ctx.torch_device), max(mm_, 4096) * 4096) for _ in range(3)]
                 small = DevArray(ctx, uniform_field(gen, 64 * 4096, P61, ctx.torch_device), 64 * 4096)
                 outm = ctx.empty(mm_ * nn_)

@@ -560,6 +560,28 @@ struct Launchers {
         hipLaunchKernelGGL((k_matvec_rows<F, NN>), dim3((unsigned)M), dim3(BLOCK), 0, st, f, A, lda, B, ldb, C, ldc, K, N, vec,
                            bvec);
     }
+    // one-word primes, 2..8 columns: column sums, one instantiation per N; two rows of A per workgroup up to 4 columns
+    template <int NN>
+    static void go_matvec_col(const F& f, int device, const E* A, size_t lda, const E* B, size_t ldb, E* C, size_t ldc, int M,
+                              int K, hipStream_t st) {
+        if constexpr (col_mac_ok<F>::value) {
+            constexpr int R = NN <= 4 ? 2 : 1;
+            const int vec = al(A) && stride_ok(lda);
+            const int bvec = al(B) && stride_ok(ldb) && (NN % (int)Pack<W>::N == 0);
+            // B contiguous and 16-byte aligned, rows of A aligned: sixteen lanes per row (a wave per row when 16 rows per
+            // workgroup would leave CUs without one), the rows of B through LDS
+            if (vec && ldb == (size_t)NN && al(B) && K >= 64) {
+                const int ncu = launch_cfg(device).num_cu;
+                if ((M + 15) / 16 >= 2 * (ncu > 0 ? ncu : 256))
+                    hipLaunchKernelGGL((k_matvec_sub_col<F, NN, 16>), dim3((unsigned)((M + 15) / 16)), dim3(BLOCK), 0, st, f, A, lda, B, C, ldc, M, K);
+                else
+                    hipLaunchKernelGGL((k_matvec_sub_col<F, NN, 64>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0, st, f, A, lda, B, C, ldc, M, K);
+            } else {
+                hipLaunchKernelGGL((k_matvec_rows_col<F, NN, R>), dim3((unsigned)((M + R - 1) / R)), dim3(BLOCK), 0, st, f, A, lda, B, ldb,
+                                   C, ldc, M, K, vec, bvec);
+            }
+        }
+    }
     template <int MM>
     static void go_vecmat(const F& f, const E* A, size_t lda, const E* B, size_t ldb, W* part, int M, int K, int N,
                           int ks, int kchunk, hipStream_t st) {
@@ -600,7 +622,23 @@ struct Launchers {
             // (three-limb words: the eight-column kernel would spill, N in 5..8 takes the tiled product)
             if (N <= (sizeof(W) > 16 ? 4 : SKINNY_MAX) && M >= 64 && K >= 1) {
                 const E* a = (const E*)A; const E* b = (const E*)B; E* c = (E*)C;
-                if (N == 1) go_matvec<1>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
+                bool done = false;
+                if constexpr (col_mac_ok<F>::value) {
+                    if (N >= 2 && K > 32) {               // (short rows keep the one-thread-per-row kernel)
+                        switch (N) {
+                            case 2: go_matvec_col<2>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            case 3: go_matvec_col<3>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            case 4: go_matvec_col<4>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            case 5: go_matvec_col<5>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            case 6: go_matvec_col<6>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            case 7: go_matvec_col<7>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                            default: go_matvec_col<8>(f, device, a, lda, b, ldb, c, ldc, M, K, st); break;
+                        }
+                        done = true;
+                    }
+                }
+                if (done) {}
+                else if (N == 1) go_matvec<1>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
                 else if (N == 2) go_matvec<2>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
                 else if (N <= 4) go_matvec<4>(f, a, lda, b, ldb, c, ldc, M, K, N, st);
                 else go_matvec<8>(f, a, lda, b, ldb, c, ldc, M, K, N, st);

@@ -847,6 +847,205 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::
     }
 }
 
+// Matrix x few columns (2 <= N <= 8) over one-word primes (col_mac_ok): column sums (fields.hpp ColAcc).  Here no operand is
+// shared between lanes (every lane walks its own k), so the entry of A is split into its three limbs in the lane -- four
+// instructions, used for all N columns -- and each term is six multiply-adds instead of the 32 instructions of acc_mac
+// (measured over 2^61 - 1, 16384 x 4096 @ 4096 x N, round-4 kernel: N = 2 132 us, N = 3 383, N = 4 473, N = 8 1415 us against
+// 85 us for reading A once).  One instantiation per N.
+//
+// k_matvec_sub_col (B contiguous, the usual case): SIXTEEN lanes per row of A, 16 rows per workgroup.  With a whole
+// workgroup per row (below) a thread sees K / 256 terms and then pays ~200 instructions per column for the reduction and the
+// butterfly over the workgroup -- as much as its share of the product at K = 4096 -- and every 16-byte load of B by a wave
+// touches 64 different cache lines.  Here a lane sees K / 16 terms, the butterfly has four steps inside the wave, and the 512
+// rows of B of one tile are copied to LDS with whole 16-byte chunks; the four row groups of a wave read the same addresses
+// (broadcast), and the two rows of a lane start an ODD number of chunks after its neighbour's (N odd: N, N even: N + 1)
+// so that 16 neighbouring lanes fall on 16 different bank groups.
+// LW lanes per row: 16, or 64 (four rows per workgroup) when there are too few rows to fill the chip with 16 per workgroup.
+constexpr int MATVEC_SUB_KT = 512, MATVEC_SUB_U = 4;
+template <class F, int NN, int LW>
+__global__ __launch_bounds__(BLOCK) void k_matvec_sub_col(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                           const typename F::elem* __restrict__ B,
+                                                           typename F::elem* __restrict__ C, size_t ldc, int M, int K) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    static_assert(P::N == 2, "two rows of B per lane and step");
+    constexpr int ROWS = BLOCK / LW, KT = MATVEC_SUB_KT, U = MATVEC_SUB_U;
+    constexpr int CH = (NN % 2) ? NN : NN + 1;                     // 16-byte chunks per pair of rows of B in the tile
+    __shared__ __attribute__((aligned(16))) W sb[(KT / 2) * CH * 2];
+    const int g = threadIdx.x / LW, l = threadIdx.x % LW;
+    const size_t row = (size_t)blockIdx.x * ROWS + g;
+    const typename F::elem* __restrict__ a = A + (row < (size_t)M ? row : (size_t)M - 1) * lda;   // rows past M re-read the last one
+    ColAcc<typename F::acc> acc[NN];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NN; ++j) acc[j].zero();
+    auto flush = [&]() {                                           // reduce, the residue re-enters as one term
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const W part = f.acc_reduce(acc[j].gather());
+            acc[j].zero();
+            acc[j].c00 = (uint32_t)part;
+            acc[j].c01 = (uint32_t)(part >> 32);
+        }
+        cnt = 1;
+    };
+    auto term = [&](W x, const W* b) {
+        const ColLimbs xl = col_limbs(f.prep(x));
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[j].mac(xl, b[j]);
+    };
+    const int keven = K & ~1;
+    for (int kt0 = 0; kt0 < keven; kt0 += KT) {
+        const int pairs = (keven - kt0 < KT ? keven - kt0 : KT) / 2;
+        __syncthreads();                                            // the previous tile has been read
+        const MP* __restrict__ src = reinterpret_cast<const MP*>(B + (size_t)kt0 * NN);
+        for (int c = threadIdx.x; c < pairs * NN; c += BLOCK)
+            *reinterpret_cast<P*>(&sb[((c / NN) * CH + c % NN) * 2]) = ldg<false>(src + c);
+        __syncthreads();
+        const MP* __restrict__ av = reinterpret_cast<const MP*>(a + kt0);
+        for (int p0 = l; p0 < pairs; p0 += LW * U) {                // U packs of A in flight per lane
+            P x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (p0 + u * LW < pairs) x[u] = ldg<true>(av + p0 + u * LW);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * LW;
+                if (p < pairs) {
+                    W w[2 * NN];
+#pragma unroll
+                    for (int c = 0; c < NN; ++c) {
+                        const P v = *reinterpret_cast<const P*>(&sb[(p * CH + c) * 2]);
+                        w[2 * c] = v.w[0];
+                        w[2 * c + 1] = v.w[1];
+                    }
+                    term(x[u].w[0], w);
+                    term(x[u].w[1], w + NN);
+                    cnt += 2;
+                    if (cnt >= SKINNY_FLUSH) flush();
+                }
+            }
+        }
+    }
+    if ((K & 1) && l == 0) {                                        // the last column of an odd K
+        W b[NN];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) b[j] = ld_elem<F>(B, (size_t)(K - 1) * NN + j);
+        term(ld_elem<F>(a, K - 1), b);
+    }
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        W v = f.acc_reduce(acc[j].gather());
+#pragma unroll
+        for (int off = LW / 2; off > 0; off >>= 1) v = f.add(v, wave_shfl_xor(v, off));
+        if (l == 0 && row < (size_t)M) st_elem<F>(C, row * ldc + j, v);
+    }
+}
+
+// The same for any layout of B (row stride, alignment): one workgroup per R rows of A, the rows of B read from global memory
+template <class F, int NN, int R>
+__global__ __launch_bounds__(BLOCK) void k_matvec_rows_col(F f, const typename F::elem* __restrict__ A, size_t lda,
+                                                            const typename F::elem* __restrict__ B, size_t ldb,
+                                                            typename F::elem* __restrict__ C, size_t ldc, int M, int K, int vec,
+                                                            int bvec) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    constexpr int EPV = P::N;
+    __shared__ W sm[R * NN * (BLOCK / 64)];
+    const size_t row0 = (size_t)blockIdx.x * R;
+    ColAcc<typename F::acc> acc[R][NN];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[r][j].zero();
+    auto flush = [&]() {                                           // reduce, the residue re-enters as one term
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                const W part = f.acc_reduce(acc[r][j].gather());
+                acc[r][j].zero();
+                acc[r][j].c00 = (uint32_t)part;
+                acc[r][j].c01 = (uint32_t)(part >> 32);
+            }
+        cnt = 1;
+    };
+    auto term = [&](const W (&x)[R], const W (&b)[NN]) {           // one k: R entries of A against a row of B
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const ColLimbs xl = col_limbs(f.prep(x[r]));
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[r][j].mac(xl, b[j]);
+        }
+    };
+    auto load_b = [&](size_t kk, W (&b)[NN]) {                     // row kk of B
+        bool packed = false;
+        if constexpr (NN % P::N == 0) {
+            if (bvec) {
+                const MP* __restrict__ br = reinterpret_cast<const MP*>(B + kk * ldb);
+#pragma unroll
+                for (int jp = 0; jp < NN / P::N; ++jp) {
+                    const P bp = ldg<false>(br + jp);
+#pragma unroll
+                    for (int q = 0; q < P::N; ++q) b[jp * P::N + q] = bp.w[q];
+                }
+                packed = true;
+            }
+        }
+        if (!packed) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) b[j] = ld_elem<F>(B, kk * ldb + j);
+        }
+    };
+    auto row_of = [&](int r) { return row0 + r < (size_t)M ? row0 + r : (size_t)M - 1; };   // rows past M re-read the last one
+    const int nvec = vec ? K / EPV : 0;
+    for (int i = threadIdx.x; i < nvec; i += BLOCK) {
+        P x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = ldg<true>(reinterpret_cast<const MP*>(A + row_of(r) * lda) + i);
+#pragma unroll
+        for (int q = 0; q < EPV; ++q) {
+            W xr[R], b[NN];
+#pragma unroll
+            for (int r = 0; r < R; ++r) xr[r] = x[r].w[q];
+            load_b((size_t)i * EPV + q, b);
+            term(xr, b);
+        }
+        cnt += EPV;
+        if (cnt >= SKINNY_FLUSH) flush();
+    }
+    for (int kk = nvec * EPV + threadIdx.x; kk < K; kk += BLOCK) {
+        W xr[R], b[NN];
+#pragma unroll
+        for (int r = 0; r < R; ++r) xr[r] = ld_elem<F>(A, row_of(r) * lda + kk);
+        load_b((size_t)kk, b);
+        term(xr, b);
+        if (++cnt >= SKINNY_FLUSH) flush();
+    }
+    // R*NN sums over the workgroup: butterfly inside each wave, then one exchange of the per-wave sums through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            W v = f.acc_reduce(acc[r][j].gather());
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = f.add(v, wave_shfl_xor(v, off));
+            if (lane == 0) sm[(r * NN + j) * (BLOCK / 64) + wv] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < R * NN) {
+        const int r = threadIdx.x / NN, j = threadIdx.x % NN;
+        W v = sm[threadIdx.x * (BLOCK / 64)];
+#pragma unroll
+        for (int w2 = 1; w2 < BLOCK / 64; ++w2) v = f.add(v, sm[threadIdx.x * (BLOCK / 64) + w2]);
+        if (row0 + r < (size_t)M) st_elem<F>(C, (row0 + r) * ldc + j, v);
+    }
+}
+
 // Same product for SHORT rows (K <= 32, many rows: sums over a trailing axis, tall-thin least squares): one
 // thread per row -- a row is K contiguous elements, neighbouring threads read neighbouring rows, and B[k][j] is
 // wave-uniform (scalar loads).

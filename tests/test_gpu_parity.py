@@ -749,6 +749,14 @@ def test_skinny_products(eng, coracle):
                 B = pack([modulus - 1] * (K * N), eb)
                 got = unpack(ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy(), eb)
                 assert got == [K * (modulus - 1) ** 2 % modulus] * (M * N), (hex(modulus), M, K, N)
+        # matrix x few columns (k_matvec_rows_col: one instantiation per N, one or two rows per workgroup, the last workgroup
+        # ragged), K beyond one flush of a thread's column sums (192 terms x 256 threads)
+        for N in range(2, 9):
+            for (M, K) in ((71, 1000 + N), (130, 389)) + (((64, 60001),) if N in (3, 8) else ()):
+                A = pack([modulus - 1] * (M * K), eb)
+                B = pack([modulus - 1] * (K * N), eb)
+                got = unpack(ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy(), eb)
+                assert got == [K * (modulus - 1) ** 2 % modulus] * (M * N), (hex(modulus), M, K, N)
     # through the mirror: 2-D @ 1-D, 1-D @ 2-D and a batch of two rows
     from mpyc_amd import finfields
     Fm = finfields.GF(P61)
@@ -878,7 +886,7 @@ def test_matmul_leading_dimensions(eng, coracle):
         ctx = ctx_for(eng, modulus, False)
         eb = ctx.elem_bytes
         cf = coracle.CField(modulus, False)
-        shapes = [(70, 33, 1), (1, 200, 130), (40, 50, 45), (9, 300, 20), (260, 270, 250)] if eb < 12 else \
+        shapes = [(70, 33, 1), (1, 200, 130), (40, 50, 45), (9, 300, 20), (260, 270, 250), (70, 300, 3), (130, 1000, 8), (5, 700, 200)] if eb < 12 else \
             [(70, 33, 1), (1, 200, 130), (20, 50, 25)]
         for (M, K, N) in shapes:
             lda, ldb, ldc = K + 5, N + 3, N + 7
