@@ -1095,7 +1095,7 @@ def main():
             # the shape the reference's author names as the np_bnnmnist bottleneck (demos/np_bnnmnist.py:10-15): a
             # 1 x 4096 activation row times a 4096 x 4096 weight matrix (and batches of 4 and 8 rows: column sums of partial
             # products, k_vecmat_partial_col), and the transposed form: matrix x vector, matrix x 4 / 8 columns (k_matvec_sub_col)
-            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (16384, 4096, 4), (16384, 4096, 8), (64, 4096, 4096)):
+            for (mm_, kk_, nn_) in ((1, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (4096, 4096, 1), (16384, 4096, 1), (16384, 4096, 4), (16384, 4096, 8), (16, 4096, 4096), (64, 4096, 4096)):
                 big = [DevArray(ctx, uniform_field(gen, max(mm_, 4096) * 4096, P61, ctx.torch_device), max(mm_, 4096) * 4096) for _ in range(3)]
                 small = DevArray(ctx, uniform_field(gen, 64 * 4096, P61, ctx.torch_device), 64 * 4096)
                 outm = ctx.empty(mm_ * nn_)
@@ -1108,7 +1108,7 @@ def main():
                 byts = eb * (mm_ * kk_ + kk_ * nn_ + mm_ * nn_)
                 kern[f'matmul_p61_{mm_}x{kk_}x{nn_}'] = dict(roof(byts, ms), units_per_s=round(mm_ * kk_ * nn_ / (ms * 1e-3), 1),
                                                             algorithmic_bytes_per_unit=None)
-                if mm_ == 64:
+                if mm_ in (16, 64):             # matrix cores, rows padded to one 64-row tile
                     kern[f'matmul_p61_{mm_}x{kk_}x{nn_}']['mfma'] = roof_mfma(float(mm_) * kk_ * nn_, 8, ms)
                 del big, small, outm
             # dense products over two-limb primes (12 / 16 signed digits, diagonals in passes on the matrix cores)

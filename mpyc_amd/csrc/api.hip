@@ -983,7 +983,7 @@ int ffgpu_matmul(ffgpu_ctx* ctx, const void* A, size_t lda, const void* B, size_
         // split-K partial sums
         size_t want = 0;
         const size_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
-        if (ctx->kind == FFGPU_PRIME && M >= 64 && N >= 64 && K >= 64 && ctx->tune.mm_mfma && (double)M * N * K >= ctx->tune.mm_mfma_min) {
+        if (ctx->kind == FFGPU_PRIME && M > 8 && N > 8 && K >= 64 && ctx->tune.mm_mfma && (double)M * N * K >= ctx->tune.mm_mfma_min) {
             want = (size_t)(ctx->elem_bytes <= 8 ? 8 : 16) * (Mp + Np) * Kp + ((size_t)64 << 20);   // digit planes per operand + split-K slabs
             if (want > ((size_t)8 << 30)) want = 0;
         }

@@ -696,7 +696,9 @@ struct Launchers {
             const uint64_t pmod = (uint64_t)f.p;
             const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
             const size_t need = (size_t)L * ((size_t)Mp + Np) * Kp;
-            if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= mfma_min && workspace && need <= workspace_bytes) {
+            // (from 9 rows / columns on: the tiles are padded to 64 -- a batch of 9..63 rows against 4096 x 4096 takes the 88 us of
+            // 64 rows instead of 670-690 us on the vector ALUs)
+            if (use_mfma && M > SKINNY_MAX && N > SKINNY_MAX && K >= 64 && (double)M * N * K >= mfma_min && workspace && need <= workspace_bytes) {
                 int8_t* Ap = (int8_t*)workspace;
                 int8_t* Bp = Ap + (size_t)L * Mp * Kp;
                 const unsigned ga = (unsigned)(((size_t)Mp * Kp + BLOCK - 1) / BLOCK);
@@ -759,7 +761,7 @@ struct Launchers {
             constexpr int LW = sizeof(E) == 12 ? 12 : 16;
             const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64, Kp = (K + 31) / 32 * 32;
             const size_t need = (size_t)LW * ((size_t)Mp + Np) * Kp;
-            if (use_mfma && M >= 64 && N >= 64 && K >= 64 && (double)M * N * K >= mfma_min && workspace &&
+            if (use_mfma && M > SKINNY_MAX && N > SKINNY_MAX && K >= 64 && (double)M * N * K >= mfma_min && workspace &&
                 need <= workspace_bytes) {
                 int8_t* Ap = (int8_t*)workspace;
                 int8_t* Bp = Ap + (size_t)LW * Mp * Kp;

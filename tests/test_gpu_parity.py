@@ -776,7 +776,8 @@ def test_matrix_core_product(eng, coracle):
     10: 64-bit moduli), ragged shapes (padding), K beyond one 8192 chunk (accumulating launches), worst-case
     operands (p - 1 everywhere in a row and a column) and sub-matrix views; and equal to the VALU kernel
     (FFGPU_MM_MFMA=0 in a fresh context is not needed: the small shapes of test_matmul take that path)."""
-    shapes = [(256, 300, 257), (65, 8300, 70), (130, 64, 2000), (64, 1030, 300)]     # the last one: split-K slabs
+    shapes = [(256, 300, 257), (65, 8300, 70), (130, 64, 2000), (64, 1030, 300),     # the last one: split-K slabs
+              (16, 2100, 520), (9, 4100, 450), (300, 2000, 33), (40, 1000, 410)]     # 9..63 rows / columns: tiles padded to 64
     for modulus, binary in [(P61, False), (P64, False), (6616326157076047771, False), (2**31 - 1, False), (2**40 - 87, False),
                             (65537, False)]:
         F = po.Field(modulus, binary)
@@ -858,7 +859,7 @@ def test_matrix_core_product_two_limb_primes(eng, coracle):
         T = int.from_bytes(b'\x7f' * nb, 'little')
         edge = sorted({v % modulus for v in (0, 1, T - 1, T, T + 1, modulus // 2, modulus // 2 + 1, modulus - 1, modulus - 2,
                                               2**64 - 1, 2**64, 2**127 % modulus, modulus - 128)})
-        for (M, K, N) in ((128, 1000, 130), (65, 4200, 70)):
+        for (M, K, N) in ((128, 1000, 130), (65, 4200, 70), (20, 2100, 400), (700, 1300, 19)):
             A, B = rand_np(F, eb, M * K, 61), rand_np(F, eb, K * N, 62)
             a = unpack(A, eb)
             b = unpack(B, eb)
