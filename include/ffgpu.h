@@ -269,8 +269,9 @@ int ffgpu_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uint64_t
 /* C (M x N) = A (M x K) @ B (K x N) over the field, row-major with leading dimensions lda/ldb/ldc in
  * ELEMENTS; C must not overlap A or B.  The result is that of the reference's object matmul followed by one `%`
  * (exact integer accumulation, reduced at the end).  Kernel families, chosen by shape and field: one output dimension <= 8 ->
- * HBM-bound matrix x vector / vector x matrix kernels; prime fields with M, N, K >= 64 and M*N*K >= 8e7 ->
- * exact signed-digit GEMMs on the int8 matrix cores; otherwise an LDS-tiled vector-ALU kernel (split over K when
+ * matrix x few columns / few rows x matrix kernels that read the big operand once (one-word primes: six multiply-adds per
+ * term into column sums); prime fields with more than 8 rows and columns, K >= 64 and M*N*K >= 8e7 -> exact signed-digit
+ * GEMMs on the int8 matrix cores (tiles padded to 64); otherwise an LDS-tiled vector-ALU kernel (split over K when
  * the output has few tiles).  The matrix-core and split-K paths keep digit planes / partial sums in grow-only
  * scratch buffers owned by the context, ONE PER STREAM (launches on different streams never share scratch): the
  * first call of a larger shape on a stream allocates its buffer (and synchronises that stream), so issue one such
