@@ -95,7 +95,17 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 if constexpr (col_mac_ok<F>::value) {
                     ColAcc<typename F::acc> ca;
                     ca.zero();
-                    for (int j = 0; j < k; ++j) ca.mac(col_limbs(f.prep(cst<F>(f, lam + 2 * j))), ldw<F>(a, (size_t)j * n + i));
+                    int cnt = 0;
+                    for (int j = 0; j < k; ++j) {
+                        ca.mac(col_limbs(f.prep(cst<F>(f, lam + 2 * j))), ldw<F>(a, (size_t)j * n + i));
+                        if (++cnt >= 192) {                     // the kernels' flush: reduce, the residue re-enters as ONE term (1 x residue)
+                            const typename F::word part = f.acc_reduce(ca.gather());
+                            ca.zero();
+                            ca.c00 = (uint32_t)part;
+                            ca.c01 = (uint32_t)(part >> 32);
+                            cnt = 1;
+                        }
+                    }
                     r = f.acc_reduce(ca.gather());
                 } else {
                     return 2;

@@ -419,14 +419,15 @@ def test_k64_lazy_chains(hostcheck):
 def test_column_accumulators_of_the_skinny_products(hostcheck):
     """fields.hpp ColAcc (k_vecmat_partial_col): the shared operand in three limbs of 22 / 22 / 20 bits, six column sums of
     partial products, rebuilt into the 192-bit sum that acc_reduce takes -- equal to the plain dot product modulo p for every
-    one-word prime policy (Mersenne, 2^64 - c, 2^k - c, reciprocal), for 1..256 terms (the bound of one flush), with all
-    operands p - 1, with limb patterns of all ones, and random."""
+    one-word prime policy (Mersenne, 2^64 - c, 2^k - c, reciprocal), below and beyond the 192 terms of one flush (then the
+    residue re-enters the column sums as the term 1 x residue, as in the kernels), with all operands p - 1, with limb patterns
+    of all ones, and random."""
     from types import SimpleNamespace
     rng = random.Random(2264)
     for p in (2**61 - 1, 2**64 - 189, 2**64 - 59, 2**40 - 87, 2**63 - 25, 2**33 - 9, 6616326157076047771, 18446744073709551557,
               (1 << 62) + 135, 4294967311):
         F = SimpleNamespace(modulus=p, binary=False, order=p)
-        for k in (1, 2, 5, 64, 192, 255, 256):
+        for k in (1, 2, 5, 64, 191, 192, 193, 383, 1000):      # from 192 terms on: the kernels' flush, the residue re-enters as a term
             n = 6
             special = [p - 1, (2**22 - 1) % p, ((2**22 - 1) << 22) % p, (2**64 - 2**44) % p, (2**32 - 1) % p, (2**64 - 2**32) % p]
             lam = [p - 1 if k >= 192 or j % 3 == 0 else special[j % 6] if j % 3 == 1 else rng.randrange(p) for j in range(k)]
