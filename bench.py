@@ -44,6 +44,33 @@ import torch
 P61 = 2**61 - 1
 P64 = 2**64 - 189
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s measured copy
+T_PROCESS_START = time.perf_counter()
+SECTIONS_S = {}            # wall seconds per section of this run (`sections_s` in the detail; `wall_s` on the line)
+
+
+class section:
+    """with section('name'): ... -- wall time of a section of the run, accumulated into SECTIONS_S."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        SECTIONS_S[self.name] = round(SECTIONS_S.get(self.name, 0.0) + time.perf_counter() - self.t0, 2)
+        return False
+
+
+_LAP = [T_PROCESS_START]
+
+
+def lap(name):
+    """Wall time since the previous lap() (or process start) goes to section `name`."""
+    now = time.perf_counter()
+    SECTIONS_S[name] = round(SECTIONS_S.get(name, 0.0) + now - _LAP[0], 2)
+    _LAP[0] = now
 
 
 def uniform_field(gen, n, p, device):
@@ -185,6 +212,8 @@ def compact_line(out):
     for key_ in ('extras_error', 'detail_file'):
         if key_ in out:
             line[key_] = str(out[key_])[:300]
+    if 'wall_s' in out:
+        line['wall_s'] = out['wall_s']
     c0 = out.get('configs0')
     if isinstance(c0, dict):
         line['configs0'] = _pick(c0, ('workload', 'mirror_secrets_per_s', 'reference_secrets_per_s', 'parity', 'error', 'skipped'))
@@ -229,6 +258,9 @@ def compact_line(out):
 
 def emit(out, detail_path=None):
     """stdout protocol: `# detail {...}` (everything measured; not a bare JSON line), then the compact line LAST."""
+    lap('rest')
+    out['sections_s'] = dict(SECTIONS_S)
+    out['wall_s'] = round(time.perf_counter() - T_PROCESS_START, 1)
     paths = [detail_path] if detail_path else [os.path.join(ROOT, 'bench_detail.json'),
                                                 os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')]
     written = []
@@ -452,6 +484,7 @@ def api_leg(n_full, parties_on_gpus=False):
         if prf:
             env['MPYC_AMD_PRSS_PRF'] = prf
         cmd = [sys.executable, os.path.join(ROOT, 'tests', 'fxp_program.py'), '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
+        t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=timeout)
         except subprocess.TimeoutExpired:
@@ -471,7 +504,7 @@ def api_leg(n_full, parties_on_gpus=False):
                 # elements off by 2^48: the REFERENCE's own np_trunc mask for array types is f bits short (runtime.py:852; about
                 # one element in 10^6; reproduced bit for bit: tests/test_fxp_path.py) -- counted, and excluded from the error
                 'outliers_reference_trunc_mask': d['outliers_reference_trunc_mask'],
-                'max_abs_error': d['max_abs_error_without_outliers']}
+                'max_abs_error': d['max_abs_error_without_outliers'], 'process_wall_s': round(time.perf_counter() - t0, 2)}
     res['fxp_m1_1e6'] = run_fxp('gpu', n_full // 10, 1)
     res['fxp_m1_1e6_chacha'] = run_fxp('gpu', n_full // 10, 1, prf='chacha')
     res['fxp_m3_1e6_ipc'] = run_fxp('gpu', n_full // 10, 3, ipc=True)
@@ -965,6 +998,7 @@ def main():
         def optional_measurements():
             """Everything beyond the step's own kernels; a failure here must not cost the headline line."""
             from mpyc_amd import gfpx as ggx, protocols
+            lap('before_extras')
             # A gate INSIDE a chain of multiplications (production mode): the k = 3 sub-share rows received in the
             # previous gate are recombined in registers, squared and re-shared with the device CSPRNG in ONE kernel
             # (ffgpu_gate_rng): 3 reads + 3 writes per element, all three stages of the headline step.
@@ -984,6 +1018,7 @@ def main():
             if not torch.equal(ctx.recombine([chk.row(j) for j in range(k)], lam).t, ctx.mul(y0, y0).t):
                 raise SystemExit('bench parity check failed for the chain gate')
             del outs, chain_sets
+            lap('chain_gate')
             # second-tier element-wise ops (finfields.py:1278-1281,1424-1458): batched inverse, sqrt = pow by (p+1)/4
             ms = time_launches(lambda s: ctx.inv(s.a, out=s.c, check_zero=False), sets, 3)
             kern['inv_p61'] = dict(roof(2 * eb * n, ms), algorithmic_bytes_per_unit=2 * eb, bound_note='integer ALU',
@@ -993,6 +1028,7 @@ def main():
                                     units_per_s=round(n / (ms * 1e-3), 1))
             # (both are bound by integer VALU work, not by HBM: `bound`, the instruction counts and `valu_frac` are filled in by
             # annotate_valu from profiles/r05_valu.json and the issue rate measured in this run)
+            lap('inv_sqrt')
             # PRSS (thresha.py:163-173) for one party of m = 7, t = 3: 20 subset keys x n x 28 B of SHAKE128 on 20 host
             # threads, squeezed / uploaded / combined in slices -- bound by the host sponge, the device part is hidden
             import itertools
@@ -1014,14 +1050,15 @@ def main():
                                            'xof_bytes_per_draw': lb_,
                                            'note': 'PARITY mode (the reference PRF): achieved = SHAKE128 output bytes/s over all subset '
                                                    'keys (host threads, ffgpu_shake128_squeeze); upload and ffgpu_prss_combine overlap it'}
+            lap('prss_parity')
             # the same shares in PRODUCTION mode (thresha.prss_prf = 'chacha'): one ChaCha stream per subset key expanded by
             # the lanes that consume the draws (ffgpu_prss_chacha) -- nothing crosses PCIe, 8 B written per share; VALU-bound
             # (20 draws of 24 keystream bytes per share at m = 7, t = 3: 7.5 ChaCha blocks), priced by annotate_valu
             keys3 = {S: bytes([sum(S) % 256]) * 16 + bytes(S) for S in itertools.combinations(range(3), 2) if 0 in S}
             prfs3 = {S: gth.PRF(kk_, F61.order) for S, kk_ in keys3.items()}
-            prev_mode, prev_rounds = gth.prss_prf, gth.prss_rounds
+            prev_mode, prev_rounds, prev_allow8 = gth.prss_prf, gth.prss_rounds, gth.prss_allow_chacha8
             try:
-                gth.prss_prf = 'chacha'
+                gth.prss_prf, gth.prss_allow_chacha8 = 'chacha', True          # (the ChaCha8 row is a measurement)
                 for (mm_, ii_, pr_), rr_ in itertools.product(((7, 2, prfs7), (3, 0, prfs3)), (20, 8)):
                     gth.prss_rounds = rr_
                     for _ in range(3):          # (the host-bound parity-mode run above lets the clocks drop: ramp them up again)
@@ -1044,7 +1081,8 @@ def main():
                 if not (shr.device_array.to_numpy() == ref_).all():
                     raise SystemExit('bench parity check failed: production-mode PRSS shares differ from the oracle')
             finally:
-                gth.prss_prf, gth.prss_rounds = prev_mode, prev_rounds
+                gth.prss_prf, gth.prss_rounds, gth.prss_allow_chacha8 = prev_mode, prev_rounds, prev_allow8
+            lap('prss_chacha')
             # boundary handed HOST buffers (pinned): h2d of both operands + mulmod + d2h of the product, end to end
             # through ffgpu_h2d / ffgpu_mul / ffgpu_d2h.  Reported for DESIGN.md only -- never the headline value.
             from mpyc_amd import _ffi
@@ -1063,6 +1101,7 @@ def main():
                                               'achieved': round(3 * eb * n / (ms * 1e-3) / 1e9, 1), 'frac': None,
                                               'units_per_s': round(n / (ms * 1e-3), 1)}
             del ha, hb, hc
+            lap('pcie')
             # launch-bound regime: a gate on 4096 elements, eager vs captured in a HIP graph.  (Run over the
             # 40-bit prime 2^40-87 so that its kernel instantiations do not mix into the rocprof averages of
             # the headline GF(2^61-1) kernels.)
@@ -1082,6 +1121,7 @@ def main():
             kern['gate_p40_n4096_eager_vs_graph'] = {'ms_per_launch': round(ms_eager, 5), 'ms_per_replay': round(ms_graph, 5),
                                                      'achieved': None, 'frac': None, 'unit': 'us',
                                                      'units_per_s': round(4096 / (ms_graph * 1e-3), 1)}
+            lap('graph_small_gate')
             # dense product over GF(2^61-1) (finfields.py:1126-1135; the author's np_bnnmnist bottleneck)
             for dim in (2048, 4096):
                 from mpyc_amd.engine import DevArray
@@ -1126,6 +1166,7 @@ def main():
                 kern[f'matmul_{nm_}_{dim}'] = dict(roof_mfma(float(dim) ** 3, 12 if cw.elem_bytes == 12 else 16, ms),
                                                    kernel='k_limb_gemm_wide (12 / 16 signed digits, diagonals in passes)')
                 del Aw, Bw, Cw
+            lap('matmul')
             # configs[2]: P64, m=7, t=3 (share + recombine from t+1 and 2t+1 rows)
             del sets[1:]
             torch.cuda.empty_cache()
@@ -1179,6 +1220,7 @@ def main():
                                     ms_per_launch=kern['split_p64_m7t3']['ms_per_launch'])
             out['configs2'] = cfg2
             del plans64
+            lap('configs2')
             # generic (non pseudo-Mersenne) primes: reciprocal / Montgomery reductions, u32 storage
             from mpyc_amd.engine import DevArray as _DA
             for label, modulus in (('rc64_generic63', 6616326157076047771), ('rc32_p31', 2**31 - 1),
@@ -1199,6 +1241,7 @@ def main():
                                             units_per_s=round(n / (ms * 1e-3), 1))
                 del bufs
                 torch.cuda.empty_cache()
+            lap('generic_primes')
             # configs[4] names GF(2^128) next to GF(2^8): wide binary fields (carry-less products on the integer
             # multiplier; gfpx.py:988-1045), mul / share generation / recombination at the m=7,t=3 setting
             for label, modulus, tail, ebg in (('gf2_64', (1 << 64) | 0x1b, (), 8), ('gf2_128', (1 << 128) | 0x87, (2,), 16)):
@@ -1244,6 +1287,7 @@ def main():
                     raise SystemExit(f'bench parity check failed for {label} split/recombine')
                 del bufs, cfb, shb, plans
                 torch.cuda.empty_cache()
+            lap('gf2w')
             # configs[3] shape on ONE GPU: 128-bit prime (two limbs), gate = mul + split(m=7,t=3) + recombine(k=7)
             del sets64[:]
             torch.cuda.empty_cache()
@@ -1291,6 +1335,7 @@ def main():
                                       'ms_per_launch': round(gate_ms, 5)}
             del sets128[:]
             torch.cuda.empty_cache()
+            lap('configs3_p128')
             # three-limb primes (SecInt(97..160) defaults; np_lpsolver's largest dataset runs over the 136-bit one):
             # 24-byte elements, one per lane, the same kernels instantiated on the PM192 policy
             from mpyc_amd.finfields import find_prime_root
@@ -1319,6 +1364,7 @@ def main():
                 raise SystemExit('bench parity check failed for the 136-bit field')
             del a3, b3, c3, sh3, y3, rec3
             torch.cuda.empty_cache()
+            lap('p136')
             # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
             ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
             # demos/np_aes.py:23-33: A = circulant([1,0,0,0,1,1,1,1]) (row j = first row rolled by j), B = 0x63
@@ -1340,6 +1386,7 @@ def main():
                                                  units_per_s=round(n8 / (ms * 1e-3), 1))
                 del bufs
                 torch.cuda.empty_cache()
+            lap('gf256_public')
             # configs[4] proper: the np_aes S-box layer over SECURE bytes (demos/np_aes.py:37-43) -- x^254 by 11 GRR
             # multiplications, bit decomposition with shared random bits, GF(2) affine map on bit shares,
             # recomposition -- the compute of all m = 3 parties (t = 1) on this GPU, no networking
@@ -1404,6 +1451,7 @@ def main():
                                                                                    kernels_per_layer=49)
                 del xs, rbits, xpub, want8
                 torch.cuda.empty_cache()
+            lap('secure_sbox_layer')
             # AES-128 encryption of secret-shared blocks under secret-shared round keys (np_aes.py:75-86): 10 S-box
             # layers + ShiftRows/MixColumns (row relabelling + the small-matrix kernel) + AddRoundKey, all 3 parties
             for nblk in (62_500, 6_250_000):
@@ -1427,6 +1475,7 @@ def main():
                                                                        'units_per_s': round(nblk / (ms * 1e-3), 1)}
                 del Ks, ps, pools, kpub, ppub
                 torch.cuda.empty_cache()
+            lap('secure_aes')
         # dominant kernel of the timed step = the one with the largest share of step time
         step_kernels = ['mul_split_fused_p61_m3t1', 'recombine_p61_k3']
         dom = max(step_kernels, key=lambda q: kern[q]['ms_per_launch'])
@@ -1475,7 +1524,9 @@ def main():
             return
         if not args.no_extras:
             try:
+                lap('headline_and_multi_gpu_leg')
                 out['valu_peak'] = measure_valu_peak(ctx)
+                lap('valu_peak')
                 optional_measurements()
                 annotate_traffic()
                 annotate_valu(kern, out)
@@ -1485,17 +1536,21 @@ def main():
                 out['configs2']['roofline']['traffic'] = kern['split_p64_m7t3'].get('traffic')
         if not args.no_cpu_baseline:
             try:
+                lap('misc')
                 out['cpu_baseline'] = cpu_baseline(n, t, m, lam)
+                lap('cpu_baseline')
             except Exception as exc:          # noqa: BLE001
                 out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
         if not args.no_api_leg and not args.no_extras:
             torch.cuda.empty_cache()
             try:
                 out['configs0'] = list_path_leg()
+                lap('configs0_list_path')
             except Exception as exc:          # noqa: BLE001 -- report, keep the main result
                 out['configs0'] = {'error': f'{type(exc).__name__}: {exc}'}
             try:
                 out['api'] = api_leg(n)
+                lap('api_leg')
             except Exception as exc:          # noqa: BLE001 -- report, keep the main result
                 out['api'] = {'error': f'{type(exc).__name__}: {exc}'}
 

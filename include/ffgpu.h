@@ -362,7 +362,8 @@ int ffgpu_prss_combine(ffgpu_ctx* ctx, const void* const* host_streams, int ks, 
  * Layout of the keystream: ffgpu_prss_chacha_layout (tb blocks per tile of dpt draws, ceil(l/4) words per draw; draw j of
  * element h sits in tile h / dpt, slot h % dpt, block counters (tile * d + j) * tb + b).  Every party must use the same
  * mode; there is no reference counterpart for the PRF itself (pinned to RFC 8439 and to oracle/fforacle.c
- * orc_prss_chacha, not to reference outputs), the combination is the reference's.  ks <= 32, ks * d <= 64 per call.
+ * orc_prss_chacha, not to reference outputs), the combination is the reference's.  Limits per call (FFGPU_EINVAL beyond
+ * them): ks <= 32, ks * d <= 64, 1 <= l <= 64 bytes per draw (the mirror raises NotImplementedError for wider draws).
  * replaces: thresha.py:163-173, 201-217 (np_pseudorandom_share, np_pseudorandom_share_0) with PRF := ChaCha.      */
 int ffgpu_prss_chacha(ffgpu_ctx* ctx, const uint8_t* host_keys, int ks, int d, int l, int mask_bits, int rounds,
                       const uint64_t* host_weights, int accumulate, void* out, size_t n, void* stream);
@@ -450,6 +451,8 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
  * instructions in 8 independent dependent-chains per wave.  out3[0] = lane-operations per second (events around the launch),
  * out3[1] = shader clock in MHz under that load (s_memtime against the 100 MHz counter), out3[2] = shader cycles per wave
  * instruction and SIMD.  scratch32: 32 bytes of device memory.  bench.py prices its VALU-bound rows with it.
+ * SYNCHRONISES `stream` (event wait + a blocking read-back of the cycle counts): not legal during stream capture, unlike
+ * the computing entry points.
  * replaces: nothing in the reference (measurement aid, like the ffgpu_time_* entry points).                            */
 int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* out3, void* stream);
 int ffgpu_time_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes,

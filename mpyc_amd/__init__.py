@@ -15,6 +15,81 @@ list_path_min = 256     # install(): thresha.random_split / recombine (the per-e
 #                         88-116) go to the device from this many secrets on; below it the reference's own
 #                         pure-Python function runs (a kernel launch + two PCIe hops per scalar is not a speed-up)
 _installed = None
+prss_confirm_timeout = 30.0     # seconds a party in production-mode PRSS waits at start-up for its peers' mode tags
+_start_hooked = []
+
+
+def _hook_prss_confirmation():
+    """Production-mode PRSS (mpyc_amd.thresha.prss_prf = 'chacha') is only correct when EVERY party runs it with the same
+    round count: the holders of a subset key must expand it with one PRF, or the shares are inconsistent and openings are
+    silently wrong.  So Runtime.start (runtime.py:231-299) is followed by one mpc.transfer of the mode tag among the
+    parties -- in production mode only: in the default (parity) mode nothing is added, and engine parties interoperate
+    with plain-mpyc parties.  A peer with another tag, or one that never answers (it runs the default mode and sends no
+    tag), ends the start-up with a RuntimeError.  Hooked as soon as mpyc.runtime is imported (install() and every arrayGF
+    call try)."""
+    if _start_hooked:
+        return True
+    import sys
+    rt = sys.modules.get('mpyc.runtime')
+    if rt is None or not hasattr(rt, 'Runtime') or not hasattr(rt.Runtime, 'start'):
+        return False
+    from . import thresha as gth
+    orig_start = rt.Runtime.start
+
+    async def start(self):
+        await orig_start(self)
+        await _confirm_prss_mode(self, gth)
+    start.__doc__ = orig_start.__doc__
+    rt.Runtime.start = start
+    _start_hooked.append(True)
+    mpc = getattr(rt, 'mpc', None)
+    if mpc is not None and getattr(mpc, 'start_time', None) and len(mpc.parties) > 1 and gth.prss_mode_tag() != 'shake':
+        import logging
+        logging.warning('mpyc_amd: production-mode PRSS (%s) installed after the runtime started: the parties have NOT '
+                        'confirmed that they all run it', gth.prss_mode_tag())
+    return True
+
+
+def _hook_after_runtime_import():
+    """mpyc.runtime is not imported yet (install() usually runs first): hook Runtime.start right after its import."""
+    import sys
+
+    class AfterRuntimeImport:
+        @staticmethod
+        def find_spec(name, path=None, target=None):
+            if name != 'mpyc.runtime':
+                return None
+            sys.meta_path.remove(AfterRuntimeImport)        # the real spec comes from the remaining finders
+            import importlib.util
+            spec = importlib.util.find_spec(name)
+            if spec is not None and spec.loader is not None and hasattr(spec.loader, 'exec_module'):
+                run_module = spec.loader.exec_module
+
+                def exec_module(module):
+                    run_module(module)
+                    _hook_prss_confirmation()
+                spec.loader.exec_module = exec_module
+            return spec
+    sys.meta_path.insert(0, AfterRuntimeImport)
+
+
+async def _confirm_prss_mode(runtime, gth):
+    tag = gth.prss_mode_tag()
+    if tag == 'shake' or len(runtime.parties) == 1 or getattr(runtime.options, 'no_prss', False):
+        return
+    import asyncio
+    import logging
+    logging.info(f'mpyc_amd: PRSS production mode {tag}: confirming with the other parties')
+    try:
+        tags = await asyncio.wait_for(asyncio.ensure_future(runtime.transfer(('mpyc_amd prss mode', tag))), prss_confirm_timeout)
+    except asyncio.TimeoutError:
+        raise RuntimeError(f'mpyc_amd: this party runs PRSS in production mode ({tag}) but a peer did not confirm its mode '
+                           f'within {prss_confirm_timeout:.0f} s: set MPYC_AMD_PRSS_PRF / MPYC_AMD_PRSS_ROUNDS identically for '
+                           'every party') from None
+    theirs = [t[1] if isinstance(t, tuple) and len(t) == 2 and t[0] == 'mpyc_amd prss mode' else repr(t)[:40] for t in tags]
+    if any(t != tag for t in theirs):
+        raise RuntimeError(f'mpyc_amd: the parties disagree on the PRSS PRF: {theirs} (this party: {tag}); shares of the '
+                           'same subset key would be inconsistent')
 
 
 def install():
@@ -86,6 +161,7 @@ def install():
     def arrayGF(field, modulus):
         from . import ipcwire
         pick_device()
+        _hook_prss_confirmation()
         if ipcwire.resolve_auto():
             ipcwire.ensure_runtime_hooks()       # (fields are made after mpyc.runtime is imported, before any gate runs)
         if not supported(field):
@@ -126,6 +202,8 @@ def install():
     for name in ('random_split', 'recombine'):
         route(name, min_len=list_path_min)
     _installed = done
+    if not _hook_prss_confirmation():
+        _hook_after_runtime_import()
     import os
     if os.environ.get('MPYC_AMD_TRACE_INSTALL') == '1':
         print(f'mpyc_amd.install: {len(done)} names substituted (pid {os.getpid()})', flush=True)

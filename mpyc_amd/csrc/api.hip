@@ -41,7 +41,7 @@ int ffgpu_launch_gf8_bits_affine_fold(const void* policy, int device, const uint
 int ffgpu_launch_gf8_group8(const void* policy, int device, const uint64_t* m2, const uint64_t* bias2, int fold,
                             const void* in, void* out, size_t ngroups, hipStream_t st);
 int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipStream_t st);
-int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* out, hipStream_t st);
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch32, double* out, hipStream_t st);
 int ffgpu_gf8_build_tables(const void* policy, void* tables_out);
 int ffgpu_gf2w_build_rtable(const void* policy, int limbs, void* rtable_out);
 int ffgpu_launch_gf2w_recombine(const void* policy, int limbs, int device, const void* const* rows, const uint64_t* lam2,

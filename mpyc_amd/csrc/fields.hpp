@@ -1429,6 +1429,7 @@ FF_HD ColLimbs col_limbs(uint64_t a) {
 }
 template <class ACC>
 struct ColAcc {
+    enum { MAX_TERMS = 256 };                                 // terms between two gather()s (the residue a flush puts back counts as one)
     uint64_t c00, c10, c20, c01, c11, c21;                    // c_ij: sum of a_i b_j, weight 2^(22 i + 32 j)
     FF_HD void zero() { c00 = c10 = c20 = c01 = c11 = c21 = 0; }
     FF_HD void mac(const ColLimbs& a, uint64_t b) {

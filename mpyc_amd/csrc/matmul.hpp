@@ -681,6 +681,8 @@ __global__ __launch_bounds__(BLOCK) void k_limb_gemm_wide(F f, const int8_t* __r
 // read exactly once, coalesced, the small one stays in L2; products are accumulated unreduced (flush every
 // 192 terms, as k_dot_partial) and reduced once.
 enum { SKINNY_MAX = 8, SKINNY_FLUSH = 192 };
+// (the column-sum kernels below test the count AFTER adding a whole group of terms: a flush happens at no more than
+// SKINNY_FLUSH - 1 + group terms, which must stay within ColAcc::MAX_TERMS = 256 -- asserted where each group size is known)
 
 // C (M x N) = A (M x K) @ B (K x N), N <= SKINNY_MAX: one workgroup per row of A
 template <class F, int NN>
@@ -877,6 +879,8 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_sub_col(F f, const typename F:
     const size_t row = (size_t)blockIdx.x * ROWS + g;
     const typename F::elem* __restrict__ a = A + (row < (size_t)M ? row : (size_t)M - 1) * lda;   // rows past M re-read the last one
     ColAcc<typename F::acc> acc[NN];
+    // two terms per step, tested after the step, + the last column of an odd K
+    static_assert(SKINNY_FLUSH - 1 + 2 + 1 <= ColAcc<typename F::acc>::MAX_TERMS, "column sums overflow before the flush");
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < NN; ++j) acc[j].zero();
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_sub_col(F f, const typename F:
         W b[NN];
 #pragma unroll
         for (int j = 0; j < NN; ++j) b[j] = ld_elem<F>(B, (size_t)(K - 1) * NN + j);
-        term(ld_elem<F>(a, K - 1), b);
+        term(ld_elem<F>(a, K - 1), b);                             // (at most SKINNY_FLUSH + 2 terms now: asserted above)
     }
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
@@ -956,6 +960,7 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_col(F f, const typename F
     __shared__ W sm[R * NN * (BLOCK / 64)];
     const size_t row0 = (size_t)blockIdx.x * R;
     ColAcc<typename F::acc> acc[R][NN];
+    static_assert(SKINNY_FLUSH - 1 + EPV <= ColAcc<typename F::acc>::MAX_TERMS, "column sums overflow before the flush");
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -1197,6 +1202,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void k_vecmat_partial_col(F f, const t
     const int k0 = blockIdx.y * kchunk;
     const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
     ColAcc<typename F::acc> acc[MM];
+    static_assert(SKINNY_FLUSH - 1 + UNR <= ColAcc<typename F::acc>::MAX_TERMS, "column sums overflow before the flush");
     int cnt = 0;
 #pragma unroll
     for (int mi = 0; mi < MM; ++mi) acc[mi].zero();

@@ -1608,14 +1608,19 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
 }
 
 // out[0] = lane-operations per second, out[1] = shader clock in MHz, out[2] = shader cycles per wave instruction and SIMD
-int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch16, double* out, hipStream_t st) {
+int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch32, double* out, hipStream_t st) {
+    // SYNCHRONISES the stream (event + a blocking read-back of the cycle counts): a measurement aid, not capturable
     LaunchCfg lc = launch_cfg(device);
     if (op < 0 || op > 8 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
     const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
-    uint32_t* sink = (uint32_t*)scratch16;
-    uint64_t* clk = (uint64_t*)((char*)scratch16 + 16);
+    uint32_t* sink = (uint32_t*)scratch32;
+    uint64_t* clk = (uint64_t*)((char*)scratch32 + 16);
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    if (hipEventCreate(&e0) != hipSuccess) return 1;
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return 1;
+    }
     auto launch = [&](int n_it) {
 #define FF_PROBE_CASE(OPV) case OPV: hipLaunchKernelGGL(k_valu_probe<OPV>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); break;
         switch (op) { FF_PROBE_CASE(0) FF_PROBE_CASE(1) FF_PROBE_CASE(2) FF_PROBE_CASE(3) FF_PROBE_CASE(4) FF_PROBE_CASE(5)
@@ -1623,16 +1628,17 @@ int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, v
 #undef FF_PROBE_CASE
     };
     launch(iters / 4 + 1);                                                    // warm-up: clocks ramp
-    hipEventRecord(e0, st);
+    hipError_t err = hipEventRecord(e0, st);
     launch(iters);
-    hipEventRecord(e1, st);
-    hipError_t err = hipEventSynchronize(e1);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) err = hipEventRecord(e1, st);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
     uint64_t host_clk[2] = {0, 0};
     if (err == hipSuccess) err = hipMemcpy(host_clk, clk, 16, hipMemcpyDeviceToHost);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     if (err != hipSuccess || ms <= 0.f) return 1;
     const double wave_instr = (double)grid * 4.0 * (double)iters * 128.0;
     out[0] = wave_instr * 64.0 / ((double)ms * 1e-3);

@@ -262,7 +262,33 @@ def recombine(field, points, x_rs=0):
 import os as _os
 
 prss_prf = _os.environ.get('MPYC_AMD_PRSS_PRF', 'shake')         # 'shake' (reference PRF, bit-exact) | 'chacha' (device PRF)
-prss_rounds = int(_os.environ.get('MPYC_AMD_PRSS_ROUNDS', '20'))   # ChaCha rounds of the device PRF: 20, 12 or 8
+prss_rounds = int(_os.environ.get('MPYC_AMD_PRSS_ROUNDS', '20'))   # ChaCha rounds of the device PRF: 20 or 12 (8: see below)
+# ChaCha8 has no published attack but a thin margin: it is for measurements, admitted only on request
+prss_allow_chacha8 = _os.environ.get('MPYC_AMD_PRSS_ALLOW_CHACHA8', '0') == '1'
+PRSS_MAX_DRAW_BYTES = 64        # ffgpu_prss_chacha: bytes per draw l = byte length of the bound (+ key length against bias)
+
+
+def prss_mode():
+    """The validated (prf, rounds) pair of this party.  EVERY party of a computation must run the same pair: the shares
+    of one subset key are only consistent when all its holders expand it with the same PRF (install() makes the parties
+    confirm it at start-up, `prss_mode_tag`)."""
+    if prss_prf not in ('shake', 'chacha'):
+        raise ValueError(f"prss_prf (MPYC_AMD_PRSS_PRF) must be 'shake' or 'chacha', not {prss_prf!r}")
+    if prss_rounds not in (20, 12, 8):
+        raise ValueError(f'prss_rounds (MPYC_AMD_PRSS_ROUNDS) must be 20, 12 or 8, not {prss_rounds!r}')
+    if prss_prf == 'chacha' and prss_rounds == 8 and not prss_allow_chacha8:
+        raise ValueError('ChaCha8 as the PRSS PRF needs prss_allow_chacha8 = True (MPYC_AMD_PRSS_ALLOW_CHACHA8=1): '
+                         'reduced-round variant, for measurements')
+    return prss_prf, prss_rounds
+
+
+def prss_mode_tag() -> str:
+    """What the parties compare at start-up: 'shake' or 'chacha<rounds>/<domain tag version>'."""
+    prf, rounds = prss_mode()
+    return 'shake' if prf == 'shake' else f'chacha{rounds}/v1'
+
+
+prss_mode()                      # a bad environment value fails at import, not at the first PRSS call
 PRSS_CHACHA_DOMAIN = b'mpyc_amd prss chacha v1\0'
 
 
@@ -349,6 +375,7 @@ PRSS_STREAM_MIN = 1 << 30        # XOF bytes of a call (all subset keys together
 
 
 def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
+    mode, rounds = prss_mode()
     ops = _fops(field)
     ctx = _context(field)
     items = list(prfs.items())
@@ -386,18 +413,26 @@ def _prss_device(field, m, i, prfs, uci, n, zero: bool, np_convention: bool):
                 for _ in range(power):
                     w = ops.mul(w, i1)
                 weights.append(w)
-    if prss_prf == 'chacha' and all(hasattr(prf, 'key') for _, prf in items):
-        # production mode: one ChaCha stream per subset key, expanded on the device (32 streams / 64 weights per launch)
-        per = max(1, min(32, 64 // d))
+    if mode == 'chacha':
+        # production mode: one ChaCha stream per subset key, expanded on the device (32 streams / 64 weights per launch).
+        # Only PRF objects known to BE "shake_128(key + s) chopped into l-byte draws" are replaced (the admission rule of the
+        # XOF path below); anything else has a __call__ of its own that a silent swap would change -- and a silent fall back
+        # to SHAKE would disagree with the other parties.
+        foreign = [type(prf).__name__ for _, prf in items if type(prf) not in SHAKE_PRF_TYPES]
+        if foreign:
+            raise TypeError(f"prss_prf = 'chacha' replaces mpyc's SHAKE128 PRF objects only; got {sorted(set(foreign))} "
+                            '(register_shake_prf admits a class after a known-answer check)')
         if d > 64:
             raise NotImplementedError('zero sharing of degree > 64')
+        if l > PRSS_MAX_DRAW_BYTES:
+            raise NotImplementedError(f'device PRF: {l} bytes per draw (byte length of the bound + key length) exceeds the '
+                                      f'kernel limit of {PRSS_MAX_DRAW_BYTES} (ffgpu_prss_chacha)')
+        per = max(1, min(32, 64 // d))
         for k0 in range(0, len(items), per):
             chunk = items[k0:k0 + per]
             ctx.prss_chacha([prss_chacha_stream_key(prf.key, uci) for _, prf in chunk], d, l, weights[k0 * d:(k0 + per) * d], n,
-                            mask_bits=mask_bits, rounds=prss_rounds, out=out, accumulate=k0 > 0)
+                            mask_bits=mask_bits, rounds=rounds, out=out, accumulate=k0 > 0)
         return out
-    if prss_prf not in ('shake', 'chacha'):
-        raise ValueError(f"prss_prf must be 'shake' or 'chacha', not {prss_prf!r}")
     # kernel argument limits: 48 streams / 96 weights per launch.  The XOF streams of a chunk (one per subset
     # key; each is inherently sequential) are expanded in parallel on host threads into pinned buffers.
     per = max(1, min(48, 96 // d))

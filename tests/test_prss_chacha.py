@@ -170,6 +170,30 @@ def test_mirror_host_logic_on_cpu_context(monkeypatch):
     monkeypatch.setattr(gth, 'prss_prf', 'keccak')
     with pytest.raises(ValueError):
         gth.np_pseudorandom_share(F, 3, 0, {(0, 1): gth.PRF(b'k' * 16, F.order)}, b'u', n)
+    # the mode is validated on every call: rounds outside {20, 12, 8}; ChaCha8 only on request; a PRF object that is not
+    # the SHAKE128 one is neither replaced nor silently expanded by SHAKE; draws wider than the kernel's 64 bytes
+    monkeypatch.setattr(gth, 'prss_prf', 'chacha')
+    one = {(0, 1): gth.PRF(b'k' * 16, F.order)}
+    for bad in (7, 10, 0):
+        monkeypatch.setattr(gth, 'prss_rounds', bad)
+        with pytest.raises(ValueError):
+            gth.np_pseudorandom_share(F, 3, 0, one, b'u', n)
+    monkeypatch.setattr(gth, 'prss_rounds', 8)
+    monkeypatch.setattr(gth, 'prss_allow_chacha8', False)
+    with pytest.raises(ValueError, match='ChaCha8'):
+        gth.np_pseudorandom_share(F, 3, 0, one, b'u', n)
+    monkeypatch.setattr(gth, 'prss_rounds', 20)
+    assert gth.prss_mode_tag() == 'chacha20/v1'
+
+    class OtherPRF(gth.PRF):
+        def __call__(self, s, n=None):
+            return [0] * (n or 1)
+    with pytest.raises(TypeError, match='SHAKE128 PRF objects only'):
+        gth.np_pseudorandom_share(F, 3, 0, {(0, 1): OtherPRF(b'k' * 16, F.order)}, b'u', n)
+    with pytest.raises(NotImplementedError, match='64'):
+        gth.np_pseudorandom_share(F, 3, 0, {(0, 1): gth.PRF(b'k' * 60, F.order)}, b'u', n)
+    monkeypatch.setattr(gth, 'prss_prf', 'shake')
+    assert gth.prss_mode_tag() == 'shake'
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
@@ -197,6 +221,7 @@ def test_device_equals_c_oracle_all_policies(api, monkeypatch):
     from oracle import coracle as co
     finfields, gfpx, thresha = api
     monkeypatch.setattr(thresha, 'prss_prf', 'chacha')
+    monkeypatch.setattr(thresha, 'prss_allow_chacha8', True)
     for name, (mod, binary) in FIELDS.items():
         F, OF, cf = gpu_field(api, mod, binary), po.Field(mod, binary), co.CField(mod, binary)
         bounds = (OF.order,) if binary else (OF.order, 2, 1 << min(40, mod.bit_length() - 2))

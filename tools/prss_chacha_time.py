@@ -32,7 +32,7 @@ for mod in ((2**61 - 1,) if os.environ.get('PRSS_ONLY61') else (2**61 - 1, 2**12
         ctx = gff._context(F)
         ctx.set_timing(True, accumulate=True)
         for mode, rounds, n in (('chacha', 20, N), ('chacha', 12, N), ('chacha', 8, N), ('shake', 0, min(N, 2_000_000))):
-            gth.prss_prf = mode
+            gth.prss_prf, gth.prss_allow_chacha8 = mode, True
             if rounds:
                 gth.prss_rounds = rounds
             ctx.busy_ms()

@@ -48,7 +48,7 @@ for (mm_, ii_), rr_ in itertools.product(((7, 2), (3, 0)), (20, 8)):
     prfs_ = {S: gth.PRF(kk_, F61.order) for S, kk_ in keys_.items()}
 
     def prss_row(mm_=mm_, ii_=ii_, rr_=rr_, prfs_=prfs_):
-        gth.prss_prf, gth.prss_rounds = 'chacha', rr_
+        gth.prss_prf, gth.prss_rounds, gth.prss_allow_chacha8 = 'chacha', rr_, True
         gth.np_pseudorandom_share(F61, mm_, ii_, prfs_, b'uci', n)
         gth.prss_prf, gth.prss_rounds = 'shake', 20
     rows.append((f'prss_share_p61_m{mm_}t{(mm_ - 1) // 2}_chacha{rr_}', prss_row))
