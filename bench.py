@@ -143,6 +143,66 @@ def roof_mfma(field_macs, digits, ms):
 COMPACT_LIMIT = 8000      # the driver's stdout tail holds ~8 KB: the FINAL line must fit it whole
 
 
+# ---- bounded sub-processes: the API-level legs and the reference baseline run OTHER programs (party processes of the
+# reference runtime, worker pools).  Each gets its own process group -- a timeout ends the parties it spawned as well, so
+# nothing lingers on the GPU or on a TCP port of the next leg -- a tight limit of its own, and they all share one budget:
+# when it is spent the remaining legs are reported as skipped and the line goes out (the driver's round-5 run took 977 s
+# because ONE leg waited for its 900 s limit).
+LEG_BUDGET = {'deadline': None, 'leg_timeout': 60.0}
+
+
+def budget_left():
+    return float('inf') if LEG_BUDGET['deadline'] is None else LEG_BUDGET['deadline'] - time.perf_counter()
+
+
+def run_bounded(cmd, env, timeout, cwd='/tmp'):
+    """-> (returncode, stdout, stderr), or None when the program did not finish within min(timeout, budget left)."""
+    import signal
+    import subprocess
+    limit = min(timeout, budget_left())
+    if limit < 3:
+        return None
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd, env=env, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=limit)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        return None
+    finally:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)          # the whole group: party processes spawned by party 0 (runtime.py:5171-5189)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            p.communicate(timeout=5)
+        except Exception:          # noqa: BLE001
+            pass
+
+
+_PORT_NEXT = [0]
+
+
+def free_base_port(count=4):
+    """A base port for one multi-party leg (`-B`): `count` consecutive ports that are free right now, a fresh range per leg
+    (the runtime's default 11365.. would be shared by consecutive legs: a party of the previous leg that is still shutting
+    down makes the next leg's connection loop, runtime.py:263-285, spin until the limit)."""
+    import socket
+    for _ in range(200):
+        base = 20000 + (os.getpid() * 7 + _PORT_NEXT[0] * 16) % 20000
+        _PORT_NEXT[0] += 1
+        ok = True
+        for q in range(count):
+            with socket.socket() as sk:
+                try:
+                    sk.bind(('127.0.0.1', base + q))
+                except OSError:
+                    ok = False
+                    break
+        if ok:
+            return base
+    return 11365
+
+
 def _pick(d, keys):
     return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d}
 
@@ -191,7 +251,7 @@ def compact_line(out):
             line['api']['m1_1e7'] = _pick(api['m1_1e7'], ('ms_per_rep', 'elements_per_s'))
         for leg in ('fxp_m1_1e6', 'fxp_m1_1e6_chacha'):
             if isinstance(api.get(leg), dict):
-                line['api'][leg] = _pick(api[leg], ('s_per_product', 's_per_product_and_opening', 'outliers_reference_trunc_mask', 'max_abs_error', 'error'))
+                line['api'][leg] = _pick(api[leg], ('s_per_product', 's_per_product_and_opening', 'outliers_reference_trunc_mask', 'max_abs_error', 'error', 'skipped'))
     dd = out.get('distributed', {})
     line['distributed'] = _pick(dd, ('backend', 'world_size', 'collective_library', 'rccl_version', 'distinct_devices'))
     ranks = dd.get('ranks') or []
@@ -374,10 +434,22 @@ def cpu_baseline(n_full, t, m, lam, seed=20260925):
     host_cores = os.cpu_count() or cores
     out = {'value': round(res['allcores'], 1), 'unit': 'field-ops/s', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
            'sample': port_sample, 'value_1core': round(res['1core'], 1)}
-    if refbaseline.available([os.path.join(ROOT, '_refstage'), '/root/reference']):
+    ref_root = next((r_ for r_ in (os.path.join(ROOT, '_refstage'), '/root/reference') if os.path.isdir(os.path.join(r_, 'mpyc'))), None)
+    r = None
+    if ref_root is not None:
         procs = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         n_one, n_each = 2_000_000, 400_000
-        r = refbaseline.measure(P61, t, m, n_one, n_each, procs, seed)
+        # (its own bounded process group: a pool of `procs` forked workers that loses one would never return)
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, ref_root]))
+        got = run_bounded([sys.executable, os.path.join(ROOT, 'oracle', 'refbaseline.py'), ref_root, str(n_one), str(n_each), str(procs)],
+                          env, 120.0, cwd=ROOT)
+        line = None if got is None else next((ln for ln in got[1].splitlines() if ln.startswith('REFBASELINE ')), None)
+        if line is not None:
+            r = json.loads(line[len('REFBASELINE '):])
+        if r is None or 'one_core' not in r:
+            out['reference_error'] = 'the reference did not finish within its limit' if got is None else (got[1] + got[2])[-300:]
+            r = None
+    if r is not None:
         allc = r.get('all_cores') or {'field_ops_per_s': r['one_core']['field_ops_per_s'], 'n_total': n_one, 'wall_s': 0.0}
         procs = r.get('procs', procs)
         out = {'value': round(allc['field_ops_per_s'], 1), 'unit': 'field-ops/s', 'cores': procs, 'procs': procs,
@@ -414,7 +486,8 @@ def api_leg(n_full, parties_on_gpus=False):
     import subprocess
     prog = os.path.join(ROOT, 'tests', 'api_program.py')
 
-    def run(mode, n, parties, reps, warmup, chain=1, timeout=900, ipc_wire=False):
+    def run(mode, n, parties, reps, warmup, chain=1, timeout=None, ipc_wire=False):
+        timeout = LEG_BUDGET['leg_timeout'] if timeout is None else timeout
         env = dict(os.environ)
         env['MPYC_AMD_IPC_WIRE'] = '1' if ipc_wire else '0'
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
@@ -423,15 +496,17 @@ def api_leg(n_full, parties_on_gpus=False):
             env.pop(k_, None)
         env['MPYC_AMD_DEVICE'] = 'party' if parties_on_gpus else 'current'
         env.update(API_MODE=mode, API_N=str(n), API_REPS=str(reps), API_WARMUP=str(warmup), API_CHAIN=str(chain))
-        cmd = [sys.executable, prog, '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
+        cmd = [sys.executable, prog, '--no-log'] + ([f'-M{parties}', '-B', str(free_base_port(parties))] if parties > 1 else [])
         t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=timeout)
-        except subprocess.TimeoutExpired:
-            return {'error': f'timeout after {timeout} s'}
-        line = next((ln for ln in r.stdout.splitlines() if ln.startswith('API_RESULT ')), None)
-        if r.returncode != 0 or line is None:
-            return {'error': (r.stdout + r.stderr)[-400:]}
+        if budget_left() < 3:
+            return {'skipped': 'time budget of the run spent (bench.py --full runs every leg)'}
+        r = run_bounded(cmd, env, timeout)
+        if r is None:
+            return {'error': f'no result within {min(timeout, LEG_BUDGET["leg_timeout"]):.0f} s (process group ended)'}
+        rc, so, se = r
+        line = next((ln for ln in so.splitlines() if ln.startswith('API_RESULT ')), None)
+        if rc != 0 or line is None:
+            return {'error': (so + se)[-400:]}
         d = json.loads(line[len('API_RESULT '):])
         med = statistics.median(d['times_s'])
         out = {'n': n, 'parties': parties, 't': d['t'], 'multiplications_per_rep': chain, 'reps': reps,
@@ -461,21 +536,23 @@ def api_leg(n_full, parties_on_gpus=False):
         if 'error' not in res['m3_1e7_ipc']:         # (never measured across GPUs: a failure must cost the line two minutes, not ten)
             res['m3_1e7_chain8_ipc'] = run('gpu', n_full, 3, 5, 1, chain=8, ipc_wire=True, timeout=120)
         return res
+    # (order: the legs the compact line quotes first -- the budget of a default run may end the list early)
     res['m1_1e7'] = run('gpu', n_full, 1, 20, 3)
-    res['m1_1e7_chain8'] = run('gpu', n_full, 1, 10, 2, chain=8)
     res['m1_1e8'] = run('gpu', 10 * n_full, 1, 5, 2)
+    # three local parties with the device-side wire: share rows cross between the party processes as interprocess handles
+    # of the device buffers (mpyc_amd/finfields.py _array_from_ipc), not as bytes through TCP
+    res['m3_1e7_ipc'] = run('gpu', n_full, 3, 10, 2, ipc_wire=True)
+    res['reference_m1_1e6'] = run('ref', n_full // 10, 1, 2, 0)
+    res['m1_1e7_chain8'] = run('gpu', n_full, 1, 10, 2, chain=8)
     res['m3_1e7'] = run('gpu', n_full, 3, 3, 1)
     res['m3_1e6'] = run('gpu', n_full // 10, 3, 5, 1)
-    # the same three local parties with the device-side wire: share rows cross between the party processes as
-    # interprocess handles of the device buffers (mpyc_amd/finfields.py _array_from_ipc), not as bytes through TCP
-    res['m3_1e7_ipc'] = run('gpu', n_full, 3, 10, 2, ipc_wire=True)
     res['m3_1e7_chain8_ipc'] = run('gpu', n_full, 3, 5, 1, chain=8, ipc_wire=True)
     res['m3_1e6_ipc'] = run('gpu', n_full // 10, 3, 10, 2, ipc_wire=True)
-    res['reference_m1_1e6'] = run('ref', n_full // 10, 1, 2, 0)
     res['reference_m3_1e6'] = run('ref', n_full // 10, 3, 1, 0)
     # the same runtime one protocol up: secure FIXED-POINT products (np_multiply + np_trunc -- random bits from PRSS, a masked
     # opening, integer arithmetic on `.value` that the device-resident views of install() keep on the GPU), SecFxp(32)
-    def run_fxp(mode, n_, parties, timeout=600, prf=None, ipc=False):
+    def run_fxp(mode, n_, parties, timeout=None, prf=None, ipc=False):
+        timeout = LEG_BUDGET['leg_timeout'] if timeout is None else timeout
         env = dict(os.environ)
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
         for k_ in ('MPYC_GPU', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'FXP_SEED', 'FXP_DIGEST', 'MPYC_AMD_PRSS_PRF'):
@@ -483,15 +560,18 @@ def api_leg(n_full, parties_on_gpus=False):
         env.update(FXP_MODE=mode, FXP_N=str(n_), FXP_REPS='3' if mode != 'ref' else '1', MPYC_AMD_IPC_WIRE='1' if ipc else '0')
         if prf:
             env['MPYC_AMD_PRSS_PRF'] = prf
-        cmd = [sys.executable, os.path.join(ROOT, 'tests', 'fxp_program.py'), '--no-log'] + ([f'-M{parties}'] if parties > 1 else [])
+        cmd = [sys.executable, os.path.join(ROOT, 'tests', 'fxp_program.py'), '--no-log'] + \
+              ([f'-M{parties}', '-B', str(free_base_port(parties))] if parties > 1 else [])
         t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, cwd='/tmp', env=env, timeout=timeout)
-        except subprocess.TimeoutExpired:
-            return {'error': f'timeout after {timeout} s'}
-        line = next((ln for ln in r.stdout.splitlines() if ln.startswith('FXP_RESULT ')), None)
-        if r.returncode != 0 or line is None:
-            return {'error': (r.stdout + r.stderr)[-300:]}
+        if budget_left() < 3:
+            return {'skipped': 'time budget of the run spent (bench.py --full runs every leg)'}
+        r = run_bounded(cmd, env, timeout)
+        if r is None:
+            return {'error': f'no result within {min(timeout, LEG_BUDGET["leg_timeout"]):.0f} s (process group ended)'}
+        rc, so, se = r
+        line = next((ln for ln in so.splitlines() if ln.startswith('FXP_RESULT ')), None)
+        if rc != 0 or line is None:
+            return {'error': (so + se)[-300:]}
         d = json.loads(line[len('FXP_RESULT '):])
         secs = d['s_per_product_and_opening']
         return {'n': n_, 'parties': parties, 'prss_prf': d['prss_prf'], 's_per_product_and_opening': round(secs, 5),
@@ -510,7 +590,7 @@ def api_leg(n_full, parties_on_gpus=False):
     res['fxp_m3_1e6_ipc'] = run_fxp('gpu', n_full // 10, 3, ipc=True)
     res['fxp_m3_1e6_ipc_chacha'] = run_fxp('gpu', n_full // 10, 3, prf='chacha', ipc=True)
     res['reference_fxp_m1_2e4'] = run_fxp('ref', n_full // 500, 1)
-    if isinstance(res['reference_fxp_m1_2e4'], dict) and 'error' not in res['reference_fxp_m1_2e4']:
+    if isinstance(res['reference_fxp_m1_2e4'], dict) and 'elements_per_s' in res['reference_fxp_m1_2e4']:
         res['reference_fxp_m1_2e4']['note'] = ('the short-mask outlier is NOT observable at this size (expected 0.02 per run; the '
                                                'reference needs ~150 s for the 10^6 elements that show one): the digest-level test runs '
                                                'both sides on keys that produce one at n = 10^5')
@@ -555,14 +635,13 @@ def list_path_leg():
     for k_ in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MPYC_AMD_CPUCTX'):
         env.pop(k_, None)
     env.update(LP_MODE='gpu', LP_N='10000', LP_M='3', LP_T='1', LP_PRIME=str(P61), LP_SEED='5', LP_REPS='5')
-    try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'list_path_program.py')], capture_output=True, text=True,
-                           cwd='/tmp', env=env, timeout=300)
-    except subprocess.TimeoutExpired:
-        return {'error': 'timeout after 300 s'}
-    line = next((ln for ln in r.stdout.splitlines() if ln.startswith('LIST_PATH_RESULT ')), None)
-    if r.returncode != 0 or line is None:
-        return {'error': (r.stdout + r.stderr)[-400:]}
+    r = run_bounded([sys.executable, os.path.join(ROOT, 'tests', 'list_path_program.py')], env, LEG_BUDGET['leg_timeout'])
+    if r is None:
+        return {'error': 'no result within the limit'}
+    rc, so, se = r
+    line = next((ln for ln in so.splitlines() if ln.startswith('LIST_PATH_RESULT ')), None)
+    if rc != 0 or line is None:
+        return {'error': (so + se)[-400:]}
     d = json.loads(line[len('LIST_PATH_RESULT '):])
     return {'workload': 'configs[0]: thresha.random_split + recombine(k=2), list path, m=3, t=1, GF(2^61-1), 10^4 secrets',
             'name': 'list_path_p61_1e4_m3t1', 'n': d['n'], 'unit': 'secrets/s',
@@ -791,6 +870,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api-leg', action='store_true', help='skip the API-level section (party processes under install())')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--budget', type=float, default=float(os.environ.get('FFGPU_BENCH_BUDGET', '240')),
+                    help='seconds the sections that run OTHER programs (reference baseline, API-level legs) may take together; '
+                         'legs that no longer fit are reported as skipped (default 240; each leg also has a 60 s limit of its own)')
+    ap.add_argument('--full', action='store_true', help='no budget, 300 s per leg: the evidence passes')
     ap.add_argument('--no-multi-gpu-leg', action='store_true', help='skip the configs[3] / party-major section')
     ap.add_argument('--parties-on-gpus', action='store_true',
                     default=os.environ.get('FFGPU_BENCH_PARTIES_ON_GPUS', '0') == '1',
@@ -812,10 +895,10 @@ def main():
             port = sk.getsockname()[1]
         # (`--n` is an ambiguous abbreviation for torch.distributed.run's own parser: it travels in the environment)
         fwd = ['--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup), '--sets', str(args.sets),
-               '--layout', args.layout]
+               '--layout', args.layout, '--budget', str(args.budget)]
         fwd += [f_ for f_, on in (('--no-cpu-baseline', args.no_cpu_baseline), ('--no-extras', args.no_extras),
                                   ('--no-api-leg', args.no_api_leg), ('--no-multi-gpu-leg', args.no_multi_gpu_leg),
-                                  ('--parties-on-gpus', args.parties_on_gpus)) if on]
+                                  ('--parties-on-gpus', args.parties_on_gpus), ('--full', args.full)) if on]
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + fwd
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, FFGPU_BENCH_N=str(args.n))))
@@ -1522,6 +1605,10 @@ def main():
         and the API-level section.  A failure here never costs the headline line."""
         if rank != 0 or world != 1:
             return
+        if args.full:
+            LEG_BUDGET.update(deadline=None, leg_timeout=300.0)
+        else:
+            LEG_BUDGET.update(deadline=time.perf_counter() + args.budget, leg_timeout=60.0)
         if not args.no_extras:
             try:
                 lap('headline_and_multi_gpu_leg')

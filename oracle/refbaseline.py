@@ -84,6 +84,12 @@ def measure(modulus, t, m, n_one, n_each, procs, seed=20260925):
 
 
 if __name__ == '__main__':
+    # python oracle/refbaseline.py <reference checkout> [n_one n_each procs]  -> one JSON line (bench.py runs it as a bounded
+    # sub-process: a worker pool that loses a worker would otherwise hang the run)
     import json
     ok = available(sys.argv[1:2])
-    print(json.dumps(measure(2**61 - 1, 1, 3, 200_000, 50_000, os.cpu_count() or 1) if ok else {'error': 'mpyc not importable'}))
+    if len(sys.argv) >= 5:
+        n_one, n_each, procs = (int(v) for v in sys.argv[2:5])
+    else:
+        n_one, n_each, procs = 200_000, 50_000, os.cpu_count() or 1
+    print('REFBASELINE ' + json.dumps(measure(2**61 - 1, 1, 3, n_one, n_each, procs) if ok else {'error': 'mpyc not importable'}))

@@ -118,3 +118,27 @@ def test_emit_prints_detail_first_and_the_compact_line_last(tmp_path):
     assert len(lines[-1]) < bench.COMPACT_LIMIT and last['value'] == out['value']
     with open(tmp_path / 'bench_detail.json') as fh:
         assert json.load(fh)['api']['note'] == out['api']['note']
+
+
+def test_bounded_subprocess_ends_the_whole_process_group(tmp_path):
+    """bench.run_bounded: a leg that does not finish within its limit is ended TOGETHER with the processes it spawned (the
+    party processes of `-M3`), reports None, and honours the run's budget; a finished leg returns its output."""
+    import time
+    marker = tmp_path / 'child_alive'
+    prog = ('import subprocess, sys, time\n'
+            f'subprocess.Popen([sys.executable, "-c", "import time; time.sleep(4); open({str(marker)!r}, \'w\').write(\'x\')"])\n'
+            'print("STARTED", flush=True)\ntime.sleep(60)\n')
+    bench.LEG_BUDGET.update(deadline=None, leg_timeout=60.0)
+    t0 = time.perf_counter()
+    assert bench.run_bounded([sys.executable, '-c', prog], dict(os.environ), 1.5, cwd=str(tmp_path)) is None
+    assert time.perf_counter() - t0 < 10
+    time.sleep(4.5)
+    assert not marker.exists()                       # the grandchild was ended with the group
+    rc, out, err = bench.run_bounded([sys.executable, '-c', 'print("ok")'], dict(os.environ), 30, cwd=str(tmp_path))
+    assert rc == 0 and out.strip() == 'ok'
+    # budget: nothing starts when less than 3 s are left; a leg gets at most what is left
+    bench.LEG_BUDGET.update(deadline=time.perf_counter() + 1.0)
+    assert bench.run_bounded([sys.executable, '-c', 'print("ok")'], dict(os.environ), 30, cwd=str(tmp_path)) is None
+    bench.LEG_BUDGET.update(deadline=None)
+    a, b = bench.free_base_port(3), bench.free_base_port(3)
+    assert a != b and 1024 < a < 65000
