@@ -2,12 +2,13 @@
 # The ONE script for passes on the GPU box (replaces the per-round gpu_r0*.sh).  STAGES (any subset, in this order):
 #   newtests  pytest -m gpu on $NEWTESTS (files / node ids)          tests   the whole -m gpu suite
 #   bench     bench.py --steps 20 --warmup 5 (the driver's line)      prof    rocprofv3 --kernel-trace --stats of the bench
+#   benchfull the same with --full (every API-level leg, no budget)
 #   pmc       FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py    valu    SQ_INSTS_VALU pass of tools/valu_probe.py
 #   counters  SQ counter passes (waves, busy / wave cycles, VALU / LDS instructions and waits) of the GF(2^n) products and PRSS
 #   probe     bash -c "$PROBE" (timeout $PROBE_TIMEOUT, default 600)
-# TAG names the outputs (default r05): gpurun_out/{pytest_gpu,bench,rocprof_$TAG,...}.
+# TAG names the outputs (default r06): gpurun_out/{pytest_gpu,bench,rocprof_$TAG,...}.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-T=${TAG:-r05}
+T=${TAG:-r06}
 STAGES=${STAGES:-"tests bench prof"}
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 export TMPDIR=/tmp
@@ -24,6 +25,12 @@ if has bench; then
   (timeout 1500 python bench.py --steps 20 --warmup 5) > $O/bench.log 2> $O/bench.err; echo "bench rc=$? wall=${SECONDS}s" | tee -a $O/bench.err
   tail -n 1 $O/bench.log | wc -c
   tail -n 1 $O/bench.log | cut -c1-2500
+fi
+if has benchfull; then
+  SECONDS=0
+  (timeout 2400 python bench.py --steps 20 --warmup 5 --full) > $O/bench_full.log 2> $O/bench_full.err; echo "bench --full rc=$? wall=${SECONDS}s" | tee -a $O/bench_full.err
+  cp bench_detail.json $O/bench_detail_full.json 2>/dev/null
+  tail -n 1 $O/bench_full.log | cut -c1-600
 fi
 if has prof; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o $T -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-leg) > $O/rocprof_$T.log 2>&1
