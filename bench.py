@@ -339,7 +339,7 @@ def emit(out, detail_path=None):
     sys.stdout.flush()
 
 
-VALU_COUNTS_FILES = ('r05_valu.json', 'r04_valu.json')     # SQ_INSTS_VALU per unit of every VALU-bound row (tools/valu_probe.py)
+VALU_COUNTS_FILES = ('r06_valu.json', 'r05_valu.json', 'r04_valu.json')     # SQ_INSTS_VALU per unit of every VALU-bound row (tools/valu_probe.py)
 
 
 def measure_valu_peak(ctx):
@@ -1571,7 +1571,7 @@ def main():
         # profiles/r03_pmc_traffic.md for the command, units and the gfx950 FETCH_SIZE correction)
         def annotate_traffic():
             try:
-                pmc_file = next(f_ for f_ in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                pmc_file = next(f_ for f_ in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                                 if os.path.exists(os.path.join(ROOT, 'profiles', f_)))
                 with open(os.path.join(ROOT, 'profiles', pmc_file)) as fh:
                     pmc = json.load(fh)

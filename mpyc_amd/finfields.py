@@ -1389,8 +1389,49 @@ class FieldArray:
         key = conv(key)
         return (key, Ellipsis, slice(None)) if self.ctx.limbs and key is not Ellipsis else key
 
+    def _positive_steps(self, key):
+        """torch has no negative slice steps: a[::-1] and friends are rewritten as the ascending slice over the same
+        elements plus a flip of the result along that axis.  -> (key, axes of the RESULT to flip); basic keys only."""
+        keys = key if isinstance(key, tuple) else (key,)
+        if not any(isinstance(k, slice) and k.step is not None and k.step < 0 for k in keys):
+            return key, ()
+        if any(not (isinstance(k, (int, np.integer, slice)) or k is None or k is Ellipsis) for k in keys):
+            raise NotImplementedError('negative slice steps together with index arrays on GPU field arrays')
+        n_real = sum(1 for k in keys if k is not None and k is not Ellipsis)
+        out, flips, dim, axis = [], [], 0, 0
+        for k in keys:
+            if k is Ellipsis:
+                skip = self.ndim - n_real
+                dim += skip
+                axis += skip
+                out.append(k)
+            elif k is None:
+                axis += 1
+                out.append(k)
+            elif isinstance(k, slice):
+                if k.step is not None and k.step < 0:
+                    start, stop, step = k.indices(self._shape[dim])
+                    cnt = max(0, (start - stop - step - 1) // (-step))
+                    if cnt == 0:
+                        out.append(slice(0, 0, 1))
+                    else:
+                        last = start + (cnt - 1) * step
+                        out.append(slice(last, start + 1, -step))
+                        flips.append(axis)
+                else:
+                    out.append(k)
+                dim += 1
+                axis += 1
+            else:
+                out.append(k)
+                dim += 1
+        return (tuple(out) if isinstance(key, tuple) else out[0]), tuple(flips)
+
     def __getitem__(self, key):
+        key, flips = self._positive_steps(key)
         sub = self._limb_view()[self._index_key(key)]
+        if flips:
+            sub = sub.flip(flips)
         shape = sub.shape[:-1] if self.ctx.limbs else sub.shape
         if len(shape) == 0:
             flat = sub.reshape(1, self.ctx.limbs) if self.ctx.limbs else sub.reshape(1)
@@ -1419,7 +1460,11 @@ class FieldArray:
             raise ValueError(f'could not broadcast input array from shape {value._shape} into shape {tuple(target)}')
         src = value._limb_view()
         self._flush_products_reading(self._dev)
-        self._limb_view()[self._index_key(key)] = src
+        key2, flips = self._positive_steps(key)
+        if flips:                                   # a[::-1] = v  ==  a[ascending slice] = v flipped (after broadcasting)
+            nl = 1 if self.ctx.limbs else 0
+            src = src.broadcast_to(tuple(target) + ((self.ctx.limbs,) if nl else ())).flip(flips)
+        self._limb_view()[self._index_key(key2)] = src
         self._cache = None
 
     def __contains__(self, value):
@@ -1981,6 +2026,10 @@ class FieldArray:
         unary = {'negative': '__neg__', 'positive': '__pos__', 'reciprocal': 'reciprocal', 'sqrt': 'sqrt'}
         if name in unary:
             return getattr(a, unary[name])()
+        if name == 'square':                          # the reference: value ** 2, reduced (finfields.py:755-764)
+            return a * a
+        if name in ('absolute', 'fabs'):              # of the canonical (non-negative) representatives: the array itself
+            return a.copy()
         return NotImplemented
 
     def __array_function__(self, func, types, args, kwargs):
@@ -2352,6 +2401,103 @@ def _np_outer(a, b):
     return a.reshape(-1, 1) * b.reshape(1, -1)
 
 
+# ---- ring arithmetic that NumPy composes from +, -, * on object arrays in the reference (its generic __array_function__
+#      path, finfields.py:766-819); here the same compositions over the device operators ---------------------------------
+def _np_diff(a, n=1, axis=-1, prepend=np._NoValue, append=np._NoValue):
+    if n < 0:
+        raise ValueError(f'order must be non-negative but got {n}')
+    cls = type(a)
+    if a.ndim == 0:
+        raise ValueError('diff requires input that is at least one dimensional')
+    axis = axis if axis >= 0 else axis + a.ndim
+    parts = []
+    for extra in (prepend, None, append):
+        if extra is None:
+            parts.append(a)
+        elif extra is not np._NoValue:
+            e = _as_arr(cls, extra)
+            if e.ndim == 0:
+                shp = list(a.shape)
+                shp[axis] = 1
+                e = _np_movement(np.broadcast_to, (e, tuple(shp)), {})
+            parts.append(e)
+    if len(parts) > 1:
+        a = _np_concatenate(parts, axis)
+    hi = [slice(None)] * a.ndim
+    lo = [slice(None)] * a.ndim
+    hi[axis], lo[axis] = slice(1, None), slice(None, -1)
+    for _ in range(n):
+        a = a[tuple(hi)] - a[tuple(lo)]
+    return a
+
+
+def _np_ediff1d(ary, to_end=None, to_begin=None):
+    cls = type(ary)
+    d = _np_diff(ary.reshape(-1))
+    parts = ([_as_arr(cls, to_begin).reshape(-1)] if to_begin is not None else []) + [d] + \
+            ([_as_arr(cls, to_end).reshape(-1)] if to_end is not None else [])
+    return d if len(parts) == 1 else _np_concatenate(parts, 0)
+
+
+def _np_cross(a, b, axisa=-1, axisb=-1, axisc=-1, axis=None):
+    cls, a, b = _pair(a, b)
+    if axis is not None:
+        axisa = axisb = axisc = axis
+    a = _ARRAY_FUNCTIONS['moveaxis'](a, axisa, -1) if a.ndim > 1 else a
+    b = _ARRAY_FUNCTIONS['moveaxis'](b, axisb, -1) if b.ndim > 1 else b
+    if a.shape[-1] != 3 or b.shape[-1] != 3:
+        raise NotImplementedError('np.cross on GPU field arrays: vectors of dimension 3')
+    a0, a1, a2 = a[..., 0:1], a[..., 1:2], a[..., 2:3]           # (slices keep the axis: 1-D inputs stay arrays)
+    b0, b1, b2 = b[..., 0:1], b[..., 1:2], b[..., 2:3]
+    c = _np_concatenate([a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0], -1)
+    return _ARRAY_FUNCTIONS['moveaxis'](c, -1, axisc) if c.ndim > 1 and axisc not in (-1, c.ndim - 1) else c
+
+def _np_polyval(p, x):
+    """Horner, as numpy.polyval: p[0] is the leading coefficient."""
+    cls = type(p) if isinstance(p, FieldArray) else type(x)
+    p, x = _as_arr(cls, p), _as_arr(cls, x)
+    if p.ndim != 1:
+        raise ValueError('polyval: 1-D coefficient array required')
+    y = x * 0
+    for k in range(len(p)):
+        y = y * x + p[k]
+    return y
+
+
+def _np_polyadd(a1, a2, sign=1):
+    cls, a1, a2 = _pair(a1, a2)
+    a1, a2 = a1.reshape(-1), a2.reshape(-1)
+    d = len(a1) - len(a2)
+    if d > 0:
+        a2 = _np_concatenate([cls(np.zeros(d, dtype=object)), a2], 0)
+    elif d < 0:
+        a1 = _np_concatenate([cls(np.zeros(-d, dtype=object)), a1], 0)
+    return a1 + a2 if sign > 0 else a1 - a2
+
+
+def _np_polymul(a1, a2):
+    cls, a1, a2 = _pair(a1, a2)
+    return _np_convolve(a1.reshape(-1), a2.reshape(-1))
+
+
+def _np_multi_dot(arrays, *, out=None):
+    arrays = list(arrays)
+    if len(arrays) < 2:
+        raise ValueError('Expecting at least two arrays.')
+    r = arrays[0]
+    for m_ in arrays[1:]:                # (left to right: the result is the same in a field; no cost-based ordering)
+        r = _np_dot(r, m_)
+    return r
+
+
+def _np_array_equiv(a1, a2):
+    cls, a1, a2 = _pair(a1, a2)
+    try:
+        return bool((a1 == a2).all())
+    except ValueError:
+        return False
+
+
 def _np_convolve(a, v, mode='full'):
     """np.convolve over the field (runtime.np_convolve's local part, runtime.py:2580): Toeplitz gather of
     the longer operand (index 0 = zero element) times the shorter one through the product kernel."""
@@ -2643,4 +2789,8 @@ _ARRAY_FUNCTIONS = {
     'solve': FieldArray.gauss_solve, 'inv': FieldArray.gauss_inv, 'det': FieldArray.gauss_det,
     'matrix_power': FieldArray.matrix_pow,
     'negative': lambda a: -a, 'add': lambda a, b: a + b, 'subtract': lambda a, b: a - b, 'multiply': lambda a, b: a * b,
+    'diff': _np_diff, 'ediff1d': _np_ediff1d, 'cross': _np_cross, 'polyval': _np_polyval, 'polyadd': _np_polyadd,
+    'polysub': lambda a1, a2: _np_polyadd(a1, a2, -1), 'polymul': _np_polymul, 'multi_dot': _np_multi_dot,
+    'array_equiv': _np_array_equiv, 'iscomplexobj': lambda a: False, 'isrealobj': lambda a: True,
+    'square': lambda a: a * a,
 }
