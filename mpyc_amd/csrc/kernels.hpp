@@ -191,9 +191,8 @@ __device__ __forceinline__ typename F::word ew_apply(const F& f, typename F::wor
 
 // ---- out = a (op) b --------------------------------------------------------
 template <class F, int OP, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __restrict__ a,
-                                                const typename F::elem* __restrict__ b,
-                                                typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+__device__ __forceinline__ void ew2_body(const F& f, const typename F::elem* __restrict__ a, const typename F::elem* __restrict__ b,
+                                         typename F::elem* __restrict__ o, size_t nvec, size_t n) {
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
     const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
@@ -215,6 +214,27 @@ __global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __re
         st_elem<F>(o, e, ew_apply<F, OP>(f, ld_elem<F>(a, e), ld_elem<F>(b, e)));
     }
 }
+template <class F, int OP, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_ew2(F f, const typename F::elem* __restrict__ a,
+                                                const typename F::elem* __restrict__ b,
+                                                typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+    ew2_body<F, OP, NT>(f, a, b, o, nvec, n);
+}
+// The same kernel held to WAVES waves per SIMD, for products that the VALU limits: left alone the compiler hoists all nine
+// 32 x 32 carry-less products of a GF(2^128) multiplication side by side (129 registers, three waves per SIMD); told to keep
+// five or more waves it needs 66 registers and no spill, and seven waves issue 4-5 % faster than three (round 6, same box:
+// 158-160 -> 151-153 us at n = 10^7).  EwOccupancy<F, OP>::waves names the kernels treated this way.
+template <class F, int OP, bool NT, int WAVES>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
+void k_ew2_occ(F f, const typename F::elem* __restrict__ a, const typename F::elem* __restrict__ b,
+               typename F::elem* __restrict__ o, size_t nvec, size_t n) {
+    ew2_body<F, OP, NT>(f, a, b, o, nvec, n);
+}
+template <class F, int OP> struct EwOccupancy { enum { waves = 0 }; };
+#ifndef FFGPU_GF2W128_OCC
+#define FFGPU_GF2W128_OCC 7
+#endif
+template <> struct EwOccupancy<GF2W128, OP_MUL> { enum { waves = FFGPU_GF2W128_OCC }; };
 
 // ---- out = a (op) scalar, or unary op (scalar ignored) ---------------------
 template <class F, int OP, bool NT>

@@ -160,10 +160,18 @@ struct Launchers {
         bool vec = al(a) && al(b) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
-        if (lc.nt)
-            hipLaunchKernelGGL((k_ew2<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
-        else
-            hipLaunchKernelGGL((k_ew2<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        constexpr int OCC = EwOccupancy<F, OP>::waves;
+        if constexpr (OCC > 0) {
+            if (lc.nt)
+                hipLaunchKernelGGL((k_ew2_occ<F, OP, true, OCC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+            else
+                hipLaunchKernelGGL((k_ew2_occ<F, OP, false, OCC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        } else {
+            if (lc.nt)
+                hipLaunchKernelGGL((k_ew2<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+            else
+                hipLaunchKernelGGL((k_ew2<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        }
     }
     static int ew2(const void* Fp, int device, int op, const void* a, const void* b, void* o, size_t n,
                    hipStream_t st) {

@@ -1,0 +1,30 @@
+"""A/B of library builds: time the GF(2^128) product (and any other row named) with the .so given as argv[1].
+usage: lib_variant_probe.py path/to/libffgpu_variant.so"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mpyc_amd._ffi as _ffi
+if len(sys.argv) > 1:
+    _ffi.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch
+import bench
+from mpyc_amd.engine import FieldContext, DevArray
+gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
+n = 10_000_000
+ctx = FieldContext((1 << 128) | 0x87, binary=True, device=0)
+sets = []
+for _ in range(3):
+    x = torch.randint(-2**63, 2**63 - 1, (3, n, 2), dtype=torch.int64, device='cuda:0', generator=gen)
+    sets.append([DevArray(ctx, x[i], n) for i in range(3)])
+best = []
+for rep in range(3):
+    ms = bench.time_launches(lambda s: ctx.mul(s[0], s[1], out=s[2]), sets, 10)
+    best.append(ms)
+print(os.path.basename(_ffi.LIB_PATH), 'gf2_128 mul us:', ' '.join(f'{m*1e3:.1f}' for m in best), f'-> {48*n/min(best)/1e6/8000:.3f} of HBM')
+if os.environ.get('VARIANT_SPLIT'):
+    P64 = 2**64 - 189
+    c64 = FieldContext(P64, device=0)
+    s64 = [bench.StepData(c64, n, 3, 7, gen) for _ in range(3)]
+    key = bytes(range(32))
+    for rounds in (20, 8):
+        best = [bench.time_launches(lambda s: c64.split_rng(s.a, 3, 7, key=key, nonce=7, rounds=rounds, out=s.shares), s64, 10) for _ in range(3)]
+        print(os.path.basename(_ffi.LIB_PATH), f'split_rng_p64_m7t3 chacha{rounds} us:', ' '.join(f'{m*1e3:.1f}' for m in best))
