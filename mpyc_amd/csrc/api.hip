@@ -147,10 +147,8 @@ LaunchCfg launch_cfg(int device) {
         int bpc = 0;  // uncapped
         const char* e = getenv("FFGPU_BLOCKS_PER_CU");
         if (e && atoi(e) >= 0) bpc = atoi(e);
-        const char* ntv = getenv("FFGPU_NT");
         cache[d].num_cu = cus;
         cache[d].blocks_per_cu = bpc;
-        cache[d].nt = (ntv && atoi(ntv) == 0) ? 0 : 1;
         have[d] = true;
     }
     return cache[d];

@@ -48,7 +48,7 @@ struct Pack<u192e> {          // three-limb elements: one per lane (24 bytes: dw
 // 16-byte global accesses with an optional non-temporal hint.  Every array here is
 // streamed exactly once per launch, so by default loads and stores carry `nt`
 // (global_load/store_dwordx4 ... nt): measured +4..10 % on the 10^7-element kernels
-// (profiles/r01_tuning.md).  FFGPU_NT=0 turns the hint off.
+// (profiles/r01_tuning.md); every launcher instantiates the hinted form only.
 typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT, class P>

@@ -8,7 +8,6 @@ namespace ffgpu {
 struct LaunchCfg {
     int blocks_per_cu;  // 0 = uncapped grid: one 16-byte pack per thread (default, measured best)
     int num_cu;
-    int nt;             // non-temporal loads/stores (default 1)
 };
 LaunchCfg launch_cfg(int device);
 
@@ -161,17 +160,12 @@ struct Launchers {
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         constexpr int OCC = EwOccupancy<F, OP>::waves;
-        if constexpr (OCC > 0) {
-            if (lc.nt)
-                hipLaunchKernelGGL((k_ew2_occ<F, OP, true, OCC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
-            else
-                hipLaunchKernelGGL((k_ew2_occ<F, OP, false, OCC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
-        } else {
-            if (lc.nt)
-                hipLaunchKernelGGL((k_ew2<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
-            else
-                hipLaunchKernelGGL((k_ew2<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
-        }
+        // (streamed loads and stores carry the non-temporal hint: +4-8 %, profiles/r01_tuning.md; the un-hinted instantiations
+        // that rounds 1-5 kept behind FFGPU_NT=0 for A/B runs are gone)
+        if constexpr (OCC > 0)
+            hipLaunchKernelGGL((k_ew2_occ<F, OP, true, OCC>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
+        else
+            hipLaunchKernelGGL((k_ew2<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, b, o, nvec, n);
     }
     static int ew2(const void* Fp, int device, int op, const void* a, const void* b, void* o, size_t n,
                    hipStream_t st) {
@@ -195,10 +189,7 @@ struct Launchers {
         bool vec = al(a) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
-        if (lc.nt)
-            hipLaunchKernelGGL((k_ew1<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
-        else
-            hipLaunchKernelGGL((k_ew1<F, OP, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
+        hipLaunchKernelGGL((k_ew1<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
     }
     static int ew1(const void* Fp, int device, int op, const void* a, const uint64_t* scalar2, void* o,
                    size_t n, hipStream_t st) {
@@ -227,12 +218,8 @@ struct Launchers {
         bool vec = al(a) && al(b) && al(c) && al(o);
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
-        if (lc.nt)
-            hipLaunchKernelGGL((k_muladd<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
-                               (const E*)b, (const E*)c, (E*)o, nvec, n);
-        else
-            hipLaunchKernelGGL((k_muladd<F, false>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
-                               (const E*)b, (const E*)c, (E*)o, nvec, n);
+        hipLaunchKernelGGL((k_muladd<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
+                           (const E*)b, (const E*)c, (E*)o, nvec, n);
         FFGPU_CHECK_LAUNCH();
         return 0;
     }
@@ -241,12 +228,9 @@ struct Launchers {
     static void go_split(const F& f, unsigned grid, bool nt, const E* a, const E* b, const E* coef,
                          size_t cstride, int m, E* out, size_t ostride, size_t nvec, size_t n, hipStream_t st,
                          const RngArgs& ra, const GateSrc<F>& gs, unsigned gy = 1) {
-        if (nt || RNG)
-            hipLaunchKernelGGL((k_split<F, T, FUSE, true, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a, b,
-                               coef, cstride, m, out, ostride, nvec, n, ra, gs);
-        else
-            hipLaunchKernelGGL((k_split<F, T, FUSE, false, false>), dim3(grid), dim3(BLOCK), 0, st, f, a, b,
-                               coef, cstride, m, out, ostride, nvec, n, ra, gs);
+        (void)nt;
+        hipLaunchKernelGGL((k_split<F, T, FUSE, true, RNG, REC>), dim3(grid, gy), dim3(BLOCK), 0, st, f, a, b,
+                           coef, cstride, m, out, ostride, nvec, n, ra, gs);
     }
     template <bool FUSE, bool RNG>
     static int split_t(const F& f, const LaunchCfg& lc, const E* a, const E* b, const E* coef, size_t cstride,
@@ -272,7 +256,7 @@ struct Launchers {
         ra.spread = spread ? 1 : 0;
         unsigned grid = grid_for(nvec ? (RNG && !spread ? (n / EPV + 2) / 2 : nvec) : n, lc);
         ra.release = !ra.no_advance && grid <= RNG_RELEASE_MAX_GRID;
-        bool nt = lc.nt != 0;
+        const bool nt = true;
         GateSrc<F> gs;
         memset(&gs, 0, sizeof(gs));
         switch (t) {
@@ -401,12 +385,8 @@ struct Launchers {
         for (int i = w * K; i < MAXW * K; ++i) ra.lam[i] = ra.lam[0];
         size_t nvec = vec ? n / EPV : 0;
         unsigned grid = grid_for(nvec ? nvec : n, lc);
-        if (lc.nt)
-            hipLaunchKernelGGL((k_recombine<F, K, true>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
-                               nvec, n);
-        else
-            hipLaunchKernelGGL((k_recombine<F, K, false>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
-                               nvec, n);
+        hipLaunchKernelGGL((k_recombine<F, K, true>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
+                           nvec, n);
     }
     static int recombine(const void* Fp, int device, const void* const* rows, const uint64_t* lam2, int k,
                          int w, void* out, size_t ostride, size_t n, hipStream_t st) {
