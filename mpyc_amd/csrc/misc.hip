@@ -1591,7 +1591,10 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
                 else if constexpr (OP == 5) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[k]));
                 else if constexpr (OP == 6) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
                 else if constexpr (OP == 7) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
-                else asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                else if constexpr (OP == 8) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                else if constexpr (OP == 9) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(a[k]));        // rotate (ChaCha)
+                else if constexpr (OP == 10) asm volatile("v_lshl_or_b32 %0, %0, 12, %1" : "+v"(a[k]) : "v"(b));
+                else asm volatile("v_alignbyte_b32 %0, %0, %0, 1" : "+v"(a[k]));
             }
         }
     }
@@ -1611,7 +1614,7 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
 int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch32, double* out, hipStream_t st) {
     // SYNCHRONISES the stream (event + a blocking read-back of the cycle counts): a measurement aid, not capturable
     LaunchCfg lc = launch_cfg(device);
-    if (op < 0 || op > 8 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
+    if (op < 0 || op > 11 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
     const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
     uint32_t* sink = (uint32_t*)scratch32;
     uint64_t* clk = (uint64_t*)((char*)scratch32 + 16);
@@ -1624,7 +1627,8 @@ int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, v
     auto launch = [&](int n_it) {
 #define FF_PROBE_CASE(OPV) case OPV: hipLaunchKernelGGL(k_valu_probe<OPV>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); break;
         switch (op) { FF_PROBE_CASE(0) FF_PROBE_CASE(1) FF_PROBE_CASE(2) FF_PROBE_CASE(3) FF_PROBE_CASE(4) FF_PROBE_CASE(5)
-                      FF_PROBE_CASE(6) FF_PROBE_CASE(7) default: hipLaunchKernelGGL(k_valu_probe<8>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); }
+                      FF_PROBE_CASE(6) FF_PROBE_CASE(7) FF_PROBE_CASE(8) FF_PROBE_CASE(9) FF_PROBE_CASE(10)
+                      default: hipLaunchKernelGGL(k_valu_probe<11>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); }
 #undef FF_PROBE_CASE
     };
     launch(iters / 4 + 1);                                                    // warm-up: clocks ramp

@@ -28,3 +28,14 @@ if os.environ.get('VARIANT_SPLIT'):
     for rounds in (20, 8):
         best = [bench.time_launches(lambda s: c64.split_rng(s.a, 3, 7, key=key, nonce=7, rounds=rounds, out=s.shares), s64, 10) for _ in range(3)]
         print(os.path.basename(_ffi.LIB_PATH), f'split_rng_p64_m7t3 chacha{rounds} us:', ' '.join(f'{m*1e3:.1f}' for m in best))
+if os.environ.get('VARIANT_PRSS'):
+    import itertools
+    from mpyc_amd import finfields as gff, thresha as gth
+    F61 = gff.GF(2**61 - 1)
+    gth.prss_prf, gth.prss_allow_chacha8 = 'chacha', True
+    for (mm, ii), rr in itertools.product(((7, 2), (3, 0)), (20, 8)):
+        keys = {S: bytes([sum(S) % 256]) * 16 for S in itertools.combinations(range(mm), mm - (mm - 1) // 2) if ii in S}
+        prfs = {S: gth.PRF(k_, F61.order) for S, k_ in keys.items()}
+        gth.prss_rounds = rr
+        best = [bench.time_launches(lambda s: gth.np_pseudorandom_share(F61, mm, ii, prfs, b'uci', n), [0], 5) for _ in range(3)]
+        print(os.path.basename(_ffi.LIB_PATH), f'prss m={mm} keys={len(keys)} chacha{rr} ms:', ' '.join(f'{m:.3f}' for m in best))
