@@ -212,7 +212,7 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
         f.emask = deg == 64 ? ~0ull : ((1ull << deg) - 1);
         f.red = deg == 64 ? m0 : (m0 ^ (1ull << deg));
         f.fast = 0;
-        if (deg > 32 && f.red && f.red < (1ull << 28)) {
+        if (f.red && f.red < (1ull << 28)) {
             // fold passes until nothing sticks out above bit n: excess e -> max(0, e + deg(r) - n)
             int rdeg = 63 - __builtin_clzll(f.red);
             int e = deg - 1, folds = 0;
@@ -221,7 +221,9 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
                 if (e < 0) e = 0;
                 ++folds;
             }
-            if (e == 0) f.fast = 1u | ((uint32_t)folds << 8);
+            // n <= 32: a pass costs ~2 + 2 popcount(red) instructions, a long-division step ~5: fold only when it is the cheaper one
+            const bool pays = deg > 32 || folds * (2 + 2 * __builtin_popcountll(f.red)) < 5 * (deg - 1);
+            if (e == 0 && pays) f.fast = 1u | ((uint32_t)folds << 8);
         }
         store_policy(c, f, POL_GF2W64, PB_RED_WIDE);
         return PB_OK;

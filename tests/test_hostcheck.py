@@ -186,6 +186,26 @@ def test_dense_binary_moduli_take_the_bitserial_path(hostcheck):
         assert got == po.vec(po.mul, F, a, b), hex(mod)
 
 
+def test_small_binary_fields_every_degree_fold_and_long_division(hostcheck):
+    """GF(2^n), 9 <= n <= 32 (they ride the one-limb policy): since round 6 sparse moduli -- the first irreducible of every
+    degree, what mpyc's find_irreducible returns -- reduce by fold passes, moduli whose low part is long (a pass would not pay)
+    keep the long division; both against the bit-level oracle, at extreme and random operands."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    for deg in range(9, 33):
+        mods = [int(BinaryPolynomial.next_irreducible(1 << deg)),                                   # sparse: fold
+                int(BinaryPolynomial.next_irreducible((1 << deg) | (1 << (deg - 1)) | (1 << (deg - 2))))]    # r of degree n-1: long division
+        for mod in mods:
+            assert mod.bit_length() == deg + 1
+            F = po.Field(mod, True)
+            ev = edge_values(F) + rand_values(F, 6, deg)
+            a, b = cross(ev)
+            got, _ = run(hostcheck, F, HC_MUL, a, b)
+            assert got == po.vec(po.mul, F, a, b), hex(mod)
+            a, b = rand_values(F, 400, 2 * deg), rand_values(F, 400, 3 * deg)
+            got, _ = run(hostcheck, F, HC_MUL, a, b)
+            assert got == po.vec(po.mul, F, a, b), hex(mod)
+
+
 def test_pseudo_mersenne_with_the_largest_admissible_c(hostcheck):
     """The golden primes all have a tiny c = 2^k - p.  The fold-based policies are selected for c up to
     2^min((k-1)/2, 31) (k <= 64) resp. 2^31 (k > 64), and that is where their carry chains are tightest:

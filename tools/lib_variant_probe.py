@@ -39,3 +39,14 @@ if os.environ.get('VARIANT_PRSS'):
         gth.prss_rounds = rr
         best = [bench.time_launches(lambda s: gth.np_pseudorandom_share(F61, mm, ii, prfs, b'uci', n), [0], 5) for _ in range(3)]
         print(os.path.basename(_ffi.LIB_PATH), f'prss m={mm} keys={len(keys)} chacha{rr} ms:', ' '.join(f'{m:.3f}' for m in best))
+if os.environ.get('VARIANT_SMALLGF'):
+    from mpyc_amd.gfpx import BinaryPolynomial
+    for deg in (9, 16, 24, 32):
+        mod = int(BinaryPolynomial.next_irreducible(1 << deg))
+        cb = FieldContext(mod, binary=True, device=0)
+        ss = []
+        for _ in range(3):
+            x = torch.randint(0, 1 << deg, (3, n), dtype=torch.int64, device='cuda:0', generator=gen)
+            ss.append([DevArray(cb, x[i], n) for i in range(3)])
+        best = [bench.time_launches(lambda s: cb.mul(s[0], s[1], out=s[2]), ss, 10) for _ in range(3)]
+        print(os.path.basename(_ffi.LIB_PATH), f'gf2_{deg} (modulus {hex(mod)}) mul us:', ' '.join(f'{m*1e3:.1f}' for m in best), f'-> {24*n/min(best)/1e6/8000:.3f} of HBM (8-byte storage)')
