@@ -9,7 +9,7 @@ Layout:
     thresha.py     host-side mirror of mpyc.thresha (np_)random_split / (np_)recombine
     install()      substitution of both into an importable mpyc
 """
-__version__ = '0.3.0'
+__version__ = '0.4.0'
 
 list_path_min = 256     # install(): thresha.random_split / recombine (the per-element list path, thresha.py:23-44,
 #                         88-116) go to the device from this many secrets on; below it the reference's own
