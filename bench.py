@@ -1370,6 +1370,16 @@ def main():
                     raise SystemExit(f'bench parity check failed for {label} split/recombine')
                 del bufs, cfb, shb, plans
                 torch.cuda.empty_cache()
+            # GF(2^32) (four-byte storage since round 6, fold reduction): element-wise product
+            c32_ = FieldContext((1 << 32) | 0x8d, binary=True, device=local_rank)
+            bufs = []
+            for _ in range(3):
+                x = torch.randint(-2**31, 2**31 - 1, (3, n), dtype=torch.int32, device=ctx.torch_device, generator=gen)
+                bufs.append(tuple(_DA(c32_, x[i], n) for i in range(3)))
+            ms = time_launches(lambda s: c32_.mul(s[0], s[1], out=s[2]), bufs, reps)
+            kern['mul_gf2_32'] = dict(roof(3 * 4 * n, ms), algorithmic_bytes_per_unit=12, units_per_s=round(n / (ms * 1e-3), 1))
+            del bufs
+            torch.cuda.empty_cache()
             lap('gf2w')
             # configs[3] shape on ONE GPU: 128-bit prime (two limbs), gate = mul + split(m=7,t=3) + recombine(k=7)
             del sets64[:]

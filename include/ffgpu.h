@@ -16,8 +16,8 @@
  *     Elements are fixed-width little-endian limbs in canonical form
  *     (0 <= x < modulus; for GF(2^n) the bit pattern of the polynomial):
  *         elem_bytes == 1   GF(2^n), n <= 8           uint8  [n]
- *         elem_bytes == 4   prime p < 2^32            uint32 [n]
- *         elem_bytes == 8   prime p < 2^64, GF(2^n) n<=64   uint64 [n]
+ *         elem_bytes == 4   prime p < 2^32, GF(2^n) 9 <= n <= 32   uint32 [n]
+ *         elem_bytes == 8   prime p < 2^64, GF(2^n) 33 <= n <= 64  uint64 [n]
  *         elem_bytes == 12  prime p = 2^k - c, 65 <= k <= 96, c < 2^31   3 x uint32 (12-byte LE integer)
  *         elem_bytes == 16  other primes p < 2^128, GF(2^n) n<=128 {lo,hi} uint64 pairs
  *         elem_bytes == 24  primes of 129..192 bits            3 x uint64 (24-byte LE integer, 8-byte aligned)

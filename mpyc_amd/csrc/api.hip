@@ -28,6 +28,7 @@ const FieldOps* ffgpu_ops_pm192();           // PM192
 const FieldOps* ffgpu_ops_mont192();         // MONT192
 const FieldOps* ffgpu_ops_mont128();
 const FieldOps* ffgpu_ops_gf2p8();
+const FieldOps* ffgpu_ops_gf2w32();
 const FieldOps* ffgpu_ops_gf2w64();
 const FieldOps* ffgpu_ops_gf2w128();
 int ffgpu_sbox_build_lut(const void* gf2p8_policy, const uint8_t* rows8, uint8_t b, uint8_t* lut256);
@@ -216,6 +217,7 @@ static const FieldOps* ops_for(int kind) {
         case POL_MONT192: return ffgpu_ops_mont192();
         case POL_MONT128: return ffgpu_ops_mont128();
         case POL_GF2P8: return ffgpu_ops_gf2p8();
+        case POL_GF2W32: return ffgpu_ops_gf2w32();
         case POL_GF2W64: return ffgpu_ops_gf2w64();
         case POL_GF2W128: return ffgpu_ops_gf2w128();
         default: return nullptr;

@@ -1181,7 +1181,7 @@ FF_HD void ff_clmul128(uint64_t alo, uint64_t ahi, uint64_t blo, uint64_t bhi, u
 }
 
 // ---------------------------------------------------------------------------
-// GF2W64 / GF2W128: GF(2^n) for 9 <= n <= 64 / 65 <= n <= 128.
+// GF2W64 / GF2W128: GF(2^n) for 33 <= n <= 64 (and 9..32 for callers that ask for 8-byte words) / 65 <= n <= 128.
 // mul: carry-less product (above) + reduction.  For moduli x^n + r(x) with a
 // short r (r < 2^28: every default MPyC irreducible, e.g. x^128+x^7+x^2+x+1) the
 // high part is folded down with one shift-xor per set bit of r (`fast`, nfold
@@ -1274,6 +1274,68 @@ struct GF2W64 {
     FF_HD void acc_zero(acc& s) const { s.a = 0; }
     FF_HD void acc_mac(acc& s, uint64_t lam, uint64_t x) const { s.a ^= mul(x, lam); }
     FF_HD uint64_t acc_reduce(const acc& s) const { return s.a; }
+};
+
+// GF2W32: GF(2^n) for 9 <= n <= 32 on FOUR-byte storage (round 6; rounds 1-5 kept these fields on the 8-byte words of GF2W64:
+// correct, twice the bytes of every streaming kernel).  Same arithmetic: 32 x 32 carry-less product on the integer multiplier, fold
+// passes for sparse moduli (`fast`), long division of the 64-bit product otherwise.
+struct GF2W32 {
+    typedef uint32_t elem;
+    typedef uint32_t word;
+    enum { EPW = 1 };
+    enum { BINARY = 1 };
+    uint32_t red;    // modulus without leading term
+    uint32_t emask;  // 2^n - 1
+    uint32_t n;      // 9..32
+    uint32_t fast;   // bit 0: fold reduction; bits 8..15: number of fold passes
+    struct acc {
+        uint32_t a;
+    };
+    FF_HD uint32_t prep(uint32_t cst) const { return cst; }
+    FF_HD uint32_t add(uint32_t a, uint32_t b) const { return a ^ b; }
+    FF_HD uint32_t sub(uint32_t a, uint32_t b) const { return a ^ b; }
+    FF_HD uint32_t neg(uint32_t a) const { return a; }
+    FF_HD uint32_t xtime(uint32_t a) const {
+        const uint32_t hi = (a >> (n - 1)) & 1u;
+        return ((a << 1) & emask) ^ ((0u - hi) & red);
+    }
+    FF_HD uint32_t reduce_raw(uint32_t a) const {
+        if (n == 32) return a;
+        uint32_t r = 0;
+        for (int i = 31; i >= 0; --i) r = xtime(r) ^ ((a >> i) & 1u);
+        return r;
+    }
+    FF_HD uint32_t mul(uint32_t a, uint32_t b) const {
+        uint64_t pr = ff_clmul32(a, b);
+        if (fast & 1) {
+            // the product and every folded excess (h has fewer than n bits, red fewer than 28) fit one 64-bit word
+            const int folds = (int)((fast >> 8) & 0xff);
+            for (int it = 0; it < folds; ++it) {
+                const uint64_t h = pr >> n;
+                pr &= (uint64_t)emask;
+                for (uint32_t rr = red; rr; rr &= rr - 1) pr ^= h << __builtin_ctz(rr);
+            }
+            return (uint32_t)pr;
+        }
+        const uint64_t fm = (uint64_t)red | (1ull << n);          // long division by f = x^n + red from the top
+        for (int i = 2 * (int)n - 2; i >= (int)n; --i) pr ^= (0 - ((pr >> i) & 1)) & (fm << (i - (int)n));
+        return (uint32_t)pr;
+    }
+    FF_HD uint32_t muladd_small(uint32_t y, uint32_t x, uint32_t cadd) const {
+        // x < 2^n public and wave-uniform: Horner over its bits from the top set one
+        if (x == 0) return cadd;
+        uint32_t c = y;
+        for (int i = 30 - __builtin_clz(x); i >= 0; --i) {
+            c = xtime(c);
+            if ((x >> i) & 1) c ^= y;
+        }
+        return c ^ cadd;
+    }
+    FF_HD uint32_t muladd(uint32_t a, uint32_t b, uint32_t cadd) const { return mul(a, b) ^ cadd; }
+    FF_HD void acc_zero(acc& s) const { s.a = 0; }
+    // (lam is wave-uniform: the runtime's own Lagrange coefficients at 0 for m in {3, 7} parties are all 1 -- plain XOR of the rows)
+    FF_HD void acc_mac(acc& s, uint32_t lam, uint32_t x) const { s.a ^= lam == 1u ? x : mul(x, lam); }
+    FF_HD uint32_t acc_reduce(const acc& s) const { return s.a; }
 };
 
 struct GF2W128 {

@@ -24,7 +24,8 @@ enum PolicyKind {
     POL_GF2W64,
     POL_GF2W128,
     POL_PM192,          // three-limb pseudo-Mersenne primes (24-byte storage)
-    POL_MONT192         // any other odd prime of 129..192 bits (24-byte storage)
+    POL_MONT192,        // any other odd prime of 129..192 bits (24-byte storage)
+    POL_GF2W32          // GF(2^n), 9 <= n <= 32, 4-byte storage (round 6)
 };
 
 // status values mirror include/ffgpu.h
@@ -204,6 +205,27 @@ inline int build_binary_policy(PolicyBlob* c, const uint64_t* mod, int nlimbs) {
         f.top = (1u << (deg - 1)) * 0x01010101u;
         f.emask = ((1u << deg) - 1) * 0x01010101u;
         store_policy(c, f, POL_GF2P8, PB_RED_SWAR);
+        return PB_OK;
+    }
+    if (deg <= 32) {
+        GF2W32 f;
+        f.n = (uint32_t)deg;
+        f.emask = deg == 32 ? ~0u : ((1u << deg) - 1);
+        f.red = (uint32_t)(m0 ^ (1ull << deg));
+        f.fast = 0;
+        if (f.red && f.red < (1u << 28)) {
+            // fold passes until nothing sticks out above bit n: excess e -> max(0, e + deg(r) - n)
+            int rdeg = 31 - __builtin_clz(f.red);
+            int e = deg - 1, folds = 0;
+            while (e > 0 && folds < 16) {
+                e = e + rdeg - deg;
+                if (e < 0) e = 0;
+                ++folds;
+            }
+            // a pass costs ~2 + 2 popcount(red) instructions, a long-division step ~5: fold only when it is the cheaper one
+            if (e == 0 && folds * (2 + 2 * __builtin_popcount(f.red)) < 5 * (deg - 1)) f.fast = 1u | ((uint32_t)folds << 8);
+        }
+        store_policy(c, f, POL_GF2W32, PB_RED_WIDE);
         return PB_OK;
     }
     if (deg <= 64) {

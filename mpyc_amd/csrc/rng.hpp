@@ -217,6 +217,11 @@ struct Sampler<GF2P8> {
     }
 };
 template <>
+struct Sampler<GF2W32> {
+    enum { S = 4, REJECT = 0 };
+    static FF_HD uint32_t sample(const GF2W32& f, uint64_t, uint64_t, const uint32_t* w, int*) { return w[0] & f.emask; }
+};
+template <>
 struct Sampler<GF2W64> {
     enum { S = 8, REJECT = 0 };
     static FF_HD uint64_t sample(const GF2W64& f, uint64_t, uint64_t, const uint32_t* w, int*) {

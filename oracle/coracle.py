@@ -38,7 +38,7 @@ def elem_bytes(modulus: int, binary: bool) -> int:
     """Storage width used on the device (include/ffgpu.h conventions)."""
     if binary:
         n = modulus.bit_length() - 1
-        return 1 if n <= 8 else 8 if n <= 64 else 16
+        return 1 if n <= 8 else 4 if n <= 32 else 8 if n <= 64 else 16
     b = modulus.bit_length()
     if 64 < b <= 96 and (1 << b) - modulus < (1 << 31):
         return 12                      # p = 2^k - c, k <= 96: three 32-bit limbs (include/ffgpu.h)

@@ -190,6 +190,7 @@ extern "C" int hc_run(int binary, const uint64_t* modulus, int nlimbs, int op, c
         case POL_PM96: return run<PM96>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_MONT128: return run<MONT128>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2P8: return run<GF2P8>(pb, op, a, b, c, out, n, x, lam, k);
+        case POL_GF2W32: return run<GF2W32>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W64: return run<GF2W64>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_GF2W128: return run<GF2W128>(pb, op, a, b, c, out, n, x, lam, k);
         case POL_PM192: return run<PM192>(pb, op, a, b, c, out, n, x, lam, k);
@@ -267,6 +268,7 @@ extern "C" int hc_rng_coeffs(int binary, const uint64_t* modulus, int nlimbs, co
         case POL_PM96: return rng_rows<PM96>(pb, rk, t, out, cstride, n);
         case POL_MONT128: return rng_rows<MONT128>(pb, rk, t, out, cstride, n);
         case POL_GF2P8: return rng_rows<GF2P8>(pb, rk, t, out, cstride, n);
+        case POL_GF2W32: return rng_rows<GF2W32>(pb, rk, t, out, cstride, n);
         case POL_GF2W64: return rng_rows<GF2W64>(pb, rk, t, out, cstride, n);
         case POL_GF2W128: return rng_rows<GF2W128>(pb, rk, t, out, cstride, n);
         case POL_PM192: return rng_rows<PM192>(pb, rk, t, out, cstride, n);

@@ -134,7 +134,10 @@ def test_golden_sbox_and_kats(eng, golden_sbox):
 # ---------------------------------------------------------------------------
 FIELDS = [(P61, False), (P64, False), (P128, False), (2**127 - 1, False), (2**96 - 17, False),
           (6616326157076047771, False), (258797994007609146293811961253269568351, False), (2**31 - 1, False),
-          (65537, False), (0x11b, True), (0b10011, True), ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]
+          (65537, False), (0x11b, True), (0b10011, True), ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True),
+          # GF(2^n), 9 <= n <= 32: four-byte storage (GF2W32, round 6) -- sparse moduli (fold reduction) and one whose low part is long
+          # (long division of the 64-bit product)
+          (0x1002b, True), (0x10000008d, True), (0x203, True), (0x1c0003, True)]
 
 
 def rand_np(F, eb, n, seed):
@@ -370,6 +373,47 @@ def test_wide_binary_products_all_degrees(eng, coracle):
         assert (ctx.mul(dA, dB).to_numpy() == want).all(), (deg, hex(mod))
         ctx.mul(dA, dB, out=dA)                                    # in place
         assert (dA.to_numpy() == want).all(), deg
+
+
+def test_small_binary_fields_every_degree(eng, coracle):
+    """GF(2^n), 9 <= n <= 32 on four-byte storage (GF2W32, round 6): every degree, the first irreducible (sparse: fold
+    reduction) and one with a long low part (long division): products at extreme and random operands, in place, the share
+    generation / recombination round trip with t = 2, k = 3 and the all-ones coefficients of the runtime (plain XOR of the
+    rows), inverse -- against the oracle."""
+    from mpyc_amd.gfpx import BinaryPolynomial
+    for deg in range(9, 33):
+        for mod in (int(BinaryPolynomial.next_irreducible(1 << deg)),
+                    int(BinaryPolynomial.next_irreducible((1 << deg) | (1 << (deg - 1)) | (1 << (deg - 2))))):
+            F = po.Field(mod, True)
+            ctx = ctx_for(eng, mod, True)
+            eb = ctx.elem_bytes
+            assert eb == 4 and F.n == deg
+            cf = coracle.CField(mod, True)
+            n = 8192 + 1027
+            A, B = rand_np(F, eb, n, 300 + deg), rand_np(F, eb, n, 400 + deg)
+            top = pack([F.order - 1, F.order >> 1, (F.order >> 1) | 1, 7 << (deg - 3), 5 << (deg - 3), 1 << (deg - 1), 1, 0], eb)
+            A[100:100 + len(top)] = top
+            B[100:100 + len(top)] = top[::-1]
+            A[200:200 + len(top)] = top
+            B[200:200 + len(top)] = top
+            dA, dB = ctx.from_numpy(A), ctx.from_numpy(B)
+            want = cf.ew(coracle.MUL, A, B)
+            assert (ctx.mul(dA, dB).to_numpy() == want).all(), (deg, hex(mod))
+            assert (ctx.add(dA, dB).to_numpy() == cf.ew(coracle.ADD, A, B)).all()
+            tmp = dA.clone()
+            ctx.mul(tmp, dB, out=tmp)
+            assert (tmp.to_numpy() == want).all(), deg
+            t, m = 2, 5
+            C = np.stack([rand_np(F, eb, n, 500 + deg + j) for j in range(t)])
+            sh = ctx.split(dA, ctx.matrix_from_numpy(C), t, m)
+            assert (sh.to_numpy() == cf.split(A, C, t, m)).all(), (deg, 'split')
+            xs = [2, 4, 5]
+            lam = po.recombination_vector(F, xs, 0)
+            assert (ctx.recombine([sh.row(x - 1) for x in xs], lam).to_numpy() == A).all(), (deg, 'recombine')
+            ones = ctx.recombine([sh.row(0), sh.row(1), sh.row(2)], [1, 1, 1]).to_numpy()
+            assert (ones == cf.recombine([sh.to_numpy()[j] for j in range(3)], [1, 1, 1])).all()
+            inv = ctx.inv(ctx.from_numpy(np.where(A == 0, 1, A).astype(A.dtype)))
+            assert (ctx.mul(inv, ctx.from_numpy(np.where(A == 0, 1, A).astype(A.dtype))).to_numpy() == 1).all(), (deg, 'inv')
 
 
 @pytest.mark.parametrize('modulus', [(1 << 64) | 0x1b, (1 << 40) | 0x39, (1 << 63) | 0x3])
@@ -690,7 +734,7 @@ def test_matmul(eng, coracle):
             assert got == [int(v, 16) for r in c['C'] for v in r], (name, M, K, N)
     for modulus, binary in [(P61, False), (P64, False), (P128, False), (6616326157076047771, False), (2**31 - 1, False),
                             (258797994007609146293811961253269568351, False), (0x11b, True), ((1 << 64) | 0x1b, True),
-                            ((1 << 128) | 0x87, True)]:
+                            ((1 << 128) | 0x87, True), (0x1002b, True), (0x10000008d, True)]:
         F = po.Field(modulus, binary)
         ctx = ctx_for(eng, modulus, binary)
         eb = ctx.elem_bytes
@@ -723,7 +767,7 @@ def test_skinny_products(eng, coracle):
              (1, 4096, 4096), (2, 300, 4098), (5, 1111, 640), (8, 4500, 300), (7, 129, 70)]   # K split over workgroups, several staged tiles
     for modulus, binary in [(P61, False), (P64, False), (2**96 - 17, False), (P128, False), (6616326157076047771, False),
                             (2**31 - 1, False), (258797994007609146293811961253269568351, False),
-                            ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True)]:
+                            ((1 << 64) | 0x1b, True), ((1 << 128) | 0x87, True), (0x10000008d, True)]:
         F = po.Field(modulus, binary)
         ctx = ctx_for(eng, modulus, binary)
         eb = ctx.elem_bytes

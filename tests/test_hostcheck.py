@@ -59,7 +59,8 @@ def test_policy_selection(hostcheck, golden_fields):
     assert kinds['P128'] == PM128_K128 and kinds['P127'] == PM128_GEN and kinds['P96'] == PM96
     assert kinds['P80'] == PM96 and kinds['P128G'] == MONT128 and kinds['P100G'] == MONT128
     assert kinds['GF2_8'] == GF2P8 and kinds['GF2_4'] == GF2P8 and kinds['GF2_1'] == GF2P8
-    assert kinds['GF2_16'] == GF2W64 and kinds['GF2_64'] == GF2W64
+    GF2W32 = 15                      # (round 6: appended to the enumeration, after the two three-limb prime policies)
+    assert kinds['GF2_16'] == GF2W32 and kinds['GF2_64'] == GF2W64
     assert kinds['GF2_100'] == GF2W128 and kinds['GF2_128'] == GF2W128
 
 

@@ -28,6 +28,7 @@ FIELDS = {                                    # name -> (modulus, binary): one p
     'RC32': (2**31 - 1, False), 'P96': (2**96 - 17, False), 'P80': (2**80 - 65, False), 'P128': (2**128 - 173, False),
     'P127': (2**127 - 1, False), 'MONT128': (258797994007609146293811961253269568351, False),
     'GF2_8': (0x11b, True), 'GF2_5': (0b100101, True), 'GF2_64': ((1 << 64) | 0x1b, True), 'GF2_128': ((1 << 128) | 0x87, True),
+    'GF2_16': (0x1002b, True), 'GF2_32': (0x10000008d, True),          # four-byte storage (GF2W32, round 6)
 }
 
 
