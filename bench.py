@@ -1358,7 +1358,9 @@ def main():
                                                             coefficients=[hex(v) for v in lamb][:4], units_per_s=round(n / (ms * 1e-3), 1))
                     # worst case for the same shape: k dense (random) coefficients -> every row goes through the LDS tables
                     import random as _rnd
-                    lamd = [_rnd.Random(1000 + kk).randrange(2, 1 << (8 * ebg)) for _ in range(kk)]
+                    rg_ = _rnd.Random(1000 + kk)                      # ONE generator: k DISTINCT coefficients = k tables (until round 6 a
+                    #                                                   fresh generator per draw made them all equal: one or two tables)
+                    lamd = [rg_.randrange(2, 1 << (8 * ebg)) for _ in range(kk)]
                     plans = [cb_.recombine_plan([shb[i_].row(j) for j in range(kk)], lamd, bufs[i_][2]) for i_ in range(2)]
                     ms = time_launches(lambda pl: pl(), plans, reps)
                     kern[f'recombine_{label}_k{kk}_dense'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu,

@@ -1272,7 +1272,8 @@ struct GF2W64 {
     }
     FF_HD uint64_t muladd(uint64_t a, uint64_t b, uint64_t cadd) const { return mul(a, b) ^ cadd; }
     FF_HD void acc_zero(acc& s) const { s.a = 0; }
-    FF_HD void acc_mac(acc& s, uint64_t lam, uint64_t x) const { s.a ^= mul(x, lam); }
+    // (lam is wave-uniform; 1 -- the runtime's Lagrange coefficients at 0 for m in {3, 7} over GF(2^n) -- is a plain XOR)
+    FF_HD void acc_mac(acc& s, uint64_t lam, uint64_t x) const { s.a ^= lam == 1ull ? x : mul(x, lam); }
     FF_HD uint64_t acc_reduce(const acc& s) const { return s.a; }
 };
 
@@ -1472,7 +1473,7 @@ struct GF2W128 {
     }
     FF_HD void acc_zero(acc& s) const { s.lo = s.hi = 0; }
     FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& x) const {
-        u128e t = mul(x, lam);
+        const u128e t = (lam.lo == 1ull && lam.hi == 0ull) ? x : mul(x, lam);      // (wave-uniform: 1 is a plain XOR)
         s.lo ^= t.lo;
         s.hi ^= t.hi;
     }

@@ -1341,7 +1341,6 @@ __global__ __launch_bounds__(REC_BLOCK) __attribute__((amdgpu_waves_per_eu(DEEP 
                                                                    typename Gf2wTraits<LIMBS>::E* __restrict__ out, size_t n) {
     typedef Gf2wTraits<LIMBS> Tr;
     typedef typename Tr::L L;
-    typedef typename Tr::E E;
     constexpr int NPOS = 16 * LIMBS;
     constexpr int NW = 2 * LIMBS;                            // 32-bit words per element
     constexpr int SH = LIMBS == 2 ? 4 : 3;                   // log2(sizeof(L))
@@ -1396,18 +1395,34 @@ __global__ __launch_bounds__(REC_BLOCK) __attribute__((amdgpu_waves_per_eu(DEEP 
                 const uint2 x = reinterpret_cast<const uint2*>(ra.trow[j])[i];
                 xw[j][0] = x.x; xw[j][1] = x.y;
             }
+        }
+        // further rows of a group (coefficients that repeat): every load is issued before the first is consumed -- the
+        // branches are scalar, and a load XORed inside its branch would wait there for its data, one HBM latency per row
+        bool extra = false;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                if (r + 1 < ra.gcnt[j]) {                        // scalar branch: taken only when coefficients repeat
-                    if constexpr (LIMBS == 2) {
-                        const uint4 x = ldg<true>(reinterpret_cast<const uint4*>(ra.erow[j][r]) + i);
-                        xw[j][0] ^= x.x; xw[j][1] ^= x.y; xw[j][2] ^= x.z; xw[j][3] ^= x.w;
-                    } else {
-                        const uint2 x = reinterpret_cast<const uint2*>(ra.erow[j][r])[i];
-                        xw[j][0] ^= x.x; xw[j][1] ^= x.y;
+        for (int j = 0; j < KT; ++j) extra |= ra.gcnt[j] > 1;
+        if (extra) {
+            uint32_t ex[KT > 0 ? KT : 1][3][NW];
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) ex[j][r][q] = 0;
+                    if (r + 1 < ra.gcnt[j]) {
+                        if constexpr (LIMBS == 2) {
+                            const uint4 x = ldg<true>(reinterpret_cast<const uint4*>(ra.erow[j][r]) + i);
+                            ex[j][r][0] = x.x; ex[j][r][1] = x.y; ex[j][r][2] = x.z; ex[j][r][3] = x.w;
+                        } else {
+                            const uint2 x = reinterpret_cast<const uint2*>(ra.erow[j][r])[i];
+                            ex[j][r][0] = x.x; ex[j][r][1] = x.y;
+                        }
                     }
                 }
-            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int q = 0; q < NW; ++q) xw[j][q] ^= ff_xor3(ex[j][0][q], ex[j][1][q], ex[j][2][q]);
         }
         for (int p = 0; p < ra.kp; ++p) {                    // coefficient 1: XOR, no table (wave-uniform trip count)
             if constexpr (LIMBS == 2) {
@@ -1515,6 +1530,21 @@ static int dispatch_gf2w_rec(const void* policy, int device, const void* const* 
                 ++ra.gcnt[kt];
             }
         ++kt;
+    }
+    if constexpr (LIMBS == 1) {
+        // all coefficients 1 (the runtime's own for m = 3, 7) over 8-byte elements: the XOR of the rows is the same for
+        // PAIRS of elements -- 16 bytes per lane and access, like every other streaming kernel here
+        bool pairs = kt == 0 && ra.kp > 0 && n >= 2 && !(n & 1) && aligned16(out);
+        for (int p = 0; p < ra.kp && pairs; ++p) pairs = aligned16(ra.prow[p]);
+        if (pairs) {
+            Gf2wRecArgs<2> r2;
+            memset(&r2, 0, sizeof(r2));
+            r2.kp = ra.kp;
+            for (int p = 0; p < ra.kp; ++p) r2.prow[p] = ra.prow[p];
+            GF2W128 unused;                                                    // (the policy is read by the table build only)
+            memset(&unused, 0, sizeof(unused));
+            return launch_gf2w_rec<2, 0, false>(&unused, device, r2, out, n / 2, st);
+        }
     }
     // (DEEP = 16 look-ups per batch in flight for every table count > 0: the round-3 measurement; kt = 0 is a plain XOR)
 #define GF2W_REC_CASE(KK)                                                                         \

@@ -30,9 +30,12 @@ for name, mod, tail, eb in (('gf2_128', (1 << 128) | 0x87, (2,), 16), ('gf2_64',
     for i in range(8):
         mtx.row(i).t.copy_(x[i])
     for k in (4, 7):
-        for tag, lam in (('Random(3)', [random.Random(3).randrange(2, F.order) for _ in range(k)]),
-                         ('Random(1000+k) [bench.py]', [random.Random(1000 + k).randrange(2, 1 << (8 * eb)) for _ in range(k)])):
+        rg3, rgb = random.Random(3), random.Random(1000 + k)
+        A = rg3.randrange(2, F.order)
+        for tag, lam in (('k DISTINCT coefficients, Random(3)', [rg3.randrange(2, F.order) for _ in range(k)]),
+                         ('k DISTINCT coefficients, Random(1000+k) [bench.py]', [rgb.randrange(2, 1 << (8 * eb)) for _ in range(k)]),
+                         ('ONE coefficient k times (grouped rows: what bench.py measured as "dense" until round 6)', [A] * k)):
             for layout, rr, oo in (('slices of one tensor', rows[:k], out), ('share-matrix rows', [mtx.row(j) for j in range(k)], mtx.row(7))):
                 plan = ctx.recombine_plan(rr, lam, oo)
                 ms = bench.time_launches(lambda s: plan(), [0], 5)
-                print(name, 'recombine k=%d DENSE %s, %s: %.1f us %.0f GB/s' % (k, tag, layout, ms * 1e3, (k + 1) * eb * n / ms / 1e6))
+                print(name, 'recombine k=%d %s, %s: %.1f us %.0f GB/s' % (k, tag, layout, ms * 1e3, (k + 1) * eb * n / ms / 1e6))

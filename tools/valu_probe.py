@@ -75,7 +75,8 @@ for label, modulus, tail, ebg in (('gf2_64', (1 << 64) | 0x1b, (), 8), ('gf2_128
     for j in range(m2):
         shb.row(j).t.copy_(bufs[j % 2].t)
     for kk in (4, 7):
-        lamd = [random.Random(1000 + kk).randrange(2, 1 << (8 * ebg)) for _ in range(kk)]
+        rg_ = random.Random(1000 + kk)
+        lamd = [rg_.randrange(2, 1 << (8 * ebg)) for _ in range(kk)]        # k distinct coefficients (as bench.py)
         plan = cb.recombine_plan([shb.row(j) for j in range(kk)], lamd, bufs[2])
         rows.append((f'recombine_{label}_k{kk}_dense', plan))
     keep.append((cb, bufs, shb))
