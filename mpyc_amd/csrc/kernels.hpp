@@ -94,6 +94,7 @@ struct MemPack<MONT192> {
     typedef u192e type;
 };
 typedef uint32_t ff_u32x2 __attribute__((ext_vector_type(2)));
+
 template <bool NT>
 __device__ __forceinline__ Pack<u192e> ldg(const u192e* p) {
     const ff_u32x2* q = reinterpret_cast<const ff_u32x2*>(p);     // 8-byte aligned elements: dwordx2 x 3
@@ -151,6 +152,104 @@ __device__ __forceinline__ void stg(e96* p, const Pack<u128e>& x) {
     else *reinterpret_cast<ff_u32x3*>(p) = v;
 }
 
+// ---- wave-contiguous accesses: ldgw / stgw ---------------------------------------------------------------------------
+// CONTRACT (the streaming loops `for (i = gid; i < nvec; i += gsz)` of this file, with the launchers' nvec): all 64 lanes of
+// the wave are active and lane L accesses pack (first lane's pack) + L.  For every pack type but the 24-byte one this is
+// ldg / stg.  24-byte elements (three-limb primes) at one element per lane have a 24-byte lane stride: as three dwordx2 per
+// lane every wave instruction touches twelve 128-byte lines and uses a third of each -- 5.2-5.4 TB/s where the 16-byte
+// fields stream at 6.2-6.4 (tools/tune_x24.hip).  Round 6: the WAVE moves its 64 elements = 1536 contiguous bytes as 96
+// dwordx4 accesses (one instruction on all lanes, one on lanes 0..31) and the lanes pick their own 24 bytes out of a
+// per-wave LDS region (written 16 bytes per lane, read back as three 8-byte words at a 24-byte stride, or the other way
+// round: conflict-free either way); no barrier: a wave's LDS instructions execute in order, a wavefront-scope fence on
+// the LDS address space alone keeps the compiler from reordering them.
+// next iteration's arrays are not held up by anything else.  The launchers (launch.hpp, Launchers<F>::nvec_of) hand 24-byte fields
+// whole waves only (nvec a multiple of 64, the rest goes through the scalar tail) and require 16-byte aligned rows.
+// Loads come in two steps so that a kernel puts ALL its global loads in flight before the first LDS round trip:   auto ra = ldgw_issue<NT>(pa), rb = ldgw_issue<NT>(pb);
+//                                                  P x = ldgw_finish(ra), y = ldgw_finish(rb);
+template <bool NT, class P>
+__device__ __forceinline__ auto ldgw_issue(const P* p) { return ldg<NT>(p); }
+template <class X>
+__device__ __forceinline__ X ldgw_finish(const X& x) { return x; }
+template <bool NT, class P, class X>
+__device__ __forceinline__ void stgw(P* p, const X& x) { stg<NT>(p, x); }
+
+typedef __attribute__((address_space(3))) ff_u32x4 x24_lds4;
+typedef __attribute__((address_space(3))) ff_u32x2 x24_lds2;
+__device__ __forceinline__ x24_lds4* x24_region() {
+    __shared__ __attribute__((aligned(16))) ff_u32x4 x24_lds[BLOCK / 64][96];
+    return (x24_lds4*)(ff_u32x4*)x24_lds[threadIdx.x >> 6];
+}
+// orders the wave's LDS accesses (and only those) for the compiler; emits no instruction -- a wave's LDS instructions execute
+// in order, which is all the lanes need to see each other's writes
+#define X24_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local")
+// first byte of the wave's 64 elements, from the lane's own pointer (the contract: lane L holds first + L): pointer
+// arithmetic on the kernel argument keeps the global address space (global_load, not flat_load)
+__device__ __forceinline__ const ff_u32x4* x24_wave_base(const u192e* p) {
+    return reinterpret_cast<const ff_u32x4*>(reinterpret_cast<const char*>(p) - (size_t)__lane_id() * 24);
+}
+__device__ __forceinline__ ff_u32x4* x24_wave_base(u192e* p) {
+    return reinterpret_cast<ff_u32x4*>(reinterpret_cast<char*>(p) - (size_t)__lane_id() * 24);
+}
+// A wave's 1536 bytes in flight: chunk `lane` and chunk 64 + (lane & 31).  Lanes 32..63 repeat the second access of lanes
+// 0..31 (same address; for stores the same data too) instead of sitting it out under an execution mask: a masked access is
+// a branch, and every branch between the loads of a kernel is a point where the compiler waits for ALL of them.
+struct X24Raw {
+    ff_u32x4 r0, r1;
+};
+template <bool NT>
+__device__ __forceinline__ X24Raw ldgw_issue(const u192e* p) {
+    const ff_u32x4* base = x24_wave_base(p);
+    const uint32_t lane = __lane_id();
+    X24Raw r;
+    if constexpr (NT) {
+        r.r0 = __builtin_nontemporal_load(base + lane);
+        r.r1 = __builtin_nontemporal_load(base + 64 + (lane & 31));
+    } else {
+        r.r0 = base[lane];
+        r.r1 = base[64 + (lane & 31)];
+    }
+    return r;
+}
+__device__ __forceinline__ Pack<u192e> ldgw_finish(const X24Raw& raw) {
+    const uint32_t lane = __lane_id();
+    x24_lds4* L = x24_region();
+    X24_LDS_FENCE();                                       // (after the reads of the previous round trip)
+    L[lane] = raw.r0;
+    L[64 + (lane & 31)] = raw.r1;
+    X24_LDS_FENCE();
+    const x24_lds2* R = reinterpret_cast<const x24_lds2*>(L) + 3 * lane;
+    const ff_u32x2 a0 = R[0], a1 = R[1], b = R[2];
+    Pack<u192e> r;
+    r.w[0].lo = (uint64_t)a0.x | ((uint64_t)a0.y << 32);
+    r.w[0].mid = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+    r.w[0].hi = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    return r;
+}
+template <bool NT>
+__device__ __forceinline__ void stgw(u192e* p, const Pack<u192e>& x) {
+    ff_u32x4* base = x24_wave_base(p);
+    const uint32_t lane = __lane_id();
+    x24_lds4* L = x24_region();
+    x24_lds2* R = reinterpret_cast<x24_lds2*>(L) + 3 * lane;
+    ff_u32x2 a0, a1, b;
+    a0.x = (uint32_t)x.w[0].lo;  a0.y = (uint32_t)(x.w[0].lo >> 32);
+    a1.x = (uint32_t)x.w[0].mid; a1.y = (uint32_t)(x.w[0].mid >> 32);
+    b.x = (uint32_t)x.w[0].hi;   b.y = (uint32_t)(x.w[0].hi >> 32);
+    X24_LDS_FENCE();
+    R[0] = a0;
+    R[1] = a1;
+    R[2] = b;
+    X24_LDS_FENCE();
+    const ff_u32x4 r0 = L[lane], r1 = L[64 + (lane & 31)];
+    if constexpr (NT) {
+        __builtin_nontemporal_store(r0, base + lane);
+        __builtin_nontemporal_store(r1, base + 64 + (lane & 31));
+    } else {
+        base[lane] = r0;
+        base[64 + (lane & 31)] = r1;
+    }
+}
+
 // element <-> word for the scalar tail (identity unless words pack elements)
 template <class F>
 __device__ __forceinline__ typename F::word ld_elem(const typename F::elem* p, size_t i) {
@@ -201,12 +300,14 @@ __device__ __forceinline__ void ew2_body(const F& f, const typename F::elem* __r
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
-        P x = ldg<NT>(av + i);
-        P y = ldg<NT>(bv + i);
+        const auto rx = ldgw_issue<NT>(av + i);
+        const auto ry = ldgw_issue<NT>(bv + i);
+        P x = ldgw_finish(rx);
+        P y = ldgw_finish(ry);
         P r;
 #pragma unroll
         for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x.w[q], y.w[q]);
-        stg<NT>(ov + i, r);
+        stgw<NT>(ov + i, r);
     }
     // scalar tail (n not a multiple of the pack size, or unaligned pointers: nvec == 0)
     const size_t done = nvec * (size_t)(P::N * F::EPW);
@@ -248,11 +349,11 @@ __global__ __launch_bounds__(BLOCK) void k_ew1(F f, const typename F::elem* __re
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
-        P x = ldg<NT>(av + i);
+        P x = ldgw_finish(ldgw_issue<NT>(av + i));
         P r;
 #pragma unroll
         for (int q = 0; q < P::N; ++q) r.w[q] = ew_apply<F, OP>(f, x.w[q], s);
-        stg<NT>(ov + i, r);
+        stgw<NT>(ov + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t e = done + gid; e < n; e += gsz) {
@@ -275,13 +376,16 @@ __global__ __launch_bounds__(BLOCK) void k_muladd(F f, const typename F::elem* _
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
-        P x = ldg<NT>(av + i);
-        P y = ldg<NT>(bv + i);
-        P z = ldg<NT>(cv + i);
+        const auto rx = ldgw_issue<NT>(av + i);
+        const auto ry = ldgw_issue<NT>(bv + i);
+        const auto rz = ldgw_issue<NT>(cv + i);
+        P x = ldgw_finish(rx);
+        P y = ldgw_finish(ry);
+        P z = ldgw_finish(rz);
         P r;
 #pragma unroll
         for (int q = 0; q < P::N; ++q) r.w[q] = f.muladd(x.w[q], y.w[q], z.w[q]);
-        stg<NT>(ov + i, r);
+        stgw<NT>(ov + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t e = done + gid; e < n; e += gsz) {
@@ -312,12 +416,13 @@ __global__ __launch_bounds__(BLOCK) void k_beaver(F f, const typename F::elem* _
         return add_de ? f.muladd(dd, ee, c) : c;       // public term: all parties (Shamir) / one party (additive)
     };
     for (size_t i = gid; i < nvec; i += gsz) {
-        P pz = ldg<NT>(reinterpret_cast<const MP*>(z) + i), px = ldg<NT>(reinterpret_cast<const MP*>(x) + i);
-        P py = ldg<NT>(reinterpret_cast<const MP*>(y) + i), pd = ldg<NT>(reinterpret_cast<const MP*>(d) + i);
-        P pe = ldg<NT>(reinterpret_cast<const MP*>(e) + i), r;
+        const auto rz = ldgw_issue<NT>(reinterpret_cast<const MP*>(z) + i), rx = ldgw_issue<NT>(reinterpret_cast<const MP*>(x) + i);
+        const auto ry = ldgw_issue<NT>(reinterpret_cast<const MP*>(y) + i), rd = ldgw_issue<NT>(reinterpret_cast<const MP*>(d) + i);
+        const auto re = ldgw_issue<NT>(reinterpret_cast<const MP*>(e) + i);
+        P pz = ldgw_finish(rz), px = ldgw_finish(rx), py = ldgw_finish(ry), pd = ldgw_finish(rd), pe = ldgw_finish(re), r;
 #pragma unroll
         for (int q = 0; q < P::N; ++q) r.w[q] = comb(pz.w[q], px.w[q], py.w[q], pd.w[q], pe.w[q]);
-        stg<NT>(reinterpret_cast<MP*>(o) + i, r);
+        stgw<NT>(reinterpret_cast<MP*>(o) + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);
     for (size_t k_ = done + gid; k_ < n; k_ += gsz)
@@ -466,6 +571,9 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     typedef typename MemPack<F>::type MP;
     typedef typename F::word W;
     constexpr int TT = T > 0 ? T : 1;
+    // wave-contiguous accesses (ldgw / stgw): the plain one-pack-per-thread loop only -- with the in-kernel generator a
+    // thread serves packs u * ngroups + ig (waves are neither whole nor aligned there), the chain gate adds row offsets
+    constexpr bool WC = !RNG && !REC;
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
@@ -486,6 +594,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             __syncthreads();
         }
     }
+    decltype(ldgw_issue<NT>(av)) rc[TT];                     // coefficient rows in flight (wave-contiguous path)
     // one pack: loads and the optional local product ...
     auto load_s = [&](size_t i) -> P {
         P s, s2;
@@ -497,8 +606,19 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                            : (gs.plainB ? ldg<NT>(reinterpret_cast<const MP*>(gs.rowsB[0]) + iB)
                                         : gate_load<F, NT>(f, gs.rowsB, gs.lamB, gs.kB, iB));
         } else {
-            s = ldg<NT>(av + i);
-            if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+            if constexpr (WC) {
+                // every load of the pack -- operands AND coefficient rows -- is in flight before the first is consumed
+                const auto rs = ldgw_issue<NT>(av + i);
+                auto rs2 = rs;
+                if constexpr (FUSE_MUL) rs2 = ldgw_issue<NT>(bv + i);
+#pragma unroll
+                for (int j = 0; j < T; ++j) rc[j] = ldgw_issue<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
+                s = ldgw_finish(rs);
+                if constexpr (FUSE_MUL) s2 = ldgw_finish(rs2);
+            } else {
+                s = ldg<NT>(av + i);
+                if constexpr (FUSE_MUL) s2 = ldg<NT>(bv + i);
+            }
         }
         if constexpr (TABMUL) {
             if (ra.aux) {
@@ -527,11 +647,20 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
     // ... then m share evaluations and m stores
     auto eval_store = [&](size_t i, const P& s, W (&c)[TT][P::N]) {
         if constexpr (!(RNG && T > 0)) {
+            if constexpr (WC) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
+                for (int j = 0; j < T; ++j) {                        // (issued by load_s)
+                    const P t_ = ldgw_finish(rc[j]);
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+                    for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const P t_ = ldg<NT>(reinterpret_cast<const MP*>(coef + (size_t)j * cstride) + i);
+#pragma unroll
+                    for (int q = 0; q < P::N; ++q) c[j][q] = t_.w[q];
+                }
             }
         }
         if constexpr (!F::BINARY && T >= 1) {
@@ -550,7 +679,8 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
             for (int party = 1; party <= m; ++party) {
 #pragma unroll
                 for (int q = 0; q < P::N; ++q) y.w[q] = share_diff_next<F, TT>(f, y.w[q], dd[q]);
-                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+                if constexpr (WC) stgw<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+                else stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
         } else {
             // GF(2^n) (the points are field elements, not integers) and T = 0: Horner by the point
@@ -567,7 +697,8 @@ __global__ __launch_bounds__(BLOCK) void k_split(F f, const typename F::elem* __
                         y.w[q] = f.muladd_small(acc, (uint32_t)party, s.w[q]);
                     }
                 }
-                stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+                if constexpr (WC) stgw<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
+                else stg<NT>(reinterpret_cast<MP*>(out + (size_t)(party - 1) * ostride) + i, y);
             }
         }
     };
@@ -800,6 +931,8 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
         P x[K];
+        // (per lane also for 24-byte elements: with K products of three-limb words per output this kernel is as much VALU-
+        // as HBM-bound there, and the LDS round trips of ldgw / stgw cost it 5-10 %: measured, round 6)
 #pragma unroll
         for (int j = 0; j < K; ++j) x[j] = ldg<NT>(reinterpret_cast<const MP*>(ra.rows[j]) + i);
         for (int r = 0; r < w; ++r) {

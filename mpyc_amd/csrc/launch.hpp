@@ -132,9 +132,16 @@ struct Launchers {
     typedef typename F::elem E;
     typedef typename F::word W;
     enum { EPV = Pack<W>::N * F::EPW };  // elements per pack (one lane's access)
-    // dwordx3 needs dword alignment only; three-limb elements go as three dwordx2
-    enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : sizeof(E) == 24 ? 8 : 16 };
+    // dwordx3 needs dword alignment only; three-limb (24-byte) elements are moved by the WAVE as dwordx4 (kernels.hpp, ldgw)
+    enum { PACK_ALIGN = sizeof(E) == 12 ? 4 : 16 };
     static bool al(const void* p) { return ((uintptr_t)p & (PACK_ALIGN - 1)) == 0; }
+    // packs that go through the vector loop of a kernel (the rest: its scalar tail).  24-byte elements: whole waves only --
+    // in `for (i = gid; i < nvec; i += gsz)` every wave is then entirely in or entirely out, which ldgw / stgw rely on
+    static size_t nvec_of(size_t n, bool vec) {
+        if (!vec) return 0;
+        if (sizeof(E) == 24) return n & ~(size_t)63;
+        return n / EPV;
+    }
     // (a member function, not a lambda inside `matmul`: clang does not emit the host stub of a kernel specialisation
     // that is only named inside a generic lambda's discarded-branch neighbourhood)
     template <bool BRAW>
@@ -157,7 +164,7 @@ struct Launchers {
     template <int OP>
     static void go_ew2(const F& f, const LaunchCfg& lc, const E* a, const E* b, E* o, size_t n, hipStream_t st) {
         bool vec = al(a) && al(b) && al(o);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         constexpr int OCC = EwOccupancy<F, OP>::waves;
         // (streamed loads and stores carry the non-temporal hint: +4-8 %, profiles/r01_tuning.md; the un-hinted instantiations
@@ -187,7 +194,7 @@ struct Launchers {
     template <int OP>
     static void go_ew1(const F& f, const LaunchCfg& lc, const E* a, W s, E* o, size_t n, hipStream_t st) {
         bool vec = al(a) && al(o);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_ew1<F, OP, true>), dim3(grid), dim3(BLOCK), 0, st, f, a, s, o, nvec, n);
     }
@@ -216,7 +223,7 @@ struct Launchers {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && al(b) && al(c) && al(o);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_muladd<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a,
                            (const E*)b, (const E*)c, (E*)o, nvec, n);
@@ -248,7 +255,7 @@ struct Launchers {
         bool vec = al(a) && (!FUSE || al(b)) && al(out) &&
                    (stride_ok(ostride) || m <= 1) &&
                    (RNG || t == 0 || (al(coef) && (stride_ok(cstride) || t <= 1)));
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         // RNG kernels serve up to 4 packs per thread (RngLayout::G); a slightly larger grid is harmless.
         // Below ~2.6e5 packs the grouped loop cannot fill the chip: one pack per thread instead (ra.spread).
         RngArgs ra = ra_in;
@@ -304,7 +311,7 @@ struct Launchers {
         constexpr int SLG = scalar_limbs<F>();
         gs.plainA = kA == 1 && lamA2[0] == 1 && lamA2[1] == 0 && (SLG < 3 || lamA2[SLG - 1] == 0);
         gs.plainB = kB == 1 && lamB2[0] == 1 && lamB2[1] == 0 && (SLG < 3 || lamB2[SLG - 1] == 0);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         RngArgs ra = *rng;
         const bool spread = nvec > 0 && nvec < 262144;
         ra.spread = spread ? 1 : 0;
@@ -357,7 +364,7 @@ struct Launchers {
             return 0;
         }
         bool vec = al(coef) && (stride_ok(cstride) || t <= 1);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         switch (t) {
             case 1: hipLaunchKernelGGL((k_rng_coeffs<F, 1>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
             case 2: hipLaunchKernelGGL((k_rng_coeffs<F, 2>), dim3(grid), dim3(BLOCK), 0, st, f, C, cstride, nvec, n, *rng); break;
@@ -383,7 +390,7 @@ struct Launchers {
                 ra.lam[r * K + j] = f.prep(word_at<F>(f, lam2, (size_t)r * K + j));
             }
         for (int i = w * K; i < MAXW * K; ++i) ra.lam[i] = ra.lam[0];
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_recombine<F, K, true>), dim3(grid), dim3(BLOCK), 0, st, f, ra, w, out, ostride,
                            nvec, n);
@@ -438,7 +445,7 @@ struct Launchers {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && al(out);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_pow<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out, nvec, n);
         FFGPU_CHECK_LAUNCH();
@@ -449,7 +456,7 @@ struct Launchers {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && al(out);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         // packs per thread: ONE exponentiation (70 products for 2^61 - 1) is shared by G x CH packs, and the
         // G x CH x N prefix words stay in registers (two waves per SIMD at CH = 8..12 for one-word fields)
         if constexpr (F::EPW == 1 && sizeof(W) == 8) {
@@ -841,7 +848,7 @@ struct Launchers {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(a) && (!b || al(b));
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         size_t iters = nvec ? nvec : n;
         size_t want = (iters + (size_t)BLOCK * 8 - 1) / ((size_t)BLOCK * 8);     // >= 8 packs per thread
         unsigned grid = (unsigned)(want < 1 ? 1 : want > DOT_MAX_BLOCKS ? DOT_MAX_BLOCKS : want);
@@ -935,7 +942,7 @@ struct Launchers {
         const F& f = *reinterpret_cast<const F*>(Fp);
         LaunchCfg lc = launch_cfg(device);
         bool vec = al(z) && al(x) && al(y) && al(d) && al(e) && al(out);
-        size_t nvec = vec ? n / EPV : 0;
+        size_t nvec = nvec_of(n, vec);
         unsigned grid = grid_for(nvec ? nvec : n, lc);
         hipLaunchKernelGGL((k_beaver<F, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)z, (const E*)x, (const E*)y,
                            (const E*)d, (const E*)e, (E*)out, add_de, nvec, n);

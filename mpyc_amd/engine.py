@@ -289,7 +289,7 @@ class FieldContext:
 
     def empty_matrix(self, rows: int, n: int) -> DevMatrix:
         eb = self.elem_bytes
-        per = 64 if eb == 12 else 256 // eb          # elements per 256-byte-aligned pitch unit (768 B for 12-byte elements)
+        per = 64 if eb == 12 else 32 if eb == 24 else 256 // eb      # elements per 256-byte-aligned pitch unit (768 B for 12- and 24-byte elements)
         stride = max(per, (n + per - 1) // per * per)
         if (stride * eb) % 16384 == 0:
             # rows a multiple of 16 KiB apart alias onto the same HBM channels when m rows are

@@ -165,3 +165,61 @@ def test_pm192_golden_vectors_from_the_reference(eng, golden_wide):
     import test_gpu_parity as tp
     tp.test_golden_elementwise(eng, golden_wide)
     tp.test_golden_sharing(eng, golden_wide)
+
+
+def test_wave_contiguous_accesses_of_24_byte_elements(eng):
+    """Round 6: the streaming kernels move 24-byte elements wave by wave (kernels.hpp ldgw / stgw: 1536 contiguous bytes
+    per wave as dwordx4, sorted out through LDS) for whole waves of 16-byte aligned rows, and fall back to the scalar
+    tail for the ragged rest and for rows that are only 8-byte aligned.  Element-wise operations, fused multiply-add,
+    share generation (supplied coefficients, fused product) and the Beaver combination around every wave boundary, on
+    views at odd element offsets, in place, for a 2^k - c prime and a prime of no special shape."""
+    from mpyc_amd.finfields import find_prime_root, next_prime
+    rng = random.Random(2406)
+    for p in (find_prime_root(136)[0], next_prime(2**192 - 2**40)):
+        F = po.Field(p, False)
+        ctx = eng.FieldContext(p, device=0)
+        big = 3 * 256 * 64 + 130                                  # several workgroups, several waves each, a ragged end
+        pool_a = [rng.randrange(p) for _ in range(big + 8)]
+        pool_b = [rng.randrange(p) for _ in range(big + 8)]
+        pool_a[:4] = [0, 1, p - 1, 2**128]
+        DA, DB = dev(ctx, pool_a), dev(ctx, pool_b)
+        for n in (63, 64, 65, 127, 128, 129, 191, 192, 256 + 64, 1000, big):
+            for off in (0, 1, 2):                                 # element offsets 1 (8-byte aligned only) and 2 (16-byte aligned)
+                a, b = pool_a[off:off + n], pool_b[off:off + n]
+                A = eng.DevArray(ctx, DA.t[off:off + n], n)
+                B = eng.DevArray(ctx, DB.t[off:off + n], n)
+                assert host(ctx.mul(A, B)) == [(x * y) % p for x, y in zip(a, b)], (hex(p), n, off)
+                assert host(ctx.add(A, B)) == [(x + y) % p for x, y in zip(a, b)], (hex(p), n, off)
+                assert host(ctx.sub(A, B)) == [(x - y) % p for x, y in zip(a, b)], (hex(p), n, off)
+                s = rng.randrange(p)
+                assert host(ctx.mul_scalar(A, s)) == [(x * s) % p for x in a]
+                assert host(ctx.neg(A)) == [(-x) % p for x in a]
+                assert host(ctx.muladd(A, B, A)) == [(x * y + x) % p for x, y in zip(a, b)]
+            # in place, and an output view at an odd offset of a larger buffer
+            a, b = pool_a[:n], pool_b[:n]
+            A, B = dev(ctx, a), dev(ctx, b)
+            ctx.mul(A, B, out=A)
+            assert host(A) == [(x * y) % p for x, y in zip(a, b)]
+            buf = ctx.empty(n + 3)
+            O = eng.DevArray(ctx, buf.t[1:1 + n], n)
+            ctx.add(dev(ctx, a), B, out=O)
+            assert host(O) == [(x + y) % p for x, y in zip(a, b)]
+            # Beaver combination z + d*y + e*x (+ d*e): five operand rows in flight
+            z, d, e = ([rng.randrange(p) for _ in range(n)] for _ in range(3))
+            got = ctx.beaver_combine(dev(ctx, z), A, B, dev(ctx, d), dev(ctx, e), True)
+            a2 = host(A)
+            assert host(got) == [(zz + dd * y + ee * x + dd * ee) % p for zz, x, y, dd, ee in zip(z, a2, b, d, e)]
+            # share generation with supplied coefficients (+ fused product) and recombination from 2t+1 rows
+            for t, m in ((1, 3), (3, 7)):
+                coef = [[rng.randrange(p) for _ in range(n)] for _ in range(t)]
+                Cm = ctx.matrix_from_numpy(pack([v for row in coef for v in row], 24).reshape(lshape(24, t, n)))
+                draws = [v for row in coef for v in row]
+                A = dev(ctx, a)
+                sh = ctx.split(A, Cm, t, m)
+                assert [unpack(sh.to_numpy()[i], 24) for i in range(m)] == po.np_random_split(F, a, t, m, draws), (hex(p), n, t)
+                prod = [(x * y) % p for x, y in zip(a, b)]
+                fused = ctx.split(A, Cm, t, m, mul_by=B)
+                assert [unpack(fused.to_numpy()[i], 24) for i in range(m)] == po.np_random_split(F, prod, t, m, draws)
+                xs = list(range(1, 2 * t + 2))
+                lam = po.recombination_vector(F, xs, 0)
+                assert host(ctx.recombine([fused.row(x - 1) for x in xs], lam)) == prod
