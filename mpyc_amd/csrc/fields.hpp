@@ -389,6 +389,71 @@ struct RC32 {
 };
 
 // ---------------------------------------------------------------------------
+// Dot products of multi-limb residues in 28-bit digits (round 6): sum_j lam_j * x_j with every operand cut into NL digits of
+// 28 bits and the digit products (< 2^56) added into 2 NL - 1 column sums of 64 bits -- one v_mad_u64_u32 per digit product,
+// no carry anywhere until the single conversion at the end.  The 128-bit arithmetic of acc_mac costs the compiler about 40
+// instructions per 64 x 64 limb product (carry compares, selects); here a three-limb term is 49 multiply-adds + 10 to cut
+// the element, a two-limb term 25 + 7 (the coefficient's digits are wave-uniform: scalar unit).  Recombination of K <= 9
+// rows over a 136-bit prime: ~1700 -> ~600 instructions per element, which puts the kernel back on HBM.
+// Bound: a column holds at most NL products per term: NL * terms * 2^56 < 2^64 for up to FF_D28_MAX_TERMS terms at NL = 7.
+// ---------------------------------------------------------------------------
+enum { FF_D28_MAX_TERMS = 32 };
+template <int NL>
+struct LazyDot {
+    uint64_t c[2 * NL - 1];
+};
+// digit i = bits [28 i, 28 i + 28) of the little-endian 32-bit words w[0..NW)
+template <int NW, int NL>
+FF_HD void ff_digits28(const uint32_t (&w)[NW], uint32_t (&d)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int bit = 28 * i, q = bit >> 5, off = bit & 31;
+        uint32_t v = q < NW ? (w[q < NW ? q : 0] >> off) : 0u;
+        if (off > 4 && q + 1 < NW) v |= w[q + 1 < NW ? q + 1 : 0] << (32 - off);
+        d[i] = v & 0x0fffffffu;
+    }
+}
+template <int NL>
+FF_HD void ff_lazy_zero(LazyDot<NL>& s) {
+#pragma unroll
+    for (int i = 0; i < 2 * NL - 1; ++i) s.c[i] = 0;
+}
+template <int NL>
+FF_HD void ff_lazy_mac(LazyDot<NL>& s, const uint32_t (&dl)[NL], const uint32_t (&dx)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) s.c[i + j] += (uint64_t)dx[i] * dl[j];
+}
+// column sums -> NA little-endian 64-bit limbs.  The value must be below 2^(28 (2 NL - 1) + 28) and below 2^(64 NA).
+template <int NL, int NA>
+FF_HD void ff_lazy_limbs(const LazyDot<NL>& s, uint64_t (&a)[NA]) {
+    constexpr int NC = 2 * NL - 1;
+    uint32_t dg[NC + 2];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const uint64_t t = s.c[i] + carry;
+        dg[i] = (uint32_t)t & 0x0fffffffu;
+        carry = t >> 28;
+    }
+    dg[NC] = (uint32_t)carry;
+    dg[NC + 1] = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        uint32_t wd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int bit = 32 * (2 * j + h), q = bit / 28, off = bit - 28 * q;      // off = 0, 4, ..., 24: two digits per word
+            const uint32_t lo = q <= NC ? dg[q <= NC ? q : 0] >> off : 0u;
+            const uint32_t hi = q + 1 <= NC ? dg[q + 1 <= NC ? q + 1 : 0] << (28 - off) : 0u;
+            wd[h] = lo | hi;
+        }
+        a[j] = (uint64_t)wd[0] | ((uint64_t)wd[1] << 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // PM128: prime p = 2^k - c, 65 <= k <= 128, c < 2^31, two 64-bit limbs
 // (2^128-173, 2^127-1, 2^96-17, the 80-bit SecFxp default, ...).
 // ---------------------------------------------------------------------------
@@ -527,6 +592,25 @@ struct PM128 {
     }
 
 
+    // dot products of at most FF_D28_MAX_TERMS terms in 28-bit digits (see LazyDot): five digits cover 128 bits
+    typedef LazyDot<5> lacc;
+    FF_HD void lacc_zero(lacc& s) const { ff_lazy_zero(s); }
+    FF_HD void lacc_mac(lacc& s, const u128e& lam, const u128e& xe) const {
+        const uint32_t wl[4] = {(uint32_t)lam.lo, (uint32_t)(lam.lo >> 32), (uint32_t)lam.hi, (uint32_t)(lam.hi >> 32)};
+        const uint32_t wx[4] = {(uint32_t)xe.lo, (uint32_t)(xe.lo >> 32), (uint32_t)xe.hi, (uint32_t)(xe.hi >> 32)};
+        uint32_t dl[5], dx[5];
+        ff_digits28(wl, dl);
+        ff_digits28(wx, dx);
+        ff_lazy_mac(s, dl, dx);
+    }
+    FF_HD u128e lacc_reduce(const lacc& s) const {
+        uint64_t a[5];
+        ff_lazy_limbs(s, a);
+        acc t;
+        t.a0 = a[0]; t.a1 = a[1]; t.a2 = a[2]; t.a3 = a[3]; t.a4 = a[4];
+        return acc_reduce(t);
+    }
+
     FF_HD void acc_zero(acc& s) const { s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = 0; }
     FF_HD void acc_mac(acc& s, const u128e& lam, const u128e& xe) const {
         uint64_t x[4];
@@ -586,6 +670,24 @@ struct e96 {
 };
 struct PM96 : PM128<false> {
     typedef e96 elem;
+    // residues below 2^96: four 28-bit digits (16 digit products per term instead of 25)
+    typedef LazyDot<4> lacc;
+    FF_HD void lacc_zero(lacc& s) const { ff_lazy_zero(s); }
+    FF_HD void lacc_mac(lacc& s, const u128e& lam, const u128e& xe) const {
+        const uint32_t wl[3] = {(uint32_t)lam.lo, (uint32_t)(lam.lo >> 32), (uint32_t)lam.hi};
+        const uint32_t wx[3] = {(uint32_t)xe.lo, (uint32_t)(xe.lo >> 32), (uint32_t)xe.hi};
+        uint32_t dl[4], dx[4];
+        ff_digits28(wl, dl);
+        ff_digits28(wx, dx);
+        ff_lazy_mac(s, dl, dx);
+    }
+    FF_HD u128e lacc_reduce(const lacc& s) const {
+        uint64_t a[4];
+        ff_lazy_limbs(s, a);                              // < 2^(192 + 5)
+        acc t;
+        t.a0 = a[0]; t.a1 = a[1]; t.a2 = a[2]; t.a3 = a[3]; t.a4 = 0;
+        return acc_reduce(t);
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -780,6 +882,25 @@ struct PM192 {
     }
     FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
 
+
+    // dot products of at most FF_D28_MAX_TERMS terms in 28-bit digits (see LazyDot): seven digits cover 192 bits
+    typedef LazyDot<7> lacc;
+    FF_HD void lacc_zero(lacc& s) const { ff_lazy_zero(s); }
+    FF_HD void lacc_mac(lacc& s, const u192e& lam, const u192e& xe) const {
+        const uint32_t wl[6] = {(uint32_t)lam.lo, (uint32_t)(lam.lo >> 32), (uint32_t)lam.mid, (uint32_t)(lam.mid >> 32),
+                                (uint32_t)lam.hi, (uint32_t)(lam.hi >> 32)};
+        const uint32_t wx[6] = {(uint32_t)xe.lo, (uint32_t)(xe.lo >> 32), (uint32_t)xe.mid, (uint32_t)(xe.mid >> 32),
+                                (uint32_t)xe.hi, (uint32_t)(xe.hi >> 32)};
+        uint32_t dl[7], dx[7];
+        ff_digits28(wl, dl);
+        ff_digits28(wx, dx);
+        ff_lazy_mac(s, dl, dx);
+    }
+    FF_HD u192e lacc_reduce(const lacc& s) const {
+        acc t;
+        ff_lazy_limbs(s, t.a);
+        return acc_reduce(t);
+    }
 
     FF_HD void acc_zero(acc& s) const {
 #pragma unroll

@@ -474,14 +474,34 @@ struct GateSrc {
     size_t yA, yB, yO;
 };
 
+// Policies with a dot product in 28-bit digits (fields.hpp LazyDot: the multi-limb 2^k - c primes) take it for sums of at
+// most FF_D28_MAX_TERMS terms -- the recombination kernels' K <= MAXK rows; everything else accumulates in F::acc.
+template <class F, class = void>
+struct HasLazyAcc : std::false_type {};
+template <class F>
+struct HasLazyAcc<F, std::void_t<typename F::lacc> > : std::true_type {};
+static_assert(MAXK <= FF_D28_MAX_TERMS, "the digit accumulator's column bound");
+template <class F, class = void>
+struct LazyAccOf {
+    typedef typename F::acc type;
+};
+template <class F>
+struct LazyAccOf<F, std::void_t<typename F::lacc> > {
+    typedef typename F::lacc type;
+};
+
 template <class F, bool NT>
 __device__ __forceinline__ Pack<typename F::word> gate_load(const F& f, const typename F::elem* const* rows,
                                                             const typename F::word* lam, int k, size_t i) {
     typedef Pack<typename F::word> P;
     typedef typename MemPack<F>::type MP;
-    typename F::acc acc[P::N];
+    static_assert(GATE_MAXK <= FF_D28_MAX_TERMS, "the digit accumulator's column bound");
+    using Acc = typename std::conditional<HasLazyAcc<F>::value, typename LazyAccOf<F>::type, typename F::acc>::type;
+    Acc acc[P::N];
 #pragma unroll
-    for (int q = 0; q < P::N; ++q) f.acc_zero(acc[q]);
+    for (int q = 0; q < P::N; ++q) {
+        if constexpr (HasLazyAcc<F>::value) f.lacc_zero(acc[q]); else f.acc_zero(acc[q]);
+    }
     // rows in chunks of four: the loads of a chunk are issued together and waited for once (k is wave-uniform, the
     // guards are scalar branches) -- one load, one wait, one multiply-add per row would expose k memory latencies
     for (int j0 = 0; j0 < k; j0 += 4) {
@@ -493,12 +513,17 @@ __device__ __forceinline__ Pack<typename F::word> gate_load(const F& f, const ty
         for (int u = 0; u < 4; ++u)
             if (j0 + u < k) {
 #pragma unroll
-                for (int q = 0; q < P::N; ++q) f.acc_mac(acc[q], lam[j0 + u], x[u].w[q]);
+                for (int q = 0; q < P::N; ++q) {
+                    if constexpr (HasLazyAcc<F>::value) f.lacc_mac(acc[q], lam[j0 + u], x[u].w[q]);
+                    else f.acc_mac(acc[q], lam[j0 + u], x[u].w[q]);
+                }
             }
     }
     P r;
 #pragma unroll
-    for (int q = 0; q < P::N; ++q) r.w[q] = f.acc_reduce(acc[q]);
+    for (int q = 0; q < P::N; ++q) {
+        if constexpr (HasLazyAcc<F>::value) r.w[q] = f.lacc_reduce(acc[q]); else r.w[q] = f.acc_reduce(acc[q]);
+    }
     return r;
 }
 template <class F>
@@ -931,21 +956,34 @@ __global__ __launch_bounds__(BLOCK) void k_recombine(F f, RecArgs<F, K> ra, int 
     const size_t gsz = (size_t)gridDim.x * BLOCK;
     for (size_t i = gid; i < nvec; i += gsz) {
         P x[K];
-        // (per lane also for 24-byte elements: with K products of three-limb words per output this kernel is as much VALU-
-        // as HBM-bound there, and the LDS round trips of ldgw / stgw cost it 5-10 %: measured, round 6)
+        {
+            // (24-byte elements wave by wave: pays since the dot product runs in 28-bit digits -- the 128-bit arithmetic
+            // before that made the kernel VALU-bound over three-limb primes and the LDS round trips a net loss)
+            decltype(ldgw_issue<NT>(reinterpret_cast<const MP*>(ra.rows[0]))) rx[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = ldg<NT>(reinterpret_cast<const MP*>(ra.rows[j]) + i);
+            for (int j = 0; j < K; ++j) rx[j] = ldgw_issue<NT>(reinterpret_cast<const MP*>(ra.rows[j]) + i);
+#pragma unroll
+            for (int j = 0; j < K; ++j) x[j] = ldgw_finish(rx[j]);
+        }
         for (int r = 0; r < w; ++r) {
             P y;
 #pragma unroll
             for (int q = 0; q < P::N; ++q) {
-                typename F::acc s;
-                f.acc_zero(s);
+                if constexpr (HasLazyAcc<F>::value) {
+                    typename F::lacc s;
+                    f.lacc_zero(s);
 #pragma unroll
-                for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], x[j].w[q]);
-                y.w[q] = f.acc_reduce(s);
+                    for (int j = 0; j < K; ++j) f.lacc_mac(s, ra.lam[r * K + j], x[j].w[q]);
+                    y.w[q] = f.lacc_reduce(s);
+                } else {
+                    typename F::acc s;
+                    f.acc_zero(s);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) f.acc_mac(s, ra.lam[r * K + j], x[j].w[q]);
+                    y.w[q] = f.acc_reduce(s);
+                }
             }
-            stg<NT>(reinterpret_cast<MP*>(out + (size_t)r * ostride) + i, y);
+            stgw<NT>(reinterpret_cast<MP*>(out + (size_t)r * ostride) + i, y);
         }
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);

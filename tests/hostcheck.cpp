@@ -12,7 +12,7 @@
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9, HC_COLDOT = 10 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9, HC_COLDOT = 10, HC_LDOT = 11 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -64,6 +64,11 @@ static typename F::word cst(const F& f, const uint64_t* l) {
     }
 }
 
+template <class F, class = void>
+struct has_lacc : std::false_type {};
+template <class F>
+struct has_lacc<F, std::void_t<typename F::lacc> > : std::true_type {};
+
 // a,b,c: n elements each; for HC_DOT: a holds k rows of n elements, lam holds k
 // canonical 2-limb constants, x ignored.  For HC_MULADD_SMALL x is the small
 // public multiplier.
@@ -88,6 +93,19 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 for (int j = 0; j < k; ++j)
                     f.acc_mac(s, f.prep(cst<F>(f, lam + (sizeof(typename F::word) == 24 ? 3 : 2) * j)), ldw<F>(a, (size_t)j * n + i));
                 r = f.acc_reduce(s);
+                break;
+            }
+            case HC_LDOT: {
+                // the recombination kernels' dot product in 28-bit digits (fields.hpp LazyDot), policies that have one
+                if constexpr (has_lacc<F>::value) {
+                    typename F::lacc s;
+                    f.lacc_zero(s);
+                    for (int j = 0; j < k; ++j)
+                        f.lacc_mac(s, f.prep(cst<F>(f, lam + (sizeof(typename F::word) == 24 ? 3 : 2) * j)), ldw<F>(a, (size_t)j * n + i));
+                    r = f.lacc_reduce(s);
+                } else {
+                    return 2;
+                }
                 break;
             }
             case HC_COLDOT: {

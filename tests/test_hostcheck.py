@@ -11,14 +11,14 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY, HC_COLDOT = range(11)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY, HC_COLDOT, HC_LDOT = range(12)
 
 
 def limbs3(x):
     return (ctypes.c_uint64 * 3)(*[(x >> (64 * i)) & (2**64 - 1) for i in range(3)])
 
 
-def run(hc, F, op, a, b=None, c=None, x=0, lam=None, k=0, n=None):
+def run(hc, F, op, a, b=None, c=None, x=0, lam=None, k=0, n=None, allow_rc=()):
     eb = elem_bytes(F.modulus, F.binary)
     A = pack(a, eb)
     n = n if n is not None else len(a)
@@ -36,6 +36,8 @@ def run(hc, F, op, a, b=None, c=None, x=0, lam=None, k=0, n=None):
     p = lambda z: z.ctypes.data_as(ctypes.c_void_p) if z is not None else None
     rc = hc.hc_run(int(F.binary), limbs3(F.modulus), 3, op, p(A), p(B), p(C), p(out), ctypes.c_size_t(n),
                    ctypes.c_uint32(x), lam_arr, k, ctypes.byref(pk), ctypes.byref(ebo))
+    if rc in allow_rc:
+        return None
     assert rc == 0, rc
     assert ebo.value == eb
     return unpack(out, eb), pk.value
@@ -520,3 +522,32 @@ def test_bitsliced_gf2_64_product(hostcheck):
             o16 = (ctypes.c_uint64 * 16)()
             assert hostcheck.hc_bs64_mul16_packed((ctypes.c_uint64 * 16)(*a[off:off + 16]), (ctypes.c_uint64 * 16)(*b[off:off + 16]), o16) == 0
             assert list(o16) == [po.mul(F, x, y) for x, y in zip(a[off:off + 16], b[off:off + 16])], (rnd, off)
+
+
+def test_dot_products_in_28_bit_digits(hostcheck):
+    """Round 6: the recombination kernels of the multi-limb 2^k - c primes accumulate sum_j lam_j * x_j in 28-bit digits
+    (fields.hpp LazyDot: column sums of digit products, one carry pass at the end).  Every bit length from 65 to 192 that
+    has such a policy, up to the declared bound of 32 terms, operands at the extremes (p - 1 everywhere: the largest
+    columns; single bits around every digit and word boundary) and random."""
+    from mpyc_amd.finfields import find_prime_root
+    rng = random.Random(28)
+    seen = set()
+    for bits in list(range(65, 193, 3)) + [80, 96, 97, 112, 113, 128, 129, 136, 160, 191, 192]:
+        p = find_prime_root(bits)[0]
+        if p in seen:
+            continue
+        seen.add(p)
+        F = po.Field(p, False)
+        k = p.bit_length()
+        marks = sorted({v % p for e in (27, 28, 29, 31, 32, 33, 55, 56, 57, 63, 64, 65, 83, 84, 85, 95, 96, 111, 112, 113, 127, 128, 139,
+                                        140, 141, 167, 168, 169, k - 1) if e < k for v in (1 << e, (1 << e) - 1)})
+        for kk in (1, 2, 3, 4, 7, 9, 32):
+            n = 12 + len(marks)
+            rows = [([p - 1] * 6 + [rng.randrange(p) for _ in range(6)] + marks) if j % 2 == 0 else
+                    ([p - 1] * 3 + [rng.randrange(p) for _ in range(9)] + marks[::-1]) for j in range(kk)]
+            for lam in ([p - 1] * kk, [rng.randrange(p) for _ in range(kk)], [marks[(3 * j) % len(marks)] for j in range(kk)]):
+                flat = [v for r in rows for v in r]
+                rc = run(hostcheck, F, HC_LDOT, flat, lam=lam, k=kk, n=n, allow_rc=(2,))
+                assert rc is not None, (bits, 'no digit accumulator for a multi-limb 2^k - c prime')
+                got, _ = rc
+                assert got == [sum(lam[j] * rows[j][i] for j in range(kk)) % p for i in range(n)], (hex(p), kk)
