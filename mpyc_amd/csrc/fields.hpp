@@ -454,6 +454,88 @@ FF_HD void ff_lazy_limbs(const LazyDot<NL>& s, uint64_t (&a)[NA]) {
 }
 
 // ---------------------------------------------------------------------------
+// Product chains in digits (round 6): the exponentiations behind sqrt / inverse sqrt / pow over the multi-limb 2^k - c
+// primes.  np_random_bits (runtime.py:4243-4273) takes the inverse square root of f x n opened squares for every
+// fixed-point product of n elements -- over the 80-bit default prime of SecFxp() that one kernel was two thirds of the
+// product's GPU time.  A value is NL digits of w bits, w = ceil(k / NL) <= 28, so that 2^(w NL) == cs := c 2^(w NL - k)
+// (mod p) folds at a DIGIT boundary: a product is NL^2 multiply-adds into column sums (NL (NL + 1) / 2 for a square), one
+// carry pass, NL multiply-adds by cs, a second carry pass and one more multiply-add -- ~45 instructions at NL = 3 where
+// the 128-bit arithmetic of mul() takes ~100 -- and values stay partially reduced until the chain ends.
+// Invariant of every value entering or leaving mul / sqr:  d[i] < 2^w (i < NL - 1),  d[NL - 1] < 2^(w + 1).
+// Needs cs < 2^20 (every default prime: c < 2^13); other moduli keep the limb arithmetic.
+// ---------------------------------------------------------------------------
+template <int NL>
+struct DigitChain {
+    uint32_t w, mask, cs;
+    struct val {
+        uint32_t d[NL];
+    };
+    FF_HD bool setup(uint32_t k, uint32_t c) {
+        w = (k + NL - 1) / NL;
+        if (w > 28 || w < 22) return false;               // (k >= 65: w >= 22; the bounds below are worked out for 22..28)
+        const uint32_t sh = w * NL - k;                      // < NL
+        if (c >> (20 - sh)) return false;                     // cs < 2^20, in 32-bit arithmetic throughout (a 64-bit
+        cs = c << sh;                                         // intermediate here made every product by cs 64 x 32)
+        mask = (1u << w) - 1u;
+        return true;
+    }
+    // column sums (< 2^61) -> value: carry pass, fold the upper NL digits (+ the carry) by cs, carry pass, fold the carry
+    FF_HD val reduce(const uint64_t (&col)[2 * NL - 1]) const {
+        uint32_t e[2 * NL];
+        uint64_t carry = 0;
+#pragma unroll
+        for (int m = 0; m < 2 * NL - 1; ++m) {
+            const uint64_t t = col[m] + carry;
+            e[m] = (uint32_t)t & mask;
+            carry = t >> w;
+        }
+        e[2 * NL - 1] = (uint32_t)carry;                     // < 2^(w + 3)
+        uint32_t fd[NL];
+        carry = 0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const uint64_t t = (uint64_t)e[NL + j] * cs + e[j] + carry;      // < 2^(w + 24)
+            fd[j] = (uint32_t)t & mask;
+            carry = t >> w;                                   // < 2^24
+        }
+        val r;
+        carry = (uint64_t)(uint32_t)carry * cs + fd[0];       // 2^(w NL) == cs once more: < 2^45
+#pragma unroll
+        for (int j = 0; j < NL - 1; ++j) {
+            r.d[j] = (uint32_t)carry & mask;
+            carry = (carry >> w) + fd[j + 1];
+        }
+        r.d[NL - 1] = (uint32_t)carry;                        // < 2^w + 2^15
+        return r;
+    }
+    FF_HD val mul(const val& x, const val& y) const {
+        uint64_t col[2 * NL - 1];
+#pragma unroll
+        for (int m = 0; m < 2 * NL - 1; ++m) col[m] = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) col[i + j] += (uint64_t)x.d[i] * y.d[j];
+        return reduce(col);
+    }
+    FF_HD val sqr(const val& x) const {
+        uint64_t col[2 * NL - 1];
+        uint32_t x2[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) x2[i] = x.d[i] << 1;     // < 2^30
+#pragma unroll
+        for (int m = 0; m < 2 * NL - 1; ++m) col[m] = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            col[2 * i] += (uint64_t)x.d[i] * x.d[i];
+#pragma unroll
+            for (int j = i + 1; j < NL; ++j) col[i + j] += (uint64_t)x2[i] * x.d[j];
+        }
+        return reduce(col);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // PM128: prime p = 2^k - c, 65 <= k <= 128, c < 2^31, two 64-bit limbs
 // (2^128-173, 2^127-1, 2^96-17, the 80-bit SecFxp default, ...).
 // ---------------------------------------------------------------------------
@@ -592,6 +674,30 @@ struct PM128 {
     }
 
 
+    // product chains in digits (see DigitChain): NL = ceil(k / 28) digits -- 3 up to 84 bits, 4 up to 112, 5 beyond
+    enum { CHAIN_MIN_NL = 3, CHAIN_MAX_NL = 5 };
+    template <int NL>
+    FF_HD bool chain_setup(DigitChain<NL>& dc) const { return dc.setup(k, c); }
+    template <int NL>
+    FF_HD typename DigitChain<NL>::val chain_in(const DigitChain<NL>& dc, const u128e& a) const {
+        const ff_u128 v = U(a);
+        typename DigitChain<NL>::val r;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r.d[i] = (uint32_t)(v >> (dc.w * i)) & dc.mask;
+        return r;
+    }
+    template <int NL>
+    FF_HD u128e chain_out(const DigitChain<NL>& dc, const typename DigitChain<NL>::val& x) const {
+        uint64_t t[3] = {0, 0, 0};                           // the digits do not overlap: OR them into place
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t pos = dc.w * i, q = pos >> 6, sh = pos & 63;
+            const uint64_t lo = (uint64_t)x.d[i] << sh, hi = sh ? (uint64_t)x.d[i] >> (64 - sh) : 0;
+            if (q == 0) { t[0] |= lo; t[1] |= hi; } else { t[1] |= lo; t[2] |= hi; }
+        }
+        return E(fold3<true>(t[2], ff_make128(t[1], t[0])));  // < 2^(k + 5) -> canonical
+    }
+
     // dot products of at most FF_D28_MAX_TERMS terms in 28-bit digits (see LazyDot): five digits cover 128 bits
     typedef LazyDot<5> lacc;
     FF_HD void lacc_zero(lacc& s) const { ff_lazy_zero(s); }
@@ -670,6 +776,7 @@ struct e96 {
 };
 struct PM96 : PM128<false> {
     typedef e96 elem;
+    enum { CHAIN_MIN_NL = 3, CHAIN_MAX_NL = 4 };          // (at most 96 bits)
     // residues below 2^96: four 28-bit digits (16 digit products per term instead of 25)
     typedef LazyDot<4> lacc;
     FF_HD void lacc_zero(lacc& s) const { ff_lazy_zero(s); }
@@ -882,6 +989,36 @@ struct PM192 {
     }
     FF_HD u192e muladd(const u192e& a, const u192e& b, const u192e& cadd) const { return add(mul(a, b), cadd); }
 
+
+    // product chains in digits (see DigitChain): NL = ceil(k / 28) digits -- 5 up to 140 bits, 6 up to 168, 7 beyond
+    enum { CHAIN_MIN_NL = 5, CHAIN_MAX_NL = 7 };
+    template <int NL>
+    FF_HD bool chain_setup(DigitChain<NL>& dc) const { return dc.setup(k, c); }
+    template <int NL>
+    FF_HD typename DigitChain<NL>::val chain_in(const DigitChain<NL>& dc, const u192e& a) const {
+        typename DigitChain<NL>::val r;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t pos = dc.w * i, q = pos >> 6, sh = pos & 63;     // wave-uniform: selects, not indexing
+            const uint64_t lo = q == 0 ? a.lo : q == 1 ? a.mid : a.hi;
+            const uint64_t hi = q == 0 ? a.mid : q == 1 ? a.hi : 0;
+            const uint64_t v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+            r.d[i] = (uint32_t)v & dc.mask;
+        }
+        return r;
+    }
+    template <int NL>
+    FF_HD u192e chain_out(const DigitChain<NL>& dc, const typename DigitChain<NL>::val& x) const {
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;             // the digits do not overlap: OR them into place
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t pos = dc.w * i, q = pos >> 6, sh = pos & 63;
+            const uint64_t lo = (uint64_t)x.d[i] << sh, hi = sh ? (uint64_t)x.d[i] >> (64 - sh) : 0;
+            if (q == 0) { t0 |= lo; t1 |= hi; } else if (q == 1) { t1 |= lo; t2 |= hi; } else { t2 |= lo; t3 |= hi; }
+        }
+        const uint64_t t[4] = {t0, t1, t2, t3};
+        return fold<false>(t);                               // < 2^(k + 8) -> canonical
+    }
 
     // dot products of at most FF_D28_MAX_TERMS terms in 28-bit digits (see LazyDot): seven digits cover 192 bits
     typedef LazyDot<7> lacc;

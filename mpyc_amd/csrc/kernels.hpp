@@ -1119,9 +1119,11 @@ struct ExpArgs {
 //  * WINDOWS = false leaves the window table out (square-and-multiply for whatever follows the leading run): the
 //    batched inverse holds its prefix products across the exponentiation and the eight odd powers cost it 16 registers
 //    plus their live ranges; the host picks this form when the exponent's tail is short (ff_pow_lean_ok).
-template <class F, bool WINDOWS = true>
-__device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
-    typedef typename F::word W;
+// (the chain itself is generic over an arithmetic `ops` -- value type V, mul, sqr --: the policy's own words with
+// ff_mul_lazy / ff_sqr_lazy, or the digit form of fields.hpp DigitChain)
+template <bool WINDOWS, class Ops>
+__device__ __forceinline__ typename Ops::V ff_pow_chain(const Ops& ops, const typename Ops::V a, const ExpArgs& ex) {
+    typedef typename Ops::V W;
     auto bit = [&](int i) -> uint32_t { return (uint32_t)(ex.e[i >> 6] >> (i & 63)) & 1u; };
     int run = 0;                                 // length of the leading run of set bits (word at a time: scalar clz)
     for (int top = ex.nbits - 1; top >= 0;) {
@@ -1139,11 +1141,11 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
         int have = 1;                            // r = a^(2^have - 1)
         for (int b = 30 - __builtin_clz((unsigned)run); b >= 0; --b) {
             W t = r;
-            for (int q = 0; q < have; ++q) t = ff_sqr_lazy(f, t);
-            r = ff_mul_lazy(f, t, r);
+            for (int q = 0; q < have; ++q) t = ops.sqr(t);
+            r = ops.mul(t, r);
             have *= 2;
             if ((run >> b) & 1) {
-                r = ff_mul_lazy(f, ff_sqr_lazy(f, r), a);
+                r = ops.mul(ops.sqr(r), a);
                 ++have;
             }
         }
@@ -1157,15 +1159,15 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
     }
     if (!WINDOWS || i < 4 || ones <= 8 + (i + 1) / 8) {
         for (; i >= 0; --i) {
-            r = ff_sqr_lazy(f, r);
-            if (bit(i)) r = ff_mul_lazy(f, r, a);
+            r = ops.sqr(r);
+            if (bit(i)) r = ops.mul(r, a);
         }
-        return ff_canon(f, r);
+        return r;
     }
-    const W a2 = ff_sqr_lazy(f, a);
-    const W t1 = a, t3 = ff_mul_lazy(f, t1, a2), t5 = ff_mul_lazy(f, t3, a2), t7 = ff_mul_lazy(f, t5, a2),
-            t9 = ff_mul_lazy(f, t7, a2), t11 = ff_mul_lazy(f, t9, a2), t13 = ff_mul_lazy(f, t11, a2),
-            t15 = ff_mul_lazy(f, t13, a2);
+    const W a2 = ops.sqr(a);
+    const W t1 = a, t3 = ops.mul(t1, a2), t5 = ops.mul(t3, a2), t7 = ops.mul(t5, a2),
+            t9 = ops.mul(t7, a2), t11 = ops.mul(t9, a2), t13 = ops.mul(t11, a2),
+            t15 = ops.mul(t13, a2);
     auto odd = [&](uint32_t v) -> W {            // v odd, 1..15, wave-uniform
         switch (v >> 1) {
             case 0: return t1;
@@ -1180,7 +1182,7 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
     };
     while (i >= 0) {
         if (!bit(i)) {
-            r = ff_sqr_lazy(f, r);
+            r = ops.sqr(r);
             --i;
             continue;
         }
@@ -1188,11 +1190,60 @@ __device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word 
         while (!bit(j)) ++j;                     // the window ends on a set bit: its value is odd
         uint32_t v = 0;
         for (int q = i; q >= j; --q) v = (v << 1) | bit(q);
-        for (int q = i; q >= j; --q) r = ff_sqr_lazy(f, r);
-        r = ff_mul_lazy(f, r, odd(v));
+        for (int q = i; q >= j; --q) r = ops.sqr(r);
+        r = ops.mul(r, odd(v));
         i = j - 1;
     }
-    return ff_canon(f, r);
+    return r;
+}
+template <class F>
+struct WordChainOps {                            // the policy's own words, partially reduced where it can (mul_lazy)
+    typedef typename F::word V;
+    const F& f;
+    __device__ __forceinline__ V mul(const V& x, const V& y) const { return ff_mul_lazy(f, x, y); }
+    __device__ __forceinline__ V sqr(const V& x) const { return ff_sqr_lazy(f, x); }
+};
+template <int NL>
+struct DigitChainOps {
+    typedef typename DigitChain<NL>::val V;
+    DigitChain<NL> dc;
+    __device__ __forceinline__ V mul(const V& x, const V& y) const { return dc.mul(x, y); }
+    __device__ __forceinline__ V sqr(const V& x) const { return dc.sqr(x); }
+};
+template <class F, bool WINDOWS = true>
+__device__ __forceinline__ typename F::word ff_pow(const F& f, typename F::word a, const ExpArgs& ex) {
+    const WordChainOps<F> ops{f};
+    return ff_canon(f, ff_pow_chain<WINDOWS>(ops, a, ex));
+}
+// The same in digits where the policy has them (fields.hpp DigitChain: the multi-limb 2^k - c primes) -- ~40 instead of ~100
+// instructions per product; used by k_pow (sqrt, inverse sqrt, pow: ~80 products per element, every element).
+template <class F, class = void>
+struct HasDigitChain : std::false_type {};
+template <class F>
+struct HasDigitChain<F, std::void_t<decltype(F::CHAIN_MAX_NL)> > : std::true_type {};
+template <class F, int NL>
+__device__ __forceinline__ bool ff_pow_digits_nl(const F& f, const typename F::word& a, const ExpArgs& ex, typename F::word& out) {
+    DigitChainOps<NL> ops;
+    if (!f.template chain_setup<NL>(ops.dc)) return false;
+    out = f.template chain_out<NL>(ops.dc, ff_pow_chain<true>(ops, f.template chain_in<NL>(ops.dc, a), ex));
+    return true;
+}
+template <class F, int NL>
+__device__ __forceinline__ bool ff_pow_digits_from(const F& f, const typename F::word& a, const ExpArgs& ex, typename F::word& out) {
+    if constexpr (NL > F::CHAIN_MAX_NL) {
+        return false;
+    } else {
+        if (f.k <= 28u * NL) return ff_pow_digits_nl<F, NL>(f, a, ex, out);     // (f.k is wave-uniform: scalar branches)
+        return ff_pow_digits_from<F, NL + 1>(f, a, ex, out);
+    }
+}
+template <class F>
+__device__ __forceinline__ typename F::word ff_pow_digits(const F& f, typename F::word a, const ExpArgs& ex) {
+    if constexpr (HasDigitChain<F>::value) {
+        typename F::word out;
+        if (ff_pow_digits_from<F, F::CHAIN_MIN_NL>(f, a, ex, out)) return out;
+    }
+    return ff_pow(f, a, ex);
 }
 
 // ---- out = a^e, public exponent e >= 1 (finfields.py:1159-1187, :1408-1414) ------------------
@@ -1209,7 +1260,7 @@ __global__ __launch_bounds__(BLOCK) void k_pow(F f, const typename F::elem* __re
         P x = ldg<NT>(av + i);
         P r;
 #pragma unroll
-        for (int q = 0; q < P::N; ++q) r.w[q] = ff_pow(f, x.w[q], ex);
+        for (int q = 0; q < P::N; ++q) r.w[q] = ff_pow_digits(f, x.w[q], ex);
         stg<NT>(ov + i, r);
     }
     const size_t done = nvec * (size_t)(P::N * F::EPW);

@@ -12,7 +12,7 @@
 
 using namespace ffgpu;
 
-enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9, HC_COLDOT = 10, HC_LDOT = 11 };
+enum { HC_ADD = 0, HC_SUB = 1, HC_MUL = 2, HC_NEG = 3, HC_REDUCE = 4, HC_MULADD = 5, HC_MULADD_SMALL = 6, HC_DOT = 7, HC_SHARE = 8, HC_LAZY = 9, HC_COLDOT = 10, HC_LDOT = 11, HC_CHAIN = 12 };
 
 template <class F>
 static typename F::word ldw(const unsigned char* p, size_t i) {
@@ -69,6 +69,11 @@ struct has_lacc : std::false_type {};
 template <class F>
 struct has_lacc<F, std::void_t<typename F::lacc> > : std::true_type {};
 
+template <class F, class = void>
+struct has_chain : std::false_type {};
+template <class F>
+struct has_chain<F, std::void_t<decltype(F::CHAIN_MAX_NL)> > : std::true_type {};
+
 // a,b,c: n elements each; for HC_DOT: a holds k rows of n elements, lam holds k
 // canonical 2-limb constants, x ignored.  For HC_MULADD_SMALL x is the small
 // public multiplier.
@@ -93,6 +98,38 @@ static int run(const PolicyBlob& pb, int op, const unsigned char* a, const unsig
                 for (int j = 0; j < k; ++j)
                     f.acc_mac(s, f.prep(cst<F>(f, lam + (sizeof(typename F::word) == 24 ? 3 : 2) * j)), ldw<F>(a, (size_t)j * n + i));
                 r = f.acc_reduce(s);
+                break;
+            }
+            case HC_CHAIN: {
+                // a product chain in digits (fields.hpp DigitChain; kernels.hpp ff_pow_digits): u v, then six times
+                // square-and-multiply, partially reduced throughout, canonical at the end.  x = number of digits (3..7)
+                if constexpr (has_chain<F>::value) {
+                    auto go = [&](auto nl) -> int {
+                        constexpr int NL = decltype(nl)::value;
+                        DigitChain<NL> dc;
+                        if (!f.template chain_setup<NL>(dc)) return 3;
+                        auto u = f.template chain_in<NL>(dc, ldw<F>(a, i)), v = f.template chain_in<NL>(dc, ldw<F>(b, i));
+                        auto t = dc.mul(u, v);
+                        for (int j = 0; j < 6; ++j) {
+                            t = dc.sqr(t);
+                            t = dc.mul(t, (j & 1) ? u : v);
+                        }
+                        r = f.template chain_out<NL>(dc, t);
+                        return 0;
+                    };
+                    int rc = 3;
+                    auto pick = [&](auto nl) {
+                        constexpr int NL = decltype(nl)::value;
+                        if constexpr (NL >= F::CHAIN_MIN_NL && NL <= F::CHAIN_MAX_NL) {
+                            if ((int)x == NL) rc = go(nl);
+                        }
+                    };
+                    pick(std::integral_constant<int, 3>()); pick(std::integral_constant<int, 4>()); pick(std::integral_constant<int, 5>());
+                    pick(std::integral_constant<int, 6>()); pick(std::integral_constant<int, 7>());
+                    if (rc) return rc;
+                } else {
+                    return 2;
+                }
                 break;
             }
             case HC_LDOT: {

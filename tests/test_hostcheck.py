@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle.coracle import elem_bytes
 from fieldutil import cross, edge_values, field_of, pack, rand_values, unhex, unpack
 
-HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY, HC_COLDOT, HC_LDOT = range(12)
+HC_ADD, HC_SUB, HC_MUL, HC_NEG, HC_REDUCE, HC_MULADD, HC_MULADD_SMALL, HC_DOT, HC_SHARE, HC_LAZY, HC_COLDOT, HC_LDOT, HC_CHAIN = range(13)
 
 
 def limbs3(x):
@@ -551,3 +551,43 @@ def test_dot_products_in_28_bit_digits(hostcheck):
                 assert rc is not None, (bits, 'no digit accumulator for a multi-limb 2^k - c prime')
                 got, _ = rc
                 assert got == [sum(lam[j] * rows[j][i] for j in range(kk)) % p for i in range(n)], (hex(p), kk)
+
+
+def test_product_chains_in_digits(hostcheck):
+    """Round 6: sqrt / inverse sqrt / pow over the two-limb 2^k - c primes run their product chain in NL digits of
+    ceil(k / NL) bits (fields.hpp DigitChain), partially reduced until the end.  Every bit length 65..192, every digit
+    count that fits, chains of 13 products from extreme and random operands, against Python integers."""
+    from mpyc_amd.finfields import find_prime_root
+    rng = random.Random(2806)
+    seen = set()
+    for bits in range(65, 193):
+        p = find_prime_root(bits)[0]
+        if p in seen:
+            continue
+        seen.add(p)
+        F = po.Field(p, False)
+        k = p.bit_length()
+        c = (1 << k) - p
+        ev = sorted({v % p for v in (0, 1, 2, p - 1, p - 2, (p - 1) // 2, 2**64 - 1, 2**64, 2**(k - 1), 2**(k - 1) - 1, c, c + 1, p - c,
+                                      2**27, 2**28 - 1, 2**54, 2**56 - 1, 2**81, 2**84 - 1, 2**128, 2**140 - 1, 2**168)})
+        a, b = cross(ev)
+        a += [rng.randrange(p) for _ in range(200)]
+        b += [rng.randrange(p) for _ in range(200)]
+        def chain(u, v):
+            t = u * v % p
+            for j in range(6):
+                t = t * t % p
+                t = t * (u if j & 1 else v) % p
+            return t
+        want = [chain(u, v) for u, v in zip(a, b)]
+        ran = 0
+        for nl in (3, 4, 5, 6, 7):
+            w = -(-k // nl)
+            rc = run(hostcheck, F, HC_CHAIN, a, b, x=nl, allow_rc=(3,))
+            if rc is None:
+                lo_nl, hi_nl = (3, 4) if k <= 96 else (3, 5) if k <= 128 else (5, 7)
+                assert not (lo_nl <= nl <= hi_nl and 22 <= w <= 28 and (c << (w * nl - k)) < 2**20), (bits, nl)
+                continue
+            assert rc[0] == want, (hex(p), nl)
+            ran += 1
+        assert ran >= 1, (bits, 'no digit chain for a default prime')
