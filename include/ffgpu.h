@@ -447,7 +447,7 @@ int ffgpu_time_recombine(ffgpu_ctx* ctx, const void* const* host_rows, const uin
 int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* stream);
 /* VALU issue-rate yardstick (the compute-side counterpart of ffgpu_time_copy): what the chip sustains for one instruction
  * kind -- op 0: v_bitop3_b32, 1: v_add_u32, 2: v_mad_u64_u32, 3: v_xor_b32, 4: v_perm_b32, 5: v_lshrrev_b32, 6: v_and_or_b32,
- * 7: v_add3_u32, 8: v_mul_lo_u32, 9: v_alignbit_b32 (rotate), 10: v_lshl_or_b32, 11: v_alignbyte_b32 -- with `waves_per_simd` waves on every SIMD and `iters` x 128
+ * 7: v_add3_u32, 8: v_mul_lo_u32, 9: v_alignbit_b32 (rotate), 10: v_lshl_or_b32, 11: v_alignbyte_b32, 12: v_lshrrev_b64, 13: v_lshl_add_u64 -- with `waves_per_simd` waves on every SIMD and `iters` x 128
  * instructions in 8 independent dependent-chains per wave.  out3[0] = lane-operations per second (events around the launch),
  * out3[1] = shader clock in MHz under that load (s_memtime against the 100 MHz counter), out3[2] = shader cycles per wave
  * instruction and SIMD.  scratch32: 32 bytes of device memory.  bench.py prices its VALU-bound rows with it.

@@ -1293,7 +1293,7 @@ int ffgpu_copy(ffgpu_ctx* ctx, const void* src, void* dst, size_t bytes, void* s
 }
 int ffgpu_valu_probe(ffgpu_ctx* ctx, int op, int iters, int waves_per_simd, void* scratch32, double* out3, void* stream) {
     ARGCHK(ctx && scratch32 && out3);
-    ARGCHK(op >= 0 && op <= 11 && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8);
+    ARGCHK(op >= 0 && op <= 13 && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8);
     DeviceGuard g(ctx->device);
     return launch_status(ffgpu_launch_valu_probe(ctx->device, op, iters, waves_per_simd, scratch32, out3, (hipStream_t)stream));
 }

@@ -1595,6 +1595,7 @@ int ffgpu_launch_copy(int device, const void* src, void* dst, size_t bytes, hipS
 //   op 0: v_bitop3_b32 (the 3-input logic op of the GF(2^n) kernels)      op 1: v_add_u32      op 3: v_xor_b32
 //   op 2: v_mad_u64_u32 (the 32 x 32 + 64 multiply-add every prime-field product is made of)     op 4: v_perm_b32
 //   op 5: v_lshrrev_b32      op 6: v_and_or_b32      op 7: v_add3_u32      op 8: v_mul_lo_u32
+//   op 9..11: v_alignbit_b32, v_lshl_or_b32, v_alignbyte_b32      op 12: v_lshrrev_b64      op 13: v_lshl_add_u64
 // (measured, round 5: two-operand VOP2 instructions issue at ~2 cycles per wave64 once a SIMD holds two or more waves, the
 // three-operand VOP3 ones and the multiplies at ~4: profiles/r05_valu_rates.md)
 template <int OP>
@@ -1624,7 +1625,9 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
                 else if constexpr (OP == 8) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
                 else if constexpr (OP == 9) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(a[k]));        // rotate (ChaCha)
                 else if constexpr (OP == 10) asm volatile("v_lshl_or_b32 %0, %0, 12, %1" : "+v"(a[k]) : "v"(b));
-                else asm volatile("v_alignbyte_b32 %0, %0, %0, 1" : "+v"(a[k]));
+                else if constexpr (OP == 11) asm volatile("v_alignbyte_b32 %0, %0, %0, 1" : "+v"(a[k]));
+                else if constexpr (OP == 12) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(q[k]));            // 64-bit shift (carry passes)
+                else asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[k]) : "v"(q[(k + 1) & 7]));          // 64-bit add
             }
         }
     }
@@ -1644,7 +1647,7 @@ __global__ __launch_bounds__(BLOCK) void k_valu_probe(uint32_t* __restrict__ sin
 int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, void* scratch32, double* out, hipStream_t st) {
     // SYNCHRONISES the stream (event + a blocking read-back of the cycle counts): a measurement aid, not capturable
     LaunchCfg lc = launch_cfg(device);
-    if (op < 0 || op > 11 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
+    if (op < 0 || op > 13 || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return 1;
     const unsigned grid = (unsigned)(lc.num_cu * waves_per_simd);           // 256 threads = 4 waves = one per SIMD
     uint32_t* sink = (uint32_t*)scratch32;
     uint64_t* clk = (uint64_t*)((char*)scratch32 + 16);
@@ -1657,8 +1660,8 @@ int ffgpu_launch_valu_probe(int device, int op, int iters, int waves_per_simd, v
     auto launch = [&](int n_it) {
 #define FF_PROBE_CASE(OPV) case OPV: hipLaunchKernelGGL(k_valu_probe<OPV>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); break;
         switch (op) { FF_PROBE_CASE(0) FF_PROBE_CASE(1) FF_PROBE_CASE(2) FF_PROBE_CASE(3) FF_PROBE_CASE(4) FF_PROBE_CASE(5)
-                      FF_PROBE_CASE(6) FF_PROBE_CASE(7) FF_PROBE_CASE(8) FF_PROBE_CASE(9) FF_PROBE_CASE(10)
-                      default: hipLaunchKernelGGL(k_valu_probe<11>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); }
+                      FF_PROBE_CASE(6) FF_PROBE_CASE(7) FF_PROBE_CASE(8) FF_PROBE_CASE(9) FF_PROBE_CASE(10) FF_PROBE_CASE(11) FF_PROBE_CASE(12)
+                      default: hipLaunchKernelGGL(k_valu_probe<13>, dim3(grid), dim3(BLOCK), 0, st, sink, clk, n_it); }
 #undef FF_PROBE_CASE
     };
     launch(iters / 4 + 1);                                                    // warm-up: clocks ramp

@@ -11,7 +11,8 @@ from mpyc_amd.engine import FieldContext
 
 OPS = ['v_bitop3_b32 (VOP3, 3 sources)', 'v_add_u32 (VOP2)', 'v_mad_u64_u32 (VOP3b)', 'v_xor_b32 (VOP2)', 'v_perm_b32 (VOP3)',
        'v_lshrrev_b32 (VOP2, constant shift)', 'v_and_or_b32 (VOP3)', 'v_add3_u32 (VOP3)', 'v_mul_lo_u32 (VOP3)',
-       'v_alignbit_b32 (VOP3, rotate)', 'v_lshl_or_b32 (VOP3)', 'v_alignbyte_b32 (VOP3)']
+       'v_alignbit_b32 (VOP3, rotate)', 'v_lshl_or_b32 (VOP3)', 'v_alignbyte_b32 (VOP3)', 'v_lshrrev_b64 (VOP3, 64-bit shift)',
+       'v_lshl_add_u64 (VOP3, 64-bit add)']
 ctx = FieldContext(2**61 - 1)
 simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
 print('| instruction | waves per SIMD | lane-ops/s | shader clock (MHz) | lanes per cycle and SIMD | cycles per wave64 instruction |')
