@@ -557,7 +557,9 @@ def api_leg(n_full, parties_on_gpus=False):
         env['PYTHONPATH'] = os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, ref_root])
         for k_ in ('MPYC_GPU', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'FXP_SEED', 'FXP_DIGEST', 'MPYC_AMD_PRSS_PRF'):
             env.pop(k_, None)
-        env.update(FXP_MODE=mode, FXP_N=str(n_), FXP_REPS='3' if mode != 'ref' else '1', MPYC_AMD_IPC_WIRE='1' if ipc else '0')
+        # (one party: six repetitions -- the first two or three still pay allocator growth and clock ramp: 54 / 45 / 26 ms seen where
+        # the steady state is 7-10)
+        env.update(FXP_MODE=mode, FXP_N=str(n_), FXP_REPS=('6' if parties == 1 else '3') if mode != 'ref' else '1', MPYC_AMD_IPC_WIRE='1' if ipc else '0')
         if prf:
             env['MPYC_AMD_PRSS_PRF'] = prf
         cmd = [sys.executable, os.path.join(ROOT, 'tests', 'fxp_program.py'), '--no-log'] + \
@@ -1460,6 +1462,36 @@ def main():
             del a3, b3, c3, sh3, y3, rec3
             torch.cuda.empty_cache()
             lap('p136')
+            # the 80-bit prime of the default SecFxp() (12-byte storage): product, recombination from 2t+1 rows, and the
+            # inverse square root that np_random_bits takes of every opened square (runtime.py:4243-4273: f x n of them per
+            # fixed-point product of n elements -- two thirds of that product's GPU time until round 6's digit chains)
+            P80 = find_prime_root(80)[0]
+            ctx80 = FieldContext(P80, device=local_rank)
+            eb80 = ctx80.elem_bytes                                       # 12
+
+            def rows80():
+                a_ = DevArray(ctx80, torch.randint(0, 2**31 - 1, (n, 3), dtype=torch.int32, device=ctx.torch_device, generator=gen), n)
+                return ctx80.reduce(a_, out=a_)
+            a8_, b8_, c8_ = rows80(), rows80(), ctx80.empty(n)
+            ms = time_launches(lambda s_: ctx80.mul(a8_, b8_, out=c8_), [0], reps)
+            kern['mul_p80'] = dict(roof(3 * eb80 * n, ms), algorithmic_bytes_per_unit=3 * eb80, units_per_s=round(n / (ms * 1e-3), 1))
+            sh80 = ctx80.empty_matrix(m2, n)
+            ctx80.split_rng(c8_, t2, m2, key=bytes(range(32)), nonce=9, out=sh80)
+            for kk in (t2 + 1, 2 * t2 + 1):
+                y80 = ctx80.empty(n)
+                rec80 = ctx80.recombine_plan([sh80.row(j) for j in range(kk)], lagrange(P80, range(1, kk + 1)), y80)
+                ms = time_launches(lambda s_: rec80(), [0], reps)
+                bpu = (kk + 1) * eb80
+                kern[f'recombine_p80_k{kk}'] = dict(roof(bpu * n, ms), algorithmic_bytes_per_unit=bpu, units_per_s=round(n / (ms * 1e-3), 1))
+                if not torch.equal(y80.t, c8_.t):
+                    raise SystemExit('bench parity check failed for the 80-bit field')
+            e_inv_sqrt = (3 * P80 - 5) >> 2                               # a^((3p-5)/4) = a^(-1/2) for p = 3 mod 4 (finfields.py:1424-1437)
+            ms = time_launches(lambda s_: ctx80.pow(a8_, e_inv_sqrt, out=c8_), [0], max(2, reps // 4))
+            kern['inv_sqrt_p80'] = dict(roof(2 * eb80 * n, ms), algorithmic_bytes_per_unit=2 * eb80, units_per_s=round(n / (ms * 1e-3), 1),
+                                        bound='valu', bound_note='~106 products per element, in three 27-bit digits (fields.hpp DigitChain)')
+            del a8_, b8_, c8_, sh80, y80, rec80
+            torch.cuda.empty_cache()
+            lap('p80')
             # configs[4]: GF(2^8) (AES field): element-wise mul and the local S-box layer
             ctx8 = FieldContext(0x11b, binary=True, device=local_rank)
             # demos/np_aes.py:23-33: A = circulant([1,0,0,0,1,1,1,1]) (row j = first row rolled by j), B = 0x63

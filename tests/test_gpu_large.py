@@ -115,7 +115,7 @@ def test_valu_probe_reports_plausible_rates():
     from mpyc_amd.engine import FieldContext
     ctx = FieldContext(2**61 - 1)
     rates = {}
-    for op in range(12):
+    for op in range(14):
         for w in (1, 4):
             rate, mhz, cyc = ctx.valu_probe(op, iters=1000, waves_per_simd=w)
             assert 5e12 < rate < 1.5e14 and 500 < mhz < 3500 and cyc > 0, (op, w, rate, mhz, cyc)
@@ -123,5 +123,7 @@ def test_valu_probe_reports_plausible_rates():
     assert rates[3, 4] > 1.3 * rates[0, 4]          # v_xor_b32 (VOP2) against v_bitop3_b32 (VOP3)
     assert rates[1, 4] > 1.5 * rates[1, 1]          # a SIMD needs two or more waves for the two-operand rate
     assert rates[1, 4] > 1.3 * rates[9, 4]          # v_alignbit_b32 (the ChaCha rotate) is an ordinary three-operand instruction
+    for op64 in (12, 13):                           # 64-bit shift / add (the carry passes of the digit arithmetic): the same class,
+        assert 0.7 * rates[2, 4] < rates[op64, 4] < 1.4 * rates[2, 4]        # not a multi-pass instruction (v_mad_u64_u32 beside them)
     with pytest.raises(ValueError):
-        ctx.valu_probe(12)
+        ctx.valu_probe(14)

@@ -58,6 +58,13 @@ t2, m2 = 3, 7
 s64 = bench.StepData(ctx64, n, t2, m2, gen)
 for rounds in (20, 12, 8):
     rows.append((f'split_rng_p64_m7t3_chacha{rounds}', lambda rounds=rounds: ctx64.split_rng(s64.a, t2, m2, key=key, nonce=7, rounds=rounds, out=s64.shares)))
+# ---- the 80-bit prime of the default SecFxp(): the inverse square roots of np_random_bits (product chain in 27-bit digits)
+P80 = find_prime_root(80)[0]
+ctx80 = FieldContext(P80, device=0)
+a80 = DevArray(ctx80, torch.randint(0, 2**31 - 1, (n, 3), dtype=torch.int32, device='cuda:0', generator=gen), n)
+a80 = ctx80.reduce(a80, out=a80)
+c80 = ctx80.empty(n)
+rows.append(('inv_sqrt_p80', lambda: ctx80.pow(a80, (3 * P80 - 5) >> 2, out=c80)))
 # ---- 136-bit prime (three limbs)
 P136 = find_prime_root(136)[0]
 ctx136 = FieldContext(P136, device=0)
