@@ -603,6 +603,7 @@ int ffgpu_muladd(ffgpu_ctx* ctx, const void* a, const void* b, const void* c, vo
 
 static int make_exp(const uint64_t* e, int limbs, ExpArgs* ex) {
     if (!e || limbs < 1 || limbs > 3) return FFGPU_EINVAL;
+    ex->post = 0;
     ex->e[0] = e[0];
     ex->e[1] = limbs > 1 ? e[1] : 0;
     ex->e[2] = limbs > 2 ? e[2] : 0;
@@ -616,12 +617,68 @@ static int make_exp(const uint64_t* e, int limbs, ExpArgs* ex) {
     return FFGPU_OK;
 }
 
+// products (squarings + multiplications) of ff_pow_chain<true> for this exponent: the same decisions, on the host
+static int exp_chain_cost(const ExpArgs& ex) {
+    auto bit = [&](int i) -> int { return (int)((ex.e[i >> 6] >> (i & 63)) & 1u); };
+    if (ex.nbits <= 1) return 0;
+    int run = 0;
+    for (int i = ex.nbits - 1; i >= 0 && bit(i); --i) ++run;
+    int cost = 0, i = ex.nbits - 2;
+    if (run >= 12) {
+        int have = 1;
+        for (int b = 30 - __builtin_clz((unsigned)run); b >= 0; --b) {
+            cost += have + 1;
+            have *= 2;
+            if ((run >> b) & 1) {
+                cost += 2;
+                ++have;
+            }
+        }
+        i = ex.nbits - 1 - run;
+    }
+    int ones = 0;
+    for (int b = i; b >= 0; --b) ones += bit(b);
+    if (i < 4 || ones <= 8 + (i + 1) / 8) return cost + (i + 1) + ones;
+    cost += 8;                                              // a^2 and the seven odd powers
+    while (i >= 0) {
+        if (!bit(i)) {
+            ++cost;
+            --i;
+            continue;
+        }
+        int j = i - 3 > 0 ? i - 3 : 0;
+        while (!bit(j)) ++j;
+        cost += (i - j + 1) + 1;
+        i = j - 1;
+    }
+    return cost;
+}
+// e = 3 e' + 1 with a shorter chain for e' (+ 3 products for r^3 * a): hand over (e', post = 1)
+static void exp_try_cube_form(ExpArgs* ex) {
+    if (ex->nbits < 16) return;
+    uint64_t q[3];
+    unsigned __int128 rem = 0;
+    for (int l = 2; l >= 0; --l) {
+        const unsigned __int128 cur = (rem << 64) | ex->e[l];
+        q[l] = (uint64_t)(cur / 3);
+        rem = cur % 3;
+    }
+    if (rem != 1) return;
+    ExpArgs alt;
+    if (make_exp(q, 3, &alt) != FFGPU_OK || alt.nbits == 0) return;
+    if (exp_chain_cost(alt) + 3 < exp_chain_cost(*ex)) {
+        alt.post = 1;
+        *ex = alt;
+    }
+}
+
 int ffgpu_pow(ffgpu_ctx* ctx, const void* a, const uint64_t* host_exp, int exp_limbs, void* out, size_t n,
               void* stream) {
     ARGCHK(ctx);
     ExpArgs ex;
     int rc = make_exp(host_exp, exp_limbs, &ex);
     if (rc != FFGPU_OK) return rc;
+    exp_try_cube_form(&ex);
     if (n == 0) return FFGPU_OK;
     ARGCHK(a && out);
     DeviceGuard g(ctx->device);
@@ -748,7 +805,7 @@ int ffgpu_inv(ffgpu_ctx* ctx, const void* a, void* out, size_t n, void* dev_zero
     LaunchTimer lt(ctx, (hipStream_t)stream);
     if (ctx->kind == FFGPU_PRIME && q == 2) {   // GF(2): 1^-1 = 1
         ExpArgs one;
-        one.e[0] = 1; one.e[1] = one.e[2] = 0; one.nbits = 1;
+        one.e[0] = 1; one.e[1] = one.e[2] = 0; one.nbits = 1; one.post = 0;
         return launch_status(ctx->ops->inv(ctx->policy, ctx->device, a, &one, out, n, (int*)dev_zero_flag,
                                            (hipStream_t)stream));
     }

@@ -1104,6 +1104,9 @@ FF_HD typename F::word ff_zero_apply(const F&, typename F::word r, uint32_t zm) 
 struct ExpArgs {
     uint64_t e[3];   // public exponent, little-endian limbs (three for the three-limb prime fields)
     int nbits;       // bit length of the exponent (>= 1)
+    int post = 0;    // 1: the result is r^3 * a for r = a^e -- ffgpu_pow hands a^(3 e' + 1) over as (e', post) when the chain
+    //                  for e' is shorter: the inverse square root exponent (3p - 5) / 4 of p = 3 mod 4 starts "10111...", which
+    //                  defeats the leading-run doubling, while e' = (p - 3) / 4 is one long run of ones (finfields.py:1424-1437)
 };
 
 // a^e for a public (wave-uniform) exponent e >= 1.  Every branch is on the exponent (scalar); intermediates are
@@ -1122,7 +1125,15 @@ struct ExpArgs {
 // (the chain itself is generic over an arithmetic `ops` -- value type V, mul, sqr --: the policy's own words with
 // ff_mul_lazy / ff_sqr_lazy, or the digit form of fields.hpp DigitChain)
 template <bool WINDOWS, class Ops>
+__device__ __forceinline__ typename Ops::V ff_pow_chain_core(const Ops& ops, const typename Ops::V a, const ExpArgs& ex);
+template <bool WINDOWS, class Ops>
 __device__ __forceinline__ typename Ops::V ff_pow_chain(const Ops& ops, const typename Ops::V a, const ExpArgs& ex) {
+    typename Ops::V r = ff_pow_chain_core<WINDOWS>(ops, a, ex);
+    if (ex.post) r = ops.mul(ops.mul(ops.sqr(r), r), a);        // (wave-uniform)
+    return r;
+}
+template <bool WINDOWS, class Ops>
+__device__ __forceinline__ typename Ops::V ff_pow_chain_core(const Ops& ops, const typename Ops::V a, const ExpArgs& ex) {
     typedef typename Ops::V W;
     auto bit = [&](int i) -> uint32_t { return (uint32_t)(ex.e[i >> 6] >> (i & 63)) & 1u; };
     int run = 0;                                 // length of the leading run of set bits (word at a time: scalar clz)
