@@ -262,6 +262,12 @@ def test_pow_and_inverse_kernels(eng, modulus, binary):
               2**59, (q - 1) // 2, q // 3 | 1, 0x9E3779B97F4A7C15F39CC0605CEDC834 % q]
     if q.bit_length() > 64:
         shapes += [2**64 - 1, 2**65 - 1, (2**70 - 1) << 5 | 9, 2**64, 2**63]
+    # exponents 3 e' + 1 with a long run of ones in e' (round 6: ffgpu_pow raises to e' and finishes with r^3 a when that
+    # chain is shorter): the inverse square root exponent (3q - 5) / 4 of a prime q = 3 mod 4 (finfields.py:1424-1437) and
+    # constructed ones, beside neighbours that must NOT take that form
+    for e1 in ((q - 3) // 4, 2**20 - 1, 2**45 - 5, (2**33 - 1) << 7 | 0x55, q // 5):
+        if e1 > 8:
+            shapes += [3 * e1 + 1, 3 * e1 + 2, 3 * e1]
     for e in [0, 1, 2, 3, 254, 65537, q - 2, q - 1, (q + 1) // 4 if q > 4 else 1] + [e for e in shapes if 0 < e < q]:
         if e < 0:
             continue
