@@ -68,4 +68,30 @@ for rep in range(3):
         rec()
 torch.cuda.synchronize()
 assert torch.equal(sets[0][4].t, sets[0][5].t)
+del sets
+torch.cuda.empty_cache()
+# 24-byte elements (136-bit prime), round 6: the wave moves 1536 contiguous bytes as dwordx4 accesses in which lanes 32..63
+# repeat the second access of lanes 0..31 -- do the repeated lanes cost HBM traffic?  (mul, share generation m=3,t=1 with
+# supplied coefficients, recombination k=3)
+P136 = gff.find_prime_root(136)[0]
+ctx = FieldContext(P136, device=0)
+t, m, k = 1, 3, 3
+lam = list(gth._recombination_vector(gff.GF(P136), tuple(range(1, k + 1)), 0))
+sets = []
+for _ in range(3):
+    x = torch.randint(0, 2**62, (3, n, 3), dtype=torch.int64, device='cuda:0', generator=gen)
+    rows = [ctx.reduce(DevArray(ctx, x[i], n)) for i in range(3)]
+    coef = ctx.empty_matrix(t, n)
+    coef.row(0).t.copy_(rows[2].t)
+    sh = ctx.empty_matrix(m, n)
+    y, c = ctx.empty(n), ctx.empty(n)
+    sets.append((rows[0], rows[1], coef, sh, y, c, ctx.recombine_plan([sh.row(j) for j in range(k)], lam, y)))
+    del x
+for rep in range(3):
+    for a_, b_, coef, sh, y, c, rec in sets:
+        ctx.mul(a_, b_, out=c)
+        ctx.split(c, coef, t, m, out=sh)
+        rec()
+torch.cuda.synchronize()
+assert torch.equal(sets[0][4].t, sets[0][5].t)
 print('pmc probe done')

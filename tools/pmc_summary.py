@@ -29,6 +29,9 @@ alg = {  # algorithmic bytes per launch at n = 10^7 64-bit elements
     'k_ew2<PM128<true>, 2, true>': (320e6, 160e6),            # 16-byte elements (configs[3])
     'k_split<PM128<true>, 3, false, true, false, false>': (640e6, 1120e6),
     'k_recombine<PM128<true>, 7, true>': (1120e6, 160e6),
+    'k_ew2<PM192, 2, true>': (480e6, 240e6),                 # 24-byte elements, wave-contiguous accesses (round 6)
+    'k_split<PM192, 1, false, true, false, false>': (480e6, 720e6),
+    'k_recombine<PM192, 3, true>': (720e6, 240e6),
 }
 out, lines = {}, ['| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | read MB (2x FETCH) | write MB | traffic MB | algorithmic MB | traffic/alg |',
                   '|---|---|---|---|---|---|---|---|---|']
