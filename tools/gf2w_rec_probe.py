@@ -1,12 +1,14 @@
-"""scratch probe: table recombination with VM direct rows (FFGPU_REC_VM), distinct / grouped coefficients"""
+"""Table recombination over GF(2^128) / GF(2^64), n = 10^7: the runtime's own coefficient vectors (parties 1..4, 1..5, 1..7), k
+distinct dense coefficients (k tables), grouped coefficients (rows that share a coefficient share a table); prints time, GB/s
+and a digest of the result (round 6: how the mislabelled "dense" bench rows were found; the FFGPU_REC_VM switch this probe was
+first written for -- some rows by direct multiplication beside the tables -- measured slower and is gone)."""
 import os, sys, torch, random, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mpyc_amd.engine import FieldContext, DevArray
 from mpyc_amd import finfields as gff, gfpx as ggx, thresha as gth
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(1)
 n = 10_000_000
-vm = os.environ.get('FFGPU_REC_VM', '0')
 for name, mod, tail, eb in (('gf2_128', (1 << 128) | 0x87, (2,), 16), ('gf2_64', (1 << 64) | 0x1b, (), 8)):
     ctx = FieldContext(mod, binary=True, device=0)
     F = gff.GF(ggx.GFpX(2)(mod))
@@ -27,4 +29,4 @@ for name, mod, tail, eb in (('gf2_128', (1 << 128) | 0x87, (2,), 16), ('gf2_64',
         ms = bench.time_launches(lambda s: plan(), [0], 20)
         torch.cuda.synchronize()
         dg = hashlib.sha256(out.t.cpu().numpy().tobytes()).hexdigest()[:12]
-        print(f'VM={vm}', name, tag, '%.1f us  %.0f GB/s' % (ms * 1e3, (len(lam) + 1) * eb * n / ms / 1e6), dg, flush=True)
+        print(name, tag, '%.1f us  %.0f GB/s' % (ms * 1e3, (len(lam) + 1) * eb * n / ms / 1e6), dg, flush=True)
