@@ -106,3 +106,28 @@ def test_random_sweep(eng, coracle):
             inv = unpack(ctx.inv(dA, check_zero=False).to_numpy(), eb)
             for i in chk:
                 assert (inv[i] == 0) if vals[i] == 0 else (po.mul(F, inv[i], vals[i]) == 1), ('inv', i) + tag
+
+
+def test_digit_arithmetic_every_bit_length(eng):
+    """Round 6: recombination (dot products in 28-bit digits, fields.hpp LazyDot) and exponentiation (product chains in
+    ceil(k / NL)-bit digits, DigitChain; exponents 3 e' + 1 as (e', r^3 a)) over the 2^k - c primes of EVERY bit length
+    65..192 -- every digit width and count the kernels can take -- against Python integers."""
+    from mpyc_amd.finfields import find_prime_root
+    from fieldutil import pack
+    rng = random.Random(6192)
+    for bits in range(65, 193):
+        p = find_prime_root(bits)[0]
+        ctx = eng.FieldContext(p, device=0)
+        eb = ctx.elem_bytes
+        n = 70
+        rows = [[0, 1, p - 1, p - 2, (p - 1) // 2, 2**64 % p] + [rng.randrange(p) for _ in range(n - 6)] for _ in range(9)]
+        dev = [ctx.from_numpy(pack(r, eb)) for r in rows]
+        for k in (1, 2, 5, 9):
+            lam = [p - 1 if j % 4 == 0 else rng.randrange(p) for j in range(k)]
+            got = unpack(ctx.recombine(dev[:k], lam).to_numpy(), eb)
+            assert got == [sum(lam[j] * rows[j][i] for j in range(k)) % p for i in range(n)], (bits, k)
+        a = rows[0]
+        exps = [(p + 1) // 4, (3 * p - 5) // 4, (p - 1) // 2, p - 2, rng.randrange(p), 3 * (2**40 - 1) + 1]
+        for e in exps:
+            got = unpack(ctx.pow(dev[0], e).to_numpy(), eb)
+            assert got == [pow(x, e, p) for x in a], (bits, hex(e))
