@@ -1489,6 +1489,9 @@ def main():
             ms = time_launches(lambda s_: ctx80.pow(a8_, e_inv_sqrt, out=c8_), [0], max(2, reps // 4))
             kern['inv_sqrt_p80'] = dict(roof(2 * eb80 * n, ms), algorithmic_bytes_per_unit=2 * eb80, units_per_s=round(n / (ms * 1e-3), 1),
                                         bound='valu', bound_note='~106 products per element, in three 27-bit digits (fields.hpp DigitChain)')
+            ms = time_launches(lambda s_: ctx80.inv(a8_, out=c8_, check_zero=False), [0], reps)
+            kern['inv_p80'] = dict(roof(2 * eb80 * n, ms), algorithmic_bytes_per_unit=2 * eb80, units_per_s=round(n / (ms * 1e-3), 1),
+                                   bound='valu', bound_note='batched inverse in digits: 32 elements per thread share one exponentiation (k_inv_digits)')
             del a8_, b8_, c8_, sh80, y80, rec80
             torch.cuda.empty_cache()
             lap('p80')

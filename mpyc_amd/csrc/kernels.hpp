@@ -1397,6 +1397,84 @@ __global__ __launch_bounds__(BLOCK) void k_inv_batch(F f, const typename F::elem
 }
 
 
+// ---- batched inverse over the multi-limb 2^k - c primes, in digits (round 6) ---------------------------------------
+// k_inv_batch carries two- and three-limb words: ~100 instructions per product and, at 8 elements per thread, a twelfth of
+// an exponentiation of ~100 products per element -- 430 us per 10^7 elements over the 80-bit prime where the one-word primes
+// take 45.  Here the whole batch lives in the digit form of fields.hpp DigitChain (NL registers per value, ~47 instructions
+// per product): CH elements per thread (32 at NL = 3) share one exponentiation; prefix products, the power and the
+// back-substitution never leave the digit domain, elements are converted on the way in and out.  Same structure and zero
+// handling as k_inv_batch (second read of the operands from the caches, zeros replaced by one and masked at the end).
+// compile-time loop: body(integral_constant<int, I>) for I = FROM, FROM + STEP, ... -- `#pragma unroll` gives up on bodies this
+// large (the prefix array then gets a run-time index and moves to scratch memory)
+template <int I, int END, int STEP, class Fn>
+__device__ __forceinline__ void ff_static_for(Fn&& fn) {
+    if constexpr ((STEP > 0 && I < END) || (STEP < 0 && I > END)) {
+        fn(std::integral_constant<int, I>());
+        ff_static_for<I + STEP, END, STEP>(fn);
+    }
+}
+template <class F, int NL, int CH, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_inv_digits(F f, const typename F::elem* __restrict__ a, ExpArgs ex,
+                                                       typename F::elem* __restrict__ o, size_t nvec, size_t n,
+                                                       int* __restrict__ flag) {
+    typedef Pack<typename F::word> P;
+    typedef typename MemPack<F>::type MP;
+    typedef typename F::word W;
+    typedef typename DigitChain<NL>::val V;
+    static_assert(P::N == 1 && CH <= 64, "one element per pack; zero mask has 64 bits");
+    DigitChainOps<NL> ops;
+    const bool ok = f.template chain_setup<NL>(ops.dc);     // (the launcher has checked it)
+    const MP* __restrict__ av = reinterpret_cast<const MP*>(a);
+    MP* __restrict__ ov = reinterpret_cast<MP*>(o);
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * BLOCK;
+    uint32_t anyzero = 0;
+    V one;
+#pragma unroll
+    for (int d = 0; d < NL; ++d) one.d[d] = d == 0 ? 1u : 0u;
+    for (size_t i0 = gid; ok && i0 < nvec; i0 += gsz * CH) {
+        V pre[CH], tot = one;
+        uint64_t zbits = 0;
+        ff_static_for<0, CH, 1>([&](auto ic) {
+            constexpr int c = decltype(ic)::value;
+            const size_t j = i0 + (size_t)c * gsz;
+            W v = ff_one(f);
+            if (j < nvec) v = ldg<false>(av + j).w[0];       // (kept cacheable: read again below)
+            uint32_t zq;
+            v = ff_zero_fix(f, v, zq);
+            zbits |= (uint64_t)(zq & 1u) << c;
+            pre[c] = tot;                                    // product of everything BEFORE this element
+            tot = ops.mul(tot, f.template chain_in<NL>(ops.dc, v));
+        });
+        anyzero |= zbits != 0;
+        V ginv = ff_pow_chain<true>(ops, tot, ex);           // (product of all)^-1
+        const bool wave_has_zero = __any(zbits != 0);
+        ff_static_for<CH - 1, -1, -1>([&](auto ic) {
+            constexpr int c = decltype(ic)::value;
+            const size_t j = i0 + (size_t)c * gsz;
+            W v = ff_one(f);
+            if (j < nvec) v = ldg<NT>(av + j).w[0];          // second read of the operands (cache hit)
+            P r;
+            r.w[0] = f.template chain_out<NL>(ops.dc, ops.mul(ginv, pre[c]));
+            if (wave_has_zero) {                             // scalar branch: rare
+                uint32_t zq;
+                v = ff_zero_fix(f, v, zq);
+                r.w[0] = ff_zero_apply(f, r.w[0], zq);
+            }
+            if constexpr (c > 0) ginv = ops.mul(ginv, f.template chain_in<NL>(ops.dc, v));
+            if (j < nvec) stg<NT>(ov + j, r);
+        });
+    }
+    const size_t done = nvec * (size_t)(P::N * F::EPW);
+    for (size_t e = done + gid; e < n; e += gsz) {
+        uint32_t z;
+        W v = ff_zero_fix(f, ld_elem<F>(a, e), z);
+        anyzero |= z;
+        st_elem<F>(o, e, ff_zero_apply(f, ff_pow(f, v, ex), z));
+    }
+    if (anyzero && flag) atomicOr(flag, 1);
+}
+
 // ---- batched inverse, one-word fields: full batches without bounds checks ------------------------------------------
 // Same arithmetic as k_inv_batch (prefix products per group, one exponentiation per thread, back-substitution with a
 // second read of the operands).  What differs is the shape of the code around it:

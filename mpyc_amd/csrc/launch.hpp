@@ -490,8 +490,35 @@ struct Launchers {
             if (best == 10) return launch_inv<10, 2>(f, lc, a, ex, out, nvec, n, flag, st);
             return launch_inv<8, 2>(f, lc, a, ex, out, nvec, n, flag, st);
         } else {
+            if constexpr (HasDigitChain<F>::value) {
+                // multi-limb 2^k - c primes: the whole batch in digits (k_inv_digits), NL = ceil(k / 28) registers per value
+                if (nvec >= 4096) {
+                    int rc = launch_inv_digits_from<F::CHAIN_MIN_NL>(f, lc, a, ex, out, nvec, n, flag, st);
+                    if (rc >= 0) return rc;
+                }
+            }
             constexpr int CH = F::EPW > 1 ? 2 : 8;          // packed bytes: 8 words per batch (zero mask)
             return launch_inv<CH, 1>(f, lc, a, ex, out, nvec, n, flag, st);
+        }
+    }
+    // -1: the modulus has no digit form at this NL (DigitChain::setup: c too large) -> the word kernel
+    template <int NL>
+    static int launch_inv_digits_from(const F& f, const LaunchCfg& lc, const void* a, const ExpArgs* ex, void* out, size_t nvec,
+                                      size_t n, int* flag, hipStream_t st) {
+        if constexpr (!HasDigitChain<F>::value) {
+            return -1;
+        } else if constexpr (NL > F::CHAIN_MAX_NL) {
+            return -1;
+        } else {
+            if (f.k > 28u * NL) return launch_inv_digits_from<NL + 1>(f, lc, a, ex, out, nvec, n, flag, st);
+            DigitChain<NL> dc;
+            if (!f.template chain_setup<NL>(dc)) return -1;
+            constexpr int CH = NL <= 3 ? 32 : NL == 4 ? 24 : NL <= 6 ? 16 : 12;      // ~96 registers of prefix products
+            unsigned grid = grid_for((nvec + CH - 1) / CH, lc);
+            hipLaunchKernelGGL((k_inv_digits<F, NL, CH, true>), dim3(grid), dim3(BLOCK), 0, st, f, (const E*)a, *ex, (E*)out, nvec, n,
+                               flag);
+            FFGPU_CHECK_LAUNCH();
+            return 0;
         }
     }
     // square-and-multiply after the leading run costs popcount(tail) products, the window table 8 up front and one per

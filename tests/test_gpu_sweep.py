@@ -131,3 +131,18 @@ def test_digit_arithmetic_every_bit_length(eng):
         for e in exps:
             got = unpack(ctx.pow(dev[0], e).to_numpy(), eb)
             assert got == [pow(x, e, p) for x in a], (bits, hex(e))
+        # batched inverse in digits (k_inv_digits: arrays of at least 4096 elements): 24-32 elements per thread share one
+        # exponentiation; zeros are flagged and map to 0, ragged sizes, every element checked by a * a^-1 = 1
+        for nn in (4096, 4096 + 37 + bits):
+            vals = [rng.randrange(1, p) for _ in range(nn)]
+            for z in (0, 31, 32, nn // 2, nn - 1):
+                vals[z] = 0
+            vals[1], vals[2], vals[3] = 1, p - 1, 2
+            d = ctx.from_numpy(pack(vals, eb))
+            with pytest.raises(ZeroDivisionError):
+                ctx.inv(d)
+            inv = unpack(ctx.inv(d, check_zero=False).to_numpy(), eb)
+            assert all((x * y) % p == (1 if x else 0) and y < p for x, y in zip(vals, inv)), (bits, nn)
+            vals2 = [v or 7 for v in vals]
+            inv2 = unpack(ctx.inv(ctx.from_numpy(pack(vals2, eb))).to_numpy(), eb)
+            assert all((x * y) % p == 1 for x, y in zip(vals2, inv2)), (bits, nn)

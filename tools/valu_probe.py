@@ -65,6 +65,7 @@ a80 = DevArray(ctx80, torch.randint(0, 2**31 - 1, (n, 3), dtype=torch.int32, dev
 a80 = ctx80.reduce(a80, out=a80)
 c80 = ctx80.empty(n)
 rows.append(('inv_sqrt_p80', lambda: ctx80.pow(a80, (3 * P80 - 5) >> 2, out=c80)))
+rows.append(('inv_p80', lambda: ctx80.inv(a80, out=c80, check_zero=False)))
 # ---- 136-bit prime (three limbs)
 P136 = find_prime_root(136)[0]
 ctx136 = FieldContext(P136, device=0)
