@@ -275,7 +275,8 @@ def test_secure_matmul_opens_to_product(mods, modulus, t, m):
 @pytest.mark.parametrize('modulus,binary,t,m', [(2**61 - 1, False, 1, 3), (2**61 - 1, False, 3, 7), (2**96 - 17, False, 2, 5),
                                                 (2**128 - 173, False, 1, 4), (0x11b, True, 1, 3), (0x11b, True, 2, 6),
                                                 (258797994007609146293811961253269568351, False, 1, 3),
-                                                ((1 << 64) | 0x1b, True, 1, 3)])
+                                                ((1 << 64) | 0x1b, True, 1, 3),
+                                                (2**80 - 65, False, 3, 7), (2**136 - 113, False, 1, 3)])     # (digit dot products in the operand fetch)
 def test_fused_chain_gate(mods, modulus, binary, t, m):
     """ffgpu_gate_rng: recombination of both factors + product + share generation in one kernel, against
     the three separate kernels on the same sub-shares and generator state (bit-exact), and through a chain
