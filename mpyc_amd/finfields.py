@@ -516,6 +516,63 @@ _HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exac
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
 
 
+_UNIFORM_MASK_MIN = 1 << 16
+
+
+class _UniformMask(np.ndarray):
+    """A read-only boolean array whose elements are all equal: a zero-stride view of one np.bool_, so it costs nothing to
+    make however large the shape.  It IS an ndarray (indexing with it, arithmetic on it etc. work as for any boolean array);
+    what the runtime does with such masks -- np.count_nonzero, .all(), .any(), ~mask -- is answered without touching 10^7
+    elements.  Only instances that still are the zero-stride view answer that way (a ufunc result of this type is ordinary)."""
+
+    def __new__(cls, shape, value):
+        return np.broadcast_to(np.bool_(bool(value)), tuple(shape)).view(cls)
+
+    def _uniform(self):
+        return self.dtype == np.bool_ and self.size > 0 and not any(self.strides) and self.base is not None
+
+    def _value(self) -> bool:
+        return bool(self.flat[0])
+
+    def __invert__(self):
+        if self._uniform():
+            return _UniformMask(self.shape, not self._value())
+        return np.invert(np.asarray(self))
+
+    def all(self, *args, **kwargs):
+        if self._uniform() and not args and not kwargs:
+            return np.bool_(self._value())
+        return np.asarray(self).all(*args, **kwargs)
+
+    def any(self, *args, **kwargs):
+        if self._uniform() and not args and not kwargs:
+            return np.bool_(self._value())
+        return np.asarray(self).any(*args, **kwargs)
+
+    def sum(self, *args, **kwargs):
+        if self._uniform() and not args and not kwargs:
+            return np.int64(self.size if self._value() else 0)
+        return np.asarray(self).sum(*args, **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if len(args) == 1 and not kwargs and args[0] is self and self._uniform():
+            name = func.__name__
+            if name == 'count_nonzero':
+                return self.size if self._value() else 0
+            if name in ('all', 'any'):
+                return np.bool_(self._value())
+        args = tuple(np.asarray(a) if isinstance(a, _UniformMask) else a for a in args)
+        return func(*args, **kwargs)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if ufunc is np.invert and method == '__call__' and len(inputs) == 1 and not kwargs and self._uniform():
+            return _UniformMask(self.shape, not self._value())
+        inputs = tuple(np.asarray(a) if isinstance(a, _UniformMask) else a for a in inputs)
+        if 'out' in kwargs:
+            kwargs['out'] = tuple(np.asarray(a) if isinstance(a, _UniformMask) else a for a in kwargs['out'])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+
 class HostView(np.ndarray):
     """What `FieldArray.value` returns: an np.ndarray (so `isinstance(v, np.ndarray)`, sectypes.py:1366,
     holds) that stands for the reference's object ndarray but keeps the data on the device for what the
@@ -1612,7 +1669,7 @@ class FieldArray:
         """Modular (inverse) square root (finfields.py:1283-1290, :1424-1458 / :1550-1563): for
         p = 3 mod 4 a^((p+1)/4) (resp. a^((3p-5)/4)); for GF(2^n) a^(q/2) (resp. q/2 - 1)."""
         ops = _fops(type(self).field)
-        if INV and self.size and bool(self._zero_mask().any()):
+        if INV and self.size and not self._no_element_equals(0) and bool(self._zero_mask().any()):
             raise ZeroDivisionError('no inverse sqrt of 0')
         if ops.binary:
             e = (ops.order >> 1) - (1 if INV else 0)
@@ -1748,12 +1805,33 @@ class FieldArray:
         z = (t == 0)
         return z.all(dim=-1) if self.ctx.limbs else z
 
+    def _no_element_equals(self, o: int) -> bool:
+        """True if NO element equals the canonical scalar o, decided on the device by the lowest limb alone (a necessary
+        condition for equality: one strided compare + one reduction instead of a compare over all limbs, a reduction over
+        the limb axis, a mask-sized copy to the host).  False = unknown (some lowest limb matches): the caller compares in full."""
+        t = self._dev.t
+        if not self.ctx.limbs:
+            if self.ctx.elem_bytes == 1 or t.dim() != 1:
+                return False
+            lim = 1 << (8 * self.ctx.elem_bytes)
+            lo = o % lim
+            return not bool((t == (lo - lim if lo >= lim >> 1 else lo)).any())
+        bits = self._limb_bits()
+        lo = o & ((1 << bits) - 1)
+        if lo >= 1 << (bits - 1):
+            lo -= 1 << bits                                  # the limb tensors are signed
+        return not bool((t[..., 0] == lo).any())
+
     def __eq__(self, other):
         opd = self._operand(other)
         if opd is None:
             return NotImplemented
         kind, o = opd
         if kind == 'scalar':
+            # large array against a scalar (np_random_bits: `_r2.value != 0` over f x n opened squares, runtime.py:4257):
+            # usually no element matches -- then the answer is a uniform mask and nothing mask-sized is built or copied
+            if self.size >= _UNIFORM_MASK_MIN and self._no_element_equals(o):
+                return _UniformMask(self._shape, False)
             o = type(self)([o])
         a, b, shape = self._broadcast(o)
         eq = (a.t == b.t)

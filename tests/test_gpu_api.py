@@ -801,3 +801,45 @@ def test_matmul_scratch_is_per_stream():
         d2 = ctx.dot(ops[1][0], ops[1][0])
     torch.cuda.synchronize()
     assert d1.to_ints() == ctx.dot(ops[0][0], ops[0][0]).to_ints() and d2.to_ints() == ctx.dot(ops[1][0], ops[1][0]).to_ints()
+
+
+def test_scalar_comparisons_of_large_arrays_uniform_masks(api):
+    """Round 6: `a == c` / `a != c` of a large array against a scalar -- np_random_bits' `_r2.value != 0` over f x n opened
+    squares (runtime.py:4257) -- is decided on the device by the lowest limb; when no element matches, the result is a
+    uniform mask (a zero-stride boolean ndarray: nothing mask-sized is built or copied).  Same values as the elementwise
+    comparison in every case: no match, one match, a match of the lowest limb only, negative / out-of-range scalars,
+    2-D shapes, every storage width; and what the runtime does with the mask (count_nonzero, boolean indexing, ~)."""
+    finfields, gfpx, _ = api
+    rng = np.random.default_rng(77)
+    for modulus in (2**61 - 1, 2**64 - 189, 2**31 - 1, 2**80 - 65, 2**128 - 173, 2**136 - 113):
+        F = finfields.GF(modulus)
+        n = (1 << 16) + 37
+        vals = [int(v) % modulus or 1 for v in rng.integers(1, 2**63, size=n, dtype=np.int64)]
+        if modulus > 2**64:
+            vals = [(v * 0x9E3779B97F4A7C15F39CC0605CEDC835 + 12345) % modulus or 1 for v in vals]
+        a = F.array(vals)
+        ref = np.array(vals, dtype=object)
+        for c in (0, modulus, -modulus):                                   # no element is 0 (mod p)
+            eq, ne = (a == c), (a != c)
+            assert isinstance(eq, np.ndarray) and eq.dtype == np.bool_ and eq.shape == (n,)
+            assert type(eq).__name__ == '_UniformMask' and not eq.any() and ne.all()
+            assert np.count_nonzero(ne) == n and np.count_nonzero(eq) == 0 and int(np.sum(ne)) == n
+            assert np.asarray(a.value)[ne].shape == (n,) and np.asarray(a.value)[eq].shape == (0,)
+            assert np.array_equal(np.asarray(~ne), np.zeros(n, dtype=bool))
+        hit = vals[1234]
+        eq = a == hit
+        assert type(eq) is np.ndarray and np.array_equal(eq, ref == hit) and eq[1234]
+        assert np.array_equal(a != hit, ref != hit)
+        assert np.array_equal(a == hit - modulus, ref == hit)               # scalars are reduced (finfields.py:1045-1054)
+        lim = 2**32 if F.array([0]).ctx.elem_bytes in (4, 12) else 2**64
+        if modulus > lim:                                                  # same lowest limb, different element
+            near = (hit + lim) % modulus
+            if near not in vals:
+                assert not (a == near).any() and type(a == near) is np.ndarray
+        b = a.reshape(37 + (1 << 16) // 1, 1) if False else a[:1 << 16].reshape(256, 256)
+        assert (b != 0).shape == (256, 256) and np.count_nonzero(b != 0) == 1 << 16
+        small = F.array(vals[:100])
+        assert type(small == 0) is np.ndarray and not (small == 0).any()    # below the threshold: the ordinary path
+    from mpyc_amd.finfields import _UniformMask
+    m = _UniformMask((3, 4), True)
+    assert (m & np.eye(3, 4, dtype=bool)).sum() == 3 and type(m & m) is np.ndarray and np.count_nonzero(m[1:]) == 8
