@@ -17,6 +17,7 @@ that read it directly (runtime.py:561,643,...) or pickle it for the wire.
 """
 from __future__ import annotations
 
+import collections
 import functools
 import os
 import random as _random
@@ -27,6 +28,11 @@ from typing import Optional
 
 import numpy as np
 import torch
+
+try:
+    from xxhash import xxh64 as _xxh64
+except ImportError:                      # (no digest, no cache of public uploads: every use converts and uploads)
+    _xxh64 = None
 
 from .engine import np_to_objects, DevArray, DevMatrix, FieldContext, ints_to_np
 from .gfpx import BinaryPolynomial, _clinvert, _clmod, _clmul
@@ -516,6 +522,31 @@ _HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exac
                      '__array_priority__', '__copy__', '__deepcopy__', '__len__'))
 
 
+# A large public integer array that meets share arrays several times in a row -- np_sgn adds, multiplies and subtracts the
+# bit matrix `c_bits` (3.2e6 bits for 10^5 32-bit values) with them, runtime.py:3663, 3671 -- was converted to limbs and uploaded
+# every time (~4 ms each).  The last few uploads are kept, keyed by field, shape, dtype and a 64-bit digest of the CONTENT (the
+# array is mutable: identity would not do); a hit hands back the device array that was made from the same values.
+_PUBLIC_UPLOADS = collections.OrderedDict()
+_PUBLIC_UPLOAD_MIN, _PUBLIC_UPLOAD_KEEP = 1 << 16, 4
+
+
+def _uploaded_public(cls, arr: np.ndarray):
+    if arr.size < _PUBLIC_UPLOAD_MIN or arr.dtype.kind not in 'iub' or _xxh64 is None:
+        return cls(arr)
+    flat = np.ascontiguousarray(arr)
+    key = (cls, arr.shape, arr.dtype.str, _xxh64(flat.view(np.uint8).reshape(-1)).intdigest())
+    kept = _PUBLIC_UPLOADS.get(key)
+    if kept is not None:
+        _PUBLIC_UPLOADS.move_to_end(key)
+    else:
+        kept = cls(flat)
+        _PUBLIC_UPLOADS[key] = kept
+        while len(_PUBLIC_UPLOADS) > _PUBLIC_UPLOAD_KEEP:
+            _PUBLIC_UPLOADS.popitem(last=False)
+    return kept.copy()                # (a device-side clone: the kept array itself never leaves this function -- a caller may
+    #                                    update what it gets in place)
+
+
 _UNIFORM_MASK_MIN = 1 << 16
 
 
@@ -754,7 +785,7 @@ class HostView(np.ndarray):
         if isinstance(other, (int, np.integer)) and not isinstance(other, (bool, np.bool_)):
             return int(other), (lambda v=int(other): v)
         if isinstance(other, np.ndarray) and other.dtype.kind in 'iub':
-            return type(self._fa)(other), (lambda v=other: v)          # public integer arrays (shifts, masks, bits)
+            return _uploaded_public(type(self._fa), other), (lambda v=other: v)      # public integer arrays (shifts, masks, bits)
         return None
 
     def _binop(self, other, name, reflected=False):

@@ -843,3 +843,31 @@ def test_scalar_comparisons_of_large_arrays_uniform_masks(api):
     from mpyc_amd.finfields import _UniformMask
     m = _UniformMask((3, 4), True)
     assert (m & np.eye(3, 4, dtype=bool)).sum() == 3 and type(m & m) is np.ndarray and np.count_nonzero(m[1:]) == 8
+
+
+def test_public_operand_uploads_are_keyed_by_content(api):
+    """Round 6: a large public integer array used with share arrays several times in a row (np_sgn's bit matrix,
+    runtime.py:3663-3671) is converted and uploaded once -- the cache is keyed by a digest of the CONTENT: an array updated
+    in place between two uses must give the new values, and what a caller does to a result must not reach the cache."""
+    finfields, _, _ = api
+    from mpyc_amd.finfields import HostView, _PUBLIC_UPLOADS
+    F = finfields.GF(2**64 - 189)
+    n = (1 << 16) + 5
+    rng = np.random.default_rng(3)
+    a = F.array([int(v) for v in rng.integers(0, 2**62, size=n)])
+    bits = rng.integers(0, 2, size=n).astype(np.int8)
+    v = HostView(a, lazy=True)
+    want = np.asarray(a.value).astype(object)
+    _PUBLIC_UPLOADS.clear()
+    s1 = (bits + v)._real()
+    assert len(_PUBLIC_UPLOADS) == 1 and (s1 == (want + bits.astype(object)) % F.order).all()
+    p1 = (bits * v)._real()
+    assert len(_PUBLIC_UPLOADS) == 1 and (p1 == (want * bits.astype(object)) % F.order).all()        # second use: a hit
+    bits[:100] ^= 1                                                                                   # in-place update
+    s2 = (bits + v)._real()
+    assert len(_PUBLIC_UPLOADS) == 2 and (s2 == (want + bits.astype(object)) % F.order).all()
+    d = v - bits                                    # a result updated in place by its owner ...
+    r = F.array(bits)                               # (ordinary construction: not through the cache)
+    r += 5
+    s3 = (bits + v)._real()                       # ... and the cached operand still holds the values of `bits`
+    assert (s3 == s2).all() and (d._real() == (want - bits.astype(object)) % F.order).all()
