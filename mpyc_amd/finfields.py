@@ -527,11 +527,11 @@ _HV_OWN = frozenset(('_fa', '_fa_value', '_fa_make', '_real', '_is_lazy', '_exac
 # every time (~4 ms each).  The last few uploads are kept, keyed by field, shape, dtype and a 64-bit digest of the CONTENT (the
 # array is mutable: identity would not do); a hit hands back the device array that was made from the same values.
 _PUBLIC_UPLOADS = collections.OrderedDict()
-_PUBLIC_UPLOAD_MIN, _PUBLIC_UPLOAD_KEEP = 1 << 16, 4
+_PUBLIC_UPLOAD_MIN, _PUBLIC_UPLOAD_MAX, _PUBLIC_UPLOAD_KEEP = 1 << 16, 1 << 25, 4      # (at most 4 x 2^25 elements stay pinned)
 
 
 def _uploaded_public(cls, arr: np.ndarray):
-    if arr.size < _PUBLIC_UPLOAD_MIN or arr.dtype.kind not in 'iub' or _xxh64 is None:
+    if not _PUBLIC_UPLOAD_MIN <= arr.size <= _PUBLIC_UPLOAD_MAX or arr.dtype.kind not in 'iub' or _xxh64 is None:
         return cls(arr)
     flat = np.ascontiguousarray(arr)
     key = (cls, arr.shape, arr.dtype.str, _xxh64(flat.view(np.uint8).reshape(-1)).intdigest())
