@@ -709,6 +709,13 @@ struct PM128 {
         ff_digits28(wx, dx);
         ff_lazy_mac(s, dl, dx);
     }
+    // the same with the operands already cut into digits (kernels that use an operand many times: the skinny products)
+    enum { LAZY_NL = 5 };
+    FF_HD void lacc_digits(const u128e& x, uint32_t (&d)[5]) const {
+        const uint32_t w[4] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi, (uint32_t)(x.hi >> 32)};
+        ff_digits28(w, d);
+    }
+    FF_HD void lacc_mac_digits(lacc& s, const uint32_t (&dl)[5], const uint32_t (&dx)[5]) const { ff_lazy_mac(s, dl, dx); }
     FF_HD u128e lacc_reduce(const lacc& s) const {
         uint64_t a[5];
         ff_lazy_limbs(s, a);
@@ -788,6 +795,12 @@ struct PM96 : PM128<false> {
         ff_digits28(wx, dx);
         ff_lazy_mac(s, dl, dx);
     }
+    enum { LAZY_NL = 4 };
+    FF_HD void lacc_digits(const u128e& x, uint32_t (&d)[4]) const {
+        const uint32_t w[3] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi};
+        ff_digits28(w, d);
+    }
+    FF_HD void lacc_mac_digits(lacc& s, const uint32_t (&dl)[4], const uint32_t (&dx)[4]) const { ff_lazy_mac(s, dl, dx); }
     FF_HD u128e lacc_reduce(const lacc& s) const {
         uint64_t a[4];
         ff_lazy_limbs(s, a);                              // < 2^(192 + 5)
@@ -1033,6 +1046,13 @@ struct PM192 {
         ff_digits28(wx, dx);
         ff_lazy_mac(s, dl, dx);
     }
+    enum { LAZY_NL = 7 };
+    FF_HD void lacc_digits(const u192e& x, uint32_t (&d)[7]) const {
+        const uint32_t w[6] = {(uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.mid, (uint32_t)(x.mid >> 32),
+                               (uint32_t)x.hi, (uint32_t)(x.hi >> 32)};
+        ff_digits28(w, d);
+    }
+    FF_HD void lacc_mac_digits(lacc& s, const uint32_t (&dl)[7], const uint32_t (&dx)[7]) const { ff_lazy_mac(s, dl, dx); }
     FF_HD u192e lacc_reduce(const lacc& s) const {
         acc t;
         ff_lazy_limbs(s, t.a);

@@ -1084,6 +1084,18 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_short_rows(F f, const typename
 // they are scalar loads in the loop, one dependent wait per row of A (measured over 2^61 - 1 at 4096 x 4096: M = 8 126 us,
 // M = 2 37.6 us against 30.5 us for M = 1), and Montgomery fields repeat the conversion in every thread.
 constexpr int VECMAT_KT = 32;
+// Policies with a dot product in 28-bit digits (the multi-limb 2^k - c primes, fields.hpp LazyDot) take it here too (round 6):
+// the staged entries of A are stored as digits, a row of B is cut once per thread and used for all M rows, every term is NL^2
+// multiply-adds into column sums, reduced every FF_D28_MAX_TERMS terms -- 8 x 4096 @ 4096^2 over the 80-bit prime: 384 us with
+// the 128-bit limb arithmetic of acc_mac (~100 instructions per term).
+template <class F, bool LZ>
+struct VecmatDigits {                      // (only named when LZ)
+    enum { NL = 1 };
+};
+template <class F>
+struct VecmatDigits<F, true> {
+    enum { NL = F::LAZY_NL };
+};
 template <class F, int MM, bool VEC, bool STAGE, int UNR = 4>
 __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F::elem* __restrict__ A, size_t lda,
                                                            const typename F::elem* __restrict__ B, size_t ldb,
@@ -1094,28 +1106,38 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
     typedef typename F::word W;
     constexpr int CW = VEC ? P::N : 1;                              // columns per thread
     constexpr int KT = VECMAT_KT;
-    __shared__ W sa[STAGE ? MM : 1][STAGE ? KT : 1];
+    constexpr bool LZ = HasLazyAcc<F>::value && STAGE;             // digit accumulators (staged A only: the digits live in LDS)
+    constexpr int NL = VecmatDigits<F, LZ>::NL;
+    constexpr int FLUSH = LZ ? (int)FF_D28_MAX_TERMS : (int)SKINNY_FLUSH;
+    static_assert(!LZ || FF_D28_MAX_TERMS % UNR == 0, "the flush test follows whole groups");
+    using Acc = typename std::conditional<LZ, typename LazyAccOf<F>::type, typename F::acc>::type;
+    __shared__ W sa[(STAGE && !LZ) ? MM : 1][(STAGE && !LZ) ? KT : 1];
+    __shared__ uint32_t sad[LZ ? MM : 1][LZ ? KT : 1][NL];
     const int j = (blockIdx.x * BLOCK + threadIdx.x) * CW;
     const bool live = j < N;
     if (!STAGE && !live) return;
     const int k0 = blockIdx.y * kchunk;
     const int k1 = k0 + kchunk < K ? k0 + kchunk : K;
-    typename F::acc acc[MM][CW];
+    Acc acc[MM][CW];
     W total[MM][CW];
     bool have = false;
     int cnt = 0;
+    auto zero = [&](Acc& a_) {
+        if constexpr (LZ) f.lacc_zero(a_); else f.acc_zero(a_);
+    };
 #pragma unroll
     for (int mi = 0; mi < MM; ++mi)
 #pragma unroll
-        for (int q = 0; q < CW; ++q) f.acc_zero(acc[mi][q]);
+        for (int q = 0; q < CW; ++q) zero(acc[mi][q]);
     auto flush = [&]() {
 #pragma unroll
         for (int mi = 0; mi < MM; ++mi)
 #pragma unroll
             for (int q = 0; q < CW; ++q) {
-                W part = f.acc_reduce(acc[mi][q]);
+                W part;
+                if constexpr (LZ) part = f.lacc_reduce(acc[mi][q]); else part = f.acc_reduce(acc[mi][q]);
                 total[mi][q] = have ? f.add(total[mi][q], part) : part;
-                f.acc_zero(acc[mi][q]);
+                zero(acc[mi][q]);
             }
         have = true;
         cnt = 0;
@@ -1137,19 +1159,42 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
                 const int mi = e / KT, kk = kt0 + e % KT;
                 W v = W();
                 if (mi < M && kk < kt1) v = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));
-                sa[mi][e % KT] = v;
+                if constexpr (LZ) {
+                    uint32_t d[NL];
+                    f.lacc_digits(v, d);
+#pragma unroll
+                    for (int t_ = 0; t_ < NL; ++t_) sad[mi][e % KT][t_] = d[t_];
+                } else {
+                    sa[mi][e % KT] = v;
+                }
             }
             __syncthreads();
         }
         auto macs = [&](int kk, const W (&b)[CW]) {
+            if constexpr (LZ) {
+                uint32_t db[CW][NL];
 #pragma unroll
-            for (int mi = 0; mi < MM; ++mi) {
-                if (MM == 1 || mi < M) {
-                    W ap;
-                    if constexpr (STAGE) ap = sa[mi][kk - kt0];                                 // broadcast read
-                    else ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                     // wave-uniform operand
+                for (int q = 0; q < CW; ++q) f.lacc_digits(b[q], db[q]);
 #pragma unroll
-                    for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, b[q]);
+                for (int mi = 0; mi < MM; ++mi) {
+                    if (MM == 1 || mi < M) {
+                        uint32_t da[NL];
+#pragma unroll
+                        for (int t_ = 0; t_ < NL; ++t_) da[t_] = sad[mi][kk - kt0][t_];         // broadcast reads
+#pragma unroll
+                        for (int q = 0; q < CW; ++q) f.lacc_mac_digits(acc[mi][q], da, db[q]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MM; ++mi) {
+                    if (MM == 1 || mi < M) {
+                        W ap;
+                        if constexpr (STAGE) ap = sa[mi][kk - kt0];                                 // broadcast read
+                        else ap = f.prep(ld_elem<F>(A, (size_t)mi * lda + kk));                     // wave-uniform operand
+#pragma unroll
+                        for (int q = 0; q < CW; ++q) f.acc_mac(acc[mi][q], ap, b[q]);
+                    }
                 }
             }
         };
@@ -1162,13 +1207,13 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) macs(kk + u, b[u]);
                 cnt += UNR;
-                if (cnt >= SKINNY_FLUSH) flush();
+                if (cnt >= FLUSH) flush();
             }
             for (; kk < kt1; ++kk) {
                 W b0[CW];
                 load_b(kk, b0);
                 macs(kk, b0);
-                if (++cnt >= SKINNY_FLUSH) flush();
+                if (++cnt >= FLUSH) flush();
             }
         }
         if constexpr (!STAGE) break;

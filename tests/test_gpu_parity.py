@@ -790,9 +790,18 @@ def test_skinny_products(eng, coracle):
             assert (got == want).all(), (hex(modulus), M, K, N)
     # every operand p - 1, every M of the few-rows kernels (one instantiation each for one-word primes: column sums of
     # 22 x 32-bit partial products, flushed every 192 terms), packed and ragged column counts
-    for modulus in (P61, P64, 6616326157076047771, 2**40 - 87):
+    # (round 6: the multi-limb 2^k - c primes accumulate in 28-bit digits, flushed every 32 terms: the same at their extremes)
+    for modulus in (P61, P64, 6616326157076047771, 2**40 - 87, 2**80 - 65, 2**96 - 17, P128, 2**136 - 113):
         ctx = ctx_for(eng, modulus, False)
         eb = ctx.elem_bytes
+        if eb > 8:
+            rng_ = random.Random(eb)
+            for (M, K, N) in ((3, 97, 70), (8, 1000, 129), (6, 33, 300)):           # random operands, ragged K around the flush
+                a = [rng_.randrange(modulus) for _ in range(M * K)]
+                b = [rng_.randrange(modulus) for _ in range(K * N)]
+                got = unpack(ctx.matmul(ctx.from_numpy(pack(a, eb)), ctx.from_numpy(pack(b, eb)), M, K, N).to_numpy(), eb)
+                assert got == [sum(a[i * K + k] * b[k * N + j] for k in range(K)) % modulus for i in range(M) for j in range(N)], \
+                    (hex(modulus), M, K, N)
         for M in range(1, 9):
             for (K, N) in ((1000 + M, 130), (389, 261)):
                 A = pack([modulus - 1] * (M * K), eb)
