@@ -32,6 +32,14 @@ __device__ __forceinline__ W ff_keep_if(W v, bool ok) {
 // B into its own (M x N) slab of C (slab stride zstride elements); k_splitk_sum adds the slabs.  Shapes whose
 // output gives fewer tiles than the chip has CUs (a batch of 64 activations times a 4096^2 weight matrix) would
 // otherwise leave most of it idle.
+template <class F, bool LZ>
+struct MatmulDigits {                      // digits per staged element when the policy accumulates in 28-bit digits (round 6)
+    enum { NL = 1 };
+};
+template <class F>
+struct MatmulDigits<F, true> {
+    enum { NL = F::LAZY_NL };
+};
 template <class F, int TM, int TN>
 __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* __restrict__ A, size_t lda,
                                                    const typename F::elem* __restrict__ B, size_t ldb,
@@ -46,18 +54,29 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* _
         C += (size_t)blockIdx.z * zstride;
         K = K - kz < kchunk ? K - kz : kchunk;
     }
-    constexpr int BK = 16, BM = 16 * TM, BN = 16 * TN, FLUSH = 192;
-    __shared__ W As[BK][BM + 1];
-    __shared__ W Bs[BK][BN + 1];
+    // multi-limb 2^k - c primes (round 6): the tiles are staged as 28-bit DIGITS and every term is NL^2 multiply-adds into
+    // column sums (fields.hpp LazyDot), reduced every 32 terms -- ~100 instructions per term with the 128-bit limb arithmetic
+    constexpr bool LZ = HasLazyAcc<F>::value;
+    constexpr int NL = MatmulDigits<F, LZ>::NL;
+    constexpr int BK = 16, BM = 16 * TM, BN = 16 * TN, FLUSH = LZ ? (int)FF_D28_MAX_TERMS : 192;
+    static_assert(FLUSH % BK == 0, "the flush test follows whole k-steps");
+    using Acc = typename std::conditional<LZ, typename LazyAccOf<F>::type, typename F::acc>::type;
+    __shared__ W As[LZ ? 1 : BK][LZ ? 1 : BM + 1];
+    __shared__ W Bs[LZ ? 1 : BK][LZ ? 1 : BN + 1];
+    __shared__ uint32_t Ad[LZ ? BK : 1][LZ ? BM + 1 : 1][NL];
+    __shared__ uint32_t Bd[LZ ? BK : 1][LZ ? BN + 1 : 1][NL];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    typename F::acc acc[TM][TN];
+    Acc acc[TM][TN];
     W tot[TM][TN];
     bool have = false;
+    auto zero = [&](Acc& a_) {
+        if constexpr (LZ) f.lacc_zero(a_); else f.acc_zero(a_);
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) f.acc_zero(acc[i][j]);
+        for (int j = 0; j < TN; ++j) zero(acc[i][j]);
     int since = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
         // stage A (BM x BK) transposed and B (BK x BN)
@@ -65,37 +84,70 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* _
             int mm = idx / BK, kk = idx % BK;
             int gm = m0 + mm, gk = k0 + kk;
             const bool ok = gm < M && gk < K;      // out-of-range: read element 0, then zero it
-            As[kk][mm] = ff_keep_if<W>(f.prep(ld_elem<F>(A, ok ? (size_t)gm * lda + gk : 0)), ok);
+            const W v = ff_keep_if<W>(f.prep(ld_elem<F>(A, ok ? (size_t)gm * lda + gk : 0)), ok);
+            if constexpr (LZ) {
+                uint32_t d[NL];
+                f.lacc_digits(v, d);
+#pragma unroll
+                for (int t_ = 0; t_ < NL; ++t_) Ad[kk][mm][t_] = d[t_];
+            } else {
+                As[kk][mm] = v;
+            }
         }
         for (int idx = threadIdx.x; idx < BK * BN; idx += BLOCK) {
             int kk = idx / BN, nn = idx % BN;
             int gk = k0 + kk, gn = n0 + nn;
             const bool ok = gk < K && gn < N;
-            Bs[kk][nn] = ff_keep_if<W>(ld_elem<F>(B, ok ? (size_t)gk * ldb + gn : 0), ok);
+            const W v = ff_keep_if<W>(ld_elem<F>(B, ok ? (size_t)gk * ldb + gn : 0), ok);
+            if constexpr (LZ) {
+                uint32_t d[NL];
+                f.lacc_digits(v, d);
+#pragma unroll
+                for (int t_ = 0; t_ < NL; ++t_) Bd[kk][nn][t_] = d[t_];
+            } else {
+                Bs[kk][nn] = v;
+            }
         }
         __syncthreads();
 #pragma unroll 4
         for (int kk = 0; kk < BK; ++kk) {
-            W a[TM], b[TN];
+            if constexpr (LZ) {
+                uint32_t a[TM][NL], b[TN][NL];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][tx + 16 * j];
+                    for (int t_ = 0; t_ < NL; ++t_) a[i][t_] = Ad[kk][ty + 16 * i][t_];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) f.acc_mac(acc[i][j], a[i], b[j]);
+                    for (int t_ = 0; t_ < NL; ++t_) b[j][t_] = Bd[kk][tx + 16 * j][t_];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) f.lacc_mac_digits(acc[i][j], a[i], b[j]);
+            } else {
+                W a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) f.acc_mac(acc[i][j], a[i], b[j]);
+            }
         }
         __syncthreads();
         since += BK;
-        if (since >= FLUSH) {   // keep the unreduced accumulators inside their headroom (2^8 products)
+        if (since >= FLUSH) {   // keep the unreduced accumulators inside their headroom (2^8 products; digit columns: 32)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    W part = f.acc_reduce(acc[i][j]);
+                    W part;
+                    if constexpr (LZ) part = f.lacc_reduce(acc[i][j]); else part = f.acc_reduce(acc[i][j]);
                     tot[i][j] = have ? f.add(tot[i][j], part) : part;
-                    f.acc_zero(acc[i][j]);
+                    zero(acc[i][j]);
                 }
             have = true;
             since = 0;
@@ -107,7 +159,8 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(F f, const typename F::elem* _
         for (int j = 0; j < TN; ++j) {
             int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
             if (gm < M && gn < N) {
-                W r = f.acc_reduce(acc[i][j]);
+                W r;
+                if constexpr (LZ) r = f.lacc_reduce(acc[i][j]); else r = f.acc_reduce(acc[i][j]);
                 if (have) r = f.add(tot[i][j], r);
                 st_elem<F>(C, (size_t)gm * ldc + gn, r);
             }

@@ -829,6 +829,26 @@ def test_skinny_products(eng, coracle):
     assert [int(v) for v in got.value] == [sum(W_[i][k] * y[k] for k in range(300)) % P61 for i in range(150)]
 
 
+def test_dense_product_in_digits_multi_limb_primes(eng):
+    """Round 6: the LDS-tiled dense product stages the multi-limb 2^k - c primes as 28-bit digits and accumulates column sums,
+    reduced every 32 terms (k_matmul with LazyDot): every operand p - 1 (the largest columns), K around the flush and the
+    k-step, split-K shapes, against Python integers -- the 80-, 96-, 128- and 136-bit primes."""
+    rng = random.Random(2806)
+    for modulus in (2**80 - 65, 2**96 - 17, P128, 2**136 - 113):
+        ctx = ctx_for(eng, modulus, False)
+        eb = ctx.elem_bytes
+        for (M, K, N) in ((33, 31, 35), (40, 32, 33), (20, 33, 40), (17, 200, 19), (64, 257, 48)):
+            A = pack([modulus - 1] * (M * K), eb)
+            B = pack([modulus - 1] * (K * N), eb)
+            got = unpack(ctx.matmul(ctx.from_numpy(A), ctx.from_numpy(B), M, K, N).to_numpy(), eb)
+            assert got == [K * (modulus - 1) ** 2 % modulus] * (M * N), (hex(modulus), M, K, N)
+            a = [rng.randrange(modulus) for _ in range(M * K)]
+            b = [rng.randrange(modulus) for _ in range(K * N)]
+            got = unpack(ctx.matmul(ctx.from_numpy(pack(a, eb)), ctx.from_numpy(pack(b, eb)), M, K, N).to_numpy(), eb)
+            assert got == [sum(a[i * K + k] * b[k * N + j] for k in range(K)) % modulus for i in range(M) for j in range(N)], \
+                (hex(modulus), M, K, N)
+
+
 def test_matrix_core_product(eng, coracle):
     """Large dense products over primes of up to 64 bits run as int8 limb GEMMs on the matrix cores
     (k_limb_gemm): bit-exact against the oracle for every limb count (5: 32-bit storage, 9: moduli below 2^63,

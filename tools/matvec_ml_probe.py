@@ -29,3 +29,7 @@ for bits in (61, 80, 128):
             lhs = rnd(M * K)
             ms = bench.time_launches(lambda B: ctx.matmul(lhs, B, M, K, K), mats, 5)
         print('p=%3d bits %-18s %8.1f us  %.3f of 8 TB/s' % (bits, tag, ms * 1e3, K * K * eb / ms / 1e6 / 8000), flush=True)
+    for S in (256, 384):                         # medium dense products: below the matrix-core threshold, the LDS-tiled k_matmul
+        A_, B_ = rnd(S * S), rnd(S * S)
+        ms = bench.time_launches(lambda z: ctx.matmul(A_, B_, S, S, S), [0], 10)
+        print('p=%3d bits %dx%dx%d dense      %8.1f us  %.2f T field-MAC/s' % (bits, S, S, S, ms * 1e3, S**3 / ms / 1e9), flush=True)
