@@ -737,6 +737,24 @@ enum { SKINNY_MAX = 8, SKINNY_FLUSH = 192 };
 // (the column-sum kernels below test the count AFTER adding a whole group of terms: a flush happens at no more than
 // SKINNY_FLUSH - 1 + group terms, which must stay within ColAcc::MAX_TERMS = 256 -- asserted where each group size is known)
 
+// The accumulator of the matrix x few-columns kernels: the policy's dot product in 28-bit digits where it has one (the
+// multi-limb 2^k - c primes, round 6: ~45 instead of ~100 instructions per term, flushed every 32 terms), else F::acc.
+template <class F>
+struct SkinnyAcc {
+    static constexpr bool LZ = HasLazyAcc<F>::value;
+    typedef typename std::conditional<LZ, typename LazyAccOf<F>::type, typename F::acc>::type T;
+    enum { FLUSH = LZ ? (int)FF_D28_MAX_TERMS : (int)SKINNY_FLUSH };
+    static __device__ __forceinline__ void zero(const F& f, T& a) {
+        if constexpr (LZ) f.lacc_zero(a); else f.acc_zero(a);
+    }
+    static __device__ __forceinline__ void mac(const F& f, T& a, const typename F::word& l, const typename F::word& x) {
+        if constexpr (LZ) f.lacc_mac(a, l, x); else f.acc_mac(a, l, x);
+    }
+    static __device__ __forceinline__ typename F::word reduce(const F& f, const T& a) {
+        if constexpr (LZ) return f.lacc_reduce(a); else return f.acc_reduce(a);
+    }
+};
+
 // C (M x N) = A (M x K) @ B (K x N), N <= SKINNY_MAX: one workgroup per row of A
 template <class F, int NN>
 __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::elem* __restrict__ A, size_t lda,
@@ -749,18 +767,19 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::el
     __shared__ W sm[BLOCK];
     const size_t row = blockIdx.x;
     const typename F::elem* __restrict__ a = A + row * lda;
-    typename F::acc acc[NN];
+    typedef SkinnyAcc<F> SA;
+    typename SA::T acc[NN];
     W total[NN];
     bool have = false;
     int cnt = 0;
 #pragma unroll
-    for (int j = 0; j < NN; ++j) f.acc_zero(acc[j]);
+    for (int j = 0; j < NN; ++j) SA::zero(f, acc[j]);
     auto flush = [&]() {
 #pragma unroll
         for (int j = 0; j < NN; ++j) {
-            W part = f.acc_reduce(acc[j]);
+            W part = SA::reduce(f, acc[j]);
             total[j] = have ? f.add(total[j], part) : part;
-            f.acc_zero(acc[j]);
+            SA::zero(f, acc[j]);
         }
         have = true;
         cnt = 0;
@@ -775,15 +794,15 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows(F f, const typename F::el
                     const P bp = ldg<false>(br + jp);
 #pragma unroll
                     for (int q = 0; q < P::N; ++q)
-                        if (jp * P::N + q < NN) f.acc_mac(acc[jp * P::N + q], xp, bp.w[q]);
+                        if (jp * P::N + q < NN) SA::mac(f, acc[jp * P::N + q], xp, bp.w[q]);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NN; ++j)
-                if (j < N) f.acc_mac(acc[j], xp, ld_elem<F>(B, kk * ldb + j));
+                if (j < N) SA::mac(f, acc[j], xp, ld_elem<F>(B, kk * ldb + j));
         }
-        if (++cnt >= SKINNY_FLUSH) flush();
+        if (++cnt >= SA::FLUSH) flush();
     };
     constexpr int EPV = P::N;
     const int nvec = vec ? K / EPV : 0;
@@ -819,22 +838,23 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::
     typedef typename F::word W;
     __shared__ W sm[BLOCK];
     const size_t row0 = (size_t)blockIdx.x * R;
-    typename F::acc acc[R][NN];
+    typedef SkinnyAcc<F> SA;
+    typename SA::T acc[R][NN];
     W total[R][NN];
     bool have = false;
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int j = 0; j < NN; ++j) f.acc_zero(acc[r][j]);
+        for (int j = 0; j < NN; ++j) SA::zero(f, acc[r][j]);
     auto flush = [&]() {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < NN; ++j) {
-                W part = f.acc_reduce(acc[r][j]);
+                W part = SA::reduce(f, acc[r][j]);
                 total[r][j] = have ? f.add(total[r][j], part) : part;
-                f.acc_zero(acc[r][j]);
+                SA::zero(f, acc[r][j]);
             }
         have = true;
         cnt = 0;
@@ -864,9 +884,9 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::
             for (int q = 0; q < EPV; ++q)
 #pragma unroll
                 for (int j = 0; j < NN; ++j)
-                    if (j < N) f.acc_mac(acc[r][j], b[q][j], x[r].w[q]);
+                    if (j < N) SA::mac(f, acc[r][j], b[q][j], x[r].w[q]);
         cnt += EPV;
-        if (cnt >= SKINNY_FLUSH) flush();
+        if (cnt >= SA::FLUSH) flush();
     }
     for (int kk = nvec * EPV + threadIdx.x; kk < K; kk += BLOCK) {
 #pragma unroll
@@ -875,9 +895,9 @@ __global__ __launch_bounds__(BLOCK) void k_matvec_rows_r(F f, const typename F::
                 const W bp = f.prep(ld_elem<F>(B, (size_t)kk * ldb + j));
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    f.acc_mac(acc[r][j], bp, ld_elem<F>(A, (row0 + r < (size_t)M ? row0 + r : (size_t)M - 1) * lda + kk));
+                    SA::mac(f, acc[r][j], bp, ld_elem<F>(A, (row0 + r < (size_t)M ? row0 + r : (size_t)M - 1) * lda + kk));
             }
-        if (++cnt >= SKINNY_FLUSH) flush();
+        if (++cnt >= SA::FLUSH) flush();
     }
     flush();
     // R*NN sums over the workgroup: butterfly inside each wave (cross-lane moves, no barrier), then ONE exchange
@@ -1159,13 +1179,13 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
     typedef typename F::word W;
     constexpr int CW = VEC ? P::N : 1;                              // columns per thread
     constexpr int KT = VECMAT_KT;
-    constexpr bool LZ = HasLazyAcc<F>::value && STAGE;             // digit accumulators (staged A only: the digits live in LDS)
+    constexpr bool LZ = HasLazyAcc<F>::value;                      // digit accumulators (staged A: its digits live in LDS)
     constexpr int NL = VecmatDigits<F, LZ>::NL;
     constexpr int FLUSH = LZ ? (int)FF_D28_MAX_TERMS : (int)SKINNY_FLUSH;
     static_assert(!LZ || FF_D28_MAX_TERMS % UNR == 0, "the flush test follows whole groups");
     using Acc = typename std::conditional<LZ, typename LazyAccOf<F>::type, typename F::acc>::type;
     __shared__ W sa[(STAGE && !LZ) ? MM : 1][(STAGE && !LZ) ? KT : 1];
-    __shared__ uint32_t sad[LZ ? MM : 1][LZ ? KT : 1][NL];
+    __shared__ uint32_t sad[(LZ && STAGE) ? MM : 1][(LZ && STAGE) ? KT : 1][NL];
     const int j = (blockIdx.x * BLOCK + threadIdx.x) * CW;
     const bool live = j < N;
     if (!STAGE && !live) return;
@@ -1232,8 +1252,12 @@ __global__ __launch_bounds__(BLOCK) void k_vecmat_partial(F f, const typename F:
                 for (int mi = 0; mi < MM; ++mi) {
                     if (MM == 1 || mi < M) {
                         uint32_t da[NL];
+                        if constexpr (STAGE) {
 #pragma unroll
-                        for (int t_ = 0; t_ < NL; ++t_) da[t_] = sad[mi][kk - kt0][t_];         // broadcast reads
+                            for (int t_ = 0; t_ < NL; ++t_) da[t_] = sad[mi][kk - kt0][t_];     // broadcast reads
+                        } else {
+                            f.lacc_digits(f.prep(ld_elem<F>(A, (size_t)mi * lda + kk)), da);    // wave-uniform operand: scalar unit
+                        }
 #pragma unroll
                         for (int q = 0; q < CW; ++q) f.lacc_mac_digits(acc[mi][q], da, db[q]);
                     }
