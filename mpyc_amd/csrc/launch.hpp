@@ -568,7 +568,7 @@ struct Launchers {
         }
         const int vec = al(A) && stride_ok(lda);
         const int bvec = al(B) && stride_ok(ldb) && (N % (int)Pack<W>::N == 0) && sizeof(E) != 12;
-        if constexpr (NN <= 2 && sizeof(E) != 12) {
+        if constexpr (NN <= 2) {              // (12-byte elements too since round 6: one element per pack, dwordx3 accesses)
             // long rows, one or two columns: R = 2 rows per workgroup share every load of B (measured at 4096^2 / 8192^2:
             // R = 1 32.5 / 117 us, R = 2 27.4 / 85 us, R = 4 28.3 / 99 us, R = 8 35.8 / 112 us)
             constexpr int R = 2;
